@@ -1,0 +1,63 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+# The seeded inputs every golden fixture was generated from (oracle/make_goldens.py).
+def tiny_case(**overrides):
+    from cassnat_asr_public_amd import synth
+
+    args = synth.make_args("tiny", **overrides)
+    state = synth.make_state(args, seed=0, gain=2.0)
+    feats, sizes = synth.make_feats(3, 61, 80, lengths=[61, 50, 37], seed=11)
+    return args, state, feats, sizes
+
+
+def config1_case():
+    from cassnat_asr_public_amd import synth
+
+    args = synth.make_args("config1")
+    state = synth.make_state(args, seed=1, blank_bias=0.0)
+    feats, sizes = synth.make_feats(1, 837, 80, seed=21)
+    return args, state, feats, sizes
+
+
+def config2_b8_case():
+    from cassnat_asr_public_amd import synth
+
+    args = synth.make_args("config2")
+    state = synth.make_state(args, seed=0, blank_bias=0.35)
+    lens = synth.ragged_lengths(8, 1000, 400, seed=7)
+    feats, sizes = synth.make_feats(8, 1000, 80, lengths=lens, seed=1234)
+    return args, state, feats, sizes
+
+
+def config2_b32_case():
+    """The benchmark workload (bench.py): B=32 x 1000 frames, blank bias 0.9."""
+    from cassnat_asr_public_amd import synth
+
+    args = synth.make_args("config2")
+    state = synth.make_state(args, seed=0, blank_bias=synth.BENCH_BLANK_BIAS)
+    feats, sizes = synth.make_feats(32, 1000, 80, seed=1234)
+    return args, state, feats, sizes

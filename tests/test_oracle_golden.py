@@ -1,0 +1,125 @@
+"""Pins oracle/cassnat_oracle.py to outputs of the reference itself (tests/golden/*.npz,
+produced by oracle/make_goldens.py).  CPU only.
+
+Tolerances: integer stages exact; float stages 2e-5 absolute (the reference's own fp32
+path moves by 1.9e-6 between thread counts, SURVEY 7 "hard parts").
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import config1_case, config2_b8_case, config2_b32_case, load_golden, tiny_case
+from oracle import cassnat_oracle as orc
+
+FTOL = 2e-5
+
+
+def _close(a, b, tol=FTOL):
+    a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a.astype(np.float64) - b.astype(np.float64)).max()
+    assert err <= tol, f"max abs err {err}"
+
+
+def _hyps_equal(out, g):
+    for b, h in enumerate(out["hyps"]):
+        assert h == g["hyp"][b, : g["hyp_len"][b]].tolist()
+    np.testing.assert_allclose(out["scores"], g["score"], rtol=0, atol=1e-3)
+
+
+def test_alignment_known_answer_vector():
+    """SURVEY 9.2 vector; expected values are the reference's own outputs."""
+    g = load_golden("align_kat")
+    shift, ylen0, ymax0 = orc.best_path_align(g["path"], g["mask"])
+    np.testing.assert_array_equal(shift, g["aligned_seq_shift"])
+    np.testing.assert_array_equal(ylen0, g["ylen0"])
+    assert ymax0 == int(g["ymax0"])
+    trig, ylen, ymax = orc.align_to_intervals(shift, ylen0, ymax0, g["mask"], g["src_size"])
+    np.testing.assert_array_equal(trig, g["trigger"])
+    np.testing.assert_array_equal(ylen, g["ylen"])
+    assert ymax == int(g["ymax"])
+    # the hand-derived statement of the same vector
+    assert shift.tolist() == [[0, 0, 0, 4, 0, 0, 5, 0, 0, 0, 3, 0], [0, 4, 0, 0, 0, 5, 0, 0, 0, 0, 0, 0]]
+    assert ylen.tolist() == [4, 3]
+    assert np.flatnonzero(trig[1, 2]).tolist() == [5, 6, 7] and not trig[1, 3].any()
+    assert orc.target_mask(ylen, ymax)[:, 0].astype(int).tolist() == [[1, 1, 1, 1], [1, 1, 1, 0]]
+
+
+def test_tiny_every_stage():
+    g = load_golden("tiny_stages")
+    args, state, feats, sizes = tiny_case()
+    out = orc.decode_nast(state, feats, sizes, args, stages=True)
+    _close(out["conv1"][:, ::8], g["conv1_c8"])
+    _close(out["conv2"], g["conv2"])
+    _close(out["x_embed"], g["x_embed"])
+    _close(out["enc_layers"][0], g["enc_layer0"])
+    _close(out["enc_layers"][1], g["enc_layer1"])
+    _close(out["enc_h"], g["enc_h"])
+    _close(out["ctc_out"], g["ctc_out"])
+    np.testing.assert_array_equal(out["aligned_seq_shift"], g["aligned_seq_shift"])
+    np.testing.assert_array_equal(out["ylen"], g["ylen"])
+    assert out["ymax"] == int(g["ymax"])
+    np.testing.assert_array_equal(out["trigger"], g["trigger"])
+    _close(out["ac_embed"], g["ac_embed"])
+    _close(out["pred_embed"], g["pred_embed"])
+    _close(out["dec_h"], g["dec_h"])
+    _close(out["att_out"], g["att_out"])
+    _hyps_equal(out, g)
+
+
+@pytest.mark.parametrize("name,ov", [
+    ("dilate", dict(left_trigger=1, right_trigger=1)),
+    ("srctrig", dict(src_trigger=True)),
+    ("unimask", dict(use_unimask=True)),
+    ("beam3", dict(beam_width=3, length_penalty=0.1)),
+])
+def test_tiny_option_variants(name, ov):
+    g = load_golden("tiny_" + name)
+    args, state, feats, sizes = tiny_case(**ov)
+    out = orc.decode_nast(state, feats, sizes, args, stages=True)
+    np.testing.assert_array_equal(out["ylen"], g["ylen"])
+    _close(out["dec_h"], g["dec_h"])
+    _close(out["att_out"], g["att_out"])
+    _hyps_equal(out, g)
+    if "beam_hyp" in g:
+        for b, beams in enumerate(out["beams"]):
+            for j, s in enumerate(beams):
+                assert s["hyp"] == g["beam_hyp"][b, j, : g["beam_len"][b, j]].tolist()
+                assert abs(s["score"] - g["beam_score"][b, j]) < 1e-3
+
+
+def _check_big(out, g, stride_t, stride_v, dec_t):
+    flips = out["best_paths"] != g["best_paths"]
+    assert (g["margin"][flips] < 1e-4).all(), "argmax differs on a frame with a clear margin"
+    if not flips.any():
+        np.testing.assert_array_equal(out["aligned_seq_shift"], g["aligned_seq_shift"])
+        np.testing.assert_array_equal(out["ylen"], g["ylen"])
+        _hyps_equal(out, g)
+    _close(out["ctc_out"][:, ::stride_t, ::stride_v], g["ctc_sample"], 1e-4)
+    _close(out["att_out"][:, ::dec_t, ::stride_v], g["att_sample"], 1e-4)
+
+
+def test_config1_single_utterance():
+    g = load_golden("config1")
+    args, state, feats, sizes = config1_case()
+    out = orc.decode_nast(state, feats, sizes, args, stages=True)
+    _check_big(out, g, 7, 13, 5)
+    _close(out["enc_h"][:, ::7, ::5], g["enc_sample"], 1e-4)
+
+
+def test_config2_shape_ragged_batch():
+    g = load_golden("config2_b8")
+    args, state, feats, sizes = config2_b8_case()
+    out = orc.decode_nast(state, feats, sizes, args, stages=True)
+    _check_big(out, g, 10, 50, 4)
+    _close(out["enc_h"][:, ::10, ::8], g["enc_sample"], 1e-4)
+    _close(out["enc_layers"][0][:, ::10, ::8], g["enc_layer0_sample"], 1e-4)
+
+
+def test_config2_bench_workload():
+    g = load_golden("config2_b32")
+    args, state, feats, sizes = config2_b32_case()
+    out = orc.decode_nast(state, feats, sizes, args, stages=True)
+    g["margin"] = g["margin"].astype(np.float32)
+    _check_big(out, g, 25, 100, 8)
+    _close(out["enc_h"][:, ::25, ::16], g["enc_sample"], 1e-4)
