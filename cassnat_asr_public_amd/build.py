@@ -1,0 +1,54 @@
+"""Builds libcassnat_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcassnat_hip.so")
+SOURCES = ["gemm.hip", "conv1.hip", "rowops.hip", "attention.hip", "ctc_align.hip", "model.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(CSRC), "..", "include", "cassnat_hip.h"))
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        path = os.path.join(CSRC, src)
+        if force or _stale(obj, [path] + headers):
+            cmd = [_hipcc()] + FLAGS + ["-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,298 @@
+// Fused multi-head attention for gfx950 (d_k = 64): QK^T -> scale -> mask -> softmax -> .V in one kernel,
+// scores never reach HBM.  Replaces `attention` + the head split/merge copies of MultiHeadedAttention
+// (reference: src/models/modules/attention.py:13-24, 44-66).
+//
+// Mask semantics are the reference's: a masked key gets the score float32-min (NOT -inf), so a query row
+// whose keys are all masked attends uniformly over all Lk keys (attention.py:19-21).  Keys that exist only
+// because the last tile is padded get -inf and never contribute.  Three mask sources are ANDed:
+//   keymask[b][j] (padding mask after subsampling), klen[b] (j < klen: target mask u < ylen),
+//   per-query frame intervals (s1,e1,s2,e2) (the CTC trigger mask, see ctc_align.hip), and `causal`.
+//
+// Structure: workgroup = 4 waves = 128 query rows of one (batch, head); each wave keeps its 32 query rows
+// as MFMA operand fragments in registers.  K/V tiles of 64 keys are staged global -> registers -> LDS
+// (next tile's loads are in flight during the current tile's MFMAs).  The score product is computed
+// "swapped" (S^T = K.Q^T, keys on accumulator rows, the query on the lane) so that
+//   * the softmax row reduction is 32 in-lane values + one cross-half exchange (wave shuffle), and
+//   * the probability tile is already laid out as the B operand of the next MFMA (O^T = V^T.P^T):
+//     no LDS round trip for P.  V^T fragments come from LDS with ds_read_b64_tr_b16 (bf16) or plain
+//     ds_read_b32 (f32 path, v_mfma_f32_32x32x2_f32).
+#include "kernels.h"
+
+struct AttnParams {
+    const unsigned char* Q;
+    const unsigned char* K;
+    const unsigned char* V;
+    void* O;
+    long long ldq_b, ldk_b, ldv_b;  // row strides in bytes
+    int ldo;
+    int H, Lq, Lk;
+    const unsigned char* keymask;
+    const int* klen;
+    const int* iv;
+    int iv_stride;
+    int causal;
+    float scale;
+};
+
+template <typename T> struct AttnCfg;
+template <> struct AttnCfg<bf16> {
+    static constexpr int KROW = 128;  // bytes per K row in LDS (64 bf16), 8 chunks, swizzle (row>>1)&7
+    static constexpr int VROW = 192;  // 128 B of data + 64 B pad: 4 consecutive rows hit disjoint banks for tr reads
+    static constexpr int CPR = 8;
+    __device__ static int swz(int row) { return (row >> 1) & 7; }
+};
+template <> struct AttnCfg<float> {
+    static constexpr int KROW = 256;  // 64 f32, 16 chunks, swizzle row&15
+    static constexpr int VROW = 256;
+    static constexpr int CPR = 16;
+    __device__ static int swz(int row) { return row & 15; }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
+    typedef AttnCfg<T> Cfg;
+    typedef typename Frag<T>::type frag_t;
+    constexpr int KROW = Cfg::KROW, VROW = Cfg::VROW, CPR = Cfg::CPR;
+    constexpr int NF = KROW / 32;           // 16-byte fragments of one 64-wide head row per lane half
+    constexpr int ST_IT = 64 * CPR / 256;   // 16-byte chunks per thread per 64-key tile
+
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * KROW];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * VROW];
+    __shared__ __attribute__((aligned(16))) unsigned int Ms[16];  // 64 mask bytes: 0 masked, 1 allowed, 2 tile padding
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+    const bool wave_active = (blockIdx.x * 128 + wave * 32) < p.Lq;
+    const int qc = q_row < p.Lq ? q_row : p.Lq - 1;
+
+    // ---- query fragments (B operand of S^T = K.Q^T): lane holds Q[q][16-byte chunk 2s+half]
+    frag_t qf[NF];
+    {
+        const unsigned char* qp = p.Q + ((long long)b * p.Lq + qc) * p.ldq_b + (long long)h * KROW;
+#pragma unroll
+        for (int s = 0; s < NF; ++s) qf[s] = as_frag<T>(ld16(qp + (2 * s + half) * 16));
+    }
+    int iv_s1 = 0, iv_e1 = 0, iv_s2 = 0, iv_e2 = 0;
+    if (p.iv) {
+        const int4 r = *reinterpret_cast<const int4*>(p.iv + ((long long)b * p.iv_stride + qc) * 4);
+        iv_s1 = r.x;
+        iv_e1 = r.y;
+        iv_s2 = r.z;
+        iv_e2 = r.w;
+    }
+    const int klen = p.klen ? p.klen[b] : p.Lk;
+
+    // ---- staging registers for the next K/V tile
+    uint4 k_reg[ST_IT], v_reg[ST_IT];
+    const unsigned char* kbase = p.K + (long long)b * p.Lk * p.ldk_b + (long long)h * KROW;
+    const unsigned char* vbase = p.V + (long long)b * p.Lk * p.ldv_b + (long long)h * KROW;
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < ST_IT; ++i) {
+            const int cidx = tid + 256 * i;
+            const int row = cidx / CPR, ch = cidx % CPR;
+            const int key = kt * 64 + row;
+            if (key < p.Lk) {
+                k_reg[i] = ld16(kbase + (long long)key * p.ldk_b + ch * 16);
+                v_reg[i] = ld16(vbase + (long long)key * p.ldv_b + ch * 16);
+            } else {
+                k_reg[i] = make_uint4(0, 0, 0, 0);
+                v_reg[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < ST_IT; ++i) {
+            const int cidx = tid + 256 * i;
+            const int row = cidx / CPR, ch = cidx % CPR;
+            st16(Ks + row * KROW + ((ch ^ Cfg::swz(row)) << 4), k_reg[i]);
+            st16(Vs + row * VROW + (ch << 4), v_reg[i]);
+        }
+        if (tid < 64) {
+            const int key = kt * 64 + tid;
+            unsigned char code = 2;
+            if (key < p.Lk) {
+                bool ok = key < klen;
+                if (p.keymask) ok = ok && p.keymask[(long long)b * p.Lk + key] != 0;
+                code = ok ? 1 : 0;
+            }
+            reinterpret_cast<unsigned char*>(Ms)[tid] = code;
+        }
+    };
+
+    f32x16 o_acc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
+    float m_run = CN_NEG_FILL, l_run = 0.f;
+
+    const int nkt = (p.Lk + 63) / 64;
+    load_tile(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();  // everyone is done reading the previous tile
+        store_tile(kt);
+        __syncthreads();
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        if (!wave_active) continue;
+
+        // ---- S^T[key][q] for the two 32-key sub-tiles
+        f32x16 sc[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[sub][r] = 0.f;
+            const int row = sub * 32 + l31;
+#pragma unroll
+            for (int s = 0; s < NF; ++s) {
+                const int chunk = 2 * s + half;
+                const frag_t kf = as_frag<T>(ld16(Ks + row * KROW + ((chunk ^ Cfg::swz(row)) << 4)));
+                sc[sub] = mfma_frag(kf, qf[s], sc[sub]);
+            }
+        }
+        // ---- scale + mask, running max
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned int mw = Ms[sub * 8 + 2 * g + half];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const int key = kt * 64 + sub * 32 + 8 * g + 4 * half + e;
+                    const unsigned int code = (mw >> (8 * e)) & 0xffu;
+                    bool ok = code == 1u;
+                    if (p.iv) ok = ok && ((key >= iv_s1 && key < iv_e1) || (key >= iv_s2 && key < iv_e2));
+                    if (p.causal) ok = ok && key <= q_row;
+                    float v = sc[sub][r] * p.scale;
+                    v = ok ? v : CN_NEG_FILL;
+                    v = code == 2u ? -INFINITY : v;
+                    sc[sub][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __expf(sc[sub][r] - m_new);
+                sc[sub][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+
+        // ---- O^T[dk][q] += V^T[dk][key] . P^T[key][q]
+        if constexpr (sizeof(T) == 2) {
+            const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 pb;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pb[j] = (bf16)sc[sub][8 * s + j];
+                    const int key0 = sub * 32 + 16 * s + 4 * half + (i16 >> 2);
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const unsigned char* a1 = Vs + key0 * VROW + (32 * d + 16 * g1 + 4 * (i16 & 3)) * 2;
+                        const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(a1));
+                        const s16x4 r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(a1 + 8 * VROW));
+                        typedef short s16x8 __attribute__((ext_vector_type(8)));
+                        s16x8 cat;
+                        cat[0] = r1[0]; cat[1] = r1[1]; cat[2] = r1[2]; cat[3] = r1[3];
+                        cat[4] = r2[0]; cat[5] = r2[1]; cat[6] = r2[2]; cat[7] = r2[3];
+                        const bf16x8 vf = __builtin_bit_cast(bf16x8, cat);
+                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o_acc[d], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key_local = sub * 32 + acc_row(r, lane);
+                    const float* vrow = reinterpret_cast<const float*>(Vs + key_local * VROW);
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * d + l31], sc[sub][r], o_acc[d], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    if (!wave_active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    if (q_row < p.Lq) {
+        T* orow = reinterpret_cast<T*>(p.O) + ((long long)b * p.Lq + q_row) * p.ldo + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dk0 = 32 * d + 8 * g + 4 * half;
+                if constexpr (sizeof(T) == 2) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(o_acc[d][4 * g + e] * inv);
+                    *reinterpret_cast<bf16x4*>(orow + dk0) = o;
+                } else {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = o_acc[d][4 * g + e] * inv;
+                    *reinterpret_cast<f32x4*>(orow + dk0) = o;
+                }
+            }
+        }
+    }
+}
+
+template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s) {
+    AttnParams p;
+    p.Q = (const unsigned char*)a.Q;
+    p.K = (const unsigned char*)a.K;
+    p.V = (const unsigned char*)a.V;
+    p.O = a.O;
+    p.ldq_b = (long long)a.ldq * sizeof(T);
+    p.ldk_b = (long long)a.ldk * sizeof(T);
+    p.ldv_b = (long long)a.ldv * sizeof(T);
+    p.ldo = a.ldo;
+    p.H = a.H;
+    p.Lq = a.Lq;
+    p.Lk = a.Lk;
+    p.keymask = a.keymask;
+    p.klen = a.klen;
+    p.iv = a.intervals;
+    p.iv_stride = a.iv_stride;
+    p.causal = a.causal;
+    p.scale = a.scale;
+    hipLaunchKernelGGL(attention_kernel<T>, dim3(cn_ceil_div(a.Lq, 128), a.H, a.B), dim3(256), 0, s, p);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_attention(int prec, const AttnArgs& a, hipStream_t s) {
+    if (a.B <= 0 || a.Lq <= 0 || a.Lk <= 0 || a.H <= 0) return 0;
+    const size_t es = cn_elem_size(prec);
+    if ((a.ldq * es) % 16 || (a.ldk * es) % 16 || (a.ldv * es) % 16 || (a.ldo * es) % 16) {
+        cn_set_error("attention: row strides must keep rows 16-byte aligned");
+        return -1;
+    }
+    return prec == CN_PREC_F32 ? run_attention<float>(a, s) : run_attention<bf16>(a, s);
+}

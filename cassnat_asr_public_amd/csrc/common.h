@@ -1,0 +1,88 @@
+// Shared device/host definitions for libcassnat_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define CN_WAVE 64
+#define CN_NEG_FILL (-3.4028234663852886e38f) /* float32 min: the reference's masked_fill value */
+
+// ----------------------------------------------------------------------------------------------
+// 16-byte fragment of the GEMM K dimension as one wave lane sees it.
+//   bf16: 8 consecutive k  -> one v_mfma_f32_32x32x16_bf16 (k = 8*(lane>>5) + j)
+//   f32 : 4 consecutive k  -> four v_mfma_f32_32x32x2_f32  (step e uses k = 4*(lane>>5) + e)
+// Both operands of a product use the same lane->k map, so the sum over k is complete; only the
+// order of the fp32 additions differs from a sequential loop.
+// ----------------------------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16> {
+    typedef bf16x8 type;
+    static constexpr int ELEMS = 8;
+};
+template <> struct Frag<float> {
+    typedef f32x4 type;
+    static constexpr int ELEMS = 4;
+};
+
+__device__ __forceinline__ f32x16 mfma_frag(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_frag(f32x4 a, f32x4 b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+}
+
+// Row of a 32x32 accumulator register: C/D layout of every 32x32 MFMA on gfx950.
+//   col = lane & 31,  row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+
+// 16-byte global load / LDS store helpers on raw bytes.
+__device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void st16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+
+template <typename T> __device__ __forceinline__ typename Frag<T>::type as_frag(uint4 v);
+template <> __device__ __forceinline__ bf16x8 as_frag<bf16>(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+template <> __device__ __forceinline__ f32x4 as_frag<float>(uint4 v) { return __builtin_bit_cast(f32x4, v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ----------------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------------
+#include <string>
+void cn_set_error(const std::string& msg);
+#define CN_HIP_CHECK(expr)                                                                        \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            cn_set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                         std::to_string(__LINE__) + ")");                                         \
+            return -2;                                                                            \
+        }                                                                                         \
+    } while (0)
+
+static inline int cn_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,79 @@
+// First subsampling convolution: Conv2d(1, C, 3, stride 2, pad 1) + ReLU on padded (B,T,F) fbank frames
+// (reference: src/models/modules/embedding.py:103,112-114).  HBM-bound: 9 MACs per output element, so
+// the kernel is shaped by its store: each lane produces 8 consecutive channels of one (b,t1,f1) position
+// and writes them with one 16-byte (bf16) / two 16-byte (f32) stores into the channels-last image
+// (B,T1,F1,C) that the implicit-GEMM second convolution reads; a wave covers two full 512-B/1-KiB rows.
+#include "kernels.h"
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
+                                                    const float* __restrict__ bias, T* __restrict__ out, int B, int Tn,
+                                                    int F, int T1, int F1, int C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* w_s = reinterpret_cast<float*>(smem);  // [9][C] then bias[C]
+    for (int i = threadIdx.x; i < 10 * C; i += 256) w_s[i] = i < 9 * C ? w9c[i] : bias[i - 9 * C];
+    __syncthreads();
+    const int cg = C >> 3;
+    const long long total = (long long)B * T1 * F1 * cg;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int g = (int)(idx % cg);
+        const long long pos = idx / cg;
+        const int f1 = (int)(pos % F1);
+        const long long bt = pos / F1;
+        const int t1 = (int)(bt % T1), b = (int)(bt / T1);
+        const int c0 = g << 3;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = w_s[9 * C + c0 + j];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int t = 2 * t1 - 1 + kh;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int f = 2 * f1 - 1 + kw;
+                float v = 0.f;
+                if (t >= 0 && t < Tn && f >= 0 && f < F) v = x[((long long)b * Tn + t) * F + f];
+                const float* wr = w_s + (kh * 3 + kw) * C + c0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+            }
+        }
+        T* dst = out + pos * C + c0;
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf(acc[j], 0.f);
+            *reinterpret_cast<bf16x8*>(dst) = o;
+        } else {
+            f32x4 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o0[j] = fmaxf(acc[j], 0.f);
+                o1[j] = fmaxf(acc[4 + j], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(dst) = o0;
+            *reinterpret_cast<f32x4*>(dst + 4) = o1;
+        }
+    }
+}
+
+int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1,
+                 int F1, int C, hipStream_t s) {
+    if (C % 8 != 0) {
+        cn_set_error("conv1: channel count must be a multiple of 8");
+        return -1;
+    }
+    const long long total = (long long)B * T1 * F1 * (C / 8);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond 64 workgroups per CU
+    if (blocks < 1) blocks = 1;
+    const size_t lds = 10 * (size_t)C * sizeof(float);
+    if (prec == CN_PREC_F32)
+        hipLaunchKernelGGL(conv1_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (float*)out, B, T,
+                           F, T1, F1, C);
+    else
+        hipLaunchKernelGGL(conv1_kernel<bf16>, dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (bf16*)out, B, T,
+                           F, T1, F1, C);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}

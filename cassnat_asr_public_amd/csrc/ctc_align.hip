@@ -1,0 +1,148 @@
+// CTC greedy alignment -> trigger intervals, and the greedy hypothesis pack.  Integer work, bit-exact.
+//
+// Reference: CassNAT.best_path_align (src/models/cassnat.py:378-389), align_to_mask (:355-365),
+// expand_trigger_mask (:259-270), "& src_mask" (:468).  The reference materialises a dense
+// (B, ymax+1, T') boolean mask; here each trigger row is kept as at most two frame intervals
+// (s1,e1,s2,e2) - the run of frames whose running token count equals u, and the forced
+// "src_size-1" frame of the EOS row - and the attention kernel ANDs them with the key mask.
+//
+// Exactness of the interval form: the dense row is {t : c[t]==u} & keymask, then (optionally) dilated
+// by one frame left/right, then & keymask again.  c is non-decreasing, so {t : c[t]==u} is a run;
+// taking the TIGHT bounds of (run & keymask) before dilating and re-masking afterwards gives the same
+// set for any mask (holes inside the run are removed by the final mask either way).
+#include "kernels.h"
+
+__global__ __launch_bounds__(256) void ctc_align_kernel(AlignArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* s_scan = reinterpret_cast<int*>(smem);  // [256]
+    int* s_carry = s_scan + 256;                 // [4] (padded)
+    int* s_lo = s_carry + 4;                     // [Tp+1] first valid frame of row u
+    int* s_hi = s_lo + (a.Tp + 1);               // [Tp+1] one past the last valid frame of row u
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Tp = a.Tp;
+    const int* best = a.best + (long long)b * Tp;
+    const unsigned char* km = a.keymask + (long long)b * Tp;
+    int* shift = a.shift + (long long)b * Tp;
+    int* iv = a.intervals + (long long)b * (Tp + 1) * 4;
+
+    // rows start empty: (INT_MAX, 0) is the identity of (min, max)
+    for (int u = tid; u <= Tp; u += 256) {
+        s_lo[u] = 0x7fffffff;
+        s_hi[u] = 0;
+    }
+    if (tid == 0) s_carry[0] = 0;
+    __syncthreads();
+
+    // path[t] = keymask ? argmax : 0 ; collapsed[t] = path[t]==path[t-1] ? 0 : path[t] (path[-1]=0)
+    // shift[t] = collapsed[t-1], shift[0] = 0 ; c[t] = #{t' <= t : shift[t'] != blank}
+    for (int base = 0; base < Tp; base += 256) {
+        const int t = base + tid;
+        int sh = 0;
+        if (t < Tp && t >= 1) {
+            const int p1 = km[t - 1] ? best[t - 1] : 0;
+            const int p2 = (t >= 2) ? (km[t - 2] ? best[t - 2] : 0) : 0;
+            sh = (p1 == p2) ? 0 : p1;
+        }
+        if (t < Tp) shift[t] = sh;
+        const int nz = (t < Tp && sh != a.blank) ? 1 : 0;
+        // inclusive block scan
+        s_scan[tid] = nz;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int v = tid >= o ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const int c = s_carry[0] + s_scan[tid];
+        if (t < Tp && km[t]) {
+            atomicMin(&s_lo[c], t);
+            atomicMax(&s_hi[c], t + 1);
+        }
+        __syncthreads();
+        if (tid == 255) s_carry[0] = c;
+        __syncthreads();
+    }
+    const int ylen0 = s_carry[0];  // number of non-blank entries of shift
+    // src_size = (ratio * T').long()  (src/models/cassnat.py:436): fp32 product, truncation toward zero
+    const int ssz = (int)(long long)(a.size_ratio[b] * (float)Tp);
+    if (tid == 0) {
+        a.src_size[b] = ssz;
+        a.ylen[b] = ylen0 + 1;
+        atomicMax(a.ymax, ylen0 + 1);
+    }
+    for (int u = tid; u <= Tp; u += 256) {
+        int s1 = s_lo[u], e1 = s_hi[u], s2 = 0, e2 = 0;
+        if (s1 == 0x7fffffff) {
+            s1 = 0;
+            e1 = 0;
+        } else {
+            if (a.left > 0) s1 = s1 > 0 ? s1 - 1 : 0;
+            if (a.right > 0) e1 = e1 < Tp ? e1 + 1 : Tp;
+        }
+        if (u == ylen0) {  // trigger_mask[b, ylens[b], src_size[b]-1] = 1, python negative index wraps
+            int f = ssz - 1;
+            if (f < 0) f += Tp;
+            if (f >= 0 && f < Tp) {
+                s2 = f;
+                e2 = f + 1;
+                if (a.left > 0) s2 = s2 > 0 ? s2 - 1 : 0;
+                if (a.right > 0) e2 = e2 < Tp ? e2 + 1 : Tp;
+            }
+        }
+        iv[4 * u + 0] = s1;
+        iv[4 * u + 1] = e1;
+        iv[4 * u + 2] = s2;
+        iv[4 * u + 3] = e2;
+    }
+}
+
+int launch_ctc_align(const AlignArgs& a, hipStream_t s) {
+    if (a.B <= 0 || a.Tp <= 0) return 0;
+    CN_HIP_CHECK(hipMemsetAsync(a.ymax, 0, sizeof(int), s));
+    const size_t lds = (256 + 4 + 2 * (size_t)(a.Tp + 1)) * sizeof(int);
+    if (lds > 160 * 1024) {
+        cn_set_error("ctc_align: T' too large for one workgroup's LDS");
+        return -1;
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)ctc_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(ctc_align_kernel, dim3(a.B), dim3(256), lds, s, a);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// beam_width == 1 case of src/models/cassnat.py:574-637: position i is consumed while i <= ylen[b]
+// (ylen already includes the EOS row), the score is a sequential double sum of the float32 maxima.
+__global__ void greedy_pack_kernel(const int* __restrict__ tok, const float* __restrict__ val,
+                                   const int* __restrict__ ylen, int B, int U, int sos, int hyp_stride,
+                                   int* __restrict__ hyp, int* __restrict__ hyp_len, double* __restrict__ score) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int n = ylen[b] + 1;
+    if (n > U) n = U;
+    if (n > hyp_stride - 1) n = hyp_stride - 1;
+    int* h = hyp + (long long)b * hyp_stride;
+    h[0] = sos;
+    double sc = 0.0;
+    for (int i = 0; i < n; ++i) {
+        h[1 + i] = tok[(long long)b * U + i];
+        sc = sc + (double)val[(long long)b * U + i];
+    }
+    for (int i = n + 1; i < hyp_stride; ++i) h[i] = 0;
+    hyp_len[b] = n + 1;
+    score[b] = sc;
+}
+
+int launch_greedy_pack(const int* tok, const float* val, const int* ylen, int B, int U, int sos, int hyp_stride,
+                       int* hyp, int* hyp_len, double* score, hipStream_t s) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(greedy_pack_kernel, dim3(cn_ceil_div(B, 64)), dim3(64), 0, s, tok, val, ylen, B, U, sos,
+                       hyp_stride, hyp, hyp_len, score);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}

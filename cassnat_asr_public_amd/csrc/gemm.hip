@@ -1,0 +1,243 @@
+// Tiled MFMA GEMM for gfx950:  C[M][N] = epi(A[M][K] . W[N][K]^T + bias).
+//
+// Replaces every nn.Linear on the hot path (reference: src/models/modules/attention.py:57-66,
+// positionff.py:15-16, embedding.py:118, cassnat.py:113) and, through the implicit-GEMM A loader,
+// the second subsampling convolution (embedding.py:104, Conv2d(d,d,3,2,1)).
+//
+// Structure: 256 threads = 4 waves in a 2x2 grid; each wave owns (BM/2)x(BN/2) of the tile as
+// 32x32 MFMA accumulators.  A and W slabs of 128 bytes of K per row (64 bf16 / 32 f32) are staged
+// global -> registers -> LDS (double buffered: the loads of slab k+1 are issued before the MFMAs of
+// slab k and written after them), 16 bytes per lane.  LDS rows are 128 B; chunk c of row r lives at
+// chunk c ^ ((r>>1)&7), which makes the ds_read_b128 fragment reads and the ds_write_b128 staging
+// writes bank-conflict free (MI355X LDS: 64 banks x 4 B, b128 reads serviced in 16-lane groups).
+#include "kernels.h"
+
+struct GemmParams {
+    const unsigned char* A;
+    const unsigned char* W;
+    const float* bias;
+    void* C;
+    const float* resid;
+    const float* pe;
+    long long lda_bytes;
+    int ldc, ldr;
+    int M, N, K;
+    int epi;
+    int pe_period;
+    float scale;
+    int ntn;  // tiles along N
+    int cT1, cF1, cC, cT2, cF2;
+};
+
+template <typename T, typename TC, int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+    constexpr int ROWB = 128;
+    constexpr int BK = ROWB / (int)sizeof(T);
+    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    constexpr int BUF = (BM + BN) * ROWB;
+    typedef typename Frag<T>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tile_m = blockIdx.x / p.ntn, tile_n = blockIdx.x % p.ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    const int st_off = lrow * ROWB + ((lchunk ^ ((lrow >> 1) & 7)) << 4);  // + 32*i rows keeps the swizzle
+
+    // ---- per-thread global sources
+    const unsigned char* a_src[A_IT];
+    const unsigned char* w_src[B_IT];
+    int cv_t[A_IT], cv_f[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        int m = m0 + lrow + 32 * i;
+        a_ok[i] = m < p.M;
+        if (m >= p.M) m = p.M - 1;
+        if (CONV) {
+            const int f2 = m % p.cF2;
+            const int bt = m / p.cF2;
+            const int t2 = bt % p.cT2, b = bt / p.cT2;
+            cv_t[i] = 2 * t2 - 1;
+            cv_f[i] = 2 * f2 - 1;
+            a_src[i] = p.A + ((long long)b * p.cT1 * p.cF1) * p.cC * (long long)sizeof(T) + lchunk * 16;
+        } else {
+            a_src[i] = p.A + (long long)m * p.lda_bytes + lchunk * 16;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        int n = n0 + lrow + 32 * i;
+        if (n >= p.N) n = p.N - 1;
+        w_src[i] = p.W + (long long)n * p.K * (long long)sizeof(T) + lchunk * 16;
+    }
+
+    uint4 a_reg[A_IT], w_reg[B_IT];
+    const int slabs_per_tap = CONV ? p.cC / BK : 1;
+
+    auto load_slab = [&](int kt) {
+        if (CONV) {
+            const int tap = kt / slabs_per_tap, c0 = (kt - tap * slabs_per_tap) * BK;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int t1 = cv_t[i] + kh, f1 = cv_f[i] + kw;
+                const bool ok = a_ok[i] && t1 >= 0 && t1 < p.cT1 && f1 >= 0 && f1 < p.cF1;
+                a_reg[i] = ok ? ld16(a_src[i] + ((long long)(t1 * p.cF1 + f1) * p.cC + c0) * (long long)sizeof(T))
+                              : make_uint4(0, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) a_reg[i] = ld16(a_src[i] + (long long)kt * ROWB);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) w_reg[i] = ld16(w_src[i] + (long long)kt * ROWB);
+    };
+    auto store_slab = [&](int buf) {
+        unsigned char* a_dst = smem + buf * BUF + st_off;
+        unsigned char* w_dst = a_dst + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) st16(a_dst + i * 32 * ROWB, a_reg[i]);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) st16(w_dst + i * 32 * ROWB, w_reg[i]);
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets (row part fixed per thread, chunk part per k-step)
+    const int a_row0 = wm * WM + l31, w_row0 = wn * WN + l31;
+
+    const int nk = p.K / BK;
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_slab(kt + 1);
+        const unsigned char* a_base = smem + cur * BUF;
+        const unsigned char* w_base = a_base + BM * ROWB;
+#pragma unroll
+        for (int cs = 0; cs < 4; ++cs) {
+            const int chunk = 2 * cs + half;
+            frag_t af[MI], wf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int r = a_row0 + 32 * i;
+                af[i] = as_frag<T>(ld16(a_base + r * ROWB + ((chunk ^ ((r >> 1) & 7)) << 4)));
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int r = w_row0 + 32 * j;
+                wf[j] = as_frag<T>(ld16(w_base + r * ROWB + ((chunk ^ ((r >> 1) & 7)) << 4)));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = mfma_frag(af[i], wf[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) store_slab(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns column n, 16 rows per 32x32 accumulator
+    TC* C = reinterpret_cast<TC*>(p.C);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WN + 32 * j + l31;
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + 32 * i + acc_row(r, lane);
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (p.epi & CN_EPI_RELU) v = fmaxf(v, 0.f);
+                if (p.epi & CN_EPI_EMBED) v = v * p.scale + p.pe[(long long)(m % p.pe_period) * p.N + n];
+                if (p.epi & CN_EPI_RESID) v = p.resid[(long long)m * p.ldr + n] + v;
+                C[(long long)m * p.ldc + n] = from_f32<TC>(v);
+            }
+        }
+    }
+}
+
+template <typename T, typename TC, int BM, int BN, bool CONV>
+static int run_gemm(const GemmArgs& a, hipStream_t s) {
+    constexpr int BK = 128 / (int)sizeof(T);
+    GemmParams p;
+    p.A = (const unsigned char*)a.A;
+    p.W = (const unsigned char*)a.W;
+    p.bias = a.bias;
+    p.C = a.C;
+    p.resid = a.resid;
+    p.pe = a.pe;
+    p.lda_bytes = (long long)a.lda * sizeof(T);
+    p.ldc = a.ldc;
+    p.ldr = a.ldr;
+    p.M = a.M;
+    p.N = a.N;
+    p.K = a.K;
+    p.epi = a.epi;
+    p.pe_period = a.pe_period > 0 ? a.pe_period : 1;
+    p.scale = a.scale;
+    p.ntn = cn_ceil_div(a.N, BN);
+    p.cT1 = a.cT1;
+    p.cF1 = a.cF1;
+    p.cC = a.cC;
+    p.cT2 = a.cT2;
+    p.cF2 = a.cF2;
+    const int ntm = cn_ceil_div(a.M, BM);
+    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    auto kern = gemm_kernel<T, TC, BM, BN, CONV>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    (void)BK;
+    hipLaunchKernelGGL(kern, dim3(ntm * p.ntn), dim3(256), lds, s, p);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <typename T> static int dispatch_gemm(const GemmArgs& a, hipStream_t s) {
+    constexpr int BK = 128 / (int)sizeof(T);
+    if (a.M <= 0 || a.N <= 0) return 0;
+    if (a.K <= 0 || a.K % BK != 0) {
+        cn_set_error("gemm: K=" + std::to_string(a.K) + " must be a positive multiple of " + std::to_string(BK));
+        return -1;
+    }
+    if (!a.conv && ((a.lda * sizeof(T)) % 16 != 0)) {
+        cn_set_error("gemm: lda must keep rows 16-byte aligned");
+        return -1;
+    }
+    if (a.conv) {
+        if (a.cC % BK != 0 || a.K != 9 * a.cC || a.M != a.cB * a.cT2 * a.cF2) {
+            cn_set_error("gemm(conv): inconsistent implicit-GEMM shape");
+            return -1;
+        }
+        return run_gemm<T, T, 128, 128, true>(a, s);
+    }
+    // Tile choice: 128x128 when that still yields >= 2 workgroups per CU, else 64x64 to fill 256 CUs.
+    const long long big = (long long)cn_ceil_div(a.M, 128) * cn_ceil_div(a.N, 128);
+    const bool use_big = big >= 512;
+    if (a.c_f32) {
+        return use_big ? run_gemm<T, float, 128, 128, false>(a, s) : run_gemm<T, float, 64, 64, false>(a, s);
+    }
+    return use_big ? run_gemm<T, T, 128, 128, false>(a, s) : run_gemm<T, T, 64, 64, false>(a, s);
+}
+
+int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
+    return prec == CN_PREC_F32 ? dispatch_gemm<float>(a, s) : dispatch_gemm<bf16>(a, s);
+}

@@ -1,0 +1,89 @@
+// Host-side launchers of the hand-written gfx950 kernels (one .hip file each).
+// Every launcher is stream-ordered, allocates nothing and returns 0 / negative error code.
+#pragma once
+#include "common.h"
+
+enum { CN_PREC_F32 = 0, CN_PREC_BF16 = 1 };
+static inline size_t cn_elem_size(int prec) { return prec == CN_PREC_F32 ? 4 : 2; }
+
+// ---- GEMM:  C[M][N] = epi( A[M][K] . W[N][K]^T + bias[N] )            (gemm.hip)
+enum { CN_EPI_RELU = 1, CN_EPI_RESID = 2, CN_EPI_EMBED = 4 };
+struct GemmArgs {
+    const void* A = nullptr;  // activations, model precision, row stride lda (elements)
+    int lda = 0;
+    const void* W = nullptr;  // weights [N][K], model precision, K contiguous
+    const float* bias = nullptr;
+    void* C = nullptr;  // output, row stride ldc; fp32 when c_f32 else model precision
+    int ldc = 0;
+    int c_f32 = 0;
+    int M = 0, N = 0, K = 0;
+    int epi = 0;
+    const float* resid = nullptr;  // CN_EPI_RESID: C = resid + (acc + bias); fp32 [M][ldr]; may alias C
+    int ldr = 0;
+    const float* pe = nullptr;  // CN_EPI_EMBED: C = (acc + bias) * scale + pe[m % pe_period][n]
+    int pe_period = 1;
+    float scale = 1.f;
+    // implicit-GEMM A operand for the second 3x3/stride-2 subsampling convolution:
+    // A[m=(b,t2,f2)][k=(kh,kw,c)] = conv1[b][2*t2+kh-1][2*f2+kw-1][c] (channels-last), zero outside.
+    int conv = 0;
+    int cB = 0, cT1 = 0, cF1 = 0, cC = 0, cT2 = 0, cF2 = 0;
+};
+int launch_gemm(int prec, const GemmArgs& a, hipStream_t s);
+
+// ---- first subsampling convolution, 1 -> C channels, 3x3 stride 2 pad 1, + ReLU   (conv1.hip)
+// x (B,T,F) fp32  ->  out (B,T1,F1,C) channels-last in model precision.  w is [9][C] (tap-major).
+int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1,
+                 int F1, int C, hipStream_t s);
+
+// ---- row kernels                                                                  (rowops.hip)
+// y = a_2 * (x - mean) / (std_unbiased + eps) + b_2 ; x fp32 [M][d] ; y model precision (or fp32 if y_f32)
+int launch_layernorm(int prec, const float* x, const float* a2, const float* b2, void* y, int y_f32, int M, int d,
+                     float eps, hipStream_t s);
+// per row of logits [M][V] (fp32): first-index argmax, max log-prob; optionally rewrites the row as log-softmax.
+int launch_logsoftmax_argmax(float* logits, int M, int V, int ldl, int* arg, float* maxlp, int write_logp,
+                             hipStream_t s);
+// keymask[b][j] = feats[b][stride*j][0] != padding  (mask[:, :, ::2][:, :, ::2] of the reference, stride 4)
+int launch_keymask(const float* feats, int B, int T, int F, int Tp, int stride, float padding, unsigned char* km,
+                   hipStream_t s);
+// out[b][u][:] = table[u][:]  (extractor queries), optional shift for use_unimask handled by caller
+int launch_fill_queries(const float* table, float* out, int B, int U, int d, hipStream_t s);
+// use_unimask: y[b][0] = 0 ; y[b][u] = x[b][u-1]
+int launch_shift_right(const float* x, float* y, int B, int U, int d, hipStream_t s);
+int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t s);       // fp32 -> model precision
+int launch_convert_back(int prec, const void* src, float* dst, size_t n, hipStream_t s);  // model precision -> fp32
+
+// ---- fused multi-head attention (flash-style, d_k = 64)                           (attention.hip)
+struct AttnArgs {
+    const void* Q = nullptr;  // [B*Lq][ldq], head h at column h*64
+    const void* K = nullptr;  // [B*Lk][ldk]
+    const void* V = nullptr;  // [B*Lk][ldv]
+    void* O = nullptr;        // [B*Lq][ldo] model precision
+    int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
+    int B = 0, H = 0, Lq = 0, Lk = 0;
+    const unsigned char* keymask = nullptr;  // [B][Lk] or null (all valid)
+    const int* klen = nullptr;               // [B] or null: key j valid iff j < klen[b]
+    const int* intervals = nullptr;          // [B][iv_stride][4] (s1,e1,s2,e2) per query row, or null
+    int iv_stride = 0;
+    int causal = 0;  // key j allowed only if j <= i
+    float scale = 0.125f;
+};
+int launch_attention(int prec, const AttnArgs& a, hipStream_t s);
+
+// ---- CTC greedy alignment -> trigger intervals (integer, exact)                   (ctc_align.hip)
+struct AlignArgs {
+    const int* best = nullptr;               // [B][Tp] argmax of the CTC posteriors
+    const unsigned char* keymask = nullptr;  // [B][Tp]
+    const float* size_ratio = nullptr;       // [B] fp32 length ratios
+    int B = 0, Tp = 0, blank = 0, left = 0, right = 0;
+    int* shift = nullptr;      // [B][Tp]  aligned_seq_shift
+    int* src_size = nullptr;   // [B]
+    int* ylen = nullptr;       // [B]   (token count + 1)
+    int* ymax = nullptr;       // [1]   max ylen
+    int* intervals = nullptr;  // [B][Tp+1][4]
+};
+int launch_ctc_align(const AlignArgs& a, hipStream_t s);
+// hyp[b] = [sos] + tok[b][0 .. min(ylen[b]+1, U)) ; score = sequential double sum of val
+int launch_greedy_pack(const int* tok, const float* val, const int* ylen, int B, int U, int sos, int hyp_stride,
+                       int* hyp, int* hyp_len, double* score, hipStream_t s);
+// per row top-k (k <= 16) of log-probs [M][V] -> idx/val [M][k], sorted descending (ties: lower index first)
+int launch_topk(const float* logp, int M, int V, int ldl, int k, int* idx, float* val, hipStream_t s);

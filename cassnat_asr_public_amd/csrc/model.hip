@@ -1,0 +1,976 @@
+// C-ABI of libcassnat_hip.so: model handle, weight packing, workspace and the stream-ordered decode
+// pipeline that replaces CassNAT.beam_decode (reference: src/models/cassnat.py:420-637) for the greedy
+// NAST configuration.  See include/cassnat_hip.h for the contract.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cassnat_hip.h"
+#include "kernels.h"
+
+static thread_local std::string g_last_error;
+void cn_set_error(const std::string& msg) { g_last_error = msg; }
+extern "C" const char* cn_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* cn_version(void) { return "cassnat_hip 0.1 (gfx950)"; }
+
+#define CN_TRY(expr)                \
+    do {                            \
+        int _rc = (expr);           \
+        if (_rc != 0) return _rc;   \
+    } while (0)
+
+namespace {
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+struct Linear {
+    void* W = nullptr;  // [N][K] model precision
+    float* b = nullptr;
+    int N = 0, K = 0;
+};
+struct Norm {
+    float* a = nullptr;
+    float* b = nullptr;
+};
+struct Layer {
+    Norm n[3];
+    Linear qkv;       // self-attention: fused Q|K|V projection
+    Linear self_o;
+    Linear src_q, src_kv, src_o;  // source attention: Q from the stream, K|V from the encoder memory
+    Linear w1, w2;
+    bool has_self = false, has_src = false;
+};
+
+struct Capture {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int dtype = CN_DTYPE_F32;
+    std::vector<int64_t> shape;
+};
+
+inline uint16_t f32_to_bf16_host(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+}  // namespace
+
+struct cn_model {
+    cn_config cfg;
+    int prec = 0;
+    size_t es = 4;
+    std::map<std::string, HostTensor> host;
+    std::vector<float> pe_host;
+    int pe_rows = 0;
+    bool finalized = false;
+
+    unsigned char* blob = nullptr;
+    size_t blob_bytes = 0;
+
+    // weight views into the blob
+    float* conv1_w = nullptr;  // [9][C]
+    float* conv1_b = nullptr;
+    Linear conv2;       // [C][9C] (kh,kw,cin)
+    Linear linear_out;  // [d][F2*C] (f,c)
+    std::vector<Layer> enc, extra, sad, mad;
+    Norm enc_norm, dec_norm;
+    Linear ctc_gen, att_gen;
+    float* pe = nullptr;  // [pe_rows][d]
+
+    // geometry of the workspace
+    int maxB = 0, maxT = 0, maxT1 = 0, maxTp = 0, F1 = 0, F2 = 0;
+    std::vector<void*> allocs;
+    unsigned char* keymask = nullptr;
+    void *c1 = nullptr, *c2 = nullptr;
+    float* x = nullptr;
+    void *xn = nullptr, *qkv = nullptr, *ctx = nullptr, *hbuf = nullptr, *enc_h = nullptr, *kvm = nullptr, *qd = nullptr,
+         *dec_h = nullptr;
+    float *xd = nullptr, *xd2 = nullptr, *logits = nullptr, *scratch_f32 = nullptr;
+    size_t scratch_elems = 0;
+    int *best = nullptr, *shift = nullptr, *src_size = nullptr, *ylen = nullptr, *ymax = nullptr, *intervals = nullptr,
+        *tok = nullptr, *topk_idx = nullptr;
+    float *ctc_maxlp = nullptr, *val = nullptr, *topk_val = nullptr;
+
+    // last call
+    int B = 0, T = 0, T1 = 0, Tp = 0, U = 0, last_k = 0;
+    std::map<std::string, Capture> captures;
+};
+
+namespace {
+
+int dev_alloc(cn_model* m, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    CN_HIP_CHECK(hipMalloc(p, bytes));
+    m->allocs.push_back(*p);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+struct Packer {
+    cn_model* m;
+    bool fill;                        // false: layout only (weights arrive by broadcast)
+    std::vector<unsigned char> host;  // staging image of the blob
+    size_t off = 256;  // offset 0 is reserved so that a null view means "not present"
+    std::string missing;
+
+    size_t reserve(size_t bytes) {
+        const size_t at = off;
+        off = (off + bytes + 255) & ~(size_t)255;
+        if (fill && host.size() < off) host.resize(off);
+        return at;
+    }
+    const HostTensor* find(const std::string& name, std::initializer_list<int64_t> shape) {
+        auto it = m->host.find(name);
+        if (it == m->host.end()) {
+            it = m->host.find("module." + name);
+            if (it == m->host.end()) {
+                if (missing.size() < 400) missing += name + " ";
+                return nullptr;
+            }
+        }
+        if (it->second.shape != std::vector<int64_t>(shape)) {
+            missing += name + "(shape) ";
+            return nullptr;
+        }
+        return &it->second;
+    }
+    void put_elem(size_t at, size_t idx, float v) {
+        if (m->prec == CN_PREC_F32)
+            std::memcpy(&host[at + idx * 4], &v, 4);
+        else {
+            const uint16_t h = f32_to_bf16_host(v);
+            std::memcpy(&host[at + idx * 2], &h, 2);
+        }
+    }
+    // fp32 vector made by concatenating several named vectors
+    float* vec(std::initializer_list<std::string> names, int64_t each) {
+        const size_t at = reserve(names.size() * each * 4);
+        if (fill) {
+            size_t k = 0;
+            for (auto& n : names) {
+                const HostTensor* t = find(n, {each});
+                if (t) std::memcpy(&host[at + k * each * 4], t->data.data(), each * 4);
+                ++k;
+            }
+        }
+        return reinterpret_cast<float*>(at);
+    }
+    // [sum rows][K] matrix in model precision from several [rows][K] matrices, optional column permutation
+    Linear linear(std::initializer_list<std::string> prefixes, int64_t rows_each, int64_t K,
+                  const std::vector<int>* colperm = nullptr) {
+        Linear l;
+        l.N = (int)(prefixes.size() * rows_each);
+        l.K = (int)K;
+        const size_t at = reserve((size_t)l.N * K * m->es);
+        if (fill) {
+            size_t r0 = 0;
+            for (auto& pfx : prefixes) {
+                const HostTensor* t = find(pfx + ".weight", {rows_each, K});
+                if (t) {
+                    for (int64_t r = 0; r < rows_each; ++r)
+                        for (int64_t c = 0; c < K; ++c) {
+                            const int64_t src_c = colperm ? (*colperm)[c] : c;
+                            put_elem(at, (r0 + r) * K + c, t->data[r * K + src_c]);
+                        }
+                }
+                r0 += rows_each;
+            }
+        }
+        l.W = reinterpret_cast<void*>(at);
+        size_t bat = reserve((size_t)l.N * 4);
+        if (fill) {
+            size_t k = 0;
+            for (auto& pfx : prefixes) {
+                const HostTensor* t = find(pfx + ".bias", {rows_each});
+                if (t) std::memcpy(&host[bat + k * rows_each * 4], t->data.data(), rows_each * 4);
+                ++k;
+            }
+        }
+        l.b = reinterpret_cast<float*>(bat);
+        return l;
+    }
+    Norm norm(const std::string& prefix, int64_t d) {
+        Norm n;
+        n.a = vec({prefix + ".a_2"}, d);
+        n.b = vec({prefix + ".b_2"}, d);
+        return n;
+    }
+};
+
+template <typename P> void rebase(P*& p, unsigned char* base) {
+    if (p) p = reinterpret_cast<P*>(base + reinterpret_cast<size_t>(p));
+}
+void rebase_linear(Linear& l, unsigned char* base) {
+    rebase(l.W, base);
+    rebase(l.b, base);
+}
+void rebase_norm(Norm& n, unsigned char* base) {
+    rebase(n.a, base);
+    rebase(n.b, base);
+}
+
+int build_weights(cn_model* m) {
+    const cn_config& c = m->cfg;
+    const int64_t d = c.d_model, V = c.vocab_size, C = c.d_model;
+    Packer pk;
+    pk.m = m;
+    pk.fill = !m->host.empty();
+    const int64_t F2 = m->F2;
+
+    // conv1: (C,1,3,3) -> [tap][C] fp32
+    {
+        const size_t at = pk.reserve(9 * C * 4);
+        if (pk.fill) {
+            const HostTensor* t = pk.find("src_embed.conv.0.weight", {C, 1, 3, 3});
+            if (t)
+                for (int64_t ch = 0; ch < C; ++ch)
+                    for (int tap = 0; tap < 9; ++tap)
+                        std::memcpy(&pk.host[at + (tap * C + ch) * 4], &t->data[ch * 9 + tap], 4);
+        }
+        m->conv1_w = reinterpret_cast<float*>(at);
+        m->conv1_b = pk.vec({"src_embed.conv.0.bias"}, C);
+    }
+    // conv2: (Co,Ci,3,3) -> [Co][(kh,kw,ci)]
+    {
+        m->conv2.N = (int)C;
+        m->conv2.K = (int)(9 * C);
+        const size_t at = pk.reserve((size_t)C * 9 * C * m->es);
+        if (pk.fill) {
+            const HostTensor* t = pk.find("src_embed.conv.2.weight", {C, C, 3, 3});
+            if (t)
+                for (int64_t co = 0; co < C; ++co)
+                    for (int64_t ci = 0; ci < C; ++ci)
+                        for (int tap = 0; tap < 9; ++tap)
+                            pk.put_elem(at, co * 9 * C + tap * C + ci, t->data[(co * C + ci) * 9 + tap]);
+        }
+        m->conv2.W = reinterpret_cast<void*>(at);
+        m->conv2.b = pk.vec({"src_embed.conv.2.bias"}, C);
+    }
+    // linear_out: column c*F2+f of the reference (embedding.py:118) -> column f*C+c (the conv2 GEMM's natural output)
+    {
+        std::vector<int> perm((size_t)(C * F2));
+        for (int64_t f = 0; f < F2; ++f)
+            for (int64_t ch = 0; ch < C; ++ch) perm[(size_t)(f * C + ch)] = (int)(ch * F2 + f);
+        m->linear_out = pk.linear({"src_embed.linear_out"}, d, C * F2, &perm);
+    }
+    auto self_layer = [&](const std::string& p, const std::string& att, int64_t dff, int nnorm) {
+        Layer L;
+        L.has_self = true;
+        L.qkv = pk.linear({p + "." + att + ".linears.0", p + "." + att + ".linears.1", p + "." + att + ".linears.2"}, d, d);
+        L.self_o = pk.linear({p + "." + att + ".linears.3"}, d, d);
+        L.w1 = pk.linear({p + ".feed_forward.w_1"}, dff, d);
+        L.w2 = pk.linear({p + ".feed_forward.w_2"}, d, dff);
+        for (int i = 0; i < nnorm; ++i) L.n[i] = pk.norm(p + ".sublayer." + std::to_string(i) + ".norm", d);
+        return L;
+    };
+    auto add_src = [&](Layer& L, const std::string& p) {
+        L.has_src = true;
+        L.src_q = pk.linear({p + ".src_attn.linears.0"}, d, d);
+        L.src_kv = pk.linear({p + ".src_attn.linears.1", p + ".src_attn.linears.2"}, d, d);
+        L.src_o = pk.linear({p + ".src_attn.linears.3"}, d, d);
+    };
+    m->enc.clear();
+    m->extra.clear();
+    m->sad.clear();
+    m->mad.clear();
+    for (int n = 0; n < c.n_enc; ++n) m->enc.push_back(self_layer("encoder.layers." + std::to_string(n), "self_attn", c.d_encff, 2));
+    m->enc_norm = pk.norm("encoder.norm", d);
+    for (int n = 0; n < c.n_extra; ++n) {
+        const std::string p = "acembed_extractor.layers." + std::to_string(n);
+        Layer L;
+        add_src(L, p);
+        L.w1 = pk.linear({p + ".feed_forward.w_1"}, c.d_decff, d);
+        L.w2 = pk.linear({p + ".feed_forward.w_2"}, d, c.d_decff);
+        L.n[0] = pk.norm(p + ".sublayer.0.norm", d);
+        L.n[1] = pk.norm(p + ".sublayer.1.norm", d);
+        m->extra.push_back(L);
+    }
+    for (int n = 0; n < c.n_self_dec; ++n)
+        m->sad.push_back(self_layer("embed_mapper.layers." + std::to_string(n), "self_attn", c.d_decff, 2));
+    for (int n = 0; n < c.n_mix_dec; ++n) {
+        const std::string p = "decoder.layers." + std::to_string(n);
+        Layer L = self_layer(p, "self_attn", c.d_decff, 3);
+        add_src(L, p);
+        m->mad.push_back(L);
+    }
+    m->dec_norm = pk.norm("decoder.norm", d);
+    m->ctc_gen = pk.linear({"ctc_generator.proj"}, V, d);
+    m->att_gen = pk.linear({"att_generator.proj"}, V, d);
+    {
+        const size_t at = pk.reserve((size_t)m->pe_rows * d * 4);
+        if (pk.fill) std::memcpy(&pk.host[at], m->pe_host.data(), (size_t)m->pe_rows * d * 4);
+        m->pe = reinterpret_cast<float*>(at);
+    }
+    if (!pk.missing.empty()) {
+        cn_set_error("cn_model_finalize: missing or mis-shaped parameters: " + pk.missing);
+        return -1;
+    }
+    if (m->blob && m->blob_bytes != pk.off) {
+        (void)hipFree(m->blob);
+        m->blob = nullptr;
+    }
+    if (!m->blob) CN_HIP_CHECK(hipMalloc((void**)&m->blob, pk.off));
+    m->blob_bytes = pk.off;
+    if (pk.fill) CN_HIP_CHECK(hipMemcpy(m->blob, pk.host.data(), pk.off, hipMemcpyHostToDevice));
+
+    unsigned char* base = m->blob;
+    rebase(m->conv1_w, base);
+    rebase(m->conv1_b, base);
+    rebase_linear(m->conv2, base);
+    rebase_linear(m->linear_out, base);
+    auto rebase_layers = [&](std::vector<Layer>& v) {
+        for (auto& L : v) {
+            for (int i = 0; i < 3; ++i) rebase_norm(L.n[i], base);
+            rebase_linear(L.qkv, base);
+            rebase_linear(L.self_o, base);
+            rebase_linear(L.src_q, base);
+            rebase_linear(L.src_kv, base);
+            rebase_linear(L.src_o, base);
+            rebase_linear(L.w1, base);
+            rebase_linear(L.w2, base);
+        }
+    };
+    rebase_layers(m->enc);
+    rebase_layers(m->extra);
+    rebase_layers(m->sad);
+    rebase_layers(m->mad);
+    rebase_norm(m->enc_norm, base);
+    rebase_norm(m->dec_norm, base);
+    rebase_linear(m->ctc_gen, base);
+    rebase_linear(m->att_gen, base);
+    rebase(m->pe, base);
+    return 0;
+}
+
+int build_workspace(cn_model* m) {
+    if (m->keymask) return 0;
+    const cn_config& c = m->cfg;
+    const size_t es = m->es;
+    const size_t B = m->maxB, T1 = m->maxT1, Tp = m->maxTp, F1 = m->F1, F2 = m->F2, d = c.d_model, V = c.vocab_size;
+    const size_t M = B * (Tp + 1);  // decoder rows can reach B*(T'+1)
+    const size_t dff = std::max(c.d_encff, c.d_decff);
+    CN_TRY(dev_alloc(m, (void**)&m->keymask, B * Tp));
+    CN_TRY(dev_alloc(m, &m->c1, B * T1 * F1 * d * es));
+    CN_TRY(dev_alloc(m, &m->c2, B * Tp * F2 * d * es));
+    CN_TRY(dev_alloc(m, (void**)&m->x, M * d * 4));
+    CN_TRY(dev_alloc(m, &m->xn, M * d * es));
+    CN_TRY(dev_alloc(m, &m->qkv, M * 3 * d * es));
+    CN_TRY(dev_alloc(m, &m->ctx, M * d * es));
+    CN_TRY(dev_alloc(m, &m->hbuf, M * dff * es));
+    CN_TRY(dev_alloc(m, &m->enc_h, M * d * es));
+    CN_TRY(dev_alloc(m, &m->kvm, M * 2 * d * es));
+    CN_TRY(dev_alloc(m, &m->qd, M * d * es));
+    CN_TRY(dev_alloc(m, &m->dec_h, M * d * es));
+    CN_TRY(dev_alloc(m, (void**)&m->xd, M * d * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->xd2, M * d * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->logits, M * V * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->best, M * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->ctc_maxlp, M * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->shift, M * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->src_size, B * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->ylen, B * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->ymax, 256));
+    CN_TRY(dev_alloc(m, (void**)&m->intervals, B * (Tp + 1) * 16));
+    CN_TRY(dev_alloc(m, (void**)&m->tok, M * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->val, M * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->topk_idx, M * 16 * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->topk_val, M * 16 * 4));
+    return 0;
+}
+
+int capture(cn_model* m, const char* name, const void* src, bool model_prec, int dtype, std::vector<int64_t> shape,
+            hipStream_t s) {
+    size_t n = 1;
+    for (auto v : shape) n *= (size_t)v;
+    const size_t esz = dtype == CN_DTYPE_U8 ? 1 : (dtype == CN_DTYPE_F64 ? 8 : 4);
+    Capture& cp = m->captures[name];
+    if (cp.bytes < n * esz) {
+        if (cp.p) (void)hipFree(cp.p);
+        CN_HIP_CHECK(hipMalloc(&cp.p, n * esz));
+        cp.bytes = n * esz;
+    }
+    cp.dtype = dtype;
+    cp.shape = shape;
+    if (model_prec)
+        CN_TRY(launch_convert_back(m->prec, src, (float*)cp.p, n, s));
+    else
+        CN_HIP_CHECK(hipMemcpyAsync(cp.p, src, n * esz, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// building blocks of the pipeline
+// ---------------------------------------------------------------------------------------------
+int run_linear(cn_model* m, const Linear& l, const void* A, int lda, void* C, int ldc, int c_f32, int M, int epi,
+               const float* resid, int ldr, hipStream_t s) {
+    GemmArgs g;
+    g.A = A;
+    g.lda = lda;
+    g.W = l.W;
+    g.bias = l.b;
+    g.C = C;
+    g.ldc = ldc;
+    g.c_f32 = c_f32;
+    g.M = M;
+    g.N = l.N;
+    g.K = l.K;
+    g.epi = epi;
+    g.resid = resid;
+    g.ldr = ldr;
+    return launch_gemm(m->prec, g, s);
+}
+
+int run_ln(cn_model* m, const Norm& n, const float* x, void* y, int M, hipStream_t s) {
+    return launch_layernorm(m->prec, x, n.a, n.b, y, 0, M, m->cfg.d_model, 1e-6f, s);
+}
+
+// x += FFN(LN(x))                      (SublayerConnection + PositionwiseFeedForward)
+int run_ffn(cn_model* m, const Layer& L, const Norm& n, float* x, int M, hipStream_t s) {
+    const int d = m->cfg.d_model;
+    CN_TRY(run_ln(m, n, x, m->xn, M, s));
+    CN_TRY(run_linear(m, L.w1, m->xn, d, m->hbuf, L.w1.N, 0, M, CN_EPI_RELU, nullptr, 0, s));
+    CN_TRY(run_linear(m, L.w2, m->hbuf, L.w1.N, x, d, 1, M, CN_EPI_RESID, x, d, s));
+    return 0;
+}
+
+// x += O(Attn(LN(x) Wq, LN(x) Wk, LN(x) Wv))
+int run_self_attn(cn_model* m, const Layer& L, const Norm& n, float* x, int B, int Lseq, const unsigned char* keymask,
+                  const int* klen, int causal, hipStream_t s) {
+    const int d = m->cfg.d_model, M = B * Lseq;
+    CN_TRY(run_ln(m, n, x, m->xn, M, s));
+    CN_TRY(run_linear(m, L.qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
+    AttnArgs a;
+    const size_t es = m->es;
+    a.Q = m->qkv;
+    a.K = (const unsigned char*)m->qkv + (size_t)d * es;
+    a.V = (const unsigned char*)m->qkv + (size_t)2 * d * es;
+    a.O = m->ctx;
+    a.ldq = a.ldk = a.ldv = 3 * d;
+    a.ldo = d;
+    a.B = B;
+    a.H = m->cfg.n_head;
+    a.Lq = a.Lk = Lseq;
+    a.keymask = keymask;
+    a.klen = klen;
+    a.causal = causal;
+    a.scale = 1.0f / sqrtf((float)(d / m->cfg.n_head));
+    CN_TRY(launch_attention(m->prec, a, s));
+    CN_TRY(run_linear(m, L.self_o, m->ctx, d, x, d, 1, M, CN_EPI_RESID, x, d, s));
+    return 0;
+}
+
+// x += O(Attn(LN(x) Wq, mem Wk, mem Wv)) with the padding mask and (optionally) trigger intervals
+int run_src_attn(cn_model* m, const Layer& L, const Norm& n, float* x, int B, int U, int Tp, const int* intervals,
+                 hipStream_t s) {
+    const int d = m->cfg.d_model;
+    CN_TRY(run_ln(m, n, x, m->xn, B * U, s));
+    CN_TRY(run_linear(m, L.src_q, m->xn, d, m->qd, d, 0, B * U, 0, nullptr, 0, s));
+    CN_TRY(run_linear(m, L.src_kv, m->enc_h, d, m->kvm, 2 * d, 0, B * Tp, 0, nullptr, 0, s));
+    AttnArgs a;
+    a.Q = m->qd;
+    a.K = m->kvm;
+    a.V = (const unsigned char*)m->kvm + (size_t)d * m->es;
+    a.O = m->ctx;
+    a.ldq = d;
+    a.ldk = a.ldv = 2 * d;
+    a.ldo = d;
+    a.B = B;
+    a.H = m->cfg.n_head;
+    a.Lq = U;
+    a.Lk = Tp;
+    a.keymask = m->keymask;
+    a.intervals = intervals;
+    a.iv_stride = Tp + 1;
+    a.scale = 1.0f / sqrtf((float)(d / m->cfg.n_head));
+    CN_TRY(launch_attention(m->prec, a, s));
+    CN_TRY(run_linear(m, L.src_o, m->ctx, d, x, d, 1, B * U, CN_EPI_RESID, x, d, s));
+    return 0;
+}
+
+int check_call(cn_model* m, int B, int T, int F) {
+    if (!m || !m->finalized) {
+        cn_set_error("model not finalized");
+        return -1;
+    }
+    if (F != m->cfg.input_size || B < 1 || B > m->maxB || T < 1 || T > m->maxT) {
+        cn_set_error("decode: batch/frames/feature dims outside the configured workspace (B=" + std::to_string(B) +
+                     " T=" + std::to_string(T) + " F=" + std::to_string(F) + ")");
+        return -1;
+    }
+    return 0;
+}
+
+// src_embed + encoder + ctc_generator + best_path_align + align_to_mask  (cassnat.py:431-468)
+int stage_encode_align(cn_model* m, const float* feats, const float* ratio, int B, int T, int F,
+                       const cn_decode_opts* o, hipStream_t s) {
+    const cn_config& c = m->cfg;
+    const int d = c.d_model;
+    const int T1 = (T - 1) / 2 + 1, Tp = (T1 - 1) / 2 + 1, F1 = m->F1, F2 = m->F2;
+    const int M = B * Tp;
+    const bool cap = o->capture != 0;
+    m->B = B;
+    m->T = T;
+    m->T1 = T1;
+    m->Tp = Tp;
+    m->U = 0;
+    CN_TRY(launch_keymask(feats, B, T, F, Tp, 4, (float)o->padding_idx, m->keymask, s));
+    CN_TRY(launch_conv1(m->prec, feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, s));
+    if (cap) CN_TRY(capture(m, "conv1", m->c1, true, CN_DTYPE_F32, {B, T1, F1, d}, s));
+    {
+        GemmArgs g;
+        g.A = m->c1;
+        g.W = m->conv2.W;
+        g.bias = m->conv2.b;
+        g.C = m->c2;
+        g.ldc = d;
+        g.M = M * F2;
+        g.N = d;
+        g.K = 9 * d;
+        g.epi = CN_EPI_RELU;
+        g.conv = 1;
+        g.cB = B;
+        g.cT1 = T1;
+        g.cF1 = F1;
+        g.cC = d;
+        g.cT2 = Tp;
+        g.cF2 = F2;
+        CN_TRY(launch_gemm(m->prec, g, s));
+    }
+    if (cap) CN_TRY(capture(m, "conv2", m->c2, true, CN_DTYPE_F32, {B, Tp, F2, d}, s));
+    {
+        GemmArgs g;
+        g.A = m->c2;
+        g.lda = F2 * d;
+        g.W = m->linear_out.W;
+        g.bias = m->linear_out.b;
+        g.C = m->x;
+        g.ldc = d;
+        g.c_f32 = 1;
+        g.M = M;
+        g.N = d;
+        g.K = F2 * d;
+        g.epi = CN_EPI_EMBED;
+        g.pe = m->pe;
+        g.pe_period = Tp;
+        g.scale = sqrtf((float)d);
+        CN_TRY(launch_gemm(m->prec, g, s));
+    }
+    if (cap) CN_TRY(capture(m, "x_embed", m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
+    for (size_t n = 0; n < m->enc.size(); ++n) {
+        const Layer& L = m->enc[n];
+        CN_TRY(run_self_attn(m, L, L.n[0], m->x, B, Tp, m->keymask, nullptr, 0, s));
+        CN_TRY(run_ffn(m, L, L.n[1], m->x, M, s));
+        if (cap) CN_TRY(capture(m, ("enc_layer" + std::to_string(n)).c_str(), m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
+    }
+    CN_TRY(run_ln(m, m->enc_norm, m->x, m->enc_h, M, s));
+    if (cap) CN_TRY(capture(m, "enc_h", m->enc_h, true, CN_DTYPE_F32, {B, Tp, d}, s));
+    CN_TRY(run_linear(m, m->ctc_gen, m->enc_h, d, m->logits, c.vocab_size, 1, M, 0, nullptr, 0, s));
+    CN_TRY(launch_logsoftmax_argmax(m->logits, M, c.vocab_size, c.vocab_size, m->best, m->ctc_maxlp, cap ? 1 : 0, s));
+    if (cap) CN_TRY(capture(m, "ctc_out", m->logits, false, CN_DTYPE_F32, {B, Tp, c.vocab_size}, s));
+    AlignArgs al;
+    al.best = m->best;
+    al.keymask = m->keymask;
+    al.size_ratio = ratio;
+    al.B = B;
+    al.Tp = Tp;
+    al.blank = o->padding_idx;
+    al.left = o->left_trigger;
+    al.right = o->right_trigger;
+    al.shift = m->shift;
+    al.src_size = m->src_size;
+    al.ylen = m->ylen;
+    al.ymax = m->ymax;
+    al.intervals = m->intervals;
+    CN_TRY(launch_ctc_align(al, s));
+    return 0;
+}
+
+// acembed_extractor + embed_mapper + decoder + att_generator + greedy finish  (cassnat.py:475-497, 574-637)
+int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int hyp_stride, int32_t* hyp_len,
+                 double* score, hipStream_t s) {
+    const cn_config& c = m->cfg;
+    const int d = c.d_model, B = m->B, Tp = m->Tp, MU = B * U;
+    const bool cap = o->capture != 0;
+    m->U = U;
+    if (U > m->pe_rows) {
+        cn_set_error("decode: token count exceeds the positional table");
+        return -1;
+    }
+    CN_TRY(launch_fill_queries(m->pe, m->xd, B, U, d, s));
+    for (auto& L : m->extra) {
+        CN_TRY(run_src_attn(m, L, L.n[0], m->xd, B, U, Tp, m->intervals, s));
+        CN_TRY(run_ffn(m, L, L.n[1], m->xd, MU, s));
+    }
+    if (cap) CN_TRY(capture(m, "ac_embed", m->xd, false, CN_DTYPE_F32, {B, U, d}, s));
+    for (auto& L : m->sad) {
+        CN_TRY(run_self_attn(m, L, L.n[0], m->xd, B, U, nullptr, m->ylen, 0, s));
+        CN_TRY(run_ffn(m, L, L.n[1], m->xd, MU, s));
+    }
+    if (cap) CN_TRY(capture(m, "pred_embed", m->xd, false, CN_DTYPE_F32, {B, U, d}, s));
+    float* xdec = m->xd;
+    if (o->use_unimask) {
+        CN_TRY(launch_shift_right(m->xd, m->xd2, B, U, d, s));
+        xdec = m->xd2;
+    }
+    for (auto& L : m->mad) {
+        CN_TRY(run_self_attn(m, L, L.n[0], xdec, B, U, nullptr, m->ylen, o->use_unimask ? 1 : 0, s));
+        CN_TRY(run_src_attn(m, L, L.n[1], xdec, B, U, Tp, o->src_trigger ? m->intervals : nullptr, s));
+        CN_TRY(run_ffn(m, L, L.n[2], xdec, MU, s));
+    }
+    CN_TRY(run_ln(m, m->dec_norm, xdec, m->dec_h, MU, s));
+    if (cap) CN_TRY(capture(m, "dec_h", m->dec_h, true, CN_DTYPE_F32, {B, U, d}, s));
+    CN_TRY(run_linear(m, m->att_gen, m->dec_h, d, m->logits, c.vocab_size, 1, MU, 0, nullptr, 0, s));
+    const int k = o->beam_width;
+    const int want_logp = (cap || k > 1) ? 1 : 0;
+    CN_TRY(launch_logsoftmax_argmax(m->logits, MU, c.vocab_size, c.vocab_size, m->tok, m->val, want_logp, s));
+    if (cap) CN_TRY(capture(m, "att_out", m->logits, false, CN_DTYPE_F32, {B, U, c.vocab_size}, s));
+    m->last_k = 0;
+    if (k > 1) {
+        CN_TRY(launch_topk(m->logits, MU, c.vocab_size, c.vocab_size, k, m->topk_idx, m->topk_val, s));
+        m->last_k = k;
+    }
+    if (hyp) CN_TRY(launch_greedy_pack(m->tok, m->val, m->ylen, B, U, o->sos, hyp_stride, hyp, hyp_len, score, s));
+    return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// exported functions
+// ---------------------------------------------------------------------------------------------
+extern "C" int cn_model_create(const cn_config* cfg, cn_model** out) {
+    if (!cfg || !out) {
+        cn_set_error("cn_model_create: null argument");
+        return -1;
+    }
+    const cn_config& c = *cfg;
+    if (c.d_model % 64 != 0 || c.n_head < 1 || c.d_model != 64 * c.n_head) {
+        cn_set_error("cn_model_create: this build needs d_model == 64 * n_head (d_k = 64)");
+        return -1;
+    }
+    if (c.d_encff % 64 || c.d_decff % 64 || c.d_model > 1024) {
+        cn_set_error("cn_model_create: feed-forward widths must be multiples of 64 and d_model <= 1024");
+        return -1;
+    }
+    if (c.precision != CN_PRECISION_F32 && c.precision != CN_PRECISION_BF16) {
+        cn_set_error("cn_model_create: unknown precision");
+        return -1;
+    }
+    if (c.input_size < 4 || c.vocab_size < 4 || c.max_batch < 1 || c.max_frames < 4 || c.n_enc < 0 || c.n_extra < 0 ||
+        c.n_self_dec < 0 || c.n_mix_dec < 0) {
+        cn_set_error("cn_model_create: bad dimensions");
+        return -1;
+    }
+    CN_HIP_CHECK(hipSetDevice(c.device));
+    cn_model* m = new cn_model();
+    m->cfg = c;
+    m->prec = c.precision;
+    m->es = cn_elem_size(c.precision);
+    m->maxB = c.max_batch;
+    m->maxT = c.max_frames;
+    m->maxT1 = (c.max_frames - 1) / 2 + 1;
+    m->maxTp = (m->maxT1 - 1) / 2 + 1;
+    m->F1 = (c.input_size - 1) / 2 + 1;
+    m->F2 = (m->F1 - 1) / 2 + 1;
+    *out = m;
+    return 0;
+}
+
+extern "C" void cn_model_destroy(cn_model* m) {
+    if (!m) return;
+    for (void* p : m->allocs) (void)hipFree(p);
+    for (auto& kv : m->captures)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    if (m->blob) (void)hipFree(m->blob);
+    delete m;
+}
+
+extern "C" int cn_model_load_weights(cn_model* m, const char* name, const float* host_data, const int64_t* shape,
+                                     int32_t ndim) {
+    if (!m || !name || !host_data || !shape || ndim < 1 || ndim > 4) {
+        cn_set_error("cn_model_load_weights: bad argument");
+        return -1;
+    }
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    t.data.assign(host_data, host_data + n);
+    m->host[name] = std::move(t);
+    m->finalized = false;
+    return 0;
+}
+
+extern "C" int cn_model_load_pe(cn_model* m, const float* host_table, int32_t rows) {
+    if (!m || !host_table || rows < 1) {
+        cn_set_error("cn_model_load_pe: bad argument");
+        return -1;
+    }
+    m->pe_host.assign(host_table, host_table + (size_t)rows * m->cfg.d_model);
+    m->pe_rows = rows;
+    m->finalized = false;
+    return 0;
+}
+
+extern "C" int cn_model_finalize(cn_model* m) {
+    if (!m) {
+        cn_set_error("cn_model_finalize: null model");
+        return -1;
+    }
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+    if (m->pe_rows < m->maxTp + 1) {
+        if (m->host.empty() && m->pe_rows == 0) {
+            m->pe_rows = 5000;  // layout-only: table arrives with the broadcast blob (create_pe max_len)
+        } else {
+            cn_set_error("cn_model_finalize: positional table missing or shorter than max_frames/4 + 1");
+            return -1;
+        }
+    }
+    CN_TRY(build_weights(m));
+    CN_TRY(build_workspace(m));
+    m->finalized = true;
+    return 0;
+}
+
+extern "C" int cn_model_weight_blob(cn_model* m, void** dev_ptr, int64_t* bytes) {
+    if (!m || !m->blob) {
+        cn_set_error("cn_model_weight_blob: finalize first");
+        return -1;
+    }
+    *dev_ptr = m->blob;
+    *bytes = (int64_t)m->blob_bytes;
+    return 0;
+}
+
+extern "C" int cn_encode_align(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T,
+                               int32_t F, const cn_decode_opts* opts, int32_t* ymax_host, void* stream) {
+    CN_TRY(check_call(m, B, T, F));
+    hipStream_t s = (hipStream_t)stream;
+    CN_TRY(stage_encode_align(m, feats_dev, size_ratio_dev, B, T, F, opts, s));
+    int ymax = 0;
+    CN_HIP_CHECK(hipMemcpyAsync(&ymax, m->ymax, sizeof(int), hipMemcpyDeviceToHost, s));
+    CN_HIP_CHECK(hipStreamSynchronize(s));
+    if (ymax_host) *ymax_host = ymax;
+    return 0;
+}
+
+extern "C" int cn_decode_nast(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T,
+                              int32_t F, const cn_decode_opts* opts, int32_t* hyp_out_dev, int32_t hyp_stride,
+                              int32_t* hyp_len_dev, double* score_dev, void* stream) {
+    CN_TRY(check_call(m, B, T, F));
+    if (!opts || opts->beam_width < 1 || opts->beam_width > 16) {
+        cn_set_error("cn_decode_nast: beam_width must be in [1,16]");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    CN_TRY(stage_encode_align(m, feats_dev, size_ratio_dev, B, T, F, opts, s));
+    int ymax = 0;
+    CN_HIP_CHECK(hipMemcpyAsync(&ymax, m->ymax, sizeof(int), hipMemcpyDeviceToHost, s));
+    CN_HIP_CHECK(hipStreamSynchronize(s));  // U is data dependent
+    if (ymax < 1 || ymax > m->Tp + 1) {
+        cn_set_error("cn_decode_nast: alignment produced an impossible token count");
+        return -3;
+    }
+    if (hyp_out_dev && hyp_stride < ymax + 1) {
+        cn_set_error("cn_decode_nast: hyp_stride " + std::to_string(hyp_stride) + " < ymax+1 = " + std::to_string(ymax + 1));
+        return -1;
+    }
+    CN_TRY(stage_decode(m, ymax, opts, hyp_out_dev, hyp_stride, hyp_len_dev, score_dev, s));
+    return 0;
+}
+
+extern "C" int cn_fetch(cn_model* m, const char* name, void* host_dst, int64_t max_bytes, int64_t* shape_out,
+                        int32_t* ndim_out, int32_t* dtype_out) {
+    if (!m || !name) {
+        cn_set_error("cn_fetch: bad argument");
+        return -1;
+    }
+    const std::string n(name);
+    const void* src = nullptr;
+    int dtype = CN_DTYPE_F32;
+    std::vector<int64_t> shape;
+    bool model_prec = false;
+    const int64_t B = m->B, Tp = m->Tp, U = m->U, d = m->cfg.d_model;
+    auto it = m->captures.find(n);
+    if (it != m->captures.end()) {
+        src = it->second.p;
+        dtype = it->second.dtype;
+        shape = it->second.shape;
+    } else if (n == "best_paths") { src = m->best; dtype = CN_DTYPE_I32; shape = {B, Tp};
+    } else if (n == "ctc_maxlp") { src = m->ctc_maxlp; shape = {B, Tp};
+    } else if (n == "aligned_seq_shift") { src = m->shift; dtype = CN_DTYPE_I32; shape = {B, Tp};
+    } else if (n == "keymask") { src = m->keymask; dtype = CN_DTYPE_U8; shape = {B, Tp};
+    } else if (n == "src_size") { src = m->src_size; dtype = CN_DTYPE_I32; shape = {B};
+    } else if (n == "ylen") { src = m->ylen; dtype = CN_DTYPE_I32; shape = {B};
+    } else if (n == "ymax") { src = m->ymax; dtype = CN_DTYPE_I32; shape = {1};
+    } else if (n == "intervals") { src = m->intervals; dtype = CN_DTYPE_I32; shape = {B, Tp + 1, 4};
+    } else if (n == "tok") { src = m->tok; dtype = CN_DTYPE_I32; shape = {B, U};
+    } else if (n == "val") { src = m->val; shape = {B, U};
+    } else if (n == "topk_idx") { src = m->topk_idx; dtype = CN_DTYPE_I32; shape = {B, U, m->last_k};
+    } else if (n == "topk_val") { src = m->topk_val; shape = {B, U, m->last_k};
+    } else if (n == "enc_h_live") { src = m->enc_h; model_prec = true; shape = {B, Tp, d};
+    } else {
+        cn_set_error("cn_fetch: unknown tensor '" + n + "' (captures need opts.capture=1)");
+        return -1;
+    }
+    size_t cnt = 1;
+    for (auto v : shape) cnt *= (size_t)v;
+    const size_t esz = dtype == CN_DTYPE_U8 ? 1 : (dtype == CN_DTYPE_F64 ? 8 : 4);
+    if (shape_out) {
+        for (size_t i = 0; i < shape.size() && i < 4; ++i) shape_out[i] = shape[i];
+    }
+    if (ndim_out) *ndim_out = (int)shape.size();
+    if (dtype_out) *dtype_out = dtype;
+    if (!host_dst) return 0;  // shape query
+    if ((int64_t)(cnt * esz) > max_bytes) {
+        cn_set_error("cn_fetch: destination too small");
+        return -1;
+    }
+    CN_HIP_CHECK(hipDeviceSynchronize());
+    if (model_prec && m->prec != CN_PREC_F32) {
+        float* tmp = nullptr;
+        CN_HIP_CHECK(hipMalloc((void**)&tmp, cnt * 4));
+        int rc = launch_convert_back(m->prec, src, tmp, cnt, 0);
+        if (rc == 0 && hipMemcpy(host_dst, tmp, cnt * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = -2;
+        (void)hipFree(tmp);
+        if (rc) {
+            cn_set_error("cn_fetch: convert/copy failed");
+            return rc;
+        }
+        return 0;
+    }
+    CN_HIP_CHECK(hipMemcpy(host_dst, src, cnt * esz, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- single-kernel entry points ------------------------------------------------------------------
+extern "C" int cn_op_gemm(int32_t precision, const void* A, int32_t lda, const void* W, const float* bias, void* C,
+                          int32_t ldc, int32_t c_is_f32, int32_t M, int32_t N, int32_t K, int32_t relu,
+                          const float* resid, int32_t ldr, const float* pe, int32_t pe_period, float scale,
+                          void* stream) {
+    GemmArgs g;
+    g.A = A;
+    g.lda = lda;
+    g.W = W;
+    g.bias = bias;
+    g.C = C;
+    g.ldc = ldc;
+    g.c_f32 = c_is_f32;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.epi = (relu ? CN_EPI_RELU : 0) | (resid ? CN_EPI_RESID : 0) | (pe ? CN_EPI_EMBED : 0);
+    g.resid = resid;
+    g.ldr = ldr;
+    g.pe = pe;
+    g.pe_period = pe_period;
+    g.scale = scale;
+    return launch_gemm(precision, g, (hipStream_t)stream);
+}
+
+extern "C" int cn_op_conv1(int32_t precision, const float* x, const float* w9c, const float* bias, void* out, int32_t B,
+                           int32_t T, int32_t F, int32_t C, void* stream) {
+    return launch_conv1(precision, x, w9c, bias, out, B, T, F, (T - 1) / 2 + 1, (F - 1) / 2 + 1, C, (hipStream_t)stream);
+}
+
+extern "C" int cn_op_conv2(int32_t precision, const void* conv1_out, const void* w_khwc, const float* bias, void* out,
+                           int32_t B, int32_t T1, int32_t F1, int32_t C, void* stream) {
+    GemmArgs g;
+    const int T2 = (T1 - 1) / 2 + 1, F2 = (F1 - 1) / 2 + 1;
+    g.A = conv1_out;
+    g.W = w_khwc;
+    g.bias = bias;
+    g.C = out;
+    g.ldc = C;
+    g.M = B * T2 * F2;
+    g.N = C;
+    g.K = 9 * C;
+    g.epi = CN_EPI_RELU;
+    g.conv = 1;
+    g.cB = B;
+    g.cT1 = T1;
+    g.cF1 = F1;
+    g.cC = C;
+    g.cT2 = T2;
+    g.cF2 = F2;
+    return launch_gemm(precision, g, (hipStream_t)stream);
+}
+
+extern "C" int cn_op_layernorm(int32_t precision, const float* x, const float* a2, const float* b2, void* y, int32_t M,
+                               int32_t d, float eps, void* stream) {
+    return launch_layernorm(precision, x, a2, b2, y, 0, M, d, eps, (hipStream_t)stream);
+}
+
+extern "C" int cn_op_attention(int32_t precision, const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V,
+                               int32_t ldv, void* O, int32_t ldo, int32_t B, int32_t H, int32_t Lq, int32_t Lk,
+                               const uint8_t* keymask, const int32_t* klen, const int32_t* intervals, int32_t iv_stride,
+                               int32_t causal, float scale, void* stream) {
+    AttnArgs a;
+    a.Q = Q;
+    a.K = K;
+    a.V = V;
+    a.O = O;
+    a.ldq = ldq;
+    a.ldk = ldk;
+    a.ldv = ldv;
+    a.ldo = ldo;
+    a.B = B;
+    a.H = H;
+    a.Lq = Lq;
+    a.Lk = Lk;
+    a.keymask = keymask;
+    a.klen = klen;
+    a.intervals = intervals;
+    a.iv_stride = iv_stride;
+    a.causal = causal;
+    a.scale = scale;
+    return launch_attention(precision, a, (hipStream_t)stream);
+}
+
+extern "C" int cn_op_logsoftmax_argmax(float* logits, int32_t M, int32_t V, int32_t* arg, float* maxlp,
+                                       int32_t write_logp, void* stream) {
+    return launch_logsoftmax_argmax(logits, M, V, V, arg, maxlp, write_logp, (hipStream_t)stream);
+}
+
+extern "C" int cn_op_ctc_align(const int32_t* best, const uint8_t* keymask, const float* size_ratio, int32_t B,
+                               int32_t Tp, int32_t blank, int32_t left, int32_t right, int32_t* shift,
+                               int32_t* src_size, int32_t* ylen, int32_t* ymax, int32_t* intervals, void* stream) {
+    AlignArgs a;
+    a.best = best;
+    a.keymask = keymask;
+    a.size_ratio = size_ratio;
+    a.B = B;
+    a.Tp = Tp;
+    a.blank = blank;
+    a.left = left;
+    a.right = right;
+    a.shift = shift;
+    a.src_size = src_size;
+    a.ylen = ylen;
+    a.ymax = ymax;
+    a.intervals = intervals;
+    return launch_ctc_align(a, (hipStream_t)stream);
+}
+
+extern "C" int cn_op_greedy_pack(const int32_t* tok, const float* val, const int32_t* ylen, int32_t B, int32_t U,
+                                 int32_t sos, int32_t hyp_stride, int32_t* hyp, int32_t* hyp_len, double* score,
+                                 void* stream) {
+    return launch_greedy_pack(tok, val, ylen, B, U, sos, hyp_stride, hyp, hyp_len, score, (hipStream_t)stream);
+}
+
+extern "C" int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, int32_t* idx, float* val, void* stream) {
+    return launch_topk(logp, M, V, V, k, idx, val, (hipStream_t)stream);
+}

@@ -1,0 +1,298 @@
+// Row-wise, HBM-bound kernels of the hot path: the reference's custom LayerNorm, the generator's
+// log-softmax + argmax, the padding mask, query-table broadcast and precision converts.
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm exactly as src/models/modules/norm.py:15-18: unbiased std (divide by d-1), eps added to
+// the std (not the variance).  One wave per row, 16 bytes per lane per step, two-pass in registers.
+// ---------------------------------------------------------------------------------------------
+template <typename TY>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ a2,
+                                                        const float* __restrict__ b2, TY* __restrict__ y, int M, int d,
+                                                        float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (long long)row * d;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = (i * 64 + lane) * 4;
+        if (idx < d) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + idx);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = (i * 64 + lane) * 4;
+        if (idx < d) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float c = v[i][j] - mean;
+                ss = fmaf(c, c, ss);
+            }
+        }
+    }
+    const float denom = sqrtf(wave_sum(ss) / (float)(d - 1)) + eps;
+    TY* yr = y + (long long)row * d;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = (i * 64 + lane) * 4;
+        if (idx < d) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a2 + idx);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + idx);
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[i][j] - mean) / denom + bb[j];
+            if constexpr (sizeof(TY) == 2) {
+                bf16x4 ob;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ob[j] = (bf16)o[j];
+                *reinterpret_cast<bf16x4*>(yr + idx) = ob;
+            } else {
+                f32x4 of;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) of[j] = o[j];
+                *reinterpret_cast<f32x4*>(yr + idx) = of;
+            }
+        }
+    }
+}
+
+int launch_layernorm(int prec, const float* x, const float* a2, const float* b2, void* y, int y_f32, int M, int d,
+                     float eps, hipStream_t s) {
+    if (d % 4 != 0 || d > 1024 || d < 2) {
+        cn_set_error("layernorm: d must be a multiple of 4 in [4, 1024]");
+        return -1;
+    }
+    if (M <= 0) return 0;
+    const dim3 grid(cn_ceil_div(M, 4));
+    if (y_f32 || prec == CN_PREC_F32)
+        hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, a2, b2, (float*)y, M, d, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, dim3(256), 0, s, x, a2, b2, (bf16*)y, M, d, eps);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generator tail (src/models/cassnat.py:113 log_softmax, :378 argmax, :611 topk(1)): per row of
+// fp32 logits the first-index argmax and its log-probability (x - max) - log(sum exp(x - max));
+// optionally the row is rewritten in place as log-probabilities.  One workgroup per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logsoftmax_argmax_kernel(float* __restrict__ logits, int V, int ldl,
+                                                                int* __restrict__ arg, float* __restrict__ maxlp,
+                                                                int write_logp) {
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    __shared__ float s_sum[4];
+    float* p = logits + (long long)blockIdx.x * ldl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+        const float v = p[i];
+        if (v > best || (v == best && i < bidx)) {
+            best = v;
+            bidx = i;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bidx, o);
+        if (ov > best || (ov == best && oi < bidx)) {
+            best = ov;
+            bidx = oi;
+        }
+    }
+    if (lane == 0) {
+        s_val[wave] = best;
+        s_idx[wave] = bidx;
+    }
+    __syncthreads();
+    best = s_val[0];
+    bidx = s_idx[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bidx)) {
+            best = s_val[w];
+            bidx = s_idx[w];
+        }
+    }
+    float sum = 0.f;
+    for (int i = tid; i < V; i += 256) sum += expf(p[i] - best);
+    sum = wave_sum(sum);
+    if (lane == 0) s_sum[wave] = sum;
+    __syncthreads();
+    const float lse = logf((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
+    if (tid == 0) {
+        arg[blockIdx.x] = bidx;
+        maxlp[blockIdx.x] = -lse;
+    }
+    if (write_logp)
+        for (int i = tid; i < V; i += 256) p[i] = (p[i] - best) - lse;
+}
+
+int launch_logsoftmax_argmax(float* logits, int M, int V, int ldl, int* arg, float* maxlp, int write_logp,
+                             hipStream_t s) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(logsoftmax_argmax_kernel, dim3(M), dim3(256), 0, s, logits, V, ldl, arg, maxlp, write_logp);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// per-row top-k of log-probs (beam_width > 1, src/models/cassnat.py:611). Row staged in LDS, k rounds.
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ logp, int V, int ldl, int k,
+                                                   int* __restrict__ idx, float* __restrict__ val) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* row = reinterpret_cast<float*>(smem);
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    const float* p = logp + (long long)blockIdx.x * ldl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < V; i += 256) row[i] = p[i];
+    __syncthreads();
+    for (int r = 0; r < k; ++r) {
+        float best = -INFINITY;
+        int bidx = 0x7fffffff;
+        for (int i = tid; i < V; i += 256) {
+            const float v = row[i];
+            if (v > best || (v == best && i < bidx)) {
+                best = v;
+                bidx = i;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bidx, o);
+            if (ov > best || (ov == best && oi < bidx)) {
+                best = ov;
+                bidx = oi;
+            }
+        }
+        if (lane == 0) {
+            s_val[wave] = best;
+            s_idx[wave] = bidx;
+        }
+        __syncthreads();
+        best = s_val[0];
+        bidx = s_idx[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bidx)) {
+                best = s_val[w];
+                bidx = s_idx[w];
+            }
+        }
+        if (tid == 0) {
+            idx[(long long)blockIdx.x * k + r] = bidx;
+            val[(long long)blockIdx.x * k + r] = best;
+            if (bidx < V) row[bidx] = -INFINITY;
+        }
+        __syncthreads();
+    }
+}
+
+int launch_topk(const float* logp, int M, int V, int ldl, int k, int* idx, float* val, hipStream_t s) {
+    if (k < 1 || k > 16 || V > 16384) {
+        cn_set_error("topk: need 1 <= k <= 16 and V <= 16384");
+        return -1;
+    }
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(topk_kernel, dim3(M), dim3(256), (size_t)V * sizeof(float), s, logp, V, ldl, k, idx, val);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Padding mask after 4x subsampling: src/tasks/cassnat_task.py:328 then embedding.py:121-122
+// (mask[:, :, ::2][:, :, ::2]) => keymask[b][j] = feats[b][4j][0] != padding_idx.
+// ---------------------------------------------------------------------------------------------
+__global__ void keymask_kernel(const float* __restrict__ feats, int B, int T, int F, int Tp, int stride, float padding,
+                               unsigned char* __restrict__ km) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Tp) return;
+    const int b = i / Tp, j = i - b * Tp;
+    const int t = stride * j;
+    km[i] = (t < T && feats[((long long)b * T + t) * F] != padding) ? 1 : 0;
+}
+
+int launch_keymask(const float* feats, int B, int T, int F, int Tp, int stride, float padding, unsigned char* km,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(keymask_kernel, dim3(cn_ceil_div(B * Tp, 256)), dim3(256), 0, s, feats, B, T, F, Tp, stride,
+                       padding, km);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// extractor queries: pe[:ymax] repeated over the batch (src/models/cassnat.py:481)
+__global__ void fill_queries_kernel(const float* __restrict__ table, float* __restrict__ out, int B, int U, int d) {
+    const long long n4 = (long long)B * U * d / 4;
+    const long long per = (long long)U * d / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(table)[i % per];
+}
+
+int launch_fill_queries(const float* table, float* out, int B, int U, int d, hipStream_t s) {
+    const long long n4 = (long long)B * U * d / 4;
+    if (n4 <= 0) return 0;
+    hipLaunchKernelGGL(fill_queries_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, table, out, B, U, d);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// use_unimask (src/models/cassnat.py:486-488): prepend a zero embedding, drop the last row
+__global__ void shift_right_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int U, int d) {
+    const long long n = (long long)B * U * d;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long u = (i / d) % U;
+        y[i] = u == 0 ? 0.f : x[i - d];
+    }
+}
+
+int launch_shift_right(const float* x, float* y, int B, int U, int d, hipStream_t s) {
+    const long long n = (long long)B * U * d;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(shift_right_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, B, U, d);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename TD, typename TS>
+__global__ void convert_kernel(const TS* __restrict__ src, TD* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = from_f32<TD>(to_f32(src[i]));
+}
+
+static unsigned convert_grid(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (unsigned)(g > 65536 ? 65536 : (g < 1 ? 1 : g));
+}
+
+int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    if (prec == CN_PREC_F32)
+        CN_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    else
+        hipLaunchKernelGGL((convert_kernel<bf16, float>), dim3(convert_grid(n)), dim3(256), 0, s, src, (bf16*)dst, n);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_convert_back(int prec, const void* src, float* dst, size_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    if (prec == CN_PREC_F32)
+        CN_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    else
+        hipLaunchKernelGGL((convert_kernel<float, bf16>), dim3(convert_grid(n)), dim3(256), 0, s, (const bf16*)src, dst,
+                           n);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}

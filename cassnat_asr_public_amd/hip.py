@@ -1,0 +1,182 @@
+"""ctypes binding of libcassnat_hip.so (the C ABI declared in include/cassnat_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcassnat_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cassnat_hip.h")
+
+PRECISION = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+DTYPES = {0: np.float32, 1: np.int32, 2: np.uint8, 3: np.float64}
+
+
+class CnConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "input_size", "d_model", "n_head", "d_encff", "d_decff", "n_enc", "n_extra", "n_self_dec", "n_mix_dec",
+        "vocab_size", "precision", "max_batch", "max_frames", "device")] + [("reserved", C.c_int32 * 8)]
+
+
+class CnDecodeOpts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "padding_idx", "sos", "left_trigger", "right_trigger", "src_trigger", "use_unimask", "beam_width",
+        "capture")] + [("reserved", C.c_int32 * 8)]
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def declared_symbols():
+    """Every function name include/cassnat_hip.h declares."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(cn_[a-z0-9_]+)\s*\(", text)) - {"cn_model", "cn_config", "cn_decode_opts"})
+
+
+def lib():
+    """Load the shared library (built by __graft_entry__.build / cassnat_asr_public_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback for the CASS-NAT hot path)")
+    L = C.CDLL(LIB_PATH)
+    L.cn_last_error.restype = C.c_char_p
+    L.cn_version.restype = C.c_char_p
+    L.cn_model_destroy.restype = None
+    for name in declared_symbols():
+        fn = getattr(L, name)  # AttributeError here = header and library disagree
+        if name not in ("cn_last_error", "cn_version", "cn_model_destroy"):
+            fn.restype = C.c_int
+    L.cn_op_gemm.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                             C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                             C.c_float, C.c_void_p]
+    L.cn_op_conv1.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]
+    L.cn_op_conv2.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]
+    L.cn_op_layernorm.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p]
+    L.cn_op_attention.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                  C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
+    L.cn_op_logsoftmax_argmax.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.cn_op_ctc_align.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 5 + [C.c_void_p] * 6
+    L.cn_op_greedy_pack.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p] * 4
+    L.cn_op_topk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cn_model_create.argtypes = [C.POINTER(CnConfig), C.POINTER(C.c_void_p)]
+    L.cn_model_destroy.argtypes = [C.c_void_p]
+    L.cn_model_load_weights.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
+    L.cn_model_load_pe.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.cn_model_finalize.argtypes = [C.c_void_p]
+    L.cn_model_weight_blob.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.cn_decode_nast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                 C.POINTER(CnDecodeOpts), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cn_encode_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                  C.POINTER(CnDecodeOpts), C.POINTER(C.c_int32), C.c_void_p]
+    L.cn_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                           C.POINTER(C.c_int32)]
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().cn_last_error().decode(errors="replace")
+        raise HipError(f"{what or 'libcassnat_hip'} failed (rc={rc}): {msg}")
+
+
+def _ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """Owns one ``cn_model`` handle: weights, workspace and the decode pipeline on one GPU."""
+
+    def __init__(self, args, precision="bf16", max_batch=32, max_frames=2048, device=0):
+        self.L = lib()
+        self.cfg = CnConfig(
+            input_size=args.input_size, d_model=args.d_model, n_head=args.n_head, d_encff=args.d_encff,
+            d_decff=args.d_decff, n_enc=args.N_enc, n_extra=args.N_extra, n_self_dec=args.N_self_dec,
+            n_mix_dec=args.N_mix_dec, vocab_size=args.vocab_size, precision=PRECISION[precision],
+            max_batch=max_batch, max_frames=max_frames, device=device)
+        self.precision = precision
+        self.handle = C.c_void_p()
+        check(self.L.cn_model_create(C.byref(self.cfg), C.byref(self.handle)), "cn_model_create")
+        self.finalized = False
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.cn_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state(self, state, pe_table):
+        """state: name -> float32 array/tensor (reference parameter names); pe_table: (rows, d_model)."""
+        for name, w in state.items():
+            a = np.ascontiguousarray(w.detach().cpu().numpy() if hasattr(w, "detach") else w, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            check(self.L.cn_model_load_weights(self.handle, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim),
+                  f"load {name}")
+        pe = np.ascontiguousarray(pe_table.detach().cpu().numpy() if hasattr(pe_table, "detach") else pe_table,
+                                  dtype=np.float32)
+        check(self.L.cn_model_load_pe(self.handle, pe.ctypes.data_as(C.c_void_p), pe.shape[0]), "load pe")
+        self.finalize()
+
+    def finalize(self):
+        check(self.L.cn_model_finalize(self.handle), "cn_model_finalize")
+        self.finalized = True
+
+    def weight_blob(self):
+        """(device pointer, bytes) of the packed weights - what RCCL broadcasts from rank 0."""
+        p, n = C.c_void_p(), C.c_int64()
+        check(self.L.cn_model_weight_blob(self.handle, C.byref(p), C.byref(n)), "cn_model_weight_blob")
+        return p.value, n.value
+
+    @staticmethod
+    def make_opts(args, capture=False):
+        return CnDecodeOpts(padding_idx=int(args.padding_idx), sos=1, left_trigger=int(args.left_trigger),
+                            right_trigger=int(args.right_trigger), src_trigger=int(bool(args.src_trigger)),
+                            use_unimask=int(bool(args.use_unimask)), beam_width=int(args.beam_width),
+                            capture=int(bool(capture)))
+
+    def decode(self, feats, size_ratio, opts, hyp, hyp_len, score):
+        """feats (B,T,F) f32 cuda, size_ratio (B,) f32 cuda; outputs are caller-owned cuda tensors."""
+        B, T, F = feats.shape
+        check(self.L.cn_decode_nast(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts), _ptr(hyp),
+                                    hyp.shape[1], _ptr(hyp_len), _ptr(score), current_stream()), "cn_decode_nast")
+
+    def encode_align(self, feats, size_ratio, opts):
+        B, T, F = feats.shape
+        ymax = C.c_int32()
+        check(self.L.cn_encode_align(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts),
+                                     C.byref(ymax), current_stream()), "cn_encode_align")
+        return ymax.value
+
+    def fetch(self, name):
+        shape = (C.c_int64 * 4)()
+        ndim, dtype = C.c_int32(), C.c_int32()
+        check(self.L.cn_fetch(self.handle, name.encode(), None, 0, shape, C.byref(ndim), C.byref(dtype)), f"fetch {name}")
+        out = np.empty([shape[i] for i in range(ndim.value)], dtype=DTYPES[dtype.value])
+        check(self.L.cn_fetch(self.handle, name.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes, shape,
+                              C.byref(ndim), C.byref(dtype)), f"fetch {name}")
+        return out

@@ -1,0 +1,242 @@
+"""Drop-in for the inference half of the reference's ``models.cassnat`` (src/models/cassnat.py).
+
+Same surface - ``make_model(input_size, args) -> CassNAT`` and
+``CassNAT.beam_decode(src, x_mask, src_size, vocab, args, lm_model=None, ...) -> (batch_top_seqs, args)`` -
+and the same parameter names (they are the checkpoint keys loaded by
+``BaseTask.load_test_model``, src/tasks/base_task.py:45-54), but no arithmetic lives here: the module
+tree only *holds* parameters; ``beam_decode`` hands them once to libcassnat_hip.so and every stage
+(conv subsampling, encoder, CTC alignment, extractor, NAT decoder, greedy finish) runs as hand-written
+gfx950 kernels behind the C ABI (include/cassnat_hip.h).  There is no CPU fallback.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import hip
+
+
+def create_pe(d_model, max_len=5000):
+    """Sinusoid table, same closed form as src/models/cassnat.py:91-99 (a buffer, not a parameter)."""
+    position = torch.arange(0.0, max_len).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0.0, d_model, 2) * -(math.log(10000.0) / d_model))
+    pe = torch.zeros(max_len, d_model)
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+# ---- parameter holders: names mirror the reference module tree, there is deliberately no forward() ----
+class _Params(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder: computation runs in libcassnat_hip.so via CassNAT.beam_decode")
+
+
+class _Linear(_Params):
+    def __init__(self, n_in, n_out):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n_out, n_in))
+        self.bias = nn.Parameter(torch.empty(n_out))
+        bound = 1.0 / math.sqrt(n_in)
+        nn.init.uniform_(self.weight, -bound, bound)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _Conv(_Params):
+    def __init__(self, c_in, c_out):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(c_out, c_in, 3, 3))
+        self.bias = nn.Parameter(torch.empty(c_out))
+        bound = 1.0 / math.sqrt(c_in * 9)
+        nn.init.uniform_(self.weight, -bound, bound)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _Norm(_Params):
+    def __init__(self, d):
+        super().__init__()
+        self.a_2 = nn.Parameter(torch.ones(d))
+        self.b_2 = nn.Parameter(torch.zeros(d))
+
+
+class _Sublayer(_Params):
+    def __init__(self, d):
+        super().__init__()
+        self.norm = _Norm(d)
+
+
+class _Attention(_Params):
+    def __init__(self, d):
+        super().__init__()
+        self.linears = nn.ModuleList([_Linear(d, d) for _ in range(4)])  # 0=Q 1=K 2=V 3=O
+
+
+class _FeedForward(_Params):
+    def __init__(self, d, d_ff):
+        super().__init__()
+        self.w_1 = _Linear(d, d_ff)
+        self.w_2 = _Linear(d_ff, d)
+
+
+class _Block(_Params):
+    def __init__(self, d, d_ff, self_attn, src_attn):
+        super().__init__()
+        if self_attn:
+            self.self_attn = _Attention(d)
+        if src_attn:
+            self.src_attn = _Attention(d)
+        self.feed_forward = _FeedForward(d, d_ff)
+        self.sublayer = nn.ModuleList([_Sublayer(d) for _ in range(1 + int(self_attn) + int(src_attn))])
+
+
+class _Stack(_Params):
+    def __init__(self, d, d_ff, n, self_attn, src_attn, final_norm):
+        super().__init__()
+        self.layers = nn.ModuleList([_Block(d, d_ff, self_attn, src_attn) for _ in range(n)])
+        if final_norm:
+            self.norm = _Norm(d)
+
+
+class _ConvEmbedding(_Params):
+    def __init__(self, input_size, d):
+        super().__init__()
+        # indices 0 and 2 as in nn.Sequential(conv1, ReLU, conv2, ReLU)  (src/models/modules/embedding.py:102-105)
+        self.conv = nn.ModuleDict({"0": _Conv(1, d), "2": _Conv(d, d)})
+        self.linear_out = _Linear(d * (((input_size - 1) // 2) // 2 + 1), d)
+
+
+class _Generator(_Params):
+    def __init__(self, d, vocab):
+        super().__init__()
+        self.proj = _Linear(d, vocab)
+
+
+class CassNAT(nn.Module):
+    """Attribute names are the checkpoint key prefixes of the reference (src/models/cassnat.py:118-125)."""
+
+    #: engine settings, overridable through ``args`` (hip_precision, hip_max_batch, hip_max_frames)
+    def __init__(self, input_size, args):
+        super().__init__()
+        d = args.d_model
+        self.input_size = input_size
+        self.src_embed = _ConvEmbedding(input_size, d)
+        self.encoder = _Stack(d, args.d_encff, args.N_enc, True, False, True)
+        self.acembed_extractor = _Stack(d, args.d_decff, args.N_extra, False, True, False)
+        self.embed_mapper = _Stack(d, args.d_decff, args.N_self_dec, True, False, False)
+        self.decoder = _Stack(d, args.d_decff, args.N_mix_dec, True, True, True)
+        self.ctc_generator = _Generator(d, args.vocab_size)
+        self.att_generator = _Generator(d, args.vocab_size)
+        self.pe = create_pe(d)
+        self._hyper = dict(input_size=input_size, d_model=d, n_head=args.n_head, d_encff=args.d_encff,
+                           d_decff=args.d_decff, N_enc=args.N_enc, N_extra=args.N_extra, N_self_dec=args.N_self_dec,
+                           N_mix_dec=args.N_mix_dec, vocab_size=args.vocab_size)
+        self.hip_precision = getattr(args, "hip_precision", "bf16")
+        self.hip_max_batch = getattr(args, "hip_max_batch", 32)
+        self.hip_max_frames = getattr(args, "hip_max_frames", 2048)
+        self._engine = None
+        self._engine_key = None
+
+    # the reference moves the module with .cuda(); parameters stay where they are - the engine owns HBM copies
+    def cuda(self, device=None):
+        self._device = 0 if device is None else (device if isinstance(device, int) else torch.device(device).index or 0)
+        return self
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training forward is out of scope; use beam_decode")
+
+    # ------------------------------------------------------------------------------------------ engine
+    def _weights_version(self):
+        return tuple(p._version for p in self.parameters())
+
+    def engine(self, batch, frames):
+        """(Re)build the HIP engine when weights changed or the workspace is too small."""
+        key = (self._weights_version(), self.hip_precision)
+        need_new = (self._engine is None or self._engine_key != key or batch > self._engine.cfg.max_batch
+                    or frames > self._engine.cfg.max_frames)
+        if need_new:
+            if self._engine is not None:
+                self._engine.close()
+            from types import SimpleNamespace
+
+            eng = hip.Engine(SimpleNamespace(**self._hyper), precision=self.hip_precision,
+                             max_batch=max(batch, self.hip_max_batch), max_frames=max(frames, self.hip_max_frames),
+                             device=getattr(self, "_device", torch.cuda.current_device()))
+            eng.load_state({k: v.detach() for k, v in self.named_parameters()}, self.pe)
+            self._engine, self._engine_key = eng, key
+        return self._engine
+
+    # ------------------------------------------------------------------------------------------ decode
+    def beam_decode(self, src, x_mask, src_size, vocab, args, lm_model=None, ctc_top_seqs=None, labels=None,
+                    label_sizes=None):
+        """Same contract as the reference's CassNAT.beam_decode (src/models/cassnat.py:420-637) for
+        ``use_trigger=True, sample_num<=1, decode_type='att_only', lm_weight==0`` (anything else raises).
+
+        ``x_mask`` is accepted for signature compatibility; like the reference's caller
+        (src/tasks/cassnat_task.py:328) the padding mask is ``src[:,:,0] != padding_idx`` and is re-derived on
+        the device from ``src`` itself.
+        """
+        if not getattr(args, "use_trigger", True):
+            raise NotImplementedError("use_trigger=False is not on the accelerated path")
+        if getattr(args, "sample_num", 0) > 1 or getattr(args, "decode_type", "att_only") not in ("att_only",):
+            raise NotImplementedError("ESA sampling / ctc_att / oracle_att decoding are outside the accelerated path")
+        if getattr(args, "lm_weight", 0) > 0 and lm_model is not None:
+            raise NotImplementedError("LM fusion is outside the accelerated path")
+        if getattr(args, "test_hitrate", False):
+            raise NotImplementedError("test_hitrate needs the training-time viterbi aligner")
+        sos = vocab.word2index["sos"]
+        assert vocab.word2index["blank"] == args.padding_idx, "CTC blank id and padding_idx must agree"
+        dev = torch.device("cuda", getattr(self, "_device", torch.cuda.current_device()))
+        feats = src.to(dev, torch.float32).contiguous()
+        ratio = src_size.to(dev, torch.float32).contiguous()
+        B, T, _ = feats.shape
+        eng = self.engine(B, T)
+        opts = hip.Engine.make_opts(args, capture=getattr(args, "hip_capture", False))
+        opts.sos = sos
+        stride = ((T - 1) // 2 + 1 - 1) // 2 + 1 + 2
+        hyp = torch.empty(B, stride, dtype=torch.int32, device=dev)
+        hyp_len = torch.empty(B, dtype=torch.int32, device=dev)
+        score = torch.empty(B, dtype=torch.float64, device=dev)
+        eng.decode(feats, ratio, opts, hyp, hyp_len, score)
+        if args.beam_width > 1:
+            return self._host_beam(eng, args, sos), args
+        hyp_h, len_h, score_h = hyp.cpu().numpy(), hyp_len.cpu().numpy(), score.cpu().numpy()
+        ys = torch.ones(1, 1).fill_(sos).long()
+        out = []
+        for b in range(B):
+            out.append([{"ys": ys, "score": float(score_h[b]), "hyp": hyp_h[b, : len_h[b]].tolist()}])
+        return out, args
+
+    @staticmethod
+    def _host_beam(eng, args, sos):
+        """beam_width > 1 (src/models/cassnat.py:580-636 with lm_weight == 0): the per-position top-k comes from
+        the device, the O(U * beam^2) bookkeeping is plain Python on B*U*k numbers."""
+        idx, val, ylen = eng.fetch("topk_idx"), eng.fetch("topk_val"), eng.fetch("ylen")
+        B, U, k = idx.shape
+        ys = torch.ones(1, 1).fill_(sos).long()
+        lp = args.length_penalty
+        out = []
+        for b in range(B):
+            beams = [{"ys": ys, "score": 0.0, "hyp": [sos]}]
+            for i in range(min(int(ylen[b]) + 1, U)):
+                cand = [{"ys": ys, "score": s["score"] + float(val[b, i, j]), "hyp": s["hyp"] + [int(idx[b, i, j])]}
+                        for s in beams for j in range(k)]
+                if lp is not None:
+                    cand.sort(key=lambda s: s["score"] + (len(s["hyp"]) - 1) * lp, reverse=True)
+                else:
+                    cand.sort(key=lambda s: s["score"], reverse=True)
+                beams = cand[:k]
+            out.append(beams)
+        return out
+
+
+def make_model(input_size, args):
+    """Same role as src/models/cassnat.py:21-89 for ``model_type == 'transformer'`` without conformer blocks."""
+    if getattr(args, "use_conv_enc", False) or getattr(args, "use_conv_dec", False):
+        raise NotImplementedError("conformer encoder/decoder blocks are not on the accelerated path yet")
+    assert args.model_type == "transformer"
+    model = CassNAT(input_size, args)
+    for p in model.parameters():  # src/models/cassnat.py:86-88
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+    return model

@@ -1,0 +1,118 @@
+/* libcassnat_hip.so - C ABI of the MI355X-native CASS-NAT inference hot path.
+ *
+ * The reference (balaji1312/cassnat_asr_public) is pure Python/PyTorch and has no FFI of its own; the
+ * boundary this library sits behind is the Python call
+ *     CassNAT.beam_decode(src, x_mask, src_size, vocab, args, ...)      src/models/cassnat.py:420-637
+ * made once per batch by CassNATTask.decode                             src/tasks/cassnat_task.py:326-343
+ * on a model built by make_model(input_size, args)                      src/models/cassnat.py:21-89
+ * whose parameters are loaded by name from {'model_state': ...}         src/tasks/base_task.py:45-54.
+ * The Python shim (cassnat_asr_public_amd/models/cassnat.py) binds these entry points with ctypes.
+ *
+ * Conventions: every function returns 0 on success, a negative code on failure (cn_last_error() gives the
+ * text); nothing throws across the ABI.  Pointers named *_dev are device (HBM) pointers owned by the
+ * caller; the library owns weights and workspace.  Calls are ordered on the given hipStream_t (passed as
+ * void*, NULL = default stream).  One cn_model per device; a handle is not thread-safe.
+ */
+#ifndef CASSNAT_HIP_H
+#define CASSNAT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cn_model cn_model;
+
+enum { CN_PRECISION_F32 = 0, CN_PRECISION_BF16 = 1 };
+enum { CN_DTYPE_F32 = 0, CN_DTYPE_I32 = 1, CN_DTYPE_U8 = 2, CN_DTYPE_F64 = 3 };
+
+/* Model hyper-parameters: the subset of the flat `args` bag that make_model reads for the transformer
+ * NAST model (src/models/cassnat.py:41-66). */
+typedef struct cn_config {
+    int32_t input_size; /* feature dim after splicing (80) */
+    int32_t d_model, n_head, d_encff, d_decff;
+    int32_t n_enc, n_extra, n_self_dec, n_mix_dec;
+    int32_t vocab_size;
+    int32_t precision;  /* CN_PRECISION_F32: exact-f32 MFMA (parity gate); CN_PRECISION_BF16: throughput */
+    int32_t max_batch;  /* workspace is sized for max_batch x max_frames */
+    int32_t max_frames;
+    int32_t device; /* HIP device ordinal */
+    int32_t reserved[8];
+} cn_config;
+
+/* Decode-time switches read by beam_decode from `args` (src/models/cassnat.py:435-636). */
+typedef struct cn_decode_opts {
+    int32_t padding_idx; /* also the CTC blank id */
+    int32_t sos;
+    int32_t left_trigger, right_trigger;
+    int32_t src_trigger;
+    int32_t use_unimask;
+    int32_t beam_width; /* 1: greedy finish on device; 2..16: per-position top-k kept for the host beam */
+    int32_t capture;    /* debug: keep an fp32 copy of every stage tensor for cn_fetch */
+    int32_t reserved[8];
+} cn_decode_opts;
+
+const char* cn_last_error(void);
+const char* cn_version(void);
+
+/* replaces models.cassnat.make_model (src/models/cassnat.py:21) */
+int cn_model_create(const cn_config* cfg, cn_model** out);
+void cn_model_destroy(cn_model* m);
+
+/* replaces the per-parameter copy of BaseTask.load_test_model (src/tasks/base_task.py:50-54): called once per
+ * state-dict entry with its reference name ("encoder.layers.0.self_attn.linears.0.weight", ...). fp32 host data. */
+int cn_model_load_weights(cn_model* m, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+/* sinusoid table shared by src_embed.pos_enc.pe and CassNAT.pe (src/models/cassnat.py:91-99): rows x d_model fp32 */
+int cn_model_load_pe(cn_model* m, const float* host_table, int32_t rows);
+/* repack into MFMA-friendly layouts / model precision and upload; must follow the last load */
+int cn_model_finalize(cn_model* m);
+/* rank-0 -> all ranks weight hand-off for the multi-GPU path: the packed device blob that RCCL broadcasts */
+int cn_model_weight_blob(cn_model* m, void** dev_ptr, int64_t* bytes);
+
+/* replaces CassNAT.beam_decode for the greedy NAST configuration (use_trigger, sample_num <= 1, no LM).
+ *   feats_dev      (B,T,F) fp32 contiguous, padded frames exactly == padding_idx in feature 0
+ *   size_ratio_dev (B) fp32 length ratios (SuperviseLoader.collate_fn, src/data/speech_loader.py:354)
+ *   hyp_out_dev    (B,hyp_stride) int32: [sos, tok...]; hyp_len_dev (B); score_dev (B) float64
+ * All stages through the greedy pack run on `stream`; the call synchronises the stream once (the token
+ * count U is data dependent). */
+int cn_decode_nast(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,
+                   const cn_decode_opts* opts, int32_t* hyp_out_dev, int32_t hyp_stride, int32_t* hyp_len_dev,
+                   double* score_dev, void* stream);
+
+/* stage-level entry: src_embed + encoder + ctc_generator + alignment only (src/models/cassnat.py:431-468) */
+int cn_encode_align(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,
+                    const cn_decode_opts* opts, int32_t* ymax_host, void* stream);
+
+/* Copy a named internal / captured tensor to the host (synchronous; test + host-beam use).  Activations are
+ * returned as fp32 whatever the model precision.  shape_out has room for 4 dims. */
+int cn_fetch(cn_model* m, const char* name, void* host_dst, int64_t max_bytes, int64_t* shape_out, int32_t* ndim_out,
+             int32_t* dtype_out);
+
+/* ---- single-kernel entry points (parity tests drive each hand-written kernel through the ABI) ---------- */
+/* all pointers device; `precision` selects the element type of activations/weights (fp32 or bf16) */
+int cn_op_gemm(int32_t precision, const void* A, int32_t lda, const void* W, const float* bias, void* C, int32_t ldc,
+               int32_t c_is_f32, int32_t M, int32_t N, int32_t K, int32_t relu, const float* resid, int32_t ldr,
+               const float* pe, int32_t pe_period, float scale, void* stream);
+int cn_op_conv1(int32_t precision, const float* x, const float* w9c, const float* bias, void* out, int32_t B, int32_t T,
+                int32_t F, int32_t C, void* stream);
+int cn_op_conv2(int32_t precision, const void* conv1_out, const void* w_khwc, const float* bias, void* out, int32_t B,
+                int32_t T1, int32_t F1, int32_t C, void* stream);
+int cn_op_layernorm(int32_t precision, const float* x, const float* a2, const float* b2, void* y, int32_t M, int32_t d,
+                    float eps, void* stream);
+int cn_op_attention(int32_t precision, const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V,
+                    int32_t ldv, void* O, int32_t ldo, int32_t B, int32_t H, int32_t Lq, int32_t Lk,
+                    const uint8_t* keymask, const int32_t* klen, const int32_t* intervals, int32_t iv_stride,
+                    int32_t causal, float scale, void* stream);
+int cn_op_logsoftmax_argmax(float* logits, int32_t M, int32_t V, int32_t* arg, float* maxlp, int32_t write_logp,
+                            void* stream);
+int cn_op_ctc_align(const int32_t* best, const uint8_t* keymask, const float* size_ratio, int32_t B, int32_t Tp,
+                    int32_t blank, int32_t left, int32_t right, int32_t* shift, int32_t* src_size, int32_t* ylen,
+                    int32_t* ymax, int32_t* intervals, void* stream);
+int cn_op_greedy_pack(const int32_t* tok, const float* val, const int32_t* ylen, int32_t B, int32_t U, int32_t sos,
+                      int32_t hyp_stride, int32_t* hyp, int32_t* hyp_len, double* score, void* stream);
+int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, int32_t* idx, float* val, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,352 @@
+"""GPU parity of every hand-written kernel, driven through the C ABI (cn_op_*).
+
+Float kernels are compared with a plain torch fp32 reference of the same op on the host; tolerances are
+written next to each check.  Integer kernels (CTC alignment, greedy pack) must be bit-exact with the oracle.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cassnat_asr_public_amd import hip
+
+pytestmark = pytest.mark.gpu
+
+PRECS = ["fp32", "bf16"]
+# fp32 path = exact-f32 MFMA: only summation order differs from the reference.  bf16 path: inputs are
+# rounded to bf16 (8 significant bits) and the reference is computed on the same rounded inputs, so what
+# is left is accumulation order and the bf16 rounding of the output.
+RTOL = {"fp32": 2e-5, "bf16": 1.2e-2}
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(x)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.contiguous().cuda()
+
+
+def tdtype(prec):
+    return torch.float32 if prec == "fp32" else torch.bfloat16
+
+
+def p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return hip.current_stream()
+
+
+def relerr(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def rounded(x, prec):
+    return x.to(tdtype(prec)).float()
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,N,K", [(300, 200, 256), (64, 64, 64), (1, 5000, 256), (4100, 2048, 128), (777, 256, 2048)])
+def test_gemm_bias(prec, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    ref = F.linear(rounded(A, prec), rounded(W, prec), bias)
+    for c_f32 in (1, 0):
+        out = torch.full((M, N), float("nan"), dtype=torch.float32 if c_f32 else tdtype(prec), device="cuda")
+        Ad, Wd, bd = dev(A, tdtype(prec)), dev(W, tdtype(prec)), dev(bias)
+        hip.check(hip.lib().cn_op_gemm(hip.PRECISION[prec], p(Ad), K, p(Wd), p(bd), p(out), N, c_f32, M, N, K, 0, None, 0,
+                                       None, 1, 1.0, stream()))
+        torch.cuda.synchronize()
+        assert relerr(out, ref) < RTOL[prec] * (1 if c_f32 or prec == "fp32" else 1.5)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_gemm_epilogues(prec):
+    g = torch.Generator().manual_seed(3)
+    M, N, K, period = 515, 256, 320, 103
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    pe = torch.randn(period, N, generator=g)
+    lin = F.linear(rounded(A, prec), rounded(W, prec), bias)
+    Ad, Wd, bd = dev(A, tdtype(prec)), dev(W, tdtype(prec)), dev(bias)
+    L = hip.lib()
+    # ReLU
+    out = torch.empty(M, N, dtype=tdtype(prec), device="cuda")
+    hip.check(L.cn_op_gemm(hip.PRECISION[prec], p(Ad), K, p(Wd), p(bd), p(out), N, 0, M, N, K, 1, None, 0, None, 1, 1.0, stream()))
+    assert relerr(out, F.relu(lin)) < RTOL[prec] * 1.5
+    # residual, in place (C aliases resid), fp32 stream
+    xres = dev(resid)
+    hip.check(L.cn_op_gemm(hip.PRECISION[prec], p(Ad), K, p(Wd), p(bd), p(xres), N, 1, M, N, K, 0, p(xres), N, None, 1, 1.0, stream()))
+    assert relerr(xres, resid + lin) < RTOL[prec]
+    # embedding epilogue: (acc + bias) * sqrt(d) + pe[m % period]
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ped = dev(pe)
+    hip.check(L.cn_op_gemm(hip.PRECISION[prec], p(Ad), K, p(Wd), p(bd), p(out), N, 1, M, N, K, 0, None, 0, p(ped), period, 16.0, stream()))
+    ref = lin * 16.0 + pe[torch.arange(M) % period]
+    assert relerr(out, ref) < RTOL[prec]
+
+
+def test_gemm_rejects_bad_k():
+    a = torch.zeros(4, 100, device="cuda")
+    rc = hip.lib().cn_op_gemm(0, p(a), 100, p(a), None, p(a), 4, 1, 4, 4, 100, 0, None, 0, None, 1, 1.0, stream())
+    assert rc != 0 and b"multiple" in hip.lib().cn_last_error()
+
+
+# ----------------------------------------------------------------------------------------------- convs
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("B,T,Fd,Cc", [(2, 61, 80, 128), (1, 8, 6, 64), (3, 100, 83, 64)])
+def test_conv1_conv2(prec, B, T, Fd, Cc):
+    g = torch.Generator().manual_seed(B * T)
+    x = torch.randn(B, T, Fd, generator=g)
+    w1 = torch.randn(Cc, 1, 3, 3, generator=g) / 3
+    b1 = torch.randn(Cc, generator=g) * 0.1
+    w2 = torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc)
+    b2 = torch.randn(Cc, generator=g) * 0.1
+    ref1 = F.relu(F.conv2d(x.unsqueeze(1), w1, b1, stride=2, padding=1))  # (B,C,T1,F1)
+    T1, F1 = ref1.shape[2], ref1.shape[3]
+    L = hip.lib()
+    out1 = torch.empty(B, T1, F1, Cc, dtype=tdtype(prec), device="cuda")
+    w9c, xd, b1d, b2d = dev(w1.reshape(Cc, 9).t()), dev(x), dev(b1), dev(b2)
+    hip.check(L.cn_op_conv1(hip.PRECISION[prec], p(xd), p(w9c), p(b1d), p(out1), B, T, Fd, Cc, stream()))
+    torch.cuda.synchronize()
+    assert relerr(out1.float().permute(0, 3, 1, 2), ref1) < (2e-6 if prec == "fp32" else 5e-3)
+    # conv2 on the kernel's own (rounded) conv1 output so that only conv2's arithmetic is compared
+    c1 = out1.float().cpu().permute(0, 3, 1, 2)
+    ref2 = F.relu(F.conv2d(c1, rounded(w2, prec), b2, stride=2, padding=1))  # (B,C,T2,F2)
+    T2, F2 = ref2.shape[2], ref2.shape[3]
+    out2 = torch.empty(B, T2, F2, Cc, dtype=tdtype(prec), device="cuda")
+    wk = dev(w2.permute(0, 2, 3, 1).reshape(Cc, 9 * Cc), tdtype(prec))
+    hip.check(L.cn_op_conv2(hip.PRECISION[prec], p(out1), p(wk), p(b2d), p(out2), B, T1, F1, Cc, stream()))
+    torch.cuda.synchronize()
+    assert relerr(out2.float().permute(0, 3, 1, 2), ref2) < RTOL[prec]
+
+
+# ----------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,d", [(1, 128), (1001, 256), (37, 512), (5, 1024)])
+def test_layernorm(prec, M, d):
+    from oracle.cassnat_oracle import layer_norm
+
+    g = torch.Generator().manual_seed(d)
+    x = torch.randn(M, d, generator=g) * 3 + 0.5
+    a2, b2 = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    y = torch.empty(M, d, dtype=tdtype(prec), device="cuda")
+    xd, ad, bd = dev(x), dev(a2), dev(b2)
+    hip.check(hip.lib().cn_op_layernorm(hip.PRECISION[prec], p(xd), p(ad), p(bd), p(y), M, d, 1e-6, stream()))
+    torch.cuda.synchronize()
+    assert relerr(y, layer_norm(x, a2, b2)) < (3e-6 if prec == "fp32" else 5e-3)
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def attention_reference(q, k, v, mask):
+    """q (B,Lq,H,64) etc; mask (B,Lq|1,Lk) bool.  src/models/modules/attention.py:13-24 semantics."""
+    scores = torch.einsum("bqhd,bkhd->bhqk", q, k) / 8.0
+    scores = scores.masked_fill(mask.unsqueeze(1) == 0, float(np.finfo(np.float32).min))
+    pa = torch.softmax(scores, dim=-1)
+    return torch.einsum("bhqk,bkhd->bqhd", pa, v)
+
+
+def run_attention(prec, q, k, v, keymask=None, klen=None, intervals=None, causal=0):
+    B, Lq, H, _ = q.shape
+    Lk = k.shape[1]
+    td = tdtype(prec)
+    qd, kd, vd = dev(q.reshape(B * Lq, H * 64), td), dev(k.reshape(B * Lk, H * 64), td), dev(v.reshape(B * Lk, H * 64), td)
+    o = torch.full((B * Lq, H * 64), float("nan"), dtype=td, device="cuda")
+    km = None if keymask is None else dev(keymask.to(torch.uint8))
+    kl = None if klen is None else dev(klen, torch.int32)
+    iv = None if intervals is None else dev(intervals, torch.int32)
+    hip.check(hip.lib().cn_op_attention(hip.PRECISION[prec], p(qd), H * 64, p(kd), H * 64, p(vd), H * 64, p(o), H * 64, B, H,
+                                        Lq, Lk, p(km), p(kl), p(iv), 0 if iv is None else intervals.shape[1], causal,
+                                        0.125, stream()))
+    torch.cuda.synchronize()
+    return o.float().cpu().reshape(B, Lq, H, 64)
+
+
+ATT_TOL = {"fp32": 1e-5, "bf16": 2e-2}
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("Lq,Lk", [(250, 250), (50, 16), (171, 300), (128, 64), (129, 65)])
+def test_attention_key_padding(prec, Lq, Lk):
+    g = torch.Generator().manual_seed(Lq * 7 + Lk)
+    B, H = 3, 2
+    q, k, v = (torch.randn(B, L, H, 64, generator=g) for L in (Lq, Lk, Lk))
+    lens = torch.tensor([Lk, max(1, Lk * 2 // 3), max(1, Lk // 5)])
+    keymask = torch.arange(Lk)[None, :] < lens[:, None]
+    keymask[1, Lk // 3] = False  # a hole: first feature exactly 0.0 inside an utterance
+    ref = attention_reference(rounded(q, prec), rounded(k, prec), rounded(v, prec), keymask[:, None, :])
+    got = run_attention(prec, q, k, v, keymask=keymask)
+    assert relerr(got, ref) < ATT_TOL[prec]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_attention_trigger_intervals_and_empty_rows(prec):
+    g = torch.Generator().manual_seed(99)
+    B, H, Lq, Lk = 2, 4, 70, 150
+    q, k, v = (torch.randn(B, L, H, 64, generator=g) for L in (Lq, Lk, Lk))
+    keymask = torch.ones(B, Lk, dtype=torch.bool)
+    keymask[1, 120:] = False
+    iv = torch.zeros(B, Lq + 3, 4, dtype=torch.int32)
+    dense = torch.zeros(B, Lq, Lk, dtype=torch.bool)
+    for b in range(B):
+        edges = np.sort(np.random.default_rng(b).choice(np.arange(1, Lk), size=40, replace=False))
+        lo = 0
+        for u, hi in enumerate(edges):
+            iv[b, u, 0], iv[b, u, 1] = lo, int(hi)
+            dense[b, u, lo:hi] = True
+            lo = int(hi)
+        iv[b, 40, 2], iv[b, 40, 3] = 7, 8  # a forced single frame as the second interval
+        dense[b, 40, 7] = True
+        # rows 41.. stay empty -> uniform attention over all Lk keys (float-min fill, not -inf)
+    dense &= keymask[:, None, :]
+    ref = attention_reference(rounded(q, prec), rounded(k, prec), rounded(v, prec), dense)
+    got = run_attention(prec, q, k, v, keymask=keymask, intervals=iv)
+    assert relerr(got, ref) < ATT_TOL[prec]
+    # an empty row really is the mean of V over every key, padded ones included
+    assert relerr(got[0, 50], rounded(v, prec)[0].mean(0)) < ATT_TOL[prec]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("causal", [0, 1])
+def test_attention_target_length_mask(prec, causal):
+    g = torch.Generator().manual_seed(5 + causal)
+    B, H, U = 3, 4, 97
+    q, k, v = (torch.randn(B, U, H, 64, generator=g) for _ in range(3))
+    ylen = torch.tensor([97, 40, 1])
+    mask = (torch.arange(U)[None, :] < ylen[:, None])[:, None, :].expand(B, U, U).clone()
+    if causal:
+        mask &= torch.tril(torch.ones(U, U, dtype=torch.bool))[None]
+    ref = attention_reference(rounded(q, prec), rounded(k, prec), rounded(v, prec), mask)
+    got = run_attention(prec, q, k, v, klen=ylen, causal=causal)
+    assert relerr(got, ref) < ATT_TOL[prec]
+
+
+def test_attention_large_scores_fp32():
+    """forces the online-softmax rescale: the row maximum jumps by ~80 in a late key tile"""
+    g = torch.Generator().manual_seed(1)
+    B, H, Lq, Lk = 1, 1, 40, 200
+    q, k, v = (torch.randn(B, L, H, 64, generator=g) for L in (Lq, Lk, Lk))
+    k[0, 170, 0] = q[0, 3, 0] * 10.0
+    ref = attention_reference(q, k, v, torch.ones(B, 1, Lk, dtype=torch.bool))
+    got = run_attention("fp32", q, k, v)
+    assert relerr(got, ref) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- generator tail
+@pytest.mark.parametrize("M,V", [(37, 5000), (5, 40), (3, 1028)])
+def test_logsoftmax_argmax(M, V):
+    g = torch.Generator().manual_seed(V)
+    x = torch.randn(M, V, generator=g)
+    x[1, 7] = x[1].max() + 1.0
+    x[1, 3] = x[1, 7]  # exact tie: the first index must win (torch.argmax on CPU)
+    xd = dev(x)
+    arg = torch.empty(M, dtype=torch.int32, device="cuda")
+    mlp = torch.empty(M, dtype=torch.float32, device="cuda")
+    hip.check(hip.lib().cn_op_logsoftmax_argmax(p(xd), M, V, p(arg), p(mlp), 1, stream()))
+    torch.cuda.synchronize()
+    ref = torch.log_softmax(x, -1)
+    assert (xd.cpu() - ref).abs().max().item() < 2e-6
+    assert arg.cpu().tolist() == ref.argmax(-1).tolist() and arg[1].item() == 3
+    assert (mlp.cpu() - ref.max(-1).values).abs().max().item() < 2e-6
+
+
+def test_topk():
+    g = torch.Generator().manual_seed(8)
+    x = torch.log_softmax(torch.randn(19, 5000, generator=g), -1)
+    idx = torch.empty(19, 5, dtype=torch.int32, device="cuda")
+    val = torch.empty(19, 5, dtype=torch.float32, device="cuda")
+    xd = dev(x)
+    hip.check(hip.lib().cn_op_topk(p(xd), 19, 5000, 5, p(idx), p(val), stream()))
+    torch.cuda.synchronize()
+    ref = torch.topk(x, 5, dim=-1)
+    assert idx.cpu().tolist() == ref.indices.tolist()
+    assert torch.equal(val.cpu(), ref.values)
+
+
+# ----------------------------------------------------------------------------------------------- integer kernels
+def run_align(best, mask, ratio, left=0, right=0):
+    B, Tp = best.shape
+    shift = torch.empty(B, Tp, dtype=torch.int32, device="cuda")
+    src = torch.empty(B, dtype=torch.int32, device="cuda")
+    ylen = torch.empty(B, dtype=torch.int32, device="cuda")
+    ymax = torch.zeros(1, dtype=torch.int32, device="cuda")
+    iv = torch.empty(B, Tp + 1, 4, dtype=torch.int32, device="cuda")
+    bd, md, rd = dev(best, torch.int32), dev(mask.astype(np.uint8)), dev(ratio)
+    hip.check(hip.lib().cn_op_ctc_align(p(bd), p(md), p(rd), B, Tp, 0, left, right, p(shift), p(src), p(ylen), p(ymax), p(iv),
+                                        stream()))
+    torch.cuda.synchronize()
+    return shift.cpu().numpy(), src.cpu().numpy(), ylen.cpu().numpy(), int(ymax.item()), iv.cpu().numpy()
+
+
+def dense_from_intervals(iv, mask, ymax):
+    B, Tp = mask.shape
+    t = np.arange(Tp)[None, None, :]
+    s1, e1, s2, e2 = (iv[:, :ymax, i][:, :, None] for i in range(4))
+    return (((t >= s1) & (t < e1)) | ((t >= s2) & (t < e2))) & mask[:, None, :]
+
+
+def test_ctc_align_known_answer(golden):
+    g = golden("align_kat")
+    shift, src, ylen, ymax, iv = run_align(g["path"], g["mask"], np.array([1.0, 8 / 12], np.float32))
+    np.testing.assert_array_equal(shift, g["aligned_seq_shift"])
+    np.testing.assert_array_equal(src, g["src_size"])
+    np.testing.assert_array_equal(ylen, g["ylen"])
+    assert ymax == int(g["ymax"])
+    np.testing.assert_array_equal(dense_from_intervals(iv, g["mask"], ymax), g["trigger"])
+
+
+@pytest.mark.parametrize("left,right", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("Tp", [12, 250, 700])
+def test_ctc_align_random_vs_oracle(Tp, left, right):
+    from oracle import cassnat_oracle as orc
+
+    rng = np.random.default_rng(Tp + 10 * left + right)
+    B = 9
+    best = rng.integers(0, 6, size=(B, Tp)) * (rng.random((B, Tp)) < 0.5)
+    lens = rng.integers(1, Tp + 1, size=B)
+    lens[0] = Tp
+    mask = np.arange(Tp)[None, :] < lens[:, None]
+    mask[2, rng.integers(0, lens[2], size=3)] = False  # holes
+    best[3] = 0  # an utterance with no tokens at all
+    best[4, lens[4] - 1] = 5  # a token on the very last valid frame (dropped by the shift)
+    ratio = (lens / Tp).astype(np.float32)
+    ratio[5] = np.float32((lens[5] - 0.6) / Tp)  # src_size one short of the mask length
+    shift, src, ylen, ymax, iv = run_align(best, mask, ratio, left, right)
+    o_shift, o_ylen0, o_ymax0 = orc.best_path_align(best, mask)
+    o_src = orc.src_size_frames(ratio, Tp)
+    o_trig, o_ylen, o_ymax = orc.align_to_intervals(o_shift, o_ylen0, o_ymax0, mask, o_src, 0, left, right)
+    np.testing.assert_array_equal(shift, o_shift)
+    np.testing.assert_array_equal(src, o_src)
+    np.testing.assert_array_equal(ylen, o_ylen)
+    assert ymax == o_ymax
+    np.testing.assert_array_equal(dense_from_intervals(iv, mask, ymax), o_trig)
+
+
+def test_greedy_pack_matches_oracle():
+    from oracle import cassnat_oracle as orc
+
+    rng = np.random.default_rng(4)
+    B, U, V = 6, 23, 50
+    att = torch.log_softmax(torch.from_numpy(rng.standard_normal((B, U, V)).astype(np.float32)), -1)
+    ylen = np.array([23, 22, 10, 1, 5, 23])
+    best = att.max(-1)
+    hyp = torch.full((B, U + 2), -1, dtype=torch.int32, device="cuda")
+    hl = torch.empty(B, dtype=torch.int32, device="cuda")
+    sc = torch.empty(B, dtype=torch.float64, device="cuda")
+    td, vd, yd = dev(best.indices, torch.int32), dev(best.values), dev(ylen, torch.int32)
+    hip.check(hip.lib().cn_op_greedy_pack(p(td), p(vd), p(yd), B, U, 1, U + 2, p(hyp), p(hl), p(sc), stream()))
+    torch.cuda.synchronize()
+    o_hyp, o_sc = orc.greedy_finish(att, ylen, U)
+    for b in range(B):
+        assert hyp[b, : hl[b]].cpu().tolist() == o_hyp[b]
+        assert sc[b].item() == o_sc[b]  # sequential double sum: bit-identical
