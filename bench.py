@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the CASS-NAT inference hot path on MI355X (BASELINE.json: utterances/sec + RTF).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (CassNAT.beam_decode: conv subsampling -> 12L encoder -> CTC greedy
+alignment -> token-acoustic extractor -> NAT decoder -> greedy finish) over one synthetic batch of
+32 utterances x 1000 frames x 80-dim fbank per GPU (BASELINE configs[1]), features resident in HBM, bf16 MFMA
+with fp32 accumulation, random-init weights of the named architecture (seeded; blank-biased for a realistic
+token count).  With N > 1 every rank decodes its own shard (weak scaling); rank 0 packs the checkpoint once and
+the weight blob is broadcast over RCCL; each step ends with one all-gather of the hypothesis records.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (timed live with HIP events on the launch
+stream inside the timed region); `cpu_baseline` is the oracle (torch-CPU restatement of the reference's ATen op
+sequence, kind "port") timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_batch(B, T, F, U, a):
+    """Algorithmic FLOPs of one batch (SURVEY 8d formula, FLOP = 2 MAC)."""
+    d, V, dff_e, dff_d = a.d_model, a.vocab_size, a.d_encff, a.d_decff
+    T1, F1 = (T - 1) // 2 + 1, (F - 1) // 2 + 1
+    Tp, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+    mac = B * d * T1 * F1 * 9 + B * d * Tp * F2 * 9 * d + B * Tp * d * F2 * d
+    mac += a.N_enc * B * Tp * (4 * d * d + 2 * Tp * d + 2 * d * dff_e)
+    mac += B * Tp * d * V
+    mac += a.N_extra * (2 * B * U * d * d + 2 * B * Tp * d * d + 2 * B * U * Tp * d + 2 * B * U * d * dff_d)
+    mac += a.N_self_dec * B * U * (4 * d * d + 2 * U * d + 2 * d * dff_d)
+    mac += a.N_mix_dec * (B * U * (6 * d * d + 2 * U * d + 2 * Tp * d + 2 * d * dff_d) + 2 * B * Tp * d * d)
+    mac += B * U * d * V
+    return 2.0 * mac
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batches", type=int, default=3)
+    ap.add_argument("--stage-profile", action="store_true", help="also print a per-kernel-tag table to stderr")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from cassnat_asr_public_amd import dist as cdist
+    from cassnat_asr_public_amd import hip, synth
+    from cassnat_asr_public_amd.models.cassnat import make_model
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    class Vocab:
+        word2index = {"blank": 0, "sos": 1, "eos": 2, "unk": 3}
+
+    args = synth.make_args("config2")
+    args.hip_precision = a.precision
+    args.hip_max_batch, args.hip_max_frames = a.batch, a.frames
+    B, T, F = a.batch, a.frames, args.input_size
+
+    # ---- model: rank 0 owns the checkpoint, everyone else receives the packed blob over RCCL
+    model = make_model(F, args).cuda(local_rank)
+    state = None
+    if rank == 0:
+        state = synth.make_state(args, seed=0, blank_bias=synth.BENCH_BLANK_BIAS)
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                p.copy_(torch.from_numpy(state[k]))
+    eng = model.build_engine(B, T, with_weights=(rank == 0))
+    blob_bytes = eng.weight_blob()[1]
+    bcast_ms = None
+    if world > 1:
+        t0 = time.perf_counter()
+        cdist.broadcast_weights(eng, src=0)
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+
+    # ---- synthetic batch, resident in HBM before the timed region (each rank its own shard)
+    feats_h, sizes_h = synth.make_feats(B, T, F, seed=1234 + rank)
+    feats = torch.from_numpy(feats_h).cuda()
+    sizes = torch.from_numpy(sizes_h).cuda()
+
+    def step():
+        hyp, hyp_len, score = model.decode_device(feats, sizes, args)
+        rec = cdist.pack_records(hyp, hyp_len, score)
+        if world > 1:
+            rec = cdist.all_gather_records(rec)
+        return cdist.unpack_records(rec)  # hypotheses materialised on the host, as beam_decode returns them
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        hyps, _ = step()
+    U = int(eng.fetch("ymax")[0])
+    fence()
+    eng.profile_begin(["conv2"])  # the dominant kernel: two event records per step
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        hyps, scores = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_end()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- per-stage breakdown outside the timed region
+    eng.profile_begin(None)
+    for _ in range(3):
+        step()
+    stages = eng.profile_end()
+    stage_ms = {k: round(v["ms"] / 3, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])}
+    if a.stage_profile and rank == 0:
+        for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"]):
+            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0
+            gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0
+            print(f"{k:20s} n={v['count'] // 3:3d} {v['ms'] / 3:8.3f} ms  {tf:8.1f} TFLOP/s  {gb:8.1f} GB/s(alg)", file=sys.stderr)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    utts = a.steps * B * world
+    value = utts / elapsed
+    audio_s = utts * T * 0.01
+    flops = flops_per_batch(B, T, F, U, args)
+    c2 = prof.get("conv2", {"count": 0, "ms": 0.0, "flops": 0.0})
+    roofline = None
+    if c2["count"]:
+        avg_s = c2["ms"] / c2["count"] * 1e-3
+        ach = c2["flops"] / c2["count"] / avg_s / 1e12
+        pmc = None
+        pmc_path = os.path.join(REPO, "profiles", "pmc_conv2.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                pmc = None
+        roofline = {"kernel": "gemm_kernel<bf16,128x128,implicit-conv> (conv2: 3x3/s2 256->256 subsampling conv)",
+                    "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS if a.precision == "bf16" else 157.3,
+                    "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_DENSE_TFLOPS if a.precision == "bf16" else 157.3), 4),
+                    "traffic": pmc, "flops_per_launch": c2["flops"] / c2["count"], "avg_launch_us": round(avg_s * 1e6, 2),
+                    "launches_timed": c2["count"]}
+
+    cpu = None
+    if not a.no_cpu_baseline and world == 1:
+        from oracle import cassnat_oracle as orc
+
+        # host threads: this process's CPU share, not the machine's core count (a 1-GPU box gets 16 cores)
+        try:
+            ncores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncores = os.cpu_count() or 1
+        ncores = max(1, min(ncores, int(os.environ.get("CASSNAT_CPU_THREADS", "16"))))
+        torch.set_num_threads(ncores)
+        st = orc.to_torch_state(state)
+        orc.decode_nast(st, feats_h, sizes_h, args)  # warm-up
+        times = []
+        for _ in range(a.cpu_batches):
+            c0 = time.perf_counter()
+            ref = orc.decode_nast(st, feats_h, sizes_h, args)
+            times.append(time.perf_counter() - c0)
+        med = float(np.median(times))
+        cpu = {"value": round(B / med, 3), "unit": "utt/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{a.cpu_batches} batches of {B} x {T} frames (same workload), median of per-batch wall time "
+                         f"{med:.2f} s after 1 warm-up; RTF {med / (B * T * 0.01):.5f}",
+               "hyp_agreement_with_gpu": round(float(np.mean([h == r for h, r in zip(hyps[:B], ref["hyps"])])), 3)}
+
+    out = {
+        "metric": "utterances_per_sec", "value": round(value, 2), "unit": "utt/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: CASS-NAT 12L-enc / 1+3+2 dec blocks, d_model 256, 4 heads, d_ff 2048, "
+                               "V 5000, greedy NAST; 32 utterances x 1000 frames x 80 fbank per GPU per step",
+                   "batch_per_gpu": B, "frames": T, "feat_dim": F, "global_batch": B * world, "tokens_U_max": U,
+                   "parallelism": f"utterance-sharded x{world}", "blank_bias": synth.BENCH_BLANK_BIAS},
+        "rtf": round(elapsed / audio_s, 8), "rtfx": round(audio_s / elapsed, 1),
+        "gflop_per_utt": round(flops / B / 1e9, 3),
+        "mfma_frac_end_to_end": round(flops / B * value / (PEAK_BF16_DENSE_TFLOPS * 1e12), 5),
+        "roofline": roofline, "cpu_baseline": cpu, "stage_ms": stage_ms,
+        "weight_blob_mb": round(blob_bytes / 1e6, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
+    }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,22 +9,29 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
                                                     const float* __restrict__ bias, T* __restrict__ out, int B, int Tn,
                                                     int F, int T1, int F1, int C) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* w_s = reinterpret_cast<float*>(smem);  // [9][C] then bias[C]
-    for (int i = threadIdx.x; i < 10 * C; i += 256) w_s[i] = i < 9 * C ? w9c[i] : bias[i - 9 * C];
-    __syncthreads();
+    // A thread keeps its 8 channels for the whole grid-stride loop (the stride is a multiple of C/8), so the
+    // 72 tap weights + 8 biases live in registers; per output position it issues 9 (wave-broadcast) loads,
+    // 72 FMAs and one 16-byte store.
     const int cg = C >> 3;
     const long long total = (long long)B * T1 * F1 * cg;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int g = (int)(idx % cg);
+    const long long first = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c0 = (int)(first % cg) << 3;
+    float w[9][8], bz[8];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[tap][j] = w9c[tap * C + c0 + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bz[j] = bias[c0 + j];
+    const long long stride = (long long)gridDim.x * 256;  // launcher keeps this a multiple of cg
+    for (long long idx = first; idx < total; idx += stride) {
         const long long pos = idx / cg;
         const int f1 = (int)(pos % F1);
         const long long bt = pos / F1;
         const int t1 = (int)(bt % T1), b = (int)(bt / T1);
-        const int c0 = g << 3;
         float acc[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = w_s[9 * C + c0 + j];
+        for (int j = 0; j < 8; ++j) acc[j] = bz[j];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int t = 2 * t1 - 1 + kh;
@@ -33,9 +40,8 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
                 const int f = 2 * f1 - 1 + kw;
                 float v = 0.f;
                 if (t >= 0 && t < Tn && f >= 0 && f < F) v = x[((long long)b * Tn + t) * F + f];
-                const float* wr = w_s + (kh * 3 + kw) * C + c0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, w[kh * 3 + kw][j], acc[j]);
             }
         }
         T* dst = out + pos * C + c0;
@@ -59,15 +65,15 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
 
 int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1,
                  int F1, int C, hipStream_t s) {
-    if (C % 8 != 0) {
-        cn_set_error("conv1: channel count must be a multiple of 8");
+    if (C % 8 != 0 || (256 % (C / 8)) != 0) {
+        cn_set_error("conv1: channel count must be a multiple of 8 with C/8 dividing 256");
         return -1;
     }
     const long long total = (long long)B * T1 * F1 * (C / 8);
     long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond 64 workgroups per CU
+    if (blocks > 256 * 8) blocks = 256 * 8;  // 8 workgroups per CU, grid-stride the rest (256 threads % (C/8) == 0)
     if (blocks < 1) blocks = 1;
-    const size_t lds = 10 * (size_t)C * sizeof(float);
+    const size_t lds = 0;
     if (prec == CN_PREC_F32)
         hipLaunchKernelGGL(conv1_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (float*)out, B, T,
                            F, T1, F1, C);

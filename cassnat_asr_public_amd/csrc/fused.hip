@@ -1,0 +1,330 @@
+// Fused position-wise feed-forward sublayer for gfx950 (bf16 MFMA, d_model = 256):
+//     x <- x + W2 . relu(W1 . LN(x) + b1) + b2          [and optionally  xn_next <- LN_next(x)]
+// Replaces SublayerConnection(LayerNorm -> PositionwiseFeedForward) of the reference
+// (src/models/modules/utils.py:23-32, positionff.py:15-16, norm.py:15-18) - four launches (LN, w_1+ReLU,
+// w_2+residual, next LN) and a 2 x M x d_ff round trip of the hidden activations through HBM.
+//
+// Shape of the problem at B=32: M = 8000 rows, d = 256, d_ff = 2048.  With only 32 rows per workgroup (250
+// workgroups for 256 CUs) a weight fragment is used by exactly one MFMA per workgroup, so staging weights in
+// LDS buys no reuse.  Instead:
+//   * weights are pre-tiled at pack time into MFMA fragment order; every wave streams ITS slice of d_ff as
+//     fully coalesced 1-KiB pieces (64 lanes x 16 B) by LDS-DMA (global_load_lds_dwordx4) into a private
+//     32-slot ring - one slot per fragment of a hidden tile, refilled for the next tile right after its
+//     MFMA - so ~31 KiB per wave stay in flight at no VGPR cost, every wait is a counted vmcnt(28) on the
+//     wave's own queue, and there is no barrier in the main loop;
+//   * the first product is computed swapped, X[f][m] = sum_k W1[f][k] xn[m][k], so its 32x32 accumulator
+//     (f on rows, m on lanes) is, after bias+ReLU and a bf16 pack, directly the B operand of the second
+//     product out^T[n][m] += sum_f W2[n][f] X[f][m]; W2 is packed in the k-order that operand implies.
+//     The hidden activations never leave registers.
+//   * each wave owns d_ff/4 of the hidden units and a full 256x32 fp32 partial of out^T; the four partials
+//     are summed through LDS once per workgroup, fused with bias, residual add and the next LayerNorm.
+// The kernel is bound by the per-CU L2 bandwidth of the weight stream (2 MB per workgroup), not by MFMA.
+#include <cstring>
+
+#include "kernels.h"
+
+struct FfnParams {
+    float* x;  // [M][256] residual stream, updated in place
+    const float* ln_a;
+    const float* ln_b;
+    const bf16x8* w1p;  // [dff/32][16][64]   A fragments of W1 (rows f, natural k order)
+    const float* b1;    // [dff]
+    const bf16x8* w2p;  // [dff/32][2][8][64] A fragments of W2 (rows n, k = f in accumulator-operand order)
+    const float* b2;    // [256]
+    const float* nln_a;  // next LayerNorm (may be null)
+    const float* nln_b;
+    bf16* xn_out;  // [M][256] bf16, written when nln_a != null
+    int M, dff;
+    float eps;
+};
+
+constexpr int FF_D = 256;
+constexpr int FF_BM = 32;
+constexpr int FF_XN_STRIDE = 528;      // bytes per xn row in LDS: 512 + 16 pad (conflict-free b128 reads)
+constexpr int FF_P_STRIDE = FF_D + 4;  // floats per partial row in LDS
+constexpr int FF_MAX_DFF = 2048;
+constexpr int FF_XN_BYTES = FF_BM * FF_XN_STRIDE;        // 16896
+constexpr int FF_B1_BYTES = FF_MAX_DFF * 4;              // 8192
+constexpr int FF_RING_BYTES = 32 * 1024;                 // per wave: 32 fragments of 1 KiB
+constexpr int FF_LDS_BYTES = FF_XN_BYTES + FF_B1_BYTES + 4 * FF_RING_BYTES;  // 156160 (partials alias b1 + rings)
+static_assert(4 * FF_BM * FF_P_STRIDE * 4 <= FF_B1_BYTES + 4 * FF_RING_BYTES, "partials must fit behind the xn tile");
+
+__device__ __forceinline__ void ln_row_to(const f32x4 v, float mean, float denom, const f32x4 g, const f32x4 bb,
+                                          float* o) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[j] - mean) / denom + bb[j];
+}
+
+__global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xn_s = smem;                                          // [32][528 B]
+    float* b1_s = reinterpret_cast<float*>(smem + FF_XN_BYTES);          // [dff]
+    float* part = reinterpret_cast<float*>(smem + FF_XN_BYTES);          // [4][32][260], aliases b1_s + rings at the end
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * FF_BM;
+    unsigned char* ring = smem + FF_XN_BYTES + FF_B1_BYTES + __builtin_amdgcn_readfirstlane(wave) * FF_RING_BYTES;
+
+    const int tiles_per_wave = p.dff / 32 / 4;
+    const int ft0 = wave * tiles_per_wave;
+    // fragment stream of this wave: tile t, fragment i (0-15: W1 k-steps, 16-31: W2 (s, nt)) -> 1 KiB piece
+    const uint4* w1 = reinterpret_cast<const uint4*>(p.w1p) + (long long)ft0 * 16 * 64 + lane;
+    const uint4* w2 = reinterpret_cast<const uint4*>(p.w2p) + (long long)ft0 * 16 * 64 + lane;
+#define FF_DMA(src, slot)                                                                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
+                                     (__attribute__((address_space(3))) void*)(ring + (slot) * 1024), 16, 0, 0)
+    // prologue: the whole first tile goes in flight before the LayerNorm below
+#pragma unroll
+    for (int i = 0; i < 16; ++i) FF_DMA(w1 + i * 64, i);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) FF_DMA(w2 + i * 64, 16 + i);
+    for (int i = tid; i < p.dff / 4; i += 256)
+        reinterpret_cast<f32x4*>(b1_s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
+
+    // ---- LayerNorm of the workgroup's 32 rows -> bf16 tile in LDS (wave w: rows w, w+4, ...)
+    {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_a + 4 * lane);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * lane);
+#pragma unroll
+        for (int i = 0; i < FF_BM / 4; ++i) {
+            const int r = wave + 4 * i;
+            int m = m0 + r;
+            if (m >= p.M) m = p.M - 1;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (long long)m * FF_D + 4 * lane);
+            const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)FF_D;
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ss = fmaf(v[j] - mean, v[j] - mean, ss);
+            const float denom = sqrtf(wave_sum(ss) / (float)(FF_D - 1)) + p.eps;
+            float o[4];
+            ln_row_to(v, mean, denom, g, bb, o);
+            bf16x4 ob;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ob[j] = (bf16)o[j];
+            *reinterpret_cast<bf16x4*>(xn_s + r * FF_XN_STRIDE + 8 * lane) = ob;
+        }
+    }
+    __syncthreads();
+    // LDS byte addresses for the inline-asm reads below.  hipcc inserts a full vmcnt(0) in front of every ordinary
+    // LDS access while an LDS-DMA is outstanding (it cannot tell the slots apart), so all main-loop LDS reads are
+    // issued from asm statements that carry their own counted vmcnt / lgkmcnt(0) (cdna_hip_programming.md 5.7, form i).
+    const unsigned xrow_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(xn_s + l31 * FF_XN_STRIDE + 16 * half);
+    const unsigned slot_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(ring + lane * 16);
+    const unsigned bias_a = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(b1_s + 32 * ft0 + 4 * half);
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    // One hidden tile = 8 groups of 4 fragments.  Before group g is read, the DMAs younger than it number
+    // 4*(7-g) (rest of this tile) + 4*g (already re-issued for the next tile) = 28 in steady state, and
+    // 4*(7-g) in the last tile, which issues nothing: each wait is a literal vmcnt on the wave's own queue.
+#define FF_STR2(x) #x
+#define FF_STR(x) FF_STR2(x)
+    // phase A group g: W1 fragments in slots 4g..4g+3, xn fragments of k-steps 4g..4g+3
+#define FF_PHASE_A(g, WAITN, NEXT)                                                                            \
+    {                                                                                                         \
+        bf16x8 wf0, wf1, wf2, wf3, xq0, xq1, xq2, xq3;                                                        \
+        asm volatile("s_waitcnt vmcnt(" FF_STR(WAITN) ")\n\t"                                                 \
+                     "ds_read_b128 %0, %8 offset:" FF_STR((4 * (g) + 0) * 1024) "\n\t"                        \
+                     "ds_read_b128 %1, %8 offset:" FF_STR((4 * (g) + 1) * 1024) "\n\t"                        \
+                     "ds_read_b128 %2, %8 offset:" FF_STR((4 * (g) + 2) * 1024) "\n\t"                        \
+                     "ds_read_b128 %3, %8 offset:" FF_STR((4 * (g) + 3) * 1024) "\n\t"                        \
+                     "ds_read_b128 %4, %9 offset:" FF_STR((4 * (g) + 0) * 32) "\n\t"                          \
+                     "ds_read_b128 %5, %9 offset:" FF_STR((4 * (g) + 1) * 32) "\n\t"                          \
+                     "ds_read_b128 %6, %9 offset:" FF_STR((4 * (g) + 2) * 32) "\n\t"                          \
+                     "ds_read_b128 %7, %9 offset:" FF_STR((4 * (g) + 3) * 32) "\n\t"                          \
+                     "s_waitcnt lgkmcnt(0)"                                                                   \
+                     : "=&v"(wf0), "=&v"(wf1), "=&v"(wf2), "=&v"(wf3), "=&v"(xq0), "=&v"(xq1), "=&v"(xq2),    \
+                       "=&v"(xq3)                                                                             \
+                     : "v"(slot_a), "v"(xrow_a)                                                               \
+                     : "memory");                                                                             \
+        xh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, xq0, xh, 0, 0, 0);                                  \
+        xh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, xq1, xh, 0, 0, 0);                                  \
+        xh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2, xq2, xh, 0, 0, 0);                                  \
+        xh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf3, xq3, xh, 0, 0, 0);                                  \
+        if (NEXT) { _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+            FF_DMA(w1 + ((long long)(t + 1) * 16 + 4 * (g) + j) * 64, 4 * (g) + j); }                         \
+    }
+    // phase B group g: W2 fragments (s = g>>1, nt = 4(g&1)..+3) in slots 16+4g..
+#define FF_PHASE_B(g, WAITN, NEXT)                                                                            \
+    {                                                                                                         \
+        bf16x8 wf0, wf1, wf2, wf3;                                                                            \
+        asm volatile("s_waitcnt vmcnt(" FF_STR(WAITN) ")\n\t"                                                 \
+                     "ds_read_b128 %0, %4 offset:" FF_STR((16 + 4 * (g) + 0) * 1024) "\n\t"                   \
+                     "ds_read_b128 %1, %4 offset:" FF_STR((16 + 4 * (g) + 1) * 1024) "\n\t"                   \
+                     "ds_read_b128 %2, %4 offset:" FF_STR((16 + 4 * (g) + 2) * 1024) "\n\t"                   \
+                     "ds_read_b128 %3, %4 offset:" FF_STR((16 + 4 * (g) + 3) * 1024) "\n\t"                   \
+                     "s_waitcnt lgkmcnt(0)"                                                                   \
+                     : "=&v"(wf0), "=&v"(wf1), "=&v"(wf2), "=&v"(wf3)                                         \
+                     : "v"(slot_a)                                                                            \
+                     : "memory");                                                                             \
+        acc[4 * ((g) & 1) + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, pb[(g) >> 1], acc[4 * ((g) & 1) + 0], 0, 0, 0); \
+        acc[4 * ((g) & 1) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, pb[(g) >> 1], acc[4 * ((g) & 1) + 1], 0, 0, 0); \
+        acc[4 * ((g) & 1) + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2, pb[(g) >> 1], acc[4 * ((g) & 1) + 2], 0, 0, 0); \
+        acc[4 * ((g) & 1) + 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf3, pb[(g) >> 1], acc[4 * ((g) & 1) + 3], 0, 0, 0); \
+        if (NEXT) { _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+            FF_DMA(w2 + ((long long)(t + 1) * 16 + 4 * (g) + j) * 64, 16 + 4 * (g) + j); }                    \
+    }
+    // bias + ReLU on hidden unit f = 32*(ft0+t) + acc_row(r, lane), then pack as the B operand of phase B
+#define FF_RELU_PACK()                                                                                        \
+    bf16x8 pb[2];                                                                                             \
+    {                                                                                                         \
+        f32x4 bv0, bv1, bv2, bv3;                                                                             \
+        const unsigned ba = bias_a + 128 * t;                                                                 \
+        asm volatile("ds_read_b128 %0, %4\n\t"                                                                \
+                     "ds_read_b128 %1, %4 offset:32\n\t"                                                      \
+                     "ds_read_b128 %2, %4 offset:64\n\t"                                                      \
+                     "ds_read_b128 %3, %4 offset:96\n\t"                                                      \
+                     "s_waitcnt lgkmcnt(0)"                                                                   \
+                     : "=&v"(bv0), "=&v"(bv1), "=&v"(bv2), "=&v"(bv3)                                         \
+                     : "v"(ba)                                                                                \
+                     : "memory");                                                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
+            pb[0][e] = (bf16)fmaxf(xh[e] + bv0[e], 0.f);                                                      \
+            pb[0][4 + e] = (bf16)fmaxf(xh[4 + e] + bv1[e], 0.f);                                              \
+            pb[1][e] = (bf16)fmaxf(xh[8 + e] + bv2[e], 0.f);                                                  \
+            pb[1][4 + e] = (bf16)fmaxf(xh[12 + e] + bv3[e], 0.f);                                             \
+        }                                                                                                     \
+    }
+
+    int t = 0;
+    for (; t + 1 < tiles_per_wave; ++t) {
+        f32x16 xh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xh[r] = 0.f;
+        FF_PHASE_A(0, 28, true) FF_PHASE_A(1, 28, true) FF_PHASE_A(2, 28, true) FF_PHASE_A(3, 28, true)
+        FF_RELU_PACK()
+        FF_PHASE_B(0, 28, true) FF_PHASE_B(1, 28, true) FF_PHASE_B(2, 28, true) FF_PHASE_B(3, 28, true)
+    }
+    {
+        f32x16 xh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xh[r] = 0.f;
+        FF_PHASE_A(0, 28, false) FF_PHASE_A(1, 24, false) FF_PHASE_A(2, 20, false) FF_PHASE_A(3, 16, false)
+        FF_RELU_PACK()
+        FF_PHASE_B(0, 12, false) FF_PHASE_B(1, 8, false) FF_PHASE_B(2, 4, false) FF_PHASE_B(3, 0, false)
+    }
+#undef FF_PHASE_A
+#undef FF_PHASE_B
+#undef FF_RELU_PACK
+#undef FF_DMA
+    __syncthreads();  // every wave is done with b1_s and its ring (all DMAs landed: last wait was vmcnt(0))
+
+    // ---- cross-wave reduction of out^T partials, + b2 + residual, next LayerNorm
+    float* mine = part + (wave * FF_BM + l31) * FF_P_STRIDE;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[nt][4 * g + e];
+            *reinterpret_cast<f32x4*>(mine + 32 * nt + 8 * g + 4 * half) = o;
+        }
+    __syncthreads();
+    const f32x4 b2v = *reinterpret_cast<const f32x4*>(p.b2 + 4 * lane);
+    f32x4 ng, nb;
+    if (p.nln_a) {
+        ng = *reinterpret_cast<const f32x4*>(p.nln_a + 4 * lane);
+        nb = *reinterpret_cast<const f32x4*>(p.nln_b + 4 * lane);
+    }
+#pragma unroll
+    for (int i = 0; i < FF_BM / 4; ++i) {
+        const int r = wave + 4 * i;
+        const int m = m0 + r;
+        if (m >= p.M) continue;  // wave-uniform
+        float* xr = p.x + (long long)m * FF_D + 4 * lane;
+        f32x4 v = *reinterpret_cast<const f32x4*>(xr);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(part + (w * FF_BM + r) * FF_P_STRIDE + 4 * lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += q[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += b2v[j];
+        *reinterpret_cast<f32x4*>(xr) = v;
+        if (p.nln_a) {
+            const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)FF_D;
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ss = fmaf(v[j] - mean, v[j] - mean, ss);
+            const float denom = sqrtf(wave_sum(ss) / (float)(FF_D - 1)) + p.eps;
+            float o[4];
+            ln_row_to(v, mean, denom, ng, nb, o);
+            bf16x4 ob;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ob[j] = (bf16)o[j];
+            *reinterpret_cast<bf16x4*>(p.xn_out + (long long)m * FF_D + 4 * lane) = ob;
+        }
+    }
+}
+
+int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s) {
+    if (a.d != FF_D || a.dff <= 0 || a.dff % 128 != 0 || a.dff > FF_MAX_DFF) {
+        cn_set_error("ffn_fused: needs d_model == 256 and d_ff % 128 == 0, d_ff <= 2048");
+        return -1;
+    }
+    if (a.M <= 0) return 0;
+    FfnParams p;
+    p.x = a.x;
+    p.ln_a = a.ln_a;
+    p.ln_b = a.ln_b;
+    p.w1p = reinterpret_cast<const bf16x8*>(a.w1p);
+    p.b1 = a.b1;
+    p.w2p = reinterpret_cast<const bf16x8*>(a.w2p);
+    p.b2 = a.b2;
+    p.nln_a = a.nln_a;
+    p.nln_b = a.nln_b;
+    p.xn_out = reinterpret_cast<bf16*>(a.xn_out);
+    p.M = a.M;
+    p.dff = a.dff;
+    p.eps = a.eps;
+    static bool attr_done = false;
+    if (!attr_done) {
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         FF_LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(ffn_fused_kernel, dim3(cn_ceil_div(a.M, FF_BM)), dim3(256), FF_LDS_BYTES, s, p);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- host-side packing of nn.Linear weights into the fragment streams above -----------------------------
+static inline uint16_t bf16_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// W1 [dff][256] fp32 -> [dff/32][16][64][8] bf16 :  frag(ft, ks, lane)[j] = W1[32ft + (lane&31)][16ks + 8(lane>>5) + j]
+void pack_ffn_w1(const float* w1, int dff, uint16_t* out) {
+    for (int ft = 0; ft < dff / 32; ++ft)
+        for (int ks = 0; ks < 16; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j)
+                    out[(((size_t)ft * 16 + ks) * 64 + lane) * 8 + j] =
+                        bf16_bits(w1[(size_t)(32 * ft + (lane & 31)) * FF_D + 16 * ks + 8 * (lane >> 5) + j]);
+}
+
+// W2 [256][dff] fp32 -> [dff/32][2][8][64][8] bf16 :
+//   frag(ft, s, nt, lane)[j] = W2[32nt + (lane&31)][32ft + 16s + 8(j>>2) + 4(lane>>5) + (j&3)]
+// (element j of lane half h of an accumulator used as a 32x32x16 B operand is accumulator row 16s + 8(j>>2) + 4h + (j&3))
+void pack_ffn_w2(const float* w2, int dff, uint16_t* out) {
+    for (int ft = 0; ft < dff / 32; ++ft)
+        for (int s = 0; s < 2; ++s)
+            for (int nt = 0; nt < 8; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int f = 32 * ft + 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+                        out[((((size_t)ft * 2 + s) * 8 + nt) * 64 + lane) * 8 + j] =
+                            bf16_bits(w2[(size_t)(32 * nt + (lane & 31)) * dff + f]);
+                    }
+}

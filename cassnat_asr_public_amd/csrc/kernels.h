@@ -87,3 +87,21 @@ int launch_greedy_pack(const int* tok, const float* val, const int* ylen, int B,
                        int* hyp, int* hyp_len, double* score, hipStream_t s);
 // per row top-k (k <= 16) of log-probs [M][V] -> idx/val [M][k], sorted descending (ties: lower index first)
 int launch_topk(const float* logp, int M, int V, int ldl, int k, int* idx, float* val, hipStream_t s);
+
+// ---- fused FFN sublayer, bf16 / d_model == 256                                     (fused.hip)
+//   x <- x + W2 relu(W1 LN(x) + b1) + b2 ;  optionally xn_out <- LN_next(x) in bf16
+struct FfnFusedArgs {
+    float* x = nullptr;
+    const float *ln_a = nullptr, *ln_b = nullptr;
+    const void* w1p = nullptr;  // pack_ffn_w1 image
+    const float* b1 = nullptr;
+    const void* w2p = nullptr;  // pack_ffn_w2 image
+    const float* b2 = nullptr;
+    const float *nln_a = nullptr, *nln_b = nullptr;
+    void* xn_out = nullptr;
+    int M = 0, d = 0, dff = 0;
+    float eps = 1e-6f;
+};
+int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s);
+void pack_ffn_w1(const float* w1, int dff, uint16_t* out);  // [dff][256] fp32 -> fragment stream (dff*256 bf16)
+void pack_ffn_w2(const float* w2, int dff, uint16_t* out);  // [256][dff] fp32 -> fragment stream (dff*256 bf16)

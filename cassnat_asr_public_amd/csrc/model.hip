@@ -44,7 +44,18 @@ struct Layer {
     Linear self_o;
     Linear src_q, src_kv, src_o;  // source attention: Q from the stream, K|V from the encoder memory
     Linear w1, w2;
+    void *w1p = nullptr, *w2p = nullptr;  // fused-FFN fragment streams (bf16, d_model == 256); then w1/w2 hold biases only
     bool has_self = false, has_src = false;
+};
+
+struct ProfPending {
+    const char* tag;
+    hipEvent_t a, b;
+    double flops, bytes;
+};
+struct ProfStat {
+    long long count = 0;
+    double ms = 0, flops = 0, bytes = 0;
 };
 
 struct Capture {
@@ -103,6 +114,14 @@ struct cn_model {
     // last call
     int B = 0, T = 0, T1 = 0, Tp = 0, U = 0, last_k = 0;
     std::map<std::string, Capture> captures;
+
+    // per-kernel-tag timing with HIP events on the launch stream (cn_profile_begin / cn_profile_end)
+    bool prof_on = false;
+    std::string prof_filter;  // empty: every tag
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<ProfPending> prof_pending;
+    std::map<std::string, ProfStat> prof_stats;
 };
 
 namespace {
@@ -113,6 +132,32 @@ int dev_alloc(cn_model* m, void** p, size_t bytes) {
     m->allocs.push_back(*p);
     return 0;
 }
+
+// Brackets the launches of one kernel tag with two events on the stream when profiling is on.
+struct ProfScope {
+    cn_model* m;
+    hipStream_t s;
+    ProfPending pp;
+    bool live = false;
+    ProfScope(cn_model* m_, const char* tag, double flops, double bytes, hipStream_t s_) : m(m_), s(s_) {
+        if (!m->prof_on) return;
+        if (!m->prof_filter.empty() && m->prof_filter.find(std::string("|") + tag + "|") == std::string::npos) return;
+        while (m->ev_pool.size() < m->ev_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            m->ev_pool.push_back(e);
+        }
+        pp.tag = tag;
+        pp.a = m->ev_pool[m->ev_used++];
+        pp.b = m->ev_pool[m->ev_used++];
+        pp.flops = flops;
+        pp.bytes = bytes;
+        live = hipEventRecord(pp.a, s) == hipSuccess;
+    }
+    ~ProfScope() {
+        if (live && hipEventRecord(pp.b, s) == hipSuccess) m->prof_pending.push_back(pp);
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // weight packing
@@ -200,6 +245,30 @@ struct Packer {
         l.b = reinterpret_cast<float*>(bat);
         return l;
     }
+    // feed-forward weights: fragment streams for the fused kernel when it applies, plain matrices otherwise
+    void ffn(Layer& L, const std::string& p, int64_t dff, int64_t d) {
+        const bool fused = m->prec == CN_PREC_BF16 && d == 256 && dff % 128 == 0 && dff <= 2048;
+        if (!fused) {
+            L.w1 = linear({p + ".feed_forward.w_1"}, dff, d);
+            L.w2 = linear({p + ".feed_forward.w_2"}, d, dff);
+            return;
+        }
+        const size_t a1 = reserve((size_t)dff * d * 2), a2 = reserve((size_t)dff * d * 2);
+        if (fill) {
+            const HostTensor* t1 = find(p + ".feed_forward.w_1.weight", {dff, d});
+            const HostTensor* t2 = find(p + ".feed_forward.w_2.weight", {d, dff});
+            if (t1) pack_ffn_w1(t1->data.data(), (int)dff, reinterpret_cast<uint16_t*>(&host[a1]));
+            if (t2) pack_ffn_w2(t2->data.data(), (int)dff, reinterpret_cast<uint16_t*>(&host[a2]));
+        }
+        L.w1p = reinterpret_cast<void*>(a1);
+        L.w2p = reinterpret_cast<void*>(a2);
+        L.w1.N = (int)dff;
+        L.w1.K = (int)d;
+        L.w1.b = vec({p + ".feed_forward.w_1.bias"}, dff);
+        L.w2.N = (int)d;
+        L.w2.K = (int)dff;
+        L.w2.b = vec({p + ".feed_forward.w_2.bias"}, d);
+    }
     Norm norm(const std::string& prefix, int64_t d) {
         Norm n;
         n.a = vec({prefix + ".a_2"}, d);
@@ -269,8 +338,7 @@ int build_weights(cn_model* m) {
         L.has_self = true;
         L.qkv = pk.linear({p + "." + att + ".linears.0", p + "." + att + ".linears.1", p + "." + att + ".linears.2"}, d, d);
         L.self_o = pk.linear({p + "." + att + ".linears.3"}, d, d);
-        L.w1 = pk.linear({p + ".feed_forward.w_1"}, dff, d);
-        L.w2 = pk.linear({p + ".feed_forward.w_2"}, d, dff);
+        pk.ffn(L, p, dff, d);
         for (int i = 0; i < nnorm; ++i) L.n[i] = pk.norm(p + ".sublayer." + std::to_string(i) + ".norm", d);
         return L;
     };
@@ -290,8 +358,7 @@ int build_weights(cn_model* m) {
         const std::string p = "acembed_extractor.layers." + std::to_string(n);
         Layer L;
         add_src(L, p);
-        L.w1 = pk.linear({p + ".feed_forward.w_1"}, c.d_decff, d);
-        L.w2 = pk.linear({p + ".feed_forward.w_2"}, d, c.d_decff);
+        pk.ffn(L, p, c.d_decff, d);
         L.n[0] = pk.norm(p + ".sublayer.0.norm", d);
         L.n[1] = pk.norm(p + ".sublayer.1.norm", d);
         m->extra.push_back(L);
@@ -339,6 +406,8 @@ int build_weights(cn_model* m) {
             rebase_linear(L.src_o, base);
             rebase_linear(L.w1, base);
             rebase_linear(L.w2, base);
+            rebase(L.w1p, base);
+            rebase(L.w2p, base);
         }
     };
     rebase_layers(m->enc);
@@ -412,8 +481,10 @@ int capture(cn_model* m, const char* name, const void* src, bool model_prec, int
 // ---------------------------------------------------------------------------------------------
 // building blocks of the pipeline
 // ---------------------------------------------------------------------------------------------
-int run_linear(cn_model* m, const Linear& l, const void* A, int lda, void* C, int ldc, int c_f32, int M, int epi,
-               const float* resid, int ldr, hipStream_t s) {
+int run_linear(cn_model* m, const char* tag, const Linear& l, const void* A, int lda, void* C, int ldc, int c_f32, int M,
+               int epi, const float* resid, int ldr, hipStream_t s) {
+    ProfScope ps(m, tag, 2.0 * M * l.N * l.K,
+                 (double)M * l.K * m->es + (double)l.N * l.K * m->es + (double)M * l.N * (c_f32 ? 4 : m->es), s);
     GemmArgs g;
     g.A = A;
     g.lda = lda;
@@ -432,24 +503,50 @@ int run_linear(cn_model* m, const Linear& l, const void* A, int lda, void* C, in
 }
 
 int run_ln(cn_model* m, const Norm& n, const float* x, void* y, int M, hipStream_t s) {
+    ProfScope ps(m, "layernorm", 0, (double)M * m->cfg.d_model * (4 + m->es), s);
     return launch_layernorm(m->prec, x, n.a, n.b, y, 0, M, m->cfg.d_model, 1e-6f, s);
 }
 
-// x += FFN(LN(x))                      (SublayerConnection + PositionwiseFeedForward)
-int run_ffn(cn_model* m, const Layer& L, const Norm& n, float* x, int M, hipStream_t s) {
+// x += FFN(LN(x)); when `next` is given, next_out <- LN_next(x) in model precision (fused into the FFN kernel on
+// the bf16/d256 path, a separate LayerNorm launch otherwise)
+int run_ffn(cn_model* m, const Layer& L, const Norm& n, float* x, int M, const Norm* next, void* next_out,
+            hipStream_t s) {
     const int d = m->cfg.d_model;
+    if (L.w1p) {
+        ProfScope ps(m, "ffn_fused", 4.0 * M * (double)L.w1.N * d,
+                     (double)M * d * 8 + 2.0 * L.w1.N * d * 2 + (next ? (double)M * d * 2 : 0.0), s);
+        FfnFusedArgs a;
+        a.x = x;
+        a.ln_a = n.a;
+        a.ln_b = n.b;
+        a.w1p = L.w1p;
+        a.b1 = L.w1.b;
+        a.w2p = L.w2p;
+        a.b2 = L.w2.b;
+        if (next) {
+            a.nln_a = next->a;
+            a.nln_b = next->b;
+            a.xn_out = next_out;
+        }
+        a.M = M;
+        a.d = d;
+        a.dff = L.w1.N;
+        return launch_ffn_fused(a, s);
+    }
     CN_TRY(run_ln(m, n, x, m->xn, M, s));
-    CN_TRY(run_linear(m, L.w1, m->xn, d, m->hbuf, L.w1.N, 0, M, CN_EPI_RELU, nullptr, 0, s));
-    CN_TRY(run_linear(m, L.w2, m->hbuf, L.w1.N, x, d, 1, M, CN_EPI_RESID, x, d, s));
+    CN_TRY(run_linear(m, "ffn_w1_relu", L.w1, m->xn, d, m->hbuf, L.w1.N, 0, M, CN_EPI_RELU, nullptr, 0, s));
+    CN_TRY(run_linear(m, "ffn_w2_resid", L.w2, m->hbuf, L.w1.N, x, d, 1, M, CN_EPI_RESID, x, d, s));
+    if (next) CN_TRY(run_ln(m, *next, x, next_out, M, s));
     return 0;
 }
 
 // x += O(Attn(LN(x) Wq, LN(x) Wk, LN(x) Wv))
-int run_self_attn(cn_model* m, const Layer& L, const Norm& n, float* x, int B, int Lseq, const unsigned char* keymask,
+// `pre` == nullptr: m->xn already holds LN(x) (written by the preceding FFN)
+int run_self_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B, int Lseq, const unsigned char* keymask,
                   const int* klen, int causal, hipStream_t s) {
     const int d = m->cfg.d_model, M = B * Lseq;
-    CN_TRY(run_ln(m, n, x, m->xn, M, s));
-    CN_TRY(run_linear(m, L.qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
+    if (pre) CN_TRY(run_ln(m, *pre, x, m->xn, M, s));
+    CN_TRY(run_linear(m, "qkv_proj", L.qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
     AttnArgs a;
     const size_t es = m->es;
     a.Q = m->qkv;
@@ -465,18 +562,22 @@ int run_self_attn(cn_model* m, const Layer& L, const Norm& n, float* x, int B, i
     a.klen = klen;
     a.causal = causal;
     a.scale = 1.0f / sqrtf((float)(d / m->cfg.n_head));
-    CN_TRY(launch_attention(m->prec, a, s));
-    CN_TRY(run_linear(m, L.self_o, m->ctx, d, x, d, 1, M, CN_EPI_RESID, x, d, s));
+    {
+        ProfScope ps(m, "self_attention", 4.0 * B * a.H * (double)Lseq * Lseq * 64,
+                     (double)M * 4 * d * m->es, s);
+        CN_TRY(launch_attention(m->prec, a, s));
+    }
+    CN_TRY(run_linear(m, "out_proj_resid", L.self_o, m->ctx, d, x, d, 1, M, CN_EPI_RESID, x, d, s));
     return 0;
 }
 
 // x += O(Attn(LN(x) Wq, mem Wk, mem Wv)) with the padding mask and (optionally) trigger intervals
-int run_src_attn(cn_model* m, const Layer& L, const Norm& n, float* x, int B, int U, int Tp, const int* intervals,
+int run_src_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B, int U, int Tp, const int* intervals,
                  hipStream_t s) {
     const int d = m->cfg.d_model;
-    CN_TRY(run_ln(m, n, x, m->xn, B * U, s));
-    CN_TRY(run_linear(m, L.src_q, m->xn, d, m->qd, d, 0, B * U, 0, nullptr, 0, s));
-    CN_TRY(run_linear(m, L.src_kv, m->enc_h, d, m->kvm, 2 * d, 0, B * Tp, 0, nullptr, 0, s));
+    if (pre) CN_TRY(run_ln(m, *pre, x, m->xn, B * U, s));
+    CN_TRY(run_linear(m, "src_q_proj", L.src_q, m->xn, d, m->qd, d, 0, B * U, 0, nullptr, 0, s));
+    CN_TRY(run_linear(m, "src_kv_proj", L.src_kv, m->enc_h, d, m->kvm, 2 * d, 0, B * Tp, 0, nullptr, 0, s));
     AttnArgs a;
     a.Q = m->qd;
     a.K = m->kvm;
@@ -493,8 +594,12 @@ int run_src_attn(cn_model* m, const Layer& L, const Norm& n, float* x, int B, in
     a.intervals = intervals;
     a.iv_stride = Tp + 1;
     a.scale = 1.0f / sqrtf((float)(d / m->cfg.n_head));
-    CN_TRY(launch_attention(m->prec, a, s));
-    CN_TRY(run_linear(m, L.src_o, m->ctx, d, x, d, 1, B * U, CN_EPI_RESID, x, d, s));
+    {
+        ProfScope ps(m, "src_attention", 4.0 * B * a.H * (double)U * Tp * 64,
+                     ((double)B * U * 2 * d + (double)B * Tp * 2 * d) * m->es, s);
+        CN_TRY(launch_attention(m->prec, a, s));
+    }
+    CN_TRY(run_linear(m, "out_proj_resid", L.src_o, m->ctx, d, x, d, 1, B * U, CN_EPI_RESID, x, d, s));
     return 0;
 }
 
@@ -525,7 +630,10 @@ int stage_encode_align(cn_model* m, const float* feats, const float* ratio, int 
     m->Tp = Tp;
     m->U = 0;
     CN_TRY(launch_keymask(feats, B, T, F, Tp, 4, (float)o->padding_idx, m->keymask, s));
-    CN_TRY(launch_conv1(m->prec, feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, s));
+    {
+        ProfScope ps(m, "conv1", 2.0 * 9 * B * T1 * F1 * d, (double)B * T * F * 4 + (double)B * T1 * F1 * d * m->es, s);
+        CN_TRY(launch_conv1(m->prec, feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, s));
+    }
     if (cap) CN_TRY(capture(m, "conv1", m->c1, true, CN_DTYPE_F32, {B, T1, F1, d}, s));
     {
         GemmArgs g;
@@ -545,6 +653,8 @@ int stage_encode_align(cn_model* m, const float* feats, const float* ratio, int 
         g.cC = d;
         g.cT2 = Tp;
         g.cF2 = F2;
+        ProfScope ps(m, "conv2", 2.0 * g.M * g.N * g.K,
+                     ((double)B * T1 * F1 * d + (double)g.N * g.K + (double)g.M * g.N) * m->es, s);
         CN_TRY(launch_gemm(m->prec, g, s));
     }
     if (cap) CN_TRY(capture(m, "conv2", m->c2, true, CN_DTYPE_F32, {B, Tp, F2, d}, s));
@@ -564,19 +674,25 @@ int stage_encode_align(cn_model* m, const float* feats, const float* ratio, int 
         g.pe = m->pe;
         g.pe_period = Tp;
         g.scale = sqrtf((float)d);
+        ProfScope ps(m, "linear_out_embed", 2.0 * g.M * g.N * g.K,
+                     ((double)g.M * g.K + (double)g.N * g.K) * m->es + (double)g.M * g.N * 4, s);
         CN_TRY(launch_gemm(m->prec, g, s));
     }
     if (cap) CN_TRY(capture(m, "x_embed", m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
     for (size_t n = 0; n < m->enc.size(); ++n) {
         const Layer& L = m->enc[n];
-        CN_TRY(run_self_attn(m, L, L.n[0], m->x, B, Tp, m->keymask, nullptr, 0, s));
-        CN_TRY(run_ffn(m, L, L.n[1], m->x, M, s));
+        const bool last = n + 1 == m->enc.size();
+        CN_TRY(run_self_attn(m, L, n == 0 ? &L.n[0] : nullptr, m->x, B, Tp, m->keymask, nullptr, 0, s));
+        CN_TRY(run_ffn(m, L, L.n[1], m->x, M, last ? &m->enc_norm : &m->enc[n + 1].n[0], last ? m->enc_h : m->xn, s));
         if (cap) CN_TRY(capture(m, ("enc_layer" + std::to_string(n)).c_str(), m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
     }
-    CN_TRY(run_ln(m, m->enc_norm, m->x, m->enc_h, M, s));
+    if (m->enc.empty()) CN_TRY(run_ln(m, m->enc_norm, m->x, m->enc_h, M, s));
     if (cap) CN_TRY(capture(m, "enc_h", m->enc_h, true, CN_DTYPE_F32, {B, Tp, d}, s));
-    CN_TRY(run_linear(m, m->ctc_gen, m->enc_h, d, m->logits, c.vocab_size, 1, M, 0, nullptr, 0, s));
-    CN_TRY(launch_logsoftmax_argmax(m->logits, M, c.vocab_size, c.vocab_size, m->best, m->ctc_maxlp, cap ? 1 : 0, s));
+    CN_TRY(run_linear(m, "generator_proj", m->ctc_gen, m->enc_h, d, m->logits, c.vocab_size, 1, M, 0, nullptr, 0, s));
+    {
+        ProfScope ps(m, "logsoftmax_argmax", 0, (double)M * c.vocab_size * 4, s);
+        CN_TRY(launch_logsoftmax_argmax(m->logits, M, c.vocab_size, c.vocab_size, m->best, m->ctc_maxlp, cap ? 1 : 0, s));
+    }
     if (cap) CN_TRY(capture(m, "ctc_out", m->logits, false, CN_DTYPE_F32, {B, Tp, c.vocab_size}, s));
     AlignArgs al;
     al.best = m->best;
@@ -592,7 +708,10 @@ int stage_encode_align(cn_model* m, const float* feats, const float* ratio, int 
     al.ylen = m->ylen;
     al.ymax = m->ymax;
     al.intervals = m->intervals;
-    CN_TRY(launch_ctc_align(al, s));
+    {
+        ProfScope ps(m, "ctc_align", 0, (double)B * Tp * 9 + (double)B * (Tp + 1) * 16, s);
+        CN_TRY(launch_ctc_align(al, s));
+    }
     return 0;
 }
 
@@ -608,32 +727,58 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
         return -1;
     }
     CN_TRY(launch_fill_queries(m->pe, m->xd, B, U, d, s));
-    for (auto& L : m->extra) {
-        CN_TRY(run_src_attn(m, L, L.n[0], m->xd, B, U, Tp, m->intervals, s));
-        CN_TRY(run_ffn(m, L, L.n[1], m->xd, MU, s));
+    // The LayerNorm that follows an FFN is produced by that FFN (-> m->xn); `pending` says whether the next
+    // sublayer may skip its own LayerNorm.  use_unimask shifts the stream between SAD and MAD, so no carry there.
+    const bool uni = o->use_unimask != 0;
+    auto first_norm_after = [&](int stage, size_t idx) -> const Norm* {  // stage 0 extractor, 1 SAD, 2 MAD
+        if (stage == 0 && idx + 1 < m->extra.size()) return &m->extra[idx + 1].n[0];
+        if (stage <= 0 && !m->sad.empty()) return &m->sad[0].n[0];
+        if (stage == 1 && idx + 1 < m->sad.size()) return &m->sad[idx + 1].n[0];
+        if (stage <= 1) return (uni || m->mad.empty()) ? nullptr : &m->mad[0].n[0];
+        if (idx + 1 < m->mad.size()) return &m->mad[idx + 1].n[0];
+        return nullptr;
+    };
+    bool pending = false;
+    for (size_t i = 0; i < m->extra.size(); ++i) {
+        const Layer& L = m->extra[i];
+        CN_TRY(run_src_attn(m, L, pending ? nullptr : &L.n[0], m->xd, B, U, Tp, m->intervals, s));
+        const Norm* nx = first_norm_after(0, i);
+        CN_TRY(run_ffn(m, L, L.n[1], m->xd, MU, nx, m->xn, s));
+        pending = nx != nullptr;
     }
     if (cap) CN_TRY(capture(m, "ac_embed", m->xd, false, CN_DTYPE_F32, {B, U, d}, s));
-    for (auto& L : m->sad) {
-        CN_TRY(run_self_attn(m, L, L.n[0], m->xd, B, U, nullptr, m->ylen, 0, s));
-        CN_TRY(run_ffn(m, L, L.n[1], m->xd, MU, s));
+    for (size_t i = 0; i < m->sad.size(); ++i) {
+        const Layer& L = m->sad[i];
+        CN_TRY(run_self_attn(m, L, pending ? nullptr : &L.n[0], m->xd, B, U, nullptr, m->ylen, 0, s));
+        const Norm* nx = first_norm_after(1, i);
+        CN_TRY(run_ffn(m, L, L.n[1], m->xd, MU, nx, m->xn, s));
+        pending = nx != nullptr;
     }
     if (cap) CN_TRY(capture(m, "pred_embed", m->xd, false, CN_DTYPE_F32, {B, U, d}, s));
     float* xdec = m->xd;
-    if (o->use_unimask) {
+    if (uni) {
         CN_TRY(launch_shift_right(m->xd, m->xd2, B, U, d, s));
         xdec = m->xd2;
+        pending = false;
     }
-    for (auto& L : m->mad) {
-        CN_TRY(run_self_attn(m, L, L.n[0], xdec, B, U, nullptr, m->ylen, o->use_unimask ? 1 : 0, s));
-        CN_TRY(run_src_attn(m, L, L.n[1], xdec, B, U, Tp, o->src_trigger ? m->intervals : nullptr, s));
-        CN_TRY(run_ffn(m, L, L.n[2], xdec, MU, s));
+    for (size_t i = 0; i < m->mad.size(); ++i) {
+        const Layer& L = m->mad[i];
+        const bool last = i + 1 == m->mad.size();
+        CN_TRY(run_self_attn(m, L, pending ? nullptr : &L.n[0], xdec, B, U, nullptr, m->ylen, uni ? 1 : 0, s));
+        CN_TRY(run_src_attn(m, L, &L.n[1], xdec, B, U, Tp, o->src_trigger ? m->intervals : nullptr, s));
+        const Norm* nx = last ? &m->dec_norm : first_norm_after(2, i);
+        CN_TRY(run_ffn(m, L, L.n[2], xdec, MU, nx, last ? m->dec_h : m->xn, s));
+        pending = !last && nx != nullptr;
     }
-    CN_TRY(run_ln(m, m->dec_norm, xdec, m->dec_h, MU, s));
+    if (m->mad.empty()) CN_TRY(run_ln(m, m->dec_norm, xdec, m->dec_h, MU, s));
     if (cap) CN_TRY(capture(m, "dec_h", m->dec_h, true, CN_DTYPE_F32, {B, U, d}, s));
-    CN_TRY(run_linear(m, m->att_gen, m->dec_h, d, m->logits, c.vocab_size, 1, MU, 0, nullptr, 0, s));
+    CN_TRY(run_linear(m, "generator_proj", m->att_gen, m->dec_h, d, m->logits, c.vocab_size, 1, MU, 0, nullptr, 0, s));
     const int k = o->beam_width;
     const int want_logp = (cap || k > 1) ? 1 : 0;
-    CN_TRY(launch_logsoftmax_argmax(m->logits, MU, c.vocab_size, c.vocab_size, m->tok, m->val, want_logp, s));
+    {
+        ProfScope ps(m, "logsoftmax_argmax", 0, (double)MU * c.vocab_size * 4, s);
+        CN_TRY(launch_logsoftmax_argmax(m->logits, MU, c.vocab_size, c.vocab_size, m->tok, m->val, want_logp, s));
+    }
     if (cap) CN_TRY(capture(m, "att_out", m->logits, false, CN_DTYPE_F32, {B, U, c.vocab_size}, s));
     m->last_k = 0;
     if (k > 1) {
@@ -692,6 +837,7 @@ extern "C" void cn_model_destroy(cn_model* m) {
     for (void* p : m->allocs) (void)hipFree(p);
     for (auto& kv : m->captures)
         if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->blob) (void)hipFree(m->blob);
     delete m;
 }
@@ -789,6 +935,57 @@ extern "C" int cn_decode_nast(cn_model* m, const float* feats_dev, const float* 
         return -1;
     }
     CN_TRY(stage_decode(m, ymax, opts, hyp_out_dev, hyp_stride, hyp_len_dev, score_dev, s));
+    return 0;
+}
+
+extern "C" int cn_profile_begin(cn_model* m, const char* tags) {
+    if (!m) {
+        cn_set_error("cn_profile_begin: null model");
+        return -1;
+    }
+    m->prof_on = true;
+    m->prof_filter = (tags && *tags) ? std::string("|") + tags + "|" : std::string();
+    m->prof_pending.clear();
+    m->prof_stats.clear();
+    m->ev_used = 0;
+    return 0;
+}
+
+extern "C" int cn_profile_end(cn_model* m, char* json_out, int64_t cap) {
+    if (!m) {
+        cn_set_error("cn_profile_end: null model");
+        return -1;
+    }
+    CN_HIP_CHECK(hipDeviceSynchronize());
+    for (auto& pp : m->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pp.a, pp.b) != hipSuccess) continue;
+        ProfStat& st = m->prof_stats[pp.tag];
+        st.count += 1;
+        st.ms += ms;
+        st.flops += pp.flops;
+        st.bytes += pp.bytes;
+    }
+    m->prof_pending.clear();
+    m->prof_on = false;
+    m->ev_used = 0;
+    std::string js = "{";
+    bool first = true;
+    for (auto& kv : m->prof_stats) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "%s\"%s\": {\"count\": %lld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                 first ? "" : ", ", kv.first.c_str(), kv.second.count, kv.second.ms, kv.second.flops, kv.second.bytes);
+        js += buf;
+        first = false;
+    }
+    js += "}";
+    if (json_out && cap > 0) {
+        if ((int64_t)js.size() + 1 > cap) {
+            cn_set_error("cn_profile_end: buffer too small");
+            return -1;
+        }
+        std::memcpy(json_out, js.c_str(), js.size() + 1);
+    }
     return 0;
 }
 
@@ -973,4 +1170,47 @@ extern "C" int cn_op_greedy_pack(const int32_t* tok, const float* val, const int
 
 extern "C" int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, int32_t* idx, float* val, void* stream) {
     return launch_topk(logp, M, V, V, k, idx, val, (hipStream_t)stream);
+}
+
+extern "C" int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, const float* w1_host,
+                               const float* b1_dev, const float* w2_host, const float* b2_dev, const float* nln_a_dev,
+                               const float* nln_b_dev, void* xn_out_dev, int32_t M, int32_t dff, float eps,
+                               void* stream) {
+    if (dff <= 0 || dff % 128 != 0 || dff > 2048) {
+        cn_set_error("cn_op_ffn_fused: d_ff must be a positive multiple of 128, at most 2048");
+        return -1;
+    }
+    const size_t n = (size_t)dff * 256;
+    std::vector<uint16_t> h1(n), h2(n);
+    pack_ffn_w1(w1_host, dff, h1.data());
+    pack_ffn_w2(w2_host, dff, h2.data());
+    void *d1 = nullptr, *d2 = nullptr;
+    CN_HIP_CHECK(hipMalloc(&d1, n * 2));
+    CN_HIP_CHECK(hipMalloc(&d2, n * 2));
+    CN_HIP_CHECK(hipMemcpy(d1, h1.data(), n * 2, hipMemcpyHostToDevice));
+    CN_HIP_CHECK(hipMemcpy(d2, h2.data(), n * 2, hipMemcpyHostToDevice));
+    FfnFusedArgs a;
+    a.x = x_dev;
+    a.ln_a = ln_a_dev;
+    a.ln_b = ln_b_dev;
+    a.w1p = d1;
+    a.b1 = b1_dev;
+    a.w2p = d2;
+    a.b2 = b2_dev;
+    a.nln_a = nln_a_dev;
+    a.nln_b = nln_b_dev;
+    a.xn_out = xn_out_dev;
+    a.M = M;
+    a.d = 256;
+    a.dff = dff;
+    a.eps = eps;
+    int rc = launch_ffn_fused(a, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(d1);
+    (void)hipFree(d2);
+    if (rc == 0 && e != hipSuccess) {
+        cn_set_error(std::string("cn_op_ffn_fused: ") + hipGetErrorString(e));
+        rc = -2;
+    }
+    return rc;
 }

@@ -1,0 +1,63 @@
+"""Utterance sharding across the GPUs of one node: one process per GPU, torch.distributed (RCCL over xGMI).
+
+The reference shards decoding by splitting feats.scp into nj files and starting one process per GPU, each
+loading the checkpoint from disk and writing its own result file (egs/librispeech/run_hubert.sh:94-116):
+utterances are independent, there is no collective.  Here rank 0 alone reads/packs the checkpoint and the
+packed weight blob is broadcast once (57 MB bf16 for the config-2 model); every batch ends with one
+all-gather of fixed-size hypothesis records (B x (stride+3) int32 per rank - latency bound).  No other
+collective exists on the path.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(lengths, world, rank):
+    """Length-sorted round-robin deal: every rank gets a similar mix of lengths.
+
+    Returns indices into the global utterance list for `rank`, longest first.
+    """
+    order = np.argsort(-np.asarray(lengths), kind="stable")
+    return order[rank::world]
+
+
+class _CudaBlob:
+    """Zero-copy view of raw device memory for torch (``__cuda_array_interface__`` v2)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def broadcast_weights(engine, src=0, group=None):
+    """RCCL broadcast of the packed weight blob from `src` into every other rank's (layout-identical) blob."""
+    ptr, nbytes = engine.weight_blob()
+    t = torch.as_tensor(_CudaBlob(ptr, nbytes), device="cuda")
+    sizes = [None] * dist.get_world_size(group)
+    dist.all_gather_object(sizes, nbytes, group=group)
+    if len(set(sizes)) != 1:
+        raise RuntimeError(f"weight blob layout differs across ranks: {sizes}")
+    dist.broadcast(t, src=src, group=group)
+    torch.cuda.synchronize()
+    return nbytes
+
+
+def pack_records(hyp, hyp_len, score):
+    """(B,S) int32, (B,) int32, (B,) float64 -> (B, S+3) int32 records [len, score_lo, score_hi, tokens...]."""
+    sc = score.contiguous().view(torch.int32).view(-1, 2)
+    return torch.cat([hyp_len.view(-1, 1), sc, hyp], dim=1).contiguous()
+
+
+def unpack_records(rec):
+    rec = rec.cpu()
+    lens = rec[:, 0].numpy()
+    score = rec[:, 1:3].contiguous().view(torch.float64).view(-1).numpy()
+    toks = rec[:, 3:].numpy()
+    return [toks[b, : lens[b]].tolist() for b in range(rec.shape[0])], score
+
+
+def all_gather_records(rec, group=None):
+    """One all-gather per batch: (B, S+3) -> (world*B, S+3), rank-major."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, rec, group=group)
+    return out

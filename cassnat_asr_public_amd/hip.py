@@ -83,6 +83,9 @@ def lib():
                                   C.POINTER(CnDecodeOpts), C.POINTER(C.c_int32), C.c_void_p]
     L.cn_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                            C.POINTER(C.c_int32)]
+    L.cn_op_ffn_fused.argtypes = [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p]
+    L.cn_profile_begin.argtypes = [C.c_void_p, C.c_char_p]
+    L.cn_profile_end.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     _lib = L
     return L
 
@@ -171,6 +174,18 @@ class Engine:
         check(self.L.cn_encode_align(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts),
                                      C.byref(ymax), current_stream()), "cn_encode_align")
         return ymax.value
+
+    def profile_begin(self, tags=None):
+        """Start HIP-event timing of the tagged kernels (None = all) on the launch stream."""
+        check(self.L.cn_profile_begin(self.handle, None if not tags else "|".join(tags).encode()), "cn_profile_begin")
+
+    def profile_end(self):
+        """-> {tag: {count, ms, flops, bytes}} accumulated since profile_begin (synchronises the device)."""
+        import json
+
+        buf = C.create_string_buffer(1 << 16)
+        check(self.L.cn_profile_end(self.handle, buf, len(buf)), "cn_profile_end")
+        return json.loads(buf.value.decode())
 
     def fetch(self, name):
         shape = (C.c_int64 * 4)()

@@ -149,33 +149,41 @@ class CassNAT(nn.Module):
     def _weights_version(self):
         return tuple(p._version for p in self.parameters())
 
+    def build_engine(self, batch, frames, with_weights=True):
+        """Create the HIP engine.  ``with_weights=False`` allocates the (layout-identical) weight blob only: the
+        contents then arrive by RCCL broadcast from the rank that read the checkpoint (cassnat_asr_public_amd.dist)."""
+        from types import SimpleNamespace
+
+        if self._engine is not None:
+            self._engine.close()
+        eng = hip.Engine(SimpleNamespace(**self._hyper), precision=self.hip_precision,
+                         max_batch=max(batch, self.hip_max_batch), max_frames=max(frames, self.hip_max_frames),
+                         device=getattr(self, "_device", torch.cuda.current_device()))
+        if with_weights:
+            eng.load_state({k: v.detach() for k, v in self.named_parameters()}, self.pe)
+        else:
+            eng.finalize()
+        self._engine, self._engine_key = eng, (self._weights_version(), self.hip_precision)
+        return eng
+
+    def invalidate_engine(self):
+        """Call after changing parameters through ``.data`` (which does not bump tensor versions)."""
+        self._engine_key = None
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate_engine()
+        return super().load_state_dict(*a, **k)
+
     def engine(self, batch, frames):
         """(Re)build the HIP engine when weights changed or the workspace is too small."""
         key = (self._weights_version(), self.hip_precision)
-        need_new = (self._engine is None or self._engine_key != key or batch > self._engine.cfg.max_batch
-                    or frames > self._engine.cfg.max_frames)
-        if need_new:
-            if self._engine is not None:
-                self._engine.close()
-            from types import SimpleNamespace
-
-            eng = hip.Engine(SimpleNamespace(**self._hyper), precision=self.hip_precision,
-                             max_batch=max(batch, self.hip_max_batch), max_frames=max(frames, self.hip_max_frames),
-                             device=getattr(self, "_device", torch.cuda.current_device()))
-            eng.load_state({k: v.detach() for k, v in self.named_parameters()}, self.pe)
-            self._engine, self._engine_key = eng, key
+        if (self._engine is None or self._engine_key != key or batch > self._engine.cfg.max_batch
+                or frames > self._engine.cfg.max_frames):
+            self.build_engine(batch, frames)
         return self._engine
 
     # ------------------------------------------------------------------------------------------ decode
-    def beam_decode(self, src, x_mask, src_size, vocab, args, lm_model=None, ctc_top_seqs=None, labels=None,
-                    label_sizes=None):
-        """Same contract as the reference's CassNAT.beam_decode (src/models/cassnat.py:420-637) for
-        ``use_trigger=True, sample_num<=1, decode_type='att_only', lm_weight==0`` (anything else raises).
-
-        ``x_mask`` is accepted for signature compatibility; like the reference's caller
-        (src/tasks/cassnat_task.py:328) the padding mask is ``src[:,:,0] != padding_idx`` and is re-derived on
-        the device from ``src`` itself.
-        """
+    def _check_args(self, args, lm_model):
         if not getattr(args, "use_trigger", True):
             raise NotImplementedError("use_trigger=False is not on the accelerated path")
         if getattr(args, "sample_num", 0) > 1 or getattr(args, "decode_type", "att_only") not in ("att_only",):
@@ -184,8 +192,9 @@ class CassNAT(nn.Module):
             raise NotImplementedError("LM fusion is outside the accelerated path")
         if getattr(args, "test_hitrate", False):
             raise NotImplementedError("test_hitrate needs the training-time viterbi aligner")
-        sos = vocab.word2index["sos"]
-        assert vocab.word2index["blank"] == args.padding_idx, "CTC blank id and padding_idx must agree"
+
+    def decode_device(self, src, src_size, args, sos=1):
+        """The device half of beam_decode: returns cuda tensors (hyp (B,S) int32, hyp_len (B,) int32, score (B,) f64)."""
         dev = torch.device("cuda", getattr(self, "_device", torch.cuda.current_device()))
         feats = src.to(dev, torch.float32).contiguous()
         ratio = src_size.to(dev, torch.float32).contiguous()
@@ -198,12 +207,27 @@ class CassNAT(nn.Module):
         hyp_len = torch.empty(B, dtype=torch.int32, device=dev)
         score = torch.empty(B, dtype=torch.float64, device=dev)
         eng.decode(feats, ratio, opts, hyp, hyp_len, score)
+        return hyp, hyp_len, score
+
+    def beam_decode(self, src, x_mask, src_size, vocab, args, lm_model=None, ctc_top_seqs=None, labels=None,
+                    label_sizes=None):
+        """Same contract as the reference's CassNAT.beam_decode (src/models/cassnat.py:420-637) for
+        ``use_trigger=True, sample_num<=1, decode_type='att_only', lm_weight==0`` (anything else raises).
+
+        ``x_mask`` is accepted for signature compatibility; like the reference's caller
+        (src/tasks/cassnat_task.py:328) the padding mask is ``src[:,:,0] != padding_idx`` and is re-derived on
+        the device from ``src`` itself.
+        """
+        self._check_args(args, lm_model)
+        sos = vocab.word2index["sos"]
+        assert vocab.word2index["blank"] == args.padding_idx, "CTC blank id and padding_idx must agree"
+        hyp, hyp_len, score = self.decode_device(src, src_size, args, sos)
         if args.beam_width > 1:
-            return self._host_beam(eng, args, sos), args
+            return self._host_beam(self._engine, args, sos), args
         hyp_h, len_h, score_h = hyp.cpu().numpy(), hyp_len.cpu().numpy(), score.cpu().numpy()
         ys = torch.ones(1, 1).fill_(sos).long()
         out = []
-        for b in range(B):
+        for b in range(hyp_h.shape[0]):
             out.append([{"ys": ys, "score": float(score_h[b]), "hyp": hyp_h[b, : len_h[b]].tolist()}])
         return out, args
 

@@ -88,6 +88,12 @@ int cn_encode_align(cn_model* m, const float* feats_dev, const float* size_ratio
 int cn_fetch(cn_model* m, const char* name, void* host_dst, int64_t max_bytes, int64_t* shape_out, int32_t* ndim_out,
              int32_t* dtype_out);
 
+/* Per-kernel timing with HIP events recorded on the launch stream around each tagged kernel.
+ * tags: '|'-separated list ("conv2|self_attention") or NULL for every tag.  cn_profile_end synchronises the device and
+ * writes {"tag": {"count": n, "ms": total, "flops": algorithmic flops, "bytes": algorithmic bytes}, ...}. */
+int cn_profile_begin(cn_model* m, const char* tags);
+int cn_profile_end(cn_model* m, char* json_out, int64_t cap);
+
 /* ---- single-kernel entry points (parity tests drive each hand-written kernel through the ABI) ---------- */
 /* all pointers device; `precision` selects the element type of activations/weights (fp32 or bf16) */
 int cn_op_gemm(int32_t precision, const void* A, int32_t lda, const void* W, const float* bias, void* C, int32_t ldc,
@@ -110,6 +116,12 @@ int cn_op_ctc_align(const int32_t* best, const uint8_t* keymask, const float* si
                     int32_t* ymax, int32_t* intervals, void* stream);
 int cn_op_greedy_pack(const int32_t* tok, const float* val, const int32_t* ylen, int32_t B, int32_t U, int32_t sos,
                       int32_t hyp_stride, int32_t* hyp, int32_t* hyp_len, double* score, void* stream);
+/* fused LN -> W1 -> ReLU -> W2 -> residual (-> next LN) sublayer, bf16 / d_model 256.  x_dev fp32 [M][256] is updated
+ * in place; weights are HOST fp32 nn.Linear matrices (w1 [dff][256], w2 [256][dff]) packed and uploaded by the call
+ * (test entry: the model packs once at cn_model_finalize).  xn_out_dev (bf16 [M][256]) may be NULL. */
+int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, const float* w1_host,
+                    const float* b1_dev, const float* w2_host, const float* b2_dev, const float* nln_a_dev,
+                    const float* nln_b_dev, void* xn_out_dev, int32_t M, int32_t dff, float eps, void* stream);
 int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, int32_t* idx, float* val, void* stream);
 
 #ifdef __cplusplus

@@ -350,3 +350,32 @@ def test_greedy_pack_matches_oracle():
     for b in range(B):
         assert hyp[b, : hl[b]].cpu().tolist() == o_hyp[b]
         assert sc[b].item() == o_sc[b]  # sequential double sum: bit-identical
+
+
+# ----------------------------------------------------------------------------------------------- fused FFN sublayer
+@pytest.mark.parametrize("M,dff,with_next", [(8000, 2048, True), (45, 256, False), (2304, 2048, True), (32, 128, True)])
+def test_ffn_fused_bf16(M, dff, with_next):
+    from oracle.cassnat_oracle import layer_norm
+
+    g = torch.Generator().manual_seed(M + dff)
+    d = 256
+    x = torch.randn(M, d, generator=g) * 2 + 0.3
+    a, b = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    na, nb = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    w1 = (torch.randn(dff, d, generator=g) / math.sqrt(d)).contiguous()
+    b1 = 0.1 * torch.randn(dff, generator=g)
+    w2 = (torch.randn(d, dff, generator=g) / math.sqrt(dff)).contiguous()
+    b2 = 0.1 * torch.randn(d, generator=g)
+    # reference with the same roundings the kernel applies: LN output, weights and hidden activations in bf16
+    xn = rounded(layer_norm(x, a, b), "bf16")
+    h = rounded(F.relu(F.linear(xn, rounded(w1, "bf16"), b1)), "bf16")
+    ref = x + F.linear(h, rounded(w2, "bf16"), b2)
+    xd, ad, bd, b1d, b2d, nad, nbd = (dev(t) for t in (x, a, b, b1, b2, na, nb))
+    xn_out = torch.full((M, d), float("nan"), dtype=torch.bfloat16, device="cuda") if with_next else None
+    hip.check(hip.lib().cn_op_ffn_fused(p(xd), p(ad), p(bd), C.c_void_p(w1.data_ptr()), p(b1d), C.c_void_p(w2.data_ptr()),
+                                        p(b2d), p(nad) if with_next else None, p(nbd) if with_next else None,
+                                        p(xn_out), M, dff, 1e-6, stream()))
+    torch.cuda.synchronize()
+    assert relerr(xd, ref) < 2e-3  # fp32 residual stream; error = accumulation order + rare bf16 double-rounding of h
+    if with_next:
+        assert relerr(xn_out, layer_norm(xd.cpu(), na, nb)) < 5e-3
