@@ -1,0 +1,73 @@
+"""Minimal Kaldi table I/O (binary float/double matrices in .ark files addressed by .scp lines).
+
+The reference delegates this to the third-party `kaldiio` package (src/data/speech_loader.py:6,142, pinned 2.15.1 in
+requirements_original.txt), which is not available offline; only the uncompressed binary matrix format that
+`copy-feats` / `compute-cmvn-stats` write by default is implemented here.
+"""
+import struct
+
+import numpy as np
+
+_DTYPES = {b"FM ": np.float32, b"DM ": np.float64}
+
+
+def _read_matrix(f):
+    if f.read(2) != b"\0B":
+        raise ValueError("not a binary Kaldi object")
+    tag = f.read(3)
+    if tag not in _DTYPES:
+        raise ValueError("unsupported Kaldi matrix type %r (compressed matrices are not supported)" % tag)
+    dims = []
+    for _ in range(2):
+        if f.read(1) != b"\x04":
+            raise ValueError("corrupt Kaldi matrix header")
+        dims.append(struct.unpack("<i", f.read(4))[0])
+    rows, cols = dims
+    dt = np.dtype(_DTYPES[tag]).newbyteorder("<")
+    data = np.frombuffer(f.read(rows * cols * dt.itemsize), dtype=dt)
+    if data.size != rows * cols:
+        raise ValueError("truncated Kaldi matrix")
+    return data.reshape(rows, cols).copy()
+
+
+def load_mat(rxspecifier):
+    """"path" or "path:offset" (an .scp entry) -> numpy matrix."""
+    path, _, off = rxspecifier.rpartition(":")
+    if not path or not off.isdigit():
+        path, off = rxspecifier, None
+    with open(path, "rb") as f:
+        if off is not None:
+            f.seek(int(off))
+        else:  # a bare file may start with "key "
+            head = f.read(2)
+            f.seek(0)
+            if head != b"\0B":
+                while f.read(1) not in (b" ", b""):
+                    pass
+        return _read_matrix(f)
+
+
+def read_scp(scp_path):
+    """-> list of (utt, rxspecifier) in file order."""
+    out = []
+    with open(scp_path, "r") as f:
+        for line in f:
+            line = line.strip()
+            if line:
+                utt, spec = line.split(None, 1)
+                out.append((utt, spec))
+    return out
+
+
+def write_ark_scp(ark_path, scp_path, items):
+    """items: iterable of (utt, matrix).  Writes float32/float64 binary matrices and the matching .scp."""
+    with open(ark_path, "wb") as ark, open(scp_path, "w") as scp:
+        for utt, mat in items:
+            mat = np.ascontiguousarray(mat)
+            tag = b"DM " if mat.dtype == np.float64 else b"FM "
+            if tag == b"FM ":
+                mat = mat.astype("<f4", copy=False)
+            ark.write(utt.encode() + b" ")
+            scp.write("%s %s:%d\n" % (utt, ark_path, ark.tell()))
+            ark.write(b"\0B" + tag + b"\x04" + struct.pack("<i", mat.shape[0]) + b"\x04" + struct.pack("<i", mat.shape[1]))
+            ark.write(mat.tobytes())

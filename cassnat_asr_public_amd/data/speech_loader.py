@@ -1,0 +1,97 @@
+"""Test-time feature pipeline of the reference (src/data/speech_loader.py): Kaldi ark -> global CMVN -> splice /
+skip -> zero-padded batch + length ratios.  Only what CassNATTask("test") uses is mirrored (SpeechDataset,
+SpeechDataLoader); the training-only DynamicDataset / SSL loaders are out of scope.
+"""
+import functools
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from . import kaldi_io
+from .feat_op import context_feat, skip_feat
+
+
+class SingleSet(object):
+    """One {name, scp_path[, text_label]} stream -> list of (utt, ark specifier, token ids)."""
+
+    def __init__(self, vocab, data_path, rank=0):
+        self.name = data_path["name"]
+        entries = kaldi_io.read_scp(data_path["scp_path"])
+        if rank == 0:
+            print("Reading %d lines from %s" % (len(entries), data_path["scp_path"]))
+        labels = None
+        if "text_label" in data_path:
+            labels = {}
+            unk, sos, eos = vocab.word2index["unk"], vocab.word2index["sos"], vocab.word2index["eos"]
+            with open(data_path["text_label"], "r") as f:
+                for line in f:
+                    utt, _, text = line.strip().partition(" ")
+                    labels[utt] = [sos] + [vocab.word2index.get(w, unk) for w in text.split(" ")] + [eos]
+        self.items = [(utt, spec, labels[utt] if labels is not None else [1]) for utt, spec in entries]
+
+    def get_len(self):
+        return len(self.items)
+
+
+class SpeechDataset(Dataset):
+    def __init__(self, vocab, data_paths, args):
+        self.left_context, self.right_context = args.left_ctx, args.right_ctx
+        self.skip_frame = args.skip_frame
+        self.use_cmvn = False
+        self.data_streams = [SingleSet(vocab, p, getattr(args, "rank", 0)) for p in data_paths]
+        self._items = [it for s in self.data_streams for it in s.items]
+
+    def _load_cmvn(self, cmvn_file):
+        """Kaldi global CMVN stats: row 0 = sums (last column = frame count), row 1 = sums of squares."""
+        stats = kaldi_io.load_mat(cmvn_file)
+        count = stats[0, -1]
+        self.mean = stats[0, :-1] / count
+        self.std = np.sqrt(stats[1, :-1] / count - self.mean ** 2)
+        self.use_cmvn = True
+        return 0
+
+    def __len__(self):
+        return len(self._items)
+
+    def __getitem__(self, idx):
+        utt, spec, text = self._items[idx]
+        feat = kaldi_io.load_mat(spec)
+        if self.use_cmvn:
+            assert feat.shape[1] == self.mean.shape[0]
+            feat = (feat - self.mean) / self.std
+        rem = feat.shape[0] % self.skip_frame if self.skip_frame > 1 else 0
+        if rem:
+            feat = np.vstack([feat, np.zeros((self.skip_frame - rem, feat.shape[1]))])
+        feat = skip_feat(context_feat(feat, self.left_context, self.right_context), self.skip_frame)
+        return utt, feat, text
+
+
+def collate(batch, padding_idx=0):
+    """list of (utt, feat (T,F), text) -> (utts, feats (B,Tmax,F) f32, texts (B,L) i64, feat ratios (B,) f32,
+    text sizes (B,) i64), padded with `padding_idx` exactly as the reference's SuperviseLoader.collate_fn."""
+    t_max = max(x[1].shape[0] for x in batch)
+    l_max = max(len(x[2]) for x in batch)
+    feats = torch.full((len(batch), t_max, batch[0][1].shape[1]), float(padding_idx))
+    texts = torch.full((len(batch), l_max), int(padding_idx), dtype=torch.long)
+    ratios = torch.zeros(len(batch))
+    sizes = torch.zeros(len(batch), dtype=torch.long)
+    utts = []
+    for b, (utt, feat, text) in enumerate(batch):
+        feats[b, : feat.shape[0]] = torch.as_tensor(np.asarray(feat), dtype=torch.float32)
+        texts[b, : len(text)] = torch.as_tensor(text, dtype=torch.long)
+        ratios[b] = feat.shape[0] / t_max
+        sizes[b] = len(text) - 2
+        utts.append(utt)
+    return utts, feats, texts, ratios, sizes
+
+
+class SpeechDataLoader(DataLoader):
+    def __init__(self, dataset, batch_size, padding_idx=-1, distributed=False, shuffle=False, num_workers=0, indices=None):
+        if distributed or shuffle:
+            raise NotImplementedError("training-time sampling is out of scope")
+        self.padding_idx = padding_idx
+        order = list(range(len(dataset))) if indices is None else list(indices)
+        batches = [order[i : i + batch_size] for i in range(0, len(order), batch_size)]
+        super().__init__(dataset, batch_sampler=batches, num_workers=num_workers,
+                         collate_fn=functools.partial(collate, padding_idx=padding_idx))

@@ -13,12 +13,13 @@ import torch.distributed as dist
 
 
 def shard_indices(lengths, world, rank):
-    """Length-sorted round-robin deal: every rank gets a similar mix of lengths.
-
-    Returns indices into the global utterance list for `rank`, longest first.
-    """
+    """Length-sorted snake deal (0,1,..,W-1,W-1,..,1,0,0,1,..): every rank gets a similar mix of lengths and a
+    similar total number of frames.  Returns this rank's indices into the global list, longest first."""
     order = np.argsort(-np.asarray(lengths), kind="stable")
-    return order[rank::world]
+    pos = np.arange(len(order))
+    lap, k = pos // world, pos % world
+    owner = np.where(lap % 2 == 0, k, world - 1 - k)
+    return order[owner == rank]
 
 
 class _CudaBlob:

@@ -1,0 +1,129 @@
+"""Decode half of the reference's CassNATTask (src/tasks/cassnat_task.py:24-50, 85-131, 307-377).
+
+Same constructor / load_lm_model / decode surface and the same result-file format ("<utt> tok tok ...");
+the model is the HIP-backed CassNAT.  When torch.distributed is initialised (one process per GPU) the utterance
+list is dealt over the ranks by length, rank 0 broadcasts the packed weights over RCCL, and every batch's
+hypothesis records are all-gathered so that rank 0 writes one complete, input-ordered result file - replacing the
+reference's split_scp.pl + per-GPU result files + `cat | sort` (egs/librispeech/run_hubert.sh:94-116).
+"""
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import dist as cdist
+from ..data.vocab import Vocab
+from ..models import make_cassnat_model
+from ..utils import util
+from .base_task import BaseTask
+
+# YAML-only keys the reference reads without defaults: explicit defaults here
+_DEFAULTS = dict(use_gpu=True, decode_type="att_only", use_cmvn=False, dataset_type="SpeechDataset",
+                 print_utt2diff=False, save_embedding=False, use_conv_enc=False, use_conv_dec=False,
+                 use_trigger=True, src_trigger=False, use_unimask=False, left_trigger=0, right_trigger=0,
+                 sample_num=0, threshold=0.9, test_hitrate=False, beam_width=1, length_penalty=0, lm_weight=0,
+                 ctc_lm_weight=0, rank_model="lm", left_ctx=0, right_ctx=0, skip_frame=1, padding_idx=0,
+                 model_type="transformer", dropout=0.0, rank=0)
+
+
+def hyp_to_words(hyp, vocab, padding_idx):
+    """Drop sos / padding ids, stop at the first eos (src/tasks/cassnat_task.py:346-353)."""
+    sos, eos = vocab.word2index["sos"], vocab.word2index["eos"]
+    words = []
+    for idx in hyp:
+        if idx == sos or idx == padding_idx:
+            continue
+        if idx == eos:
+            break
+        words.append(vocab.index2word[idx])
+    return words
+
+
+class CassNATTask(BaseTask):
+    def __init__(self, mode, args):
+        for k, v in _DEFAULTS.items():
+            if not hasattr(args, k):
+                setattr(args, k, v)
+        super(CassNATTask, self).__init__(args)
+        if mode != "test":
+            raise NotImplementedError("training is out of scope of the accelerated path")
+        self.vocab = Vocab(args.vocab_file, args.rank)
+        args.vocab_size = self.vocab.n_words
+        for k in ("interctc_alpha", "interctc_layer", "interce_alpha", "interce_layer", "label_smooth"):
+            setattr(args, k, 0)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.set_model(args)
+        self.set_test_dataloader(args, indices=self._shard(args))
+        if self.rank == 0:
+            self.load_test_model(args.resume_model)
+        local = int(os.environ.get("LOCAL_RANK", "0")) if self.world > 1 else 0
+        self.model_stats(local, False, False)
+        self.lm_model = None
+
+    def set_model(self, args):
+        assert args.input_size == (args.left_ctx + args.right_ctx + 1) // args.skip_frame * args.n_features
+        self.model = make_cassnat_model(args.input_size, args)
+
+    def _shard(self, args):
+        """Indices of this rank's utterances (None = all).  Lengths come from utt2num_frames when given."""
+        self._order = None
+        if self.world == 1:
+            return None
+        n = sum(1 for _ in open(args.test_paths[0]["scp_path"]))
+        lengths = np.zeros(n)
+        u2n = args.test_paths[0].get("utt2num_frames")
+        if u2n:
+            lengths = np.array([int(line.split()[1]) for line in open(u2n)])
+        return cdist.shard_indices(lengths, self.world, self.rank)
+
+    def load_lm_model(self, args):
+        if args.lm_weight > 0 or getattr(args, "ctc_lm_weight", 0) > 0:
+            raise NotImplementedError("LM fusion / ESA ranking are outside the accelerated path (SURVEY 8f)")
+        self.lm_model = None
+
+    def decode(self, args):
+        batch_time = util.AverageMeter("Time", ":6.3f")
+        progress = util.ProgressMeter(len(self.test_loader), batch_time)
+        results = {}
+        frames = 0
+        if self.world > 1:  # weights travel once over RCCL instead of N checkpoint reads
+            lens = [b[1].shape[1] for b in [next(iter(self.test_loader))]] if len(self.test_loader) else [16]
+            eng = self.model.build_engine(args.batch_size, max(getattr(args, "hip_max_frames", 4096), max(lens)),
+                                          with_weights=(self.rank == 0))
+            cdist.broadcast_weights(eng, src=0)
+        end = time.time()
+        i = -1
+        with torch.no_grad():
+            self.model.eval()
+            for i, (utt_list, feats, labels, feat_sizes, label_sizes) in enumerate(self.test_loader):
+                frames += int(feats.shape[0] * feats.shape[1])
+                src_mask = (feats[:, :, 0] != args.padding_idx).unsqueeze(1)
+                recog, args = self.model.beam_decode(feats, src_mask, feat_sizes, self.vocab, args, self.lm_model,
+                                                     labels=labels, label_sizes=label_sizes)
+                for utt, seqs, lab in zip(utt_list, recog, labels):
+                    results[utt] = (hyp_to_words(seqs[0]["hyp"], self.vocab, args.padding_idx),
+                                    len(seqs[0]["hyp"]) - int((lab != args.padding_idx).sum()))
+                batch_time.update(time.time() - end)
+                end = time.time()
+                if i % args.print_freq == 0 and self.rank == 0:
+                    progress.print(i)
+        if self.rank == 0 and i >= 0:
+            progress.print(i)
+        if self.world > 1:
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, results)
+            results = {k: v for part in gathered for k, v in part.items()}
+        if self.rank == 0:
+            order = [line.split()[0] for line in open(args.test_paths[0]["scp_path"]) if line.strip()]
+            with open(args.result_file, "w") as out:
+                for utt in order:
+                    print(utt + " " + " ".join(results[utt][0]), flush=True, file=out)
+            if args.print_utt2diff:
+                with open(os.path.join(os.path.dirname(args.result_file), "utt2diff"), "w") as f:
+                    for utt in order:
+                        print(utt + " " + str(max(-3, min(3, results[utt][1]))), file=f)
+        self.decoded_frames = frames
+        return 0

@@ -189,3 +189,59 @@ def test_decode_rejects_oversize_batch():
     with pytest.raises(hip.HipError, match="outside the configured workspace"):
         eng.decode(f, torch.from_numpy(sizes).cuda(), hip.Engine.make_opts(args), hyp,
                    torch.empty(3, dtype=torch.int32, device="cuda"), torch.empty(3, dtype=torch.float64, device="cuda"))
+
+
+def test_weight_blob_handoff_reproduces_rank0_engine():
+    """The multi-GPU weight path minus the RCCL call: a layout-only engine that receives rank 0's packed blob
+    byte-for-byte must decode identically."""
+    from cassnat_asr_public_amd import dist as cdist
+
+    args, state, feats, sizes = config1_case()
+    src = build(args, state, "bf16")
+    out_a = decode(src, args, feats, sizes)
+    dst = make_model(args.input_size, args).cuda()  # xavier-initialised, never loaded
+    eng = dst.build_engine(1, feats.shape[1], with_weights=False)
+    pa, na = src._engine.weight_blob()
+    pb, nb = eng.weight_blob()
+    assert na == nb and na > 4_000_000
+    ta = torch.as_tensor(cdist._CudaBlob(pa, na), device="cuda")
+    tb = torch.as_tensor(cdist._CudaBlob(pb, nb), device="cuda")
+    assert ta.data_ptr() == pa and tb.data_ptr() == pb  # zero-copy views
+    tb.copy_(ta)
+    torch.cuda.synchronize()
+    out_b = decode(dst, args, feats, sizes)
+    assert [s[0]["hyp"] for s in out_a] == [s[0]["hyp"] for s in out_b]
+    assert [s[0]["score"] for s in out_a] == [s[0]["score"] for s in out_b]
+
+
+def test_decode_asr_cli_end_to_end(tmp_path):
+    """decode_asr.py --task cassnat on a synthetic Kaldi table: result file == oracle hypotheses as text."""
+    import yaml
+
+    from cassnat_asr_public_amd.bin import decode_asr
+    from cassnat_asr_public_amd.data import kaldi_io
+    from oracle import cassnat_oracle as orc
+
+    args, state, feats, sizes = tiny_case()
+    lengths = [61, 50, 37]
+    mats = [(f"spk-utt{b}", feats[b, :n]) for b, n in enumerate(lengths)]
+    scp = str(tmp_path / "feats.scp")
+    kaldi_io.write_ark_scp(str(tmp_path / "feats.ark"), scp, mats)
+    vocab_file = tmp_path / "vocab.txt"
+    vocab_file.write_text("".join(f"w{i}\n" for i in range(args.vocab_size - 4)))
+    ckpt = str(tmp_path / "model.mdl")
+    torch.save({"model_state": {"module." + k: torch.from_numpy(v) for k, v in state.items()}}, ckpt)
+    conf = {k: getattr(args, k) for k in ("input_size", "d_model", "n_head", "d_encff", "d_decff", "d_ff", "N_enc", "N_extra",
+                                          "N_self_dec", "N_mix_dec", "model_type", "n_features", "left_ctx", "right_ctx",
+                                          "skip_frame", "padding_idx", "beam_width", "length_penalty", "use_trigger")}
+    conf.update(vocab_file=str(vocab_file), use_gpu=True)
+    cfg = tmp_path / "decode.yaml"
+    cfg.write_text(yaml.safe_dump(conf))
+    result = str(tmp_path / "token_results.txt")
+    rc = decode_asr.main(["--task", "cassnat", "--test_config", str(cfg), "--data_path", scp, "--resume_model", ckpt,
+                          "--result_file", result, "--batch_size", "3", "--hip_precision", "fp32", "--load_data_workers", "0"])
+    assert rc == 0
+    ref = orc.decode_nast(state, feats, sizes, args)
+    index2word = {i + 4: f"w{i}" for i in range(args.vocab_size - 4)}
+    expect = [f"spk-utt{b} " + " ".join(orc.hyp_to_text(h, index2word)) for b, h in enumerate(ref["hyps"])]
+    assert open(result).read().splitlines() == expect

@@ -1,0 +1,210 @@
+"""CPU-only tests: host-side mirror of the reference interface, C-ABI surface, multi-process sharding helpers."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden
+from cassnat_asr_public_amd import dist as cdist
+from cassnat_asr_public_amd import hip, synth
+from cassnat_asr_public_amd.data import kaldi_io
+from cassnat_asr_public_amd.data.feat_op import context_feat, skip_feat
+from cassnat_asr_public_amd.data.speech_loader import SpeechDataLoader, SpeechDataset, collate
+from cassnat_asr_public_amd.data.vocab import Vocab
+from cassnat_asr_public_amd.models.cassnat import create_pe, make_model
+from cassnat_asr_public_amd.tasks.cassnat_task import hyp_to_words
+from cassnat_asr_public_amd.utils.parser import DecodeParser
+
+
+# ------------------------------------------------------------------------------------------- C ABI surface
+def test_library_exports_every_declared_symbol():
+    L = hip.lib()  # raises if include/cassnat_hip.h declares something the .so does not export
+    names = hip.declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), n
+    assert L.cn_version().startswith(b"cassnat_hip")
+
+
+def test_create_rejects_unsupported_geometry_without_touching_the_gpu():
+    L = hip.lib()
+    h = C.c_void_p()
+    cfg = hip.CnConfig(input_size=80, d_model=100, n_head=4, d_encff=256, d_decff=256, n_enc=1, n_extra=1, n_self_dec=1,
+                       n_mix_dec=1, vocab_size=50, precision=1, max_batch=2, max_frames=64, device=0)
+    assert L.cn_model_create(C.byref(cfg), C.byref(h)) != 0
+    assert b"d_model" in L.cn_last_error()
+    cfg.d_model, cfg.precision = 256, 7
+    assert L.cn_model_create(C.byref(cfg), C.byref(h)) != 0 and b"precision" in L.cn_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(hip.HipError, match="no CPU fallback"):
+        hip.lib()
+
+
+# ------------------------------------------------------------------------------------------- model surface
+def test_parameter_names_are_the_reference_checkpoint_keys():
+    for preset in ("tiny", "config2"):
+        args = synth.make_args(preset)
+        model = make_model(args.input_size, args)
+        assert {k: tuple(v.shape) for k, v in model.named_parameters()} == dict(synth.param_shapes(args))
+        assert [k for k, _ in model.named_parameters()] == list(synth.param_shapes(args).keys())
+    assert sum(p.numel() for p in model.parameters()) == 28673296
+
+
+def test_positional_table_matches_oracle_closed_form():
+    from oracle.cassnat_oracle import sinusoid_table
+
+    assert torch.equal(create_pe(256), sinusoid_table(256))
+
+
+def test_make_model_refuses_conformer_blocks():
+    with pytest.raises(NotImplementedError):
+        make_model(80, synth.make_args("tiny", use_conv_dec=True))
+
+
+# ------------------------------------------------------------------------------------------- data side
+def test_splice_and_skip_match_reference_outputs():
+    g = load_golden("feat_op")
+    np.testing.assert_array_equal(context_feat(g["feat"], 2, 1), g["ctx_l2_r1"])
+    np.testing.assert_array_equal(context_feat(g["feat"], 0, 2), g["ctx_r2"])
+    padded = np.vstack([g["feat"], np.zeros((1, 4))])
+    np.testing.assert_array_equal(skip_feat(context_feat(padded, 1, 1), 3), g["ctx_l1_r1_skip3"])
+    assert context_feat(g["feat"], 0, 0) is g["feat"] and skip_feat(g["feat"], 1) is g["feat"]
+
+
+def _write_dataset(tmp_path, lengths, dim=6):
+    rng = np.random.default_rng(0)
+    mats = [(f"utt{i:02d}", rng.standard_normal((n, dim)).astype(np.float32)) for i, n in enumerate(lengths)]
+    ark, scp = str(tmp_path / "feats.ark"), str(tmp_path / "feats.scp")
+    kaldi_io.write_ark_scp(ark, scp, mats)
+    vocab_file = tmp_path / "vocab.txt"
+    vocab_file.write_text("a\nb\nc 7\nutt a b d\n")
+    text = tmp_path / "text"
+    text.write_text("".join(f"utt{i:02d} a b zzz\n" for i in range(len(lengths))))
+    return mats, scp, str(vocab_file), str(text)
+
+
+def test_vocab_rules(tmp_path):
+    _, _, vocab_file, _ = _write_dataset(tmp_path, [3])
+    v = Vocab(vocab_file, rank=1)
+    # single-token lines add the token; multi-field lines drop the first field
+    assert v.word2index == {"blank": 0, "sos": 1, "eos": 2, "unk": 3, "a": 4, "b": 5, "7": 6, "d": 7}
+    assert v.n_words == 8 and v.index2word[6] == "7"
+
+
+def test_kaldi_roundtrip_cmvn_and_collate(tmp_path):
+    mats, scp, vocab_file, text = _write_dataset(tmp_path, [9, 5, 7])
+    entries = kaldi_io.read_scp(scp)
+    assert [u for u, _ in entries] == [u for u, _ in mats]
+    for (_, spec), (_, m) in zip(entries, mats):
+        np.testing.assert_array_equal(kaldi_io.load_mat(spec), m)
+    # global CMVN stats file in Kaldi layout (double matrix, 2 x (dim+1))
+    allf = np.vstack([m for _, m in mats]).astype(np.float64)
+    stats = np.zeros((2, 7))
+    stats[0, :6], stats[0, 6], stats[1, :6] = allf.sum(0), len(allf), (allf ** 2).sum(0)
+    kaldi_io.write_ark_scp(str(tmp_path / "cmvn.ark"), str(tmp_path / "cmvn.scp"), [("global", stats)])
+    args = synth.make_args("tiny", left_ctx=1, right_ctx=1, skip_frame=2)
+    ds = SpeechDataset(Vocab(vocab_file, 1), [{"name": "test", "scp_path": scp, "text_label": text}], args)
+    ds._load_cmvn(kaldi_io.read_scp(str(tmp_path / "cmvn.scp"))[0][1])
+    np.testing.assert_allclose(ds.mean, allf.mean(0))
+    np.testing.assert_allclose(ds.std, allf.std(0))
+    utt, feat, label = ds[1]  # 5 frames -> padded to 6 -> spliced (18 dims) -> every 2nd frame -> 3
+    assert utt == "utt01" and feat.shape == (3, 18) and label == [1, 4, 5, 3, 2]
+    norm = (mats[1][1] - ds.mean) / ds.std
+    np.testing.assert_allclose(feat[0], np.concatenate([norm[0], norm[0], norm[1]]))  # edge replication
+    utts, feats, texts, ratios, sizes = next(iter(SpeechDataLoader(ds, 3, padding_idx=0)))
+    assert feats.shape == (3, 5, 18) and feats.dtype == torch.float32
+    assert torch.equal(ratios, torch.tensor([5 / 5, 3 / 5, 4 / 5]))
+    assert (feats[1, 3:] == 0).all() and sizes.tolist() == [3, 3, 3] and texts.shape == (3, 5)
+    # the padding mask the task derives (src/tasks/cassnat_task.py:328)
+    assert ((feats[:, :, 0] != 0).sum(1)).tolist() == [5, 3, 4]
+
+
+def test_collate_ratio_is_float32_of_python_division():
+    batch = [("a", np.ones((1000, 2)), [1, 2]), ("b", np.ones((333, 2)), [1, 2])]
+    _, _, _, ratios, _ = collate(batch)
+    assert ratios[1].item() == np.float32(333 / 1000)
+
+
+def test_hyp_to_words_follows_reference_rule():
+    class V:
+        word2index = {"blank": 0, "sos": 1, "eos": 2, "unk": 3}
+        index2word = {4: "x", 5: "y", 6: "z"}
+
+    assert hyp_to_words([1, 4, 0, 5, 2, 6], V, 0) == ["x", "y"]
+    from oracle.cassnat_oracle import hyp_to_text
+
+    assert hyp_to_text([1, 4, 0, 5, 2, 6], V.index2word) == ["x", "y"]
+
+
+def test_decode_parser_has_the_reference_flags():
+    a = DecodeParser().get_args(["--test_config", "c.yaml", "--data_path", "f.scp", "--task", "cassnat", "--batch_size", "8",
+                                 "--resume_model", "m.mdl", "--result_file", "r.txt", "--print_freq", "5", "--seed", "3",
+                                 "--lm_config", "lm.yaml", "--text_label", "t", "--load_data_workers", "2",
+                                 "--rnnlm", "x", "--rank_model", "lm", "--lm_weight", "0"])
+    assert a.batch_size == 8 and a.task == "cassnat" and a.hip_precision == "bf16"
+
+
+# ------------------------------------------------------------------------------------------- sharding helpers
+def test_shard_indices_balance_lengths():
+    lens = np.array([100, 900, 500, 300, 700, 200, 800, 400])
+    parts = [cdist.shard_indices(lens, 2, r) for r in range(2)]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(8))
+    assert abs(lens[parts[0]].sum() - lens[parts[1]].sum()) <= 100
+    assert lens[parts[0]][0] == 900 and lens[parts[1]][0] == 800
+
+
+def test_record_pack_roundtrip():
+    hyp = torch.tensor([[1, 5, 6, 0], [1, 9, 0, 0]], dtype=torch.int32)
+    hl = torch.tensor([3, 2], dtype=torch.int32)
+    sc = torch.tensor([-12.34567890123, -0.5], dtype=torch.float64)
+    hyps, scores = cdist.unpack_records(cdist.pack_records(hyp, hl, sc))
+    assert hyps == [[1, 5, 6], [1, 9]] and scores.tolist() == sc.tolist()
+
+
+_WORKER = r"""
+import os, sys, torch, numpy as np
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from cassnat_asr_public_amd import dist as cdist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=rank, world_size=world)
+lens = np.array([50, 10, 40, 20, 30, 60])
+mine = cdist.shard_indices(lens, world, rank)
+hyp = torch.zeros(len(mine), 8, dtype=torch.int32)
+for i, u in enumerate(mine):
+    hyp[i, :3] = torch.tensor([1, 100 + int(u), 2])
+rec = cdist.pack_records(hyp, torch.full((len(mine),), 3, dtype=torch.int32), torch.tensor([-float(u) for u in mine], dtype=torch.float64))
+allrec = cdist.all_gather_records(rec)
+hyps, scores = cdist.unpack_records(allrec)
+got = sorted((int(-s), h[1] - 100) for h, s in zip(hyps, scores))
+assert got == [(u, u) for u in range(6)], got
+# weight hand-off: rank 0 owns the blob, rank 1 receives it
+blob = torch.arange(1000, dtype=torch.uint8) if rank == 0 else torch.zeros(1000, dtype=torch.uint8)
+dist.broadcast(blob, src=0)
+assert blob[999].item() == 999 % 256
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_process_gloo_gather_and_broadcast(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script), REPO, port], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for r, pr in enumerate(procs):
+        out, _ = pr.communicate(timeout=120)
+        assert pr.returncode == 0, out
+        assert f"rank {r} ok" in out
