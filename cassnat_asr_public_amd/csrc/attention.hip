@@ -48,13 +48,16 @@ template <> struct AttnCfg<float> {
     __device__ static int swz(int row) { return row & 15; }
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
+// NW waves per workgroup (32 query rows each): 4 -> 128-row tiles, 2 -> 64-row tiles (more, smaller workgroups when
+// the grid would otherwise be ~1 workgroup per CU with nothing to overlap its barriers and load latency)
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
     typedef AttnCfg<T> Cfg;
     typedef typename Frag<T>::type frag_t;
     constexpr int KROW = Cfg::KROW, VROW = Cfg::VROW, CPR = Cfg::CPR;
     constexpr int NF = KROW / 32;           // 16-byte fragments of one 64-wide head row per lane half
-    constexpr int ST_IT = 64 * CPR / 256;   // 16-byte chunks per thread per 64-key tile
+    constexpr int NT = 64 * NW;
+    constexpr int ST_IT = 64 * CPR / NT;    // 16-byte chunks per thread per 64-key tile
 
     __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * KROW];
     __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * VROW];
@@ -63,8 +66,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q_row = blockIdx.x * 128 + wave * 32 + l31;
-    const bool wave_active = (blockIdx.x * 128 + wave * 32) < p.Lq;
+    const int q_row = blockIdx.x * (32 * NW) + wave * 32 + l31;
+    const bool wave_active = (blockIdx.x * (32 * NW) + wave * 32) < p.Lq;
     const int qc = q_row < p.Lq ? q_row : p.Lq - 1;
 
     // ---- query fragments (B operand of S^T = K.Q^T): lane holds Q[q][16-byte chunk 2s+half]
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < ST_IT; ++i) {
-            const int cidx = tid + 256 * i;
+            const int cidx = tid + NT * i;
             const int row = cidx / CPR, ch = cidx % CPR;
             const int key = kt * 64 + row;
             if (key < p.Lk) {
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     auto store_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < ST_IT; ++i) {
-            const int cidx = tid + 256 * i;
+            const int cidx = tid + NT * i;
             const int row = cidx / CPR, ch = cidx % CPR;
             st16(Ks + row * KROW + ((ch ^ Cfg::swz(row)) << 4), k_reg[i]);
             st16(Vs + row * VROW + (ch << 4), v_reg[i]);
@@ -282,7 +285,11 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     p.iv_stride = a.iv_stride;
     p.causal = a.causal;
     p.scale = a.scale;
-    hipLaunchKernelGGL(attention_kernel<T>, dim3(cn_ceil_div(a.Lq, 128), a.H, a.B), dim3(256), 0, s, p);
+    const long long big_grid = (long long)cn_ceil_div(a.Lq, 128) * a.H * a.B;
+    if (big_grid >= 1024)
+        hipLaunchKernelGGL((attention_kernel<T, 4>), dim3(cn_ceil_div(a.Lq, 128), a.H, a.B), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((attention_kernel<T, 2>), dim3(cn_ceil_div(a.Lq, 64), a.H, a.B), dim3(128), 0, s, p);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -19,6 +19,7 @@
 //   * each wave owns d_ff/4 of the hidden units and a full 256x32 fp32 partial of out^T; the four partials
 //     are summed through LDS once per workgroup, fused with bias, residual add and the next LayerNorm.
 // The kernel is bound by the per-CU L2 bandwidth of the weight stream (2 MB per workgroup), not by MFMA.
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels.h"
@@ -55,6 +56,8 @@ __device__ __forceinline__ void ln_row_to(const f32x4 v, float mean, float denom
     for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[j] - mean) / denom + bb[j];
 }
 
+// DBG: timing experiments only (1 = no DMA refills, 2 = no MFMAs; results are wrong in both); 0 in production
+template <int DBG>
 __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xn_s = smem;                                          // [32][528 B]
@@ -68,6 +71,10 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
 
     const int tiles_per_wave = p.dff / 32 / 4;
     const int ft0 = wave * tiles_per_wave;
+    // Every workgroup walks its hidden tiles in a different rotation: the sum over tiles is order-free, and 250
+    // workgroups no longer pull the same L2 lines at the same moment (L2 channel hot-spotting).
+    const int rot = (blockIdx.x * 7 + wave * 3) % tiles_per_wave;
+#define FF_TT(t) (((t) + rot) % tiles_per_wave)
     // fragment stream of this wave: tile t, fragment i (0-15: W1 k-steps, 16-31: W2 (s, nt)) -> 1 KiB piece
     const uint4* w1 = reinterpret_cast<const uint4*>(p.w1p) + (long long)ft0 * 16 * 64 + lane;
     const uint4* w2 = reinterpret_cast<const uint4*>(p.w2p) + (long long)ft0 * 16 * 64 + lane;
@@ -76,9 +83,9 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
                                      (__attribute__((address_space(3))) void*)(ring + (slot) * 1024), 16, 0, 0)
     // prologue: the whole first tile goes in flight before the LayerNorm below
 #pragma unroll
-    for (int i = 0; i < 16; ++i) FF_DMA(w1 + i * 64, i);
+    for (int i = 0; i < 16; ++i) FF_DMA(w1 + ((long long)FF_TT(0) * 16 + i) * 64, i);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) FF_DMA(w2 + i * 64, 16 + i);
+    for (int i = 0; i < 16; ++i) FF_DMA(w2 + ((long long)FF_TT(0) * 16 + i) * 64, 16 + i);
     for (int i = tid; i < p.dff / 4; i += 256)
         reinterpret_cast<f32x4*>(b1_s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
 
@@ -128,6 +135,7 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
 #define FF_PHASE_A(g, WAITN, NEXT)                                                                            \
     {                                                                                                         \
         bf16x8 wf0, wf1, wf2, wf3, xq0, xq1, xq2, xq3;                                                        \
+        if constexpr (DBG == 3) { asm volatile("s_waitcnt vmcnt(" FF_STR(WAITN) ")" ::: "memory"); } else     \
         asm volatile("s_waitcnt vmcnt(" FF_STR(WAITN) ")\n\t"                                                 \
                      "ds_read_b128 %0, %8 offset:" FF_STR((4 * (g) + 0) * 1024) "\n\t"                        \
                      "ds_read_b128 %1, %8 offset:" FF_STR((4 * (g) + 1) * 1024) "\n\t"                        \
@@ -142,17 +150,20 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
                        "=&v"(xq3)                                                                             \
                      : "v"(slot_a), "v"(xrow_a)                                                               \
                      : "memory");                                                                             \
+        if constexpr (DBG == 3) { } else if (DBG != 2) {                                                      \
         xh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, xq0, xh, 0, 0, 0);                                  \
         xh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, xq1, xh, 0, 0, 0);                                  \
         xh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2, xq2, xh, 0, 0, 0);                                  \
         xh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf3, xq3, xh, 0, 0, 0);                                  \
-        if (NEXT) { _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
-            FF_DMA(w1 + ((long long)(t + 1) * 16 + 4 * (g) + j) * 64, 4 * (g) + j); }                         \
+        } else { xh[0] += (float)wf0[0] + (float)wf1[0] + (float)wf2[0] + (float)wf3[0] + (float)xq0[0]; }    \
+        if (NEXT && DBG != 1) { _Pragma("unroll") for (int j = 0; j < 4; ++j)                               \
+            FF_DMA(w1 + ((long long)tnext * 16 + 4 * (g) + j) * 64, 4 * (g) + j); }                         \
     }
     // phase B group g: W2 fragments (s = g>>1, nt = 4(g&1)..+3) in slots 16+4g..
 #define FF_PHASE_B(g, WAITN, NEXT)                                                                            \
     {                                                                                                         \
         bf16x8 wf0, wf1, wf2, wf3;                                                                            \
+        if constexpr (DBG == 3) { asm volatile("s_waitcnt vmcnt(" FF_STR(WAITN) ")" ::: "memory"); } else     \
         asm volatile("s_waitcnt vmcnt(" FF_STR(WAITN) ")\n\t"                                                 \
                      "ds_read_b128 %0, %4 offset:" FF_STR((16 + 4 * (g) + 0) * 1024) "\n\t"                   \
                      "ds_read_b128 %1, %4 offset:" FF_STR((16 + 4 * (g) + 1) * 1024) "\n\t"                   \
@@ -162,19 +173,21 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
                      : "=&v"(wf0), "=&v"(wf1), "=&v"(wf2), "=&v"(wf3)                                         \
                      : "v"(slot_a)                                                                            \
                      : "memory");                                                                             \
+        if constexpr (DBG == 3) { } else                                                                      \
+        if (DBG == 2) { acc[0][0] += (float)wf0[0] + (float)wf1[0] + (float)wf2[0] + (float)wf3[0]; } else {  \
         acc[4 * ((g) & 1) + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, pb[(g) >> 1], acc[4 * ((g) & 1) + 0], 0, 0, 0); \
         acc[4 * ((g) & 1) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, pb[(g) >> 1], acc[4 * ((g) & 1) + 1], 0, 0, 0); \
         acc[4 * ((g) & 1) + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2, pb[(g) >> 1], acc[4 * ((g) & 1) + 2], 0, 0, 0); \
-        acc[4 * ((g) & 1) + 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf3, pb[(g) >> 1], acc[4 * ((g) & 1) + 3], 0, 0, 0); \
-        if (NEXT) { _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
-            FF_DMA(w2 + ((long long)(t + 1) * 16 + 4 * (g) + j) * 64, 16 + 4 * (g) + j); }                    \
+        acc[4 * ((g) & 1) + 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf3, pb[(g) >> 1], acc[4 * ((g) & 1) + 3], 0, 0, 0); } \
+        if (NEXT && DBG != 1) { _Pragma("unroll") for (int j = 0; j < 4; ++j)                               \
+            FF_DMA(w2 + ((long long)tnext * 16 + 4 * (g) + j) * 64, 16 + 4 * (g) + j); }                    \
     }
     // bias + ReLU on hidden unit f = 32*(ft0+t) + acc_row(r, lane), then pack as the B operand of phase B
 #define FF_RELU_PACK()                                                                                        \
     bf16x8 pb[2];                                                                                             \
     {                                                                                                         \
         f32x4 bv0, bv1, bv2, bv3;                                                                             \
-        const unsigned ba = bias_a + 128 * t;                                                                 \
+        const unsigned ba = bias_a + 128 * FF_TT(t);                                                          \
         asm volatile("ds_read_b128 %0, %4\n\t"                                                                \
                      "ds_read_b128 %1, %4 offset:32\n\t"                                                      \
                      "ds_read_b128 %2, %4 offset:64\n\t"                                                      \
@@ -193,6 +206,7 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
 
     int t = 0;
     for (; t + 1 < tiles_per_wave; ++t) {
+        const int tnext = FF_TT(t + 1);
         f32x16 xh;
 #pragma unroll
         for (int r = 0; r < 16; ++r) xh[r] = 0.f;
@@ -201,6 +215,8 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
         FF_PHASE_B(0, 28, true) FF_PHASE_B(1, 28, true) FF_PHASE_B(2, 28, true) FF_PHASE_B(3, 28, true)
     }
     {
+        const int tnext = 0;
+        (void)tnext;
         f32x16 xh;
 #pragma unroll
         for (int r = 0; r < 16; ++r) xh[r] = 0.f;
@@ -211,6 +227,7 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
 #undef FF_PHASE_A
 #undef FF_PHASE_B
 #undef FF_RELU_PACK
+#undef FF_TT
 #undef FF_DMA
     __syncthreads();  // every wave is done with b1_s and its ring (all DMAs landed: last wait was vmcnt(0))
 
@@ -284,13 +301,25 @@ int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s) {
     p.M = a.M;
     p.dff = a.dff;
     p.eps = a.eps;
+    static int dbg = -1;
+    if (dbg < 0) dbg = getenv("CASSNAT_FFN_DEBUG") ? atoi(getenv("CASSNAT_FFN_DEBUG")) : 0;
     static bool attr_done = false;
     if (!attr_done) {
-        CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         FF_LDS_BYTES));
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
         attr_done = true;
     }
-    hipLaunchKernelGGL(ffn_fused_kernel, dim3(cn_ceil_div(a.M, FF_BM)), dim3(256), FF_LDS_BYTES, s, p);
+    const dim3 grid(cn_ceil_div(a.M, FF_BM));
+    if (dbg == 1)
+        hipLaunchKernelGGL(ffn_fused_kernel<1>, grid, dim3(256), FF_LDS_BYTES, s, p);
+    else if (dbg == 2)
+        hipLaunchKernelGGL(ffn_fused_kernel<2>, grid, dim3(256), FF_LDS_BYTES, s, p);
+    else if (dbg == 3)
+        hipLaunchKernelGGL(ffn_fused_kernel<3>, grid, dim3(256), FF_LDS_BYTES, s, p);
+    else
+        hipLaunchKernelGGL(ffn_fused_kernel<0>, grid, dim3(256), FF_LDS_BYTES, s, p);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

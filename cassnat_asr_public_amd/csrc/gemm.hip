@@ -29,7 +29,9 @@ struct GemmParams {
     int cT1, cF1, cC, cT2, cF2;
 };
 
-template <typename T, typename TC, int BM, int BN, bool CONV>
+// FULLK: K is exactly 4 slabs (256 bf16 / 128 f32): all slabs are loaded up front and staged behind ONE barrier
+// instead of four load -> barrier round trips (the K=256 projections are latency-, not throughput-bound).
+template <typename T, typename TC, int BM, int BN, bool CONV, bool FULLK = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     constexpr int ROWB = 128;
     constexpr int BK = ROWB / (int)sizeof(T);
@@ -117,14 +119,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     // fragment read offsets (row part fixed per thread, chunk part per k-step)
     const int a_row0 = wm * WM + l31, w_row0 = wn * WN + l31;
 
-    const int nk = p.K / BK;
-    load_slab(0);
-    store_slab(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_slab(kt + 1);
-        const unsigned char* a_base = smem + cur * BUF;
+    auto compute_slab = [&](int buf) {
+        const unsigned char* a_base = smem + buf * BUF;
         const unsigned char* w_base = a_base + BM * ROWB;
 #pragma unroll
         for (int cs = 0; cs < 4; ++cs) {
@@ -145,8 +141,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = mfma_frag(af[i], wf[j], acc[i][j]);
         }
-        if (kt + 1 < nk) store_slab(cur ^ 1);
+    };
+
+    const int nk = p.K / BK;
+    if constexpr (FULLK) {
+        uint4 a_all[4][A_IT], w_all[4][B_IT];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) a_all[kt][i] = ld16(a_src[i] + (long long)kt * ROWB);
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) w_all[kt][i] = ld16(w_src[i] + (long long)kt * ROWB);
+        }
+        // keep all 4*(A_IT+B_IT) loads in flight together: without this hipcc re-uses one register quad and
+        // serialises load -> wait -> ds_write sixteen times to minimise VGPRs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            unsigned char* a_dst = smem + kt * BUF + st_off;
+            unsigned char* w_dst = a_dst + BM * ROWB;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) st16(a_dst + i * 32 * ROWB, a_all[kt][i]);
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) st16(w_dst + i * 32 * ROWB, w_all[kt][i]);
+        }
         __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) compute_slab(kt);
+    } else {
+        load_slab(0);
+        store_slab(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) load_slab(kt + 1);
+            compute_slab(cur);
+            if (kt + 1 < nk) store_slab(cur ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane owns column n, 16 rows per 32x32 accumulator
@@ -172,7 +204,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 }
 
-template <typename T, typename TC, int BM, int BN, bool CONV>
+template <typename T, typename TC, int BM, int BN, bool CONV, bool FULLK = false>
 static int run_gemm(const GemmArgs& a, hipStream_t s) {
     constexpr int BK = 128 / (int)sizeof(T);
     GemmParams p;
@@ -198,8 +230,8 @@ static int run_gemm(const GemmArgs& a, hipStream_t s) {
     p.cT2 = a.cT2;
     p.cF2 = a.cF2;
     const int ntm = cn_ceil_div(a.M, BM);
-    const size_t lds = 2 * (size_t)(BM + BN) * 128;
-    auto kern = gemm_kernel<T, TC, BM, BN, CONV>;
+    const size_t lds = (FULLK ? 4 : 2) * (size_t)(BM + BN) * 128;
+    auto kern = gemm_kernel<T, TC, BM, BN, CONV, FULLK>;
     static bool attr_done = false;
     if (!attr_done) {
         CN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -232,10 +264,13 @@ template <typename T> static int dispatch_gemm(const GemmArgs& a, hipStream_t s)
     // Tile choice: 128x128 when that still yields >= 2 workgroups per CU, else 64x64 to fill 256 CUs.
     const long long big = (long long)cn_ceil_div(a.M, 128) * cn_ceil_div(a.N, 128);
     const bool use_big = big >= 512;
+    const bool fullk = a.K == 4 * BK;
     if (a.c_f32) {
-        return use_big ? run_gemm<T, float, 128, 128, false>(a, s) : run_gemm<T, float, 64, 64, false>(a, s);
+        if (use_big) return run_gemm<T, float, 128, 128, false>(a, s);
+        return fullk ? run_gemm<T, float, 64, 64, false, true>(a, s) : run_gemm<T, float, 64, 64, false>(a, s);
     }
-    return use_big ? run_gemm<T, T, 128, 128, false>(a, s) : run_gemm<T, T, 64, 64, false>(a, s);
+    if (use_big) return run_gemm<T, T, 128, 128, false>(a, s);
+    return fullk ? run_gemm<T, T, 64, 64, false, true>(a, s) : run_gemm<T, T, 64, 64, false>(a, s);
 }
 
 int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {

@@ -111,6 +111,8 @@ struct cn_model {
         *tok = nullptr, *topk_idx = nullptr;
     float *ctc_maxlp = nullptr, *val = nullptr, *topk_val = nullptr;
 
+    int* ymax_pinned = nullptr;  // page-locked host word for the one data-dependent readback per batch
+
     // last call
     int B = 0, T = 0, T1 = 0, Tp = 0, U = 0, last_k = 0;
     std::map<std::string, Capture> captures;
@@ -455,6 +457,7 @@ int build_workspace(cn_model* m) {
     CN_TRY(dev_alloc(m, (void**)&m->val, M * 4));
     CN_TRY(dev_alloc(m, (void**)&m->topk_idx, M * 16 * 4));
     CN_TRY(dev_alloc(m, (void**)&m->topk_val, M * 16 * 4));
+    CN_HIP_CHECK(hipHostMalloc((void**)&m->ymax_pinned, 64, hipHostMallocDefault));
     return 0;
 }
 
@@ -838,6 +841,7 @@ extern "C" void cn_model_destroy(cn_model* m) {
     for (auto& kv : m->captures)
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
+    if (m->ymax_pinned) (void)hipHostFree(m->ymax_pinned);
     if (m->blob) (void)hipFree(m->blob);
     delete m;
 }
@@ -905,10 +909,11 @@ extern "C" int cn_encode_align(cn_model* m, const float* feats_dev, const float*
                                int32_t F, const cn_decode_opts* opts, int32_t* ymax_host, void* stream) {
     CN_TRY(check_call(m, B, T, F));
     hipStream_t s = (hipStream_t)stream;
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
     CN_TRY(stage_encode_align(m, feats_dev, size_ratio_dev, B, T, F, opts, s));
-    int ymax = 0;
-    CN_HIP_CHECK(hipMemcpyAsync(&ymax, m->ymax, sizeof(int), hipMemcpyDeviceToHost, s));
+    CN_HIP_CHECK(hipMemcpyAsync(m->ymax_pinned, m->ymax, sizeof(int), hipMemcpyDeviceToHost, s));
     CN_HIP_CHECK(hipStreamSynchronize(s));
+    const int ymax = *m->ymax_pinned;
     if (ymax_host) *ymax_host = ymax;
     return 0;
 }
@@ -922,10 +927,11 @@ extern "C" int cn_decode_nast(cn_model* m, const float* feats_dev, const float* 
         return -1;
     }
     hipStream_t s = (hipStream_t)stream;
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));  // callers may decode from several host threads (one handle each)
     CN_TRY(stage_encode_align(m, feats_dev, size_ratio_dev, B, T, F, opts, s));
-    int ymax = 0;
-    CN_HIP_CHECK(hipMemcpyAsync(&ymax, m->ymax, sizeof(int), hipMemcpyDeviceToHost, s));
+    CN_HIP_CHECK(hipMemcpyAsync(m->ymax_pinned, m->ymax, sizeof(int), hipMemcpyDeviceToHost, s));
     CN_HIP_CHECK(hipStreamSynchronize(s));  // U is data dependent
+    const int ymax = *m->ymax_pinned;
     if (ymax < 1 || ymax > m->Tp + 1) {
         cn_set_error("cn_decode_nast: alignment produced an impossible token count");
         return -3;
