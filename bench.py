@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batches", type=int, default=3)
     ap.add_argument("--stage-profile", action="store_true", help="also print a per-kernel-tag table to stderr")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 path on one GPU")
     ap.add_argument("--streams", type=int, default=4,
                     help="decode pipelines per GPU (own engine handle, HIP stream and host thread each): keeps the GPU fed "
                          "across the two host syncs every batch needs (token count readback, hypotheses to host)")
@@ -74,10 +75,14 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         a.gpus = world
+    local_rank = min(local_rank, torch.cuda.device_count() - 1)  # gloo rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     class Vocab:
         word2index = {"blank": 0, "sos": 1, "eos": 2, "unk": 3}
@@ -108,7 +113,6 @@ def main():
             t0 = time.perf_counter()
             cdist.broadcast_weights(eng, src=0)
             bcast_ms = (time.perf_counter() - t0) * 1e3
-            groups.append(dist.new_group())  # one communicator per pipeline: collectives of different threads never interleave
         models.append(model)
         engines.append(eng)
     blob_bytes = engines[0].weight_blob()[1]
@@ -118,12 +122,19 @@ def main():
     feats = torch.from_numpy(feats_h).cuda()
     sizes = torch.from_numpy(sizes_h).cuda()
 
-    def step(i=0):
+    def decode_step(i):
+        """device half of one step on pipeline i: returns the packed hypothesis records (still on the GPU)"""
         hyp, hyp_len, score = models[i].decode_device(feats, sizes, args)
-        rec = cdist.pack_records(hyp, hyp_len, score)
+        return cdist.pack_records(hyp, hyp_len, score)
+
+    def finish_step(rec):
+        """all-gather of the records over the ranks (one collective per batch) + hypotheses to the host"""
         if world > 1:
-            rec = cdist.all_gather_records(rec, group=groups[i])
-        return cdist.unpack_records(rec)  # hypotheses materialised on the host, as beam_decode returns them
+            rec = cdist.all_gather_records(rec)
+        return cdist.unpack_records(rec)
+
+    def step(i=0):
+        return finish_step(decode_step(i))
 
     def fence():
         torch.cuda.synchronize()
@@ -134,21 +145,34 @@ def main():
     last = {}
 
     def run_steps(n_steps):
-        """n_steps batches over NS pipelines; every rank runs the same number of steps on pipeline i (i = k % NS), so the
-        per-pipeline collectives match across ranks."""
-        def worker(i):
-            torch.cuda.set_device(local_rank)
-            with torch.cuda.stream(torch.cuda.Stream()):
-                for k in range(i, n_steps, NS):
-                    last[i] = step(i)
-                torch.cuda.current_stream().synchronize()
+        """n_steps batches over NS decode pipelines (host thread + HIP stream + engine handle each).  Collectives are
+        issued by THIS thread only, in step order, so every rank issues the same sequence on one communicator."""
         if NS == 1:
             for k in range(n_steps):
                 last[0] = step(0)
             return
+        import queue
+
+        done = [queue.Queue() for _ in range(NS)]
+
+        def worker(i):
+            torch.cuda.set_device(local_rank)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for k in range(i, n_steps, NS):
+                    rec = decode_step(i)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    done[i].put((rec, ev))
+                st.synchronize()
+
         threads = [threading.Thread(target=worker, args=(i,)) for i in range(NS)]
         for t in threads:
             t.start()
+        for k in range(n_steps):
+            rec, ev = done[k % NS].get()
+            ev.wait(torch.cuda.current_stream())
+            last[0] = finish_step(rec)
         for t in threads:
             t.join()
 

@@ -40,15 +40,13 @@ struct FfnParams {
 };
 
 constexpr int FF_D = 256;
-constexpr int FF_BM = 32;
-constexpr int FF_XN_STRIDE = 528;      // bytes per xn row in LDS: 512 + 16 pad (conflict-free b128 reads)
 constexpr int FF_P_STRIDE = FF_D + 4;  // floats per partial row in LDS
 constexpr int FF_MAX_DFF = 2048;
-constexpr int FF_XN_BYTES = FF_BM * FF_XN_STRIDE;        // 16896
-constexpr int FF_B1_BYTES = FF_MAX_DFF * 4;              // 8192
-constexpr int FF_RING_BYTES = 32 * 1024;                 // per wave: 32 fragments of 1 KiB
-constexpr int FF_LDS_BYTES = FF_XN_BYTES + FF_B1_BYTES + 4 * FF_RING_BYTES;  // 156160 (partials alias b1 + rings)
-static_assert(4 * FF_BM * FF_P_STRIDE * 4 <= FF_B1_BYTES + 4 * FF_RING_BYTES, "partials must fit behind the xn tile");
+constexpr int FF_RING_BYTES = 32 * 1024;  // per wave: 32 fragments of 1 KiB
+// LDS: [MT x 16 KiB xn fragments][4 x 32 KiB rings]; the 4 x 32 x 260 fp32 partials of the epilogue alias all of it
+template <int MT> constexpr int ff_lds_bytes() { return MT * 16384 + 4 * FF_RING_BYTES; }
+static_assert(4 * 32 * FF_P_STRIDE * 4 <= ff_lds_bytes<1>(), "partials must fit");
+static_assert(ff_lds_bytes<2>() <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ void ln_row_to(const f32x4 v, float mean, float denom, const f32x4 g, const f32x4 bb,
                                           float* o) {
@@ -56,24 +54,27 @@ __device__ __forceinline__ void ln_row_to(const f32x4 v, float mean, float denom
     for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[j] - mean) / denom + bb[j];
 }
 
-// DBG: timing experiments only (1 = no DMA refills, 2 = no MFMAs; results are wrong in both); 0 in production
-template <int DBG>
+// MT = 32-row M-tiles per workgroup (1 or 2).  With MT = 2 every streamed weight fragment feeds two MFMAs, which halves
+// the L2->LDS bytes per row - the resource this kernel is bound by.
+// DBG: timing experiments only (1 = no DMA refills, 2 = no MFMAs, 3 = DMA stream only; results are wrong); 0 in production
+template <int MT, int DBG>
 __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
+    constexpr int BM = 32 * MT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xn_s = smem;                                          // [32][528 B]
-    float* b1_s = reinterpret_cast<float*>(smem + FF_XN_BYTES);          // [dff]
-    float* part = reinterpret_cast<float*>(smem + FF_XN_BYTES);          // [4][32][260], aliases b1_s + rings at the end
+    unsigned char* xn_s = smem;                     // [MT][16 k-steps][64 lanes][16 B]: B fragments of xn^T, ready to read
+    float* part = reinterpret_cast<float*>(smem);   // [4][32][260] fp32, epilogue only (aliases everything)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.x * FF_BM;
-    unsigned char* ring = smem + FF_XN_BYTES + FF_B1_BYTES + __builtin_amdgcn_readfirstlane(wave) * FF_RING_BYTES;
+    const int m0 = blockIdx.x * BM;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned char* ring = smem + MT * 16384 + wave_u * FF_RING_BYTES;
 
     const int tiles_per_wave = p.dff / 32 / 4;
-    const int ft0 = wave * tiles_per_wave;
-    // Every workgroup walks its hidden tiles in a different rotation: the sum over tiles is order-free, and 250
+    const int ft0 = wave_u * tiles_per_wave;
+    // Every workgroup walks its hidden tiles in a different rotation: the sum over tiles is order-free, and the
     // workgroups no longer pull the same L2 lines at the same moment (L2 channel hot-spotting).
-    const int rot = (blockIdx.x * 7 + wave * 3) % tiles_per_wave;
+    const int rot = (blockIdx.x * 7 + wave_u * 3) % tiles_per_wave;
 #define FF_TT(t) (((t) + rot) % tiles_per_wave)
     // fragment stream of this wave: tile t, fragment i (0-15: W1 k-steps, 16-31: W2 (s, nt)) -> 1 KiB piece
     const uint4* w1 = reinterpret_cast<const uint4*>(p.w1p) + (long long)ft0 * 16 * 64 + lane;
@@ -81,20 +82,30 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
 #define FF_DMA(src, slot)                                                                              \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
                                      (__attribute__((address_space(3))) void*)(ring + (slot) * 1024), 16, 0, 0)
+    // The wave's biases (32 per hidden tile, <= 512) live in 8 VGPRs per lane, in PROCESSING order: register j, lane
+    // 32*p + i holds b1 of hidden unit i of the tile processed at position 2j+p.  A lane fetches the 16 it needs
+    // per tile with ds_bpermute (no LDS memory, no global load inside the DMA-pipelined loop), and the queue is
+    // shifted down every second tile so the register index stays static.
+    float bq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int pos = 2 * j + half;
+        bq[j] = pos < tiles_per_wave ? p.b1[32 * (ft0 + FF_TT(pos)) + l31] : 0.f;
+    }
     // prologue: the whole first tile goes in flight before the LayerNorm below
 #pragma unroll
     for (int i = 0; i < 16; ++i) FF_DMA(w1 + ((long long)FF_TT(0) * 16 + i) * 64, i);
 #pragma unroll
     for (int i = 0; i < 16; ++i) FF_DMA(w2 + ((long long)FF_TT(0) * 16 + i) * 64, 16 + i);
-    for (int i = tid; i < p.dff / 4; i += 256)
-        reinterpret_cast<f32x4*>(b1_s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
 
-    // ---- LayerNorm of the workgroup's 32 rows -> bf16 tile in LDS (wave w: rows w, w+4, ...)
+    // ---- LayerNorm of the workgroup's rows -> bf16 fragments in LDS (wave w: rows w, w+4, ...)
     {
         const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_a + 4 * lane);
         const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * lane);
+        // element k = 4*lane + j of row r lands in fragment (mt = r>>5, ks = k>>4), lane slot 32*((k>>3)&1) + (r&31), byte 2*(k&7)
+        const int ks = lane >> 2, kh = (lane >> 1) & 1, kb = (lane & 1) * 8;
 #pragma unroll
-        for (int i = 0; i < FF_BM / 4; ++i) {
+        for (int i = 0; i < BM / 4; ++i) {
             const int r = wave + 4 * i;
             int m = m0 + r;
             if (m >= p.M) m = p.M - 1;
@@ -109,58 +120,97 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
             bf16x4 ob;
 #pragma unroll
             for (int j = 0; j < 4; ++j) ob[j] = (bf16)o[j];
-            *reinterpret_cast<bf16x4*>(xn_s + r * FF_XN_STRIDE + 8 * lane) = ob;
+            *reinterpret_cast<bf16x4*>(xn_s + (((r >> 5) * 16 + ks) * 64 + kh * 32 + (r & 31)) * 16 + kb) = ob;
         }
     }
     __syncthreads();
+
     // LDS byte addresses for the inline-asm reads below.  hipcc inserts a full vmcnt(0) in front of every ordinary
     // LDS access while an LDS-DMA is outstanding (it cannot tell the slots apart), so all main-loop LDS reads are
     // issued from asm statements that carry their own counted vmcnt / lgkmcnt(0) (cdna_hip_programming.md 5.7, form i).
-    const unsigned xrow_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(xn_s + l31 * FF_XN_STRIDE + 16 * half);
+    const unsigned xfrag_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(xn_s + lane * 16);
     const unsigned slot_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(ring + lane * 16);
-    const unsigned bias_a = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(b1_s + 32 * ft0 + 4 * half);
 
-    f32x16 acc[8];
+    f32x16 acc[MT][8];
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // One hidden tile = 8 groups of 4 fragments.  Before group g is read, the DMAs younger than it number
-    // 4*(7-g) (rest of this tile) + 4*g (already re-issued for the next tile) = 28 in steady state, and
-    // 4*(7-g) in the last tile, which issues nothing: each wait is a literal vmcnt on the wave's own queue.
+    // One hidden tile = 8 groups of 4 fragments (0-3: W1, 4-7: W2).  Each group: [counted vmcnt] -> issue its LDS reads ->
+    // issue the DMA refills of the PREVIOUS group's slots (their data is already in registers; the refills overlap the
+    // LDS-read latency and keep the DMA queue full) -> lgkmcnt(0) -> MFMAs.  With refills trailing by one group, the DMAs
+    // younger than group g's are always 6 groups = 24 in steady state; the last tile issues none, so its counts fall
+    // 24, 24, 20, 16, 12, 8, 4, 0 (the first wait still sees the refill of the previous tile's group 7... which the last
+    // tile's group 0 block does issue).  Every wait is a literal vmcnt on the wave's own queue.
 #define FF_STR2(x) #x
 #define FF_STR(x) FF_STR2(x)
-    // phase A group g: W1 fragments in slots 4g..4g+3, xn fragments of k-steps 4g..4g+3
-#define FF_PHASE_A(g, WAITN, NEXT)                                                                            \
+#define FF_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define FF_REFILL_W1(g) { _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
+        FF_DMA(w1 + ((long long)tnext * 16 + 4 * (g) + j) * 64, 4 * (g) + j); }
+#define FF_REFILL_W2(g) { _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
+        FF_DMA(w2 + ((long long)tnext * 16 + 4 * (g) + j) * 64, 16 + 4 * (g) + j); }
+    // REFILL: statement(s) issued between the read issue and the wait (the previous group's refill, or nothing)
+#define FF_PHASE_A(g, WAITN, REFILL)                                                                          \
     {                                                                                                         \
-        bf16x8 wf0, wf1, wf2, wf3, xq0, xq1, xq2, xq3;                                                        \
-        if constexpr (DBG == 3) { asm volatile("s_waitcnt vmcnt(" FF_STR(WAITN) ")" ::: "memory"); } else     \
+        bf16x8 wf0, wf1, wf2, wf3, xq0, xq1, xq2, xq3, yq0, yq1, yq2, yq3;                                    \
+        if constexpr (DBG == 3) { asm volatile("s_waitcnt vmcnt(" FF_STR(WAITN) ")" ::: "memory"); }          \
+        else if constexpr (MT == 1)                                                                           \
         asm volatile("s_waitcnt vmcnt(" FF_STR(WAITN) ")\n\t"                                                 \
                      "ds_read_b128 %0, %8 offset:" FF_STR((4 * (g) + 0) * 1024) "\n\t"                        \
                      "ds_read_b128 %1, %8 offset:" FF_STR((4 * (g) + 1) * 1024) "\n\t"                        \
                      "ds_read_b128 %2, %8 offset:" FF_STR((4 * (g) + 2) * 1024) "\n\t"                        \
                      "ds_read_b128 %3, %8 offset:" FF_STR((4 * (g) + 3) * 1024) "\n\t"                        \
-                     "ds_read_b128 %4, %9 offset:" FF_STR((4 * (g) + 0) * 32) "\n\t"                          \
-                     "ds_read_b128 %5, %9 offset:" FF_STR((4 * (g) + 1) * 32) "\n\t"                          \
-                     "ds_read_b128 %6, %9 offset:" FF_STR((4 * (g) + 2) * 32) "\n\t"                          \
-                     "ds_read_b128 %7, %9 offset:" FF_STR((4 * (g) + 3) * 32) "\n\t"                          \
-                     "s_waitcnt lgkmcnt(0)"                                                                   \
+                     "ds_read_b128 %4, %9 offset:" FF_STR((4 * (g) + 0) * 1024) "\n\t"                        \
+                     "ds_read_b128 %5, %9 offset:" FF_STR((4 * (g) + 1) * 1024) "\n\t"                        \
+                     "ds_read_b128 %6, %9 offset:" FF_STR((4 * (g) + 2) * 1024) "\n\t"                        \
+                     "ds_read_b128 %7, %9 offset:" FF_STR((4 * (g) + 3) * 1024)                                \
                      : "=&v"(wf0), "=&v"(wf1), "=&v"(wf2), "=&v"(wf3), "=&v"(xq0), "=&v"(xq1), "=&v"(xq2),    \
                        "=&v"(xq3)                                                                             \
-                     : "v"(slot_a), "v"(xrow_a)                                                               \
+                     : "v"(slot_a), "v"(xfrag_a)                                                              \
                      : "memory");                                                                             \
-        if constexpr (DBG == 3) { } else if (DBG != 2) {                                                      \
-        xh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, xq0, xh, 0, 0, 0);                                  \
-        xh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, xq1, xh, 0, 0, 0);                                  \
-        xh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2, xq2, xh, 0, 0, 0);                                  \
-        xh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf3, xq3, xh, 0, 0, 0);                                  \
-        } else { xh[0] += (float)wf0[0] + (float)wf1[0] + (float)wf2[0] + (float)wf3[0] + (float)xq0[0]; }    \
-        if (NEXT && DBG != 1) { _Pragma("unroll") for (int j = 0; j < 4; ++j)                               \
-            FF_DMA(w1 + ((long long)tnext * 16 + 4 * (g) + j) * 64, 4 * (g) + j); }                         \
+        else                                                                                                  \
+        asm volatile("s_waitcnt vmcnt(" FF_STR(WAITN) ")\n\t"                                                 \
+                     "ds_read_b128 %0, %12 offset:" FF_STR((4 * (g) + 0) * 1024) "\n\t"                       \
+                     "ds_read_b128 %1, %12 offset:" FF_STR((4 * (g) + 1) * 1024) "\n\t"                       \
+                     "ds_read_b128 %2, %12 offset:" FF_STR((4 * (g) + 2) * 1024) "\n\t"                       \
+                     "ds_read_b128 %3, %12 offset:" FF_STR((4 * (g) + 3) * 1024) "\n\t"                       \
+                     "ds_read_b128 %4, %13 offset:" FF_STR((4 * (g) + 0) * 1024) "\n\t"                       \
+                     "ds_read_b128 %5, %13 offset:" FF_STR((4 * (g) + 1) * 1024) "\n\t"                       \
+                     "ds_read_b128 %6, %13 offset:" FF_STR((4 * (g) + 2) * 1024) "\n\t"                       \
+                     "ds_read_b128 %7, %13 offset:" FF_STR((4 * (g) + 3) * 1024) "\n\t"                       \
+                     "ds_read_b128 %8, %13 offset:" FF_STR((16 + 4 * (g) + 0) * 1024) "\n\t"                  \
+                     "ds_read_b128 %9, %13 offset:" FF_STR((16 + 4 * (g) + 1) * 1024) "\n\t"                  \
+                     "ds_read_b128 %10, %13 offset:" FF_STR((16 + 4 * (g) + 2) * 1024) "\n\t"                 \
+                     "ds_read_b128 %11, %13 offset:" FF_STR((16 + 4 * (g) + 3) * 1024)                         \
+                     : "=&v"(wf0), "=&v"(wf1), "=&v"(wf2), "=&v"(wf3), "=&v"(xq0), "=&v"(xq1), "=&v"(xq2),    \
+                       "=&v"(xq3), "=&v"(yq0), "=&v"(yq1), "=&v"(yq2), "=&v"(yq3)                             \
+                     : "v"(slot_a), "v"(xfrag_a)                                                              \
+                     : "memory");                                                                             \
+        if constexpr (DBG != 1) { REFILL }                                                                    \
+        if constexpr (DBG != 3) {                                                                             \
+            if constexpr (MT == 1)                                                                            \
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf0), "+v"(wf1), "+v"(wf2), "+v"(wf3), "+v"(xq0),  \
+                             "+v"(xq1), "+v"(xq2), "+v"(xq3) :: "memory");                                    \
+            else                                                                                              \
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf0), "+v"(wf1), "+v"(wf2), "+v"(wf3), "+v"(xq0),  \
+                             "+v"(xq1), "+v"(xq2), "+v"(xq3), "+v"(yq0), "+v"(yq1), "+v"(yq2), "+v"(yq3)      \
+                             :: "memory");                                                                    \
+        }                                                                                                     \
+        if constexpr (DBG == 0 || DBG == 1) {                                                                 \
+            FF_MFMA(wf0, xq0, xh[0]); FF_MFMA(wf1, xq1, xh[0]); FF_MFMA(wf2, xq2, xh[0]); FF_MFMA(wf3, xq3, xh[0]); \
+            if constexpr (MT == 2) {                                                                          \
+                FF_MFMA(wf0, yq0, xh[MT - 1]); FF_MFMA(wf1, yq1, xh[MT - 1]);                                 \
+                FF_MFMA(wf2, yq2, xh[MT - 1]); FF_MFMA(wf3, yq3, xh[MT - 1]);                                 \
+            }                                                                                                 \
+        } else if constexpr (DBG == 2) {                                                                      \
+            xh[0][0] += (float)wf0[0] + (float)wf1[0] + (float)wf2[0] + (float)wf3[0] + (float)xq0[0];        \
+        }                                                                                                     \
     }
     // phase B group g: W2 fragments (s = g>>1, nt = 4(g&1)..+3) in slots 16+4g..
-#define FF_PHASE_B(g, WAITN, NEXT)                                                                            \
+#define FF_PHASE_B(g, WAITN, REFILL)                                                                          \
     {                                                                                                         \
         bf16x8 wf0, wf1, wf2, wf3;                                                                            \
         if constexpr (DBG == 3) { asm volatile("s_waitcnt vmcnt(" FF_STR(WAITN) ")" ::: "memory"); } else     \
@@ -168,81 +218,79 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
                      "ds_read_b128 %0, %4 offset:" FF_STR((16 + 4 * (g) + 0) * 1024) "\n\t"                   \
                      "ds_read_b128 %1, %4 offset:" FF_STR((16 + 4 * (g) + 1) * 1024) "\n\t"                   \
                      "ds_read_b128 %2, %4 offset:" FF_STR((16 + 4 * (g) + 2) * 1024) "\n\t"                   \
-                     "ds_read_b128 %3, %4 offset:" FF_STR((16 + 4 * (g) + 3) * 1024) "\n\t"                   \
-                     "s_waitcnt lgkmcnt(0)"                                                                   \
+                     "ds_read_b128 %3, %4 offset:" FF_STR((16 + 4 * (g) + 3) * 1024)                           \
                      : "=&v"(wf0), "=&v"(wf1), "=&v"(wf2), "=&v"(wf3)                                         \
                      : "v"(slot_a)                                                                            \
                      : "memory");                                                                             \
-        if constexpr (DBG == 3) { } else                                                                      \
-        if (DBG == 2) { acc[0][0] += (float)wf0[0] + (float)wf1[0] + (float)wf2[0] + (float)wf3[0]; } else {  \
-        acc[4 * ((g) & 1) + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, pb[(g) >> 1], acc[4 * ((g) & 1) + 0], 0, 0, 0); \
-        acc[4 * ((g) & 1) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, pb[(g) >> 1], acc[4 * ((g) & 1) + 1], 0, 0, 0); \
-        acc[4 * ((g) & 1) + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2, pb[(g) >> 1], acc[4 * ((g) & 1) + 2], 0, 0, 0); \
-        acc[4 * ((g) & 1) + 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf3, pb[(g) >> 1], acc[4 * ((g) & 1) + 3], 0, 0, 0); } \
-        if (NEXT && DBG != 1) { _Pragma("unroll") for (int j = 0; j < 4; ++j)                               \
-            FF_DMA(w2 + ((long long)tnext * 16 + 4 * (g) + j) * 64, 16 + 4 * (g) + j); }                    \
-    }
-    // bias + ReLU on hidden unit f = 32*(ft0+t) + acc_row(r, lane), then pack as the B operand of phase B
-#define FF_RELU_PACK()                                                                                        \
-    bf16x8 pb[2];                                                                                             \
-    {                                                                                                         \
-        f32x4 bv0, bv1, bv2, bv3;                                                                             \
-        const unsigned ba = bias_a + 128 * FF_TT(t);                                                          \
-        asm volatile("ds_read_b128 %0, %4\n\t"                                                                \
-                     "ds_read_b128 %1, %4 offset:32\n\t"                                                      \
-                     "ds_read_b128 %2, %4 offset:64\n\t"                                                      \
-                     "ds_read_b128 %3, %4 offset:96\n\t"                                                      \
-                     "s_waitcnt lgkmcnt(0)"                                                                   \
-                     : "=&v"(bv0), "=&v"(bv1), "=&v"(bv2), "=&v"(bv3)                                         \
-                     : "v"(ba)                                                                                \
-                     : "memory");                                                                             \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
-            pb[0][e] = (bf16)fmaxf(xh[e] + bv0[e], 0.f);                                                      \
-            pb[0][4 + e] = (bf16)fmaxf(xh[4 + e] + bv1[e], 0.f);                                              \
-            pb[1][e] = (bf16)fmaxf(xh[8 + e] + bv2[e], 0.f);                                                  \
-            pb[1][4 + e] = (bf16)fmaxf(xh[12 + e] + bv3[e], 0.f);                                             \
+        if constexpr (DBG != 1) { REFILL }                                                                    \
+        if constexpr (DBG != 3)                                                                               \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf0), "+v"(wf1), "+v"(wf2), "+v"(wf3) :: "memory");    \
+        if constexpr (DBG == 0 || DBG == 1) {                                                                 \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                               \
+                FF_MFMA(wf0, pb[mt][(g) >> 1], acc[mt][4 * ((g) & 1) + 0]);                                   \
+                FF_MFMA(wf1, pb[mt][(g) >> 1], acc[mt][4 * ((g) & 1) + 1]);                                   \
+                FF_MFMA(wf2, pb[mt][(g) >> 1], acc[mt][4 * ((g) & 1) + 2]);                                   \
+                FF_MFMA(wf3, pb[mt][(g) >> 1], acc[mt][4 * ((g) & 1) + 3]);                                   \
+            }                                                                                                 \
+        } else if constexpr (DBG == 2) {                                                                      \
+            acc[0][0][0] += (float)wf0[0] + (float)wf1[0] + (float)wf2[0] + (float)wf3[0];                    \
         }                                                                                                     \
     }
+    // bias + ReLU on hidden unit f = 32*tile + acc_row(r, lane), then pack as the B operand of phase B
+#define FF_RELU_PACK(pos)                                                                                     \
+    bf16x8 pb[MT][2];                                                                                         \
+    {                                                                                                         \
+        const int src0 = 32 * ((pos) & 1) + 4 * half;                                                         \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) _Pragma("unroll") for (int e = 0; e < 4; ++e) {         \
+            const float bv = __shfl(bq[0], src0 + 8 * g + e);                                                 \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                 \
+                pb[mt][g >> 1][4 * (g & 1) + e] = (bf16)fmaxf(xh[mt][4 * g + e] + bv, 0.f);                   \
+        }                                                                                                     \
+        if ((pos) & 1) { _Pragma("unroll") for (int j = 0; j < 7; ++j) bq[j] = bq[j + 1]; }                   \
+    }
+#define FF_ZERO_XH()                                                                                          \
+    f32x16 xh[MT];                                                                                            \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int r = 0; r < 16; ++r) xh[mt][r] = 0.f;
 
+    // Refill schedule: group h of the NEXT tile is re-issued in the block of group h+1 of this tile; the refill of this
+    // tile's last W2 group (slot group 7) is issued in group 0's block of the next tile (tnext there = that tile).
     int t = 0;
+    int tnext = FF_TT(0);  // tile whose slot group 7 is still to be refilled at the start of the loop: none for t == 0
     for (; t + 1 < tiles_per_wave; ++t) {
-        const int tnext = FF_TT(t + 1);
-        f32x16 xh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xh[r] = 0.f;
-        FF_PHASE_A(0, 28, true) FF_PHASE_A(1, 28, true) FF_PHASE_A(2, 28, true) FF_PHASE_A(3, 28, true)
-        FF_RELU_PACK()
-        FF_PHASE_B(0, 28, true) FF_PHASE_B(1, 28, true) FF_PHASE_B(2, 28, true) FF_PHASE_B(3, 28, true)
+        FF_ZERO_XH()
+        if (t == 0) {
+            FF_PHASE_A(0, 28, )
+        } else {
+            FF_PHASE_A(0, 24, FF_REFILL_W2(3))
+        }
+        tnext = FF_TT(t + 1);
+        FF_PHASE_A(1, 24, FF_REFILL_W1(0)) FF_PHASE_A(2, 24, FF_REFILL_W1(1)) FF_PHASE_A(3, 24, FF_REFILL_W1(2))
+        FF_RELU_PACK(t)
+        FF_PHASE_B(0, 24, FF_REFILL_W1(3)) FF_PHASE_B(1, 24, FF_REFILL_W2(0)) FF_PHASE_B(2, 24, FF_REFILL_W2(1))
+        FF_PHASE_B(3, 24, FF_REFILL_W2(2))
     }
     {
-        const int tnext = 0;
-        (void)tnext;
-        f32x16 xh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xh[r] = 0.f;
-        FF_PHASE_A(0, 28, false) FF_PHASE_A(1, 24, false) FF_PHASE_A(2, 20, false) FF_PHASE_A(3, 16, false)
-        FF_RELU_PACK()
-        FF_PHASE_B(0, 12, false) FF_PHASE_B(1, 8, false) FF_PHASE_B(2, 4, false) FF_PHASE_B(3, 0, false)
+        FF_ZERO_XH()
+        if (t == 0) {
+            FF_PHASE_A(0, 28, )
+        } else {
+            FF_PHASE_A(0, 24, FF_REFILL_W2(3))
+        }
+        FF_PHASE_A(1, 24, ) FF_PHASE_A(2, 20, ) FF_PHASE_A(3, 16, )
+        FF_RELU_PACK(t)
+        FF_PHASE_B(0, 12, ) FF_PHASE_B(1, 8, ) FF_PHASE_B(2, 4, ) FF_PHASE_B(3, 0, )
     }
 #undef FF_PHASE_A
+#undef FF_REFILL_W1
+#undef FF_REFILL_W2
 #undef FF_PHASE_B
 #undef FF_RELU_PACK
+#undef FF_ZERO_XH
+#undef FF_MFMA
 #undef FF_TT
 #undef FF_DMA
-    __syncthreads();  // every wave is done with b1_s and its ring (all DMAs landed: last wait was vmcnt(0))
 
-    // ---- cross-wave reduction of out^T partials, + b2 + residual, next LayerNorm
-    float* mine = part + (wave * FF_BM + l31) * FF_P_STRIDE;
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = acc[nt][4 * g + e];
-            *reinterpret_cast<f32x4*>(mine + 32 * nt + 8 * g + 4 * half) = o;
-        }
-    __syncthreads();
+    // ---- cross-wave reduction of out^T partials (one 32-row M-tile at a time), + b2 + residual, next LayerNorm
     const f32x4 b2v = *reinterpret_cast<const f32x4*>(p.b2 + 4 * lane);
     f32x4 ng, nb;
     if (p.nln_a) {
@@ -250,35 +298,62 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
         nb = *reinterpret_cast<const f32x4*>(p.nln_b + 4 * lane);
     }
 #pragma unroll
-    for (int i = 0; i < FF_BM / 4; ++i) {
-        const int r = wave + 4 * i;
-        const int m = m0 + r;
-        if (m >= p.M) continue;  // wave-uniform
-        float* xr = p.x + (long long)m * FF_D + 4 * lane;
-        f32x4 v = *reinterpret_cast<const f32x4*>(xr);
+    for (int mt = 0; mt < MT; ++mt) {
+        __syncthreads();  // rings / xn fragments (mt == 0) or the previous round's partials are no longer read
+        float* mine = part + (wave * 32 + l31) * FF_P_STRIDE;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(part + (w * FF_BM + r) * FF_P_STRIDE + 4 * lane);
+        for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += q[j];
-        }
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += b2v[j];
-        *reinterpret_cast<f32x4*>(xr) = v;
-        if (p.nln_a) {
-            const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)FF_D;
-            float ss = 0.f;
+                for (int e = 0; e < 4; ++e) o[e] = acc[mt][nt][4 * g + e];
+                *reinterpret_cast<f32x4*>(mine + 32 * nt + 8 * g + 4 * half) = o;
+            }
+        __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ss = fmaf(v[j] - mean, v[j] - mean, ss);
-            const float denom = sqrtf(wave_sum(ss) / (float)(FF_D - 1)) + p.eps;
-            float o[4];
-            ln_row_to(v, mean, denom, ng, nb, o);
-            bf16x4 ob;
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave + 4 * i;
+            const int m = m0 + 32 * mt + r;
+            if (m >= p.M) continue;  // wave-uniform
+            float* xr = p.x + (long long)m * FF_D + 4 * lane;
+            f32x4 v = *reinterpret_cast<const f32x4*>(xr);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ob[j] = (bf16)o[j];
-            *reinterpret_cast<bf16x4*>(p.xn_out + (long long)m * FF_D + 4 * lane) = ob;
+            for (int w = 0; w < 4; ++w) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(part + (w * 32 + r) * FF_P_STRIDE + 4 * lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += q[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += b2v[j];
+            *reinterpret_cast<f32x4*>(xr) = v;
+            if (p.nln_a) {
+                const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)FF_D;
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ss = fmaf(v[j] - mean, v[j] - mean, ss);
+                const float denom = sqrtf(wave_sum(ss) / (float)(FF_D - 1)) + p.eps;
+                float o[4];
+                ln_row_to(v, mean, denom, ng, nb, o);
+                bf16x4 ob;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ob[j] = (bf16)o[j];
+                *reinterpret_cast<bf16x4*>(p.xn_out + (long long)m * FF_D + 4 * lane) = ob;
+            }
         }
     }
+}
+
+template <int MT, int DBG> static int launch_ffn_variant(const FfnParams& p, hipStream_t s) {
+    constexpr int lds = ff_lds_bytes<MT>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_fused_kernel<MT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((ffn_fused_kernel<MT, DBG>), dim3(cn_ceil_div(p.M, 32 * MT)), dim3(256), lds, s, p);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s) {
@@ -301,27 +376,18 @@ int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s) {
     p.M = a.M;
     p.dff = a.dff;
     p.eps = a.eps;
-    static int dbg = -1;
+    static int dbg = -1, force_mt = -1;
     if (dbg < 0) dbg = getenv("CASSNAT_FFN_DEBUG") ? atoi(getenv("CASSNAT_FFN_DEBUG")) : 0;
-    static bool attr_done = false;
-    if (!attr_done) {
-        CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
-        CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
-        CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
-        CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS_BYTES));
-        attr_done = true;
+    if (force_mt < 0) force_mt = getenv("CASSNAT_FFN_MT") ? atoi(getenv("CASSNAT_FFN_MT")) : 0;
+    const int mt = force_mt ? force_mt : (a.M > 32 ? 2 : 1);
+    if (mt == 2) {
+        if (dbg == 3) return launch_ffn_variant<2, 3>(p, s);
+        return launch_ffn_variant<2, 0>(p, s);
     }
-    const dim3 grid(cn_ceil_div(a.M, FF_BM));
-    if (dbg == 1)
-        hipLaunchKernelGGL(ffn_fused_kernel<1>, grid, dim3(256), FF_LDS_BYTES, s, p);
-    else if (dbg == 2)
-        hipLaunchKernelGGL(ffn_fused_kernel<2>, grid, dim3(256), FF_LDS_BYTES, s, p);
-    else if (dbg == 3)
-        hipLaunchKernelGGL(ffn_fused_kernel<3>, grid, dim3(256), FF_LDS_BYTES, s, p);
-    else
-        hipLaunchKernelGGL(ffn_fused_kernel<0>, grid, dim3(256), FF_LDS_BYTES, s, p);
-    CN_HIP_CHECK(hipGetLastError());
-    return 0;
+    if (dbg == 1) return launch_ffn_variant<1, 1>(p, s);
+    if (dbg == 2) return launch_ffn_variant<1, 2>(p, s);
+    if (dbg == 3) return launch_ffn_variant<1, 3>(p, s);
+    return launch_ffn_variant<1, 0>(p, s);
 }
 
 // ---- host-side packing of nn.Linear weights into the fragment streams above -----------------------------

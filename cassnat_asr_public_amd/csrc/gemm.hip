@@ -45,7 +45,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
-    const int tile_m = blockIdx.x / p.ntn, tile_n = blockIdx.x % p.ntn;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so block b and
+    // b+8 share an L2.  Give every XCD a contiguous run of tiles (bijective for any grid size): the N-tiles of one
+    // M-tile, which read the same A rows, and M-neighbours, which share conv halo rows, then meet in one L2.
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, rm = nwg & 7;
+    const int tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (blockIdx.x >> 3);
+    const int tile_m = tile / p.ntn, tile_n = tile % p.ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int lrow = tid >> 3, lchunk = tid & 7;
     const int st_off = lrow * ROWB + ((lchunk ^ ((lrow >> 1) & 7)) << 4);  // + 32*i rows keeps the swizzle
@@ -79,11 +84,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 
     uint4 a_reg[A_IT], w_reg[B_IT];
-    const int slabs_per_tap = CONV ? p.cC / BK : 1;
-
+    // Implicit-GEMM K order: channel block outermost, the 9 taps innermost.  An input element is used by up to 2.25
+    // taps of one tile; with the taps adjacent in time those re-reads are ~32 KB of traffic apart (L2 hits) instead of
+    // a whole channel sweep apart.  The weight slab for step kt is k-offset tap*C + c0 of the [Cout][(kh,kw,Cin)] matrix.
     auto load_slab = [&](int kt) {
         if (CONV) {
-            const int tap = kt / slabs_per_tap, c0 = (kt - tap * slabs_per_tap) * BK;
+            const int cb = kt / 9, tap = kt - 9 * cb, c0 = cb * BK;
             const int kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
@@ -96,8 +102,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) a_reg[i] = ld16(a_src[i] + (long long)kt * ROWB);
         }
+        if (CONV) {
+            const int cb = kt / 9, tap = kt - 9 * cb;
+            const long long koff = ((long long)tap * p.cC + (long long)cb * BK) * (long long)sizeof(T);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) w_reg[i] = ld16(w_src[i] + (long long)kt * ROWB);
+            for (int i = 0; i < B_IT; ++i) w_reg[i] = ld16(w_src[i] + koff);
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) w_reg[i] = ld16(w_src[i] + (long long)kt * ROWB);
+        }
     };
     auto store_slab = [&](int buf) {
         unsigned char* a_dst = smem + buf * BUF + st_off;

@@ -59,6 +59,10 @@ def unpack_records(rec):
 def all_gather_records(rec, group=None):
     """One all-gather per batch: (B, S+3) -> (world*B, S+3), rank-major."""
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":  # CPU rehearsal / tests: gloo has no all_gather_into_tensor
+        parts = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(parts, rec, group=group)
+        return torch.cat(parts, 0)
     out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, rec, group=group)
     return out
