@@ -105,3 +105,16 @@ struct FfnFusedArgs {
 int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s);
 void pack_ffn_w1(const float* w1, int dff, uint16_t* out);  // [dff][256] fp32 -> fragment stream (dff*256 bf16)
 void pack_ffn_w2(const float* w2, int dff, uint16_t* out);  // [256][dff] fp32 -> fragment stream (dff*256 bf16)
+
+// ---- fused generator tail, bf16 / d_model == 256: per-row argmax and max log-probability of log_softmax(W h + b)   (genmax.hip)
+struct GenmaxArgs {
+    const void* h = nullptr;   // [M][256] bf16
+    const void* wp = nullptr;  // pack_genmax weight fragments
+    const float* bp = nullptr; // pack_genmax biases
+    int* arg = nullptr;
+    float* maxlp = nullptr;
+    int M = 0, V = 0, d = 0;
+};
+int launch_genmax(const GenmaxArgs& a, hipStream_t s);
+int genmax_vtw(int V);  // vocabulary tiles per wave; packed sizes: weights 4*vtw*16 KiB, biases 4*vtw*32 floats
+void pack_genmax(const float* w, const float* b, int V, uint16_t* wout, float* bout);

@@ -33,6 +33,8 @@ struct Linear {
     void* W = nullptr;  // [N][K] model precision
     float* b = nullptr;
     int N = 0, K = 0;
+    void* gm_w = nullptr;   // generators only (bf16, d_model 256): pack_genmax fragment stream ...
+    float* gm_b = nullptr;  // ... and padded biases for the fused argmax kernel
 };
 struct Norm {
     float* a = nullptr;
@@ -271,6 +273,24 @@ struct Packer {
         L.w2.K = (int)dff;
         L.w2.b = vec({p + ".feed_forward.w_2.bias"}, d);
     }
+    // generator: the plain matrix (beam search / capture) plus the fused-argmax fragment stream when it applies
+    Linear generator(const std::string& prefix, int64_t V, int64_t d) {
+        Linear l = linear({prefix}, V, d);
+        if (m->prec == CN_PREC_BF16 && d == 256 && genmax_vtw((int)V) <= 48) {
+            const int vtw = genmax_vtw((int)V);
+            const size_t aw = reserve((size_t)4 * vtw * 16 * 1024), ab = reserve((size_t)4 * vtw * 32 * 4);
+            if (fill) {
+                const HostTensor* tw = find(prefix + ".weight", {V, d});
+                const HostTensor* tb = find(prefix + ".bias", {V});
+                if (tw && tb)
+                    pack_genmax(tw->data.data(), tb->data.data(), (int)V, reinterpret_cast<uint16_t*>(&host[aw]),
+                                reinterpret_cast<float*>(&host[ab]));
+            }
+            l.gm_w = reinterpret_cast<void*>(aw);
+            l.gm_b = reinterpret_cast<float*>(ab);
+        }
+        return l;
+    }
     Norm norm(const std::string& prefix, int64_t d) {
         Norm n;
         n.a = vec({prefix + ".a_2"}, d);
@@ -285,6 +305,8 @@ template <typename P> void rebase(P*& p, unsigned char* base) {
 void rebase_linear(Linear& l, unsigned char* base) {
     rebase(l.W, base);
     rebase(l.b, base);
+    rebase(l.gm_w, base);
+    rebase(l.gm_b, base);
 }
 void rebase_norm(Norm& n, unsigned char* base) {
     rebase(n.a, base);
@@ -374,8 +396,8 @@ int build_weights(cn_model* m) {
         m->mad.push_back(L);
     }
     m->dec_norm = pk.norm("decoder.norm", d);
-    m->ctc_gen = pk.linear({"ctc_generator.proj"}, V, d);
-    m->att_gen = pk.linear({"att_generator.proj"}, V, d);
+    m->ctc_gen = pk.generator("ctc_generator.proj", V, d);
+    m->att_gen = pk.generator("att_generator.proj", V, d);
     {
         const size_t at = pk.reserve((size_t)m->pe_rows * d * 4);
         if (pk.fill) std::memcpy(&pk.host[at], m->pe_host.data(), (size_t)m->pe_rows * d * 4);
@@ -606,6 +628,28 @@ int run_src_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B, 
     return 0;
 }
 
+// generator tail: argmax + max log-prob per row.  Fused kernel (no logits tensor) unless full rows are needed.
+int run_generator(cn_model* m, const Linear& g, const void* h, int M, int* arg, float* maxlp, bool need_rows,
+                  hipStream_t s) {
+    const int d = m->cfg.d_model, V = m->cfg.vocab_size;
+    if (g.gm_w && !need_rows) {
+        ProfScope ps(m, "generator_argmax_fused", 2.0 * M * V * d, (double)M * d * 2 + (double)V * d * 2, s);
+        GenmaxArgs a;
+        a.h = h;
+        a.wp = g.gm_w;
+        a.bp = g.gm_b;
+        a.arg = arg;
+        a.maxlp = maxlp;
+        a.M = M;
+        a.V = V;
+        a.d = d;
+        return launch_genmax(a, s);
+    }
+    CN_TRY(run_linear(m, "generator_proj", g, h, d, m->logits, V, 1, M, 0, nullptr, 0, s));
+    ProfScope ps(m, "logsoftmax_argmax", 0, (double)M * V * 4, s);
+    return launch_logsoftmax_argmax(m->logits, M, V, V, arg, maxlp, need_rows ? 1 : 0, s);
+}
+
 int check_call(cn_model* m, int B, int T, int F) {
     if (!m || !m->finalized) {
         cn_set_error("model not finalized");
@@ -691,11 +735,7 @@ int stage_encode_align(cn_model* m, const float* feats, const float* ratio, int 
     }
     if (m->enc.empty()) CN_TRY(run_ln(m, m->enc_norm, m->x, m->enc_h, M, s));
     if (cap) CN_TRY(capture(m, "enc_h", m->enc_h, true, CN_DTYPE_F32, {B, Tp, d}, s));
-    CN_TRY(run_linear(m, "generator_proj", m->ctc_gen, m->enc_h, d, m->logits, c.vocab_size, 1, M, 0, nullptr, 0, s));
-    {
-        ProfScope ps(m, "logsoftmax_argmax", 0, (double)M * c.vocab_size * 4, s);
-        CN_TRY(launch_logsoftmax_argmax(m->logits, M, c.vocab_size, c.vocab_size, m->best, m->ctc_maxlp, cap ? 1 : 0, s));
-    }
+    CN_TRY(run_generator(m, m->ctc_gen, m->enc_h, M, m->best, m->ctc_maxlp, cap, s));
     if (cap) CN_TRY(capture(m, "ctc_out", m->logits, false, CN_DTYPE_F32, {B, Tp, c.vocab_size}, s));
     AlignArgs al;
     al.best = m->best;
@@ -775,13 +815,8 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
     }
     if (m->mad.empty()) CN_TRY(run_ln(m, m->dec_norm, xdec, m->dec_h, MU, s));
     if (cap) CN_TRY(capture(m, "dec_h", m->dec_h, true, CN_DTYPE_F32, {B, U, d}, s));
-    CN_TRY(run_linear(m, "generator_proj", m->att_gen, m->dec_h, d, m->logits, c.vocab_size, 1, MU, 0, nullptr, 0, s));
     const int k = o->beam_width;
-    const int want_logp = (cap || k > 1) ? 1 : 0;
-    {
-        ProfScope ps(m, "logsoftmax_argmax", 0, (double)MU * c.vocab_size * 4, s);
-        CN_TRY(launch_logsoftmax_argmax(m->logits, MU, c.vocab_size, c.vocab_size, m->tok, m->val, want_logp, s));
-    }
+    CN_TRY(run_generator(m, m->att_gen, m->dec_h, MU, m->tok, m->val, cap || k > 1, s));
     if (cap) CN_TRY(capture(m, "att_out", m->logits, false, CN_DTYPE_F32, {B, U, c.vocab_size}, s));
     m->last_k = 0;
     if (k > 1) {
@@ -1216,6 +1251,41 @@ extern "C" int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float*
     (void)hipFree(d2);
     if (rc == 0 && e != hipSuccess) {
         cn_set_error(std::string("cn_op_ffn_fused: ") + hipGetErrorString(e));
+        rc = -2;
+    }
+    return rc;
+}
+
+extern "C" int cn_op_genmax(const void* h_dev, const float* w_host, const float* b_host, int32_t M, int32_t V,
+                            int32_t* arg_dev, float* maxlp_dev, void* stream) {
+    const int vtw = genmax_vtw(V);
+    if (vtw > 48) {
+        cn_set_error("cn_op_genmax: V too large");
+        return -1;
+    }
+    std::vector<uint16_t> hw((size_t)4 * vtw * 16 * 512);
+    std::vector<float> hb((size_t)4 * vtw * 32);
+    pack_genmax(w_host, b_host, V, hw.data(), hb.data());
+    void *dw = nullptr, *db = nullptr;
+    CN_HIP_CHECK(hipMalloc(&dw, hw.size() * 2));
+    CN_HIP_CHECK(hipMalloc(&db, hb.size() * 4));
+    CN_HIP_CHECK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    CN_HIP_CHECK(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    GenmaxArgs a;
+    a.h = h_dev;
+    a.wp = dw;
+    a.bp = (const float*)db;
+    a.arg = arg_dev;
+    a.maxlp = maxlp_dev;
+    a.M = M;
+    a.V = V;
+    a.d = 256;
+    int rc = launch_genmax(a, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(dw);
+    (void)hipFree(db);
+    if (rc == 0 && e != hipSuccess) {
+        cn_set_error(std::string("cn_op_genmax: ") + hipGetErrorString(e));
         rc = -2;
     }
     return rc;

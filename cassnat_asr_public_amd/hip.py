@@ -84,6 +84,7 @@ def lib():
     L.cn_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                            C.POINTER(C.c_int32)]
     L.cn_op_ffn_fused.argtypes = [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p]
+    L.cn_op_genmax.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_profile_begin.argtypes = [C.c_void_p, C.c_char_p]
     L.cn_profile_end.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     _lib = L

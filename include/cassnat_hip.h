@@ -122,6 +122,10 @@ int cn_op_greedy_pack(const int32_t* tok, const float* val, const int32_t* ylen,
 int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, const float* w1_host,
                     const float* b1_dev, const float* w2_host, const float* b2_dev, const float* nln_a_dev,
                     const float* nln_b_dev, void* xn_out_dev, int32_t M, int32_t dff, float eps, void* stream);
+/* fused generator tail, bf16 / d_model 256: arg[m] = argmax_v, maxlp[m] = max_v of log_softmax(W h[m] + b); h_dev bf16 [M][256],
+ * W/b HOST fp32 nn.Linear parameters (packed and uploaded by the call; the model packs once at cn_model_finalize). */
+int cn_op_genmax(const void* h_dev, const float* w_host, const float* b_host, int32_t M, int32_t V, int32_t* arg_dev,
+                 float* maxlp_dev, void* stream);
 int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, int32_t* idx, float* val, void* stream);
 
 #ifdef __cplusplus

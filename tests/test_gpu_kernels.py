@@ -379,3 +379,24 @@ def test_ffn_fused_bf16(M, dff, with_next):
     assert relerr(xd, ref) < 2e-3  # fp32 residual stream; error = accumulation order + rare bf16 double-rounding of h
     if with_next:
         assert relerr(xn_out, layer_norm(xd.cpu(), na, nb)) < 5e-3
+
+
+# ----------------------------------------------------------------------------------------------- fused generator tail
+@pytest.mark.parametrize("M,V", [(8000, 5000), (37, 5000), (2336, 1028), (32, 40), (100, 4234)])
+def test_generator_argmax_fused_bf16(M, V):
+    g = torch.Generator().manual_seed(M + V)
+    h = torch.randn(M, 256, generator=g)
+    w = (torch.randn(V, 256, generator=g) / 16).contiguous()
+    b = (0.1 * torch.randn(V, generator=g)).contiguous()
+    logits = F.linear(rounded(h, "bf16"), rounded(w, "bf16"), b)
+    ref = torch.log_softmax(logits, -1)
+    hd = dev(h, torch.bfloat16)
+    arg = torch.full((M,), -1, dtype=torch.int32, device="cuda")
+    mlp = torch.full((M,), float("nan"), dtype=torch.float32, device="cuda")
+    hip.check(hip.lib().cn_op_genmax(p(hd), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), M, V, p(arg), p(mlp), stream()))
+    torch.cuda.synchronize()
+    top2 = torch.topk(ref, 2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4  # rows with a clear winner must agree exactly (fp32 accumulation order differs)
+    assert (arg.cpu()[clear] == ref.argmax(-1)[clear].int()).all()
+    assert (arg.cpu() >= 0).all() and (arg.cpu() < V).all()
+    assert (mlp.cpu() - ref.max(-1).values).abs().max().item() < 2e-4
