@@ -16,6 +16,8 @@
 //   * the probability tile is already laid out as the B operand of the next MFMA (O^T = V^T.P^T):
 //     no LDS round trip for P.  V^T fragments come from LDS with ds_read_b64_tr_b16 (bf16) or plain
 //     ds_read_b32 (f32 path, v_mfma_f32_32x32x2_f32).
+#include <cstdlib>
+
 #include "kernels.h"
 
 struct AttnParams {
@@ -50,18 +52,24 @@ template <> struct AttnCfg<float> {
 
 // NW waves per workgroup (32 query rows each): 4 -> 128-row tiles, 2 -> 64-row tiles (more, smaller workgroups when
 // the grid would otherwise be ~1 workgroup per CU with nothing to overlap its barriers and load latency)
-template <typename T, int NW>
+// RES (bf16, Lk <= 256): ALL keys/values of the (batch, head) are brought into LDS at once by LDS-DMA (the XOR swizzles
+// are applied to the per-lane SOURCE address, the LDS image of a DMA piece is lane-linear), then every key tile is
+// processed back to back: one barrier per workgroup instead of two per tile, and a single load round trip.
+template <typename T, int NW, bool RES>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
     typedef AttnCfg<T> Cfg;
     typedef typename Frag<T>::type frag_t;
-    constexpr int KROW = Cfg::KROW, VROW = Cfg::VROW, CPR = Cfg::CPR;
+    constexpr int KROW = Cfg::KROW, CPR = Cfg::CPR;
+    constexpr int VROW = RES ? 128 : Cfg::VROW;  // RES: unpadded rows, 64-byte halves swapped on rows with (row>>1)&1
+    constexpr int KT_BYTES = 64 * KROW, VT_BYTES = 64 * VROW, NRES = RES ? 4 : 1;
     constexpr int NF = KROW / 32;           // 16-byte fragments of one 64-wide head row per lane half
     constexpr int NT = 64 * NW;
     constexpr int ST_IT = 64 * CPR / NT;    // 16-byte chunks per thread per 64-key tile
 
-    __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * KROW];
-    __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * VROW];
-    __shared__ __attribute__((aligned(16))) unsigned int Ms[16];  // 64 mask bytes: 0 masked, 1 allowed, 2 tile padding
+    __shared__ __attribute__((aligned(16))) unsigned char Ks_all[NRES * KT_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs_all[NRES * VT_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned int Ms_all[NRES * 16];  // mask bytes: 0 masked, 1 allowed, 2 tile padding
+    __shared__ unsigned int Mplain[NRES];  // 1: every key of the tile is allowed -> mask-free fast path
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -86,6 +94,10 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
         iv_e2 = r.w;
     }
     const int klen = p.klen ? p.klen[b] : p.Lk;
+    const int nkt = (p.Lk + 63) / 64;
+    unsigned char* Ks = Ks_all;
+    unsigned char* Vs = Vs_all;
+    unsigned int* Ms = Ms_all;
 
     // ---- staging registers for the next K/V tile
     uint4 k_reg[ST_IT], v_reg[ST_IT];
@@ -123,6 +135,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                 code = ok ? 1 : 0;
             }
             reinterpret_cast<unsigned char*>(Ms)[tid] = code;
+            const unsigned long long bad = __ballot(code != 1);
+            if (tid == 0) Mplain[0] = bad == 0ull ? 1u : 0u;
         }
     };
 
@@ -133,13 +147,49 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
     float m_run = CN_NEG_FILL, l_run = 0.f;
 
-    const int nkt = (p.Lk + 63) / 64;
-    load_tile(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();  // everyone is done reading the previous tile
-        store_tile(kt);
+    if constexpr (RES) {
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const int r8 = lane >> 3, cp = lane & 7;
+        for (int piece = wave_u; piece < nkt * 16; piece += NW) {  // 1-KiB pieces: 8 rows x 128 B of K or V
+            const int kt2 = piece >> 4, is_v = (piece >> 3) & 1, j = piece & 7;
+            const int row = 8 * j + r8;
+            int key = kt2 * 64 + row;
+            if (key >= p.Lk) key = p.Lk - 1;  // finite filler; its probability is exactly 0 (mask code 2)
+            const unsigned char* src =
+                is_v ? vbase + (long long)key * p.ldv_b + ((cp ^ (((row >> 1) & 1) << 2)) << 4)
+                     : kbase + (long long)key * p.ldk_b + ((cp ^ Cfg::swz(row)) << 4);
+            unsigned char* dst = (is_v ? Vs_all + kt2 * VT_BYTES : Ks_all + kt2 * KT_BYTES) + j * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        if (tid < NRES) Mplain[tid] = 1;
         __syncthreads();
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        for (int i = tid; i < nkt * 64; i += NT) {
+            unsigned char code = 2;
+            if (i < p.Lk) {
+                bool ok = i < klen;
+                if (p.keymask) ok = ok && p.keymask[(long long)b * p.Lk + i] != 0;
+                code = ok ? 1 : 0;
+            }
+            reinterpret_cast<unsigned char*>(Ms_all)[i] = code;
+            if (code != 1) atomicAnd(&Mplain[i >> 6], 0u);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        load_tile(0);
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+        if constexpr (RES) {
+            Ks = Ks_all + kt * KT_BYTES;
+            Vs = Vs_all + kt * VT_BYTES;
+            Ms = Ms_all + kt * 16;
+        } else {
+            __syncthreads();  // everyone is done reading the previous tile
+            store_tile(kt);
+            __syncthreads();
+            if (kt + 1 < nkt) load_tile(kt + 1);
+        }
         if (!wave_active) continue;
 
         // ---- S^T[key][q] for the two 32-key sub-tiles
@@ -156,47 +206,72 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                 sc[sub] = mfma_frag(kf, qf[s], sc[sub]);
             }
         }
-        // ---- scale + mask, running max
-        float tmax = -INFINITY;
+        // ---- scale + mask + online softmax.  Fast path (wave-uniform): no key of this tile is masked and there are no
+        // per-row intervals / causal limit -> one FMA + exp2 per score instead of ~15 VALU ops of mask logic.
+        const bool plain = Mplain[RES ? kt : 0] != 0 && !p.iv && !p.causal;
+        float psum = 0.f, alpha;
+        if (plain) {
+            float tmax = sc[0][0];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+            for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const unsigned int mw = Ms[sub * 8 + 2 * g + half];
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[sub][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * p.scale;
+            const float m_new = fmaxf(m_run, tmax);
+            alpha = __expf(m_run - m_new);
+            m_run = m_new;
+            const float c2 = p.scale * 1.44269504088896340736f, mb = m_new * 1.44269504088896340736f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    const int key = kt * 64 + sub * 32 + 8 * g + 4 * half + e;
-                    const unsigned int code = (mw >> (8 * e)) & 0xffu;
-                    bool ok = code == 1u;
-                    if (p.iv) ok = ok && ((key >= iv_s1 && key < iv_e1) || (key >= iv_s2 && key < iv_e2));
-                    if (p.causal) ok = ok && key <= q_row;
-                    float v = sc[sub][r] * p.scale;
-                    v = ok ? v : CN_NEG_FILL;
-                    v = code == 2u ? -INFINITY : v;
-                    sc[sub][r] = v;
-                    tmax = fmaxf(tmax, v);
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[sub][r], c2, -mb));
+                    sc[sub][r] = pv;
+                    psum += pv;
+                }
+        } else {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned int mw = Ms[sub * 8 + 2 * g + half];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const int key = kt * 64 + sub * 32 + 8 * g + 4 * half + e;
+                        const unsigned int code = (mw >> (8 * e)) & 0xffu;
+                        bool ok = code == 1u;
+                        if (p.iv) ok = ok && ((key >= iv_s1 && key < iv_e1) || (key >= iv_s2 && key < iv_e2));
+                        if (p.causal) ok = ok && key <= q_row;
+                        float v = sc[sub][r] * p.scale;
+                        v = ok ? v : CN_NEG_FILL;
+                        v = code == 2u ? -INFINITY : v;
+                        sc[sub][r] = v;
+                        tmax = fmaxf(tmax, v);
+                    }
                 }
             }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run, tmax);
+            alpha = __expf(m_run - m_new);
+            m_run = m_new;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __expf(sc[sub][r] - m_new);
+                    sc[sub][r] = pv;
+                    psum += pv;
+                }
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __expf(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __expf(sc[sub][r] - m_new);
-                sc[sub][r] = pv;
-                psum += pv;
-            }
         l_run = l_run * alpha + psum;
+        if (!__all(alpha == 1.f)) {
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+            for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+        }
 
         // ---- O^T[dk][q] += V^T[dk][key] . P^T[key][q]
         if constexpr (sizeof(T) == 2) {
@@ -211,7 +286,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                     const int key0 = sub * 32 + 16 * s + 4 * half + (i16 >> 2);
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
-                        const unsigned char* a1 = Vs + key0 * VROW + (32 * d + 16 * g1 + 4 * (i16 & 3)) * 2;
+                        const int dd = RES ? (d ^ ((i16 >> 3) & 1)) : d;  // RES: 64-byte halves swapped on rows with (row>>1)&1
+                        const unsigned char* a1 = Vs + key0 * VROW + (32 * dd + 16 * g1 + 4 * (i16 & 3)) * 2;
                         const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (s16x4 __attribute__((address_space(3)))*)(a1));
                         const s16x4 r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -286,10 +362,19 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     p.causal = a.causal;
     p.scale = a.scale;
     const long long big_grid = (long long)cn_ceil_div(a.Lq, 128) * a.H * a.B;
+    if constexpr (sizeof(T) == 2) {
+        static int no_res = -1;
+        if (no_res < 0) no_res = getenv("CASSNAT_ATTN_NO_RES") ? 1 : 0;
+        if (a.Lk <= 256 && !no_res) {  // 64 KB of LDS per workgroup: two workgroups per CU
+            hipLaunchKernelGGL((attention_kernel<T, 2, true>), dim3(cn_ceil_div(a.Lq, 64), a.H, a.B), dim3(128), 0, s, p);
+            CN_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
     if (big_grid >= 1024)
-        hipLaunchKernelGGL((attention_kernel<T, 4>), dim3(cn_ceil_div(a.Lq, 128), a.H, a.B), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((attention_kernel<T, 4, false>), dim3(cn_ceil_div(a.Lq, 128), a.H, a.B), dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((attention_kernel<T, 2>), dim3(cn_ceil_div(a.Lq, 64), a.H, a.B), dim3(128), 0, s, p);
+        hipLaunchKernelGGL((attention_kernel<T, 2, false>), dim3(cn_ceil_div(a.Lq, 64), a.H, a.B), dim3(128), 0, s, p);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }
