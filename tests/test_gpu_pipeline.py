@@ -245,3 +245,31 @@ def test_decode_asr_cli_end_to_end(tmp_path):
     index2word = {i + 4: f"w{i}" for i in range(args.vocab_size - 4)}
     expect = [f"spk-utt{b} " + " ".join(orc.hyp_to_text(h, index2word)) for b, h in enumerate(ref["hyps"])]
     assert open(result).read().splitlines() == expect
+
+
+def test_bf16_production_path_against_golden(capsys):
+    """The path bench.py times (bf16, fused FFN sublayer, fused generator arg-max, no capture) on the benchmark workload:
+    CTC arg-max agreement with the reference and hypothesis agreement on utterances whose alignment did not flip."""
+    g = load_golden("config2_b32")
+    args, state, feats, sizes = config2_b32_case()
+    model = build(args, state, "bf16", capture=False)
+    out = decode(model, args, feats, sizes)
+    eng = model._engine
+    best, shift, ylen = eng.fetch("best_paths"), eng.fetch("aligned_seq_shift"), eng.fetch("ylen")
+    flips = best != g["best_paths"]
+    same_align = (shift == g["aligned_seq_shift"]).all(1)
+    tok_agree = []
+    for b in np.flatnonzero(same_align):
+        ref = g["hyp"][b, : g["hyp_len"][b]].tolist()
+        got = out[b][0]["hyp"]
+        assert len(got) == len(ref)
+        tok_agree.append(np.mean([x == y for x, y in zip(got, ref)]))
+    rep = dict(ctc_flip_rate=float(flips.mean()), utts_with_identical_alignment=int(same_align.sum()),
+               token_agreement_on_those=float(np.mean(tok_agree)) if tok_agree else None,
+               ylen_max_abs_diff=int(np.abs(ylen - g["ylen"]).max()))
+    with capsys.disabled():
+        print(f"\n[bf16 production path] {rep}")
+    assert rep["ctc_flip_rate"] < 0.02            # SURVEY 7: 0.65-2.8 % expected from bf16 rounding alone
+    assert rep["ylen_max_abs_diff"] <= 3
+    if tok_agree:
+        assert rep["token_agreement_on_those"] > 0.9
