@@ -1,0 +1,256 @@
+// Kernels of the autoregressive (AST) decoder step with a KV cache - BASELINE config 4, SURVEY 8a row a18.
+// Reference: Transformer.beam_decode (src/models/transformer.py:122-241) re-runs the whole decoder on the full prefix
+// at every step; here only the NEW position of every live hypothesis is computed and the keys/values of the earlier
+// positions are read from a cache.
+//
+// Cache layout: K and V of decoder layer l, position j, written by the hypothesis that occupied row ("slot") s of the live
+// list at step j:  cache[l][j][s][d].  Every (j, s) cell is written exactly once (at step j), so a hypothesis never copies
+// its parent's cache: it carries an ancestor table anc[j] = slot that wrote position j of its prefix, and the attention
+// kernel gathers through it.  HBM-bound gather work - no MFMA (one query row per hypothesis).
+#include "kernels.h"
+
+// x[h][:] = lut[tok[h]][:] * sqrt(d) + pe[pos][:]        (TextEmbedding + PositionalEncoding, embedding.py:71-78, 29-31)
+__global__ void ast_embed_kernel(const int* __restrict__ tok, const float* __restrict__ lut, const float* __restrict__ pe_row,
+                                 float* __restrict__ x, int n, int d, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * d) return;
+    const int h = i / d, c = i - h * d;
+    x[i] = lut[(long long)tok[h] * d + c] * scale + pe_row[c];
+}
+
+int launch_ast_embed(const int* tok, const float* lut, const float* pe_row, float* x, int n, int d, float scale,
+                     hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(ast_embed_kernel, dim3(cn_ceil_div(n * d, 256)), dim3(256), 0, s, tok, lut, pe_row, x, n, d, scale);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// append the new position's K|V (columns d..3d of the fused projection) to the cache cell (pos, slot = row)
+template <typename T>
+__global__ void ast_kv_append_kernel(const T* __restrict__ qkv, T* __restrict__ ck, T* __restrict__ cv, int n, int d,
+                                     int slots, int pos) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // 16-byte chunks
+    const int per = d * (int)sizeof(T) / 16;
+    if (i >= n * per) return;
+    const int h = i / per, c = i - h * per;
+    const uint4* src = reinterpret_cast<const uint4*>(qkv + (long long)h * 3 * d);
+    const long long cell = ((long long)pos * slots + h) * per + c;
+    reinterpret_cast<uint4*>(ck)[cell] = src[per + c];
+    reinterpret_cast<uint4*>(cv)[cell] = src[2 * per + c];
+}
+
+int launch_ast_kv_append(int prec, const void* qkv, void* ck, void* cv, int n, int d, int slots, int pos, hipStream_t s) {
+    if (n <= 0) return 0;
+    const int per = d * (int)cn_elem_size(prec) / 16;
+    const dim3 grid(cn_ceil_div(n * per, 256));
+    if (prec == CN_PREC_F32)
+        hipLaunchKernelGGL(ast_kv_append_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, (float*)ck, (float*)cv, n, d, slots, pos);
+    else
+        hipLaunchKernelGGL(ast_kv_append_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ck, (bf16*)cv, n, d, slots, pos);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-query multi-head attention with gathered key/value rows (d_k = 64).  One workgroup per hypothesis, one wave per
+// head.  Phase 1: a lane owns a key (64-dim dot product with the query held in registers); masked keys get float-min
+// exactly like MultiHeadedAttention (attention.py:19-21).  Phase 2: a lane owns an output dimension.
+//   MODE 0 (self, cache):  key j in [0, nkeys): row (j*slots + anc[h][j]) of ck / cv (row length d), allowed iff keyok[h][j]
+//   MODE 1 (source):       key j in [0, nkeys): row (utt[h]*nkeys + j) of the fused K|V matrix (row length 2d), allowed iff
+//                          keymask[utt[h]][j]
+// ---------------------------------------------------------------------------------------------
+struct GatherAttnParams {
+    const void* q;  // [n][ldq], head hd at column hd*64
+    int ldq;
+    const void* k;
+    const void* v;
+    void* o;  // [n][ldo]
+    int ldo;
+    int n, H, nkeys, slots, d, table_stride;
+    const int* anc;              // MODE 0: [n][table_stride]
+    const unsigned char* keyok;  // MODE 0: [n][table_stride]
+    const int* utt;              // MODE 1: [n]
+    const unsigned char* keymask;  // MODE 1: [B][nkeys]
+    float scale;
+};
+
+template <typename T, int MODE>
+__global__ void ast_gather_attn_kernel(GatherAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int h = blockIdx.x, lane = threadIdx.x & 63, hd = threadIdx.x >> 6;
+    float* sc = reinterpret_cast<float*>(smem) + (long long)hd * p.nkeys;
+    const T* qrow = reinterpret_cast<const T*>(p.q) + (long long)h * p.ldq + hd * 64;
+    float q[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) q[i] = to_f32(qrow[i]);
+    const int u = MODE == 1 ? p.utt[h] : 0;
+    auto row_of = [&](int j) -> long long {
+        if (MODE == 0) return (long long)j * p.slots + p.anc[(long long)h * p.table_stride + j];
+        return (long long)u * p.nkeys + j;
+    };
+    const int kstride = MODE == 0 ? p.d : 2 * p.d;
+    float lmax = -INFINITY;
+    for (int j = lane; j < p.nkeys; j += 64) {
+        const T* kr = reinterpret_cast<const T*>(p.k) + row_of(j) * kstride + hd * 64;
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) dot = fmaf(q[i], to_f32(kr[i]), dot);
+        const bool ok = MODE == 0 ? p.keyok[(long long)h * p.table_stride + j] != 0 : p.keymask[(long long)u * p.nkeys + j] != 0;
+        const float s = ok ? dot * p.scale : CN_NEG_FILL;
+        sc[j] = s;
+        lmax = fmaxf(lmax, s);
+    }
+    lmax = wave_max(lmax);
+    float lsum = 0.f;
+    for (int j = lane; j < p.nkeys; j += 64) {
+        const float e = expf(sc[j] - lmax);
+        sc[j] = e;
+        lsum += e;
+    }
+    lsum = wave_sum(lsum);
+    __builtin_amdgcn_wave_barrier();
+    // phase 2: lane = output dimension; LDS writes above are visible to the whole wave (same wave, program order)
+    const float inv = 1.f / lsum;
+    float acc = 0.f;
+    for (int j = 0; j < p.nkeys; ++j) {
+        const T* vr = reinterpret_cast<const T*>(p.v) + row_of(j) * kstride + hd * 64;
+        acc = fmaf(sc[j], to_f32(vr[lane]), acc);
+    }
+    reinterpret_cast<T*>(p.o)[(long long)h * p.ldo + hd * 64 + lane] = from_f32<T>(acc * inv);
+}
+
+int launch_ast_gather_attn(int prec, int mode, const GatherAttnArgs& a, hipStream_t s) {
+    if (a.n <= 0) return 0;
+    if (a.H < 1 || a.H > 16 || a.nkeys < 1) {
+        cn_set_error("ast_gather_attn: need 1 <= heads <= 16 and at least one key");
+        return -1;
+    }
+    GatherAttnParams p;
+    p.q = a.q;
+    p.ldq = a.ldq;
+    p.k = a.k;
+    p.v = a.v;
+    p.o = a.o;
+    p.ldo = a.ldo;
+    p.n = a.n;
+    p.H = a.H;
+    p.nkeys = a.nkeys;
+    p.slots = a.slots;
+    p.d = a.d;
+    p.table_stride = a.table_stride;
+    p.anc = a.anc;
+    p.keyok = a.keyok;
+    p.utt = a.utt;
+    p.keymask = a.keymask;
+    p.scale = a.scale;
+    const size_t lds = (size_t)a.H * a.nkeys * sizeof(float);
+    if (lds > 64 * 1024) {
+        cn_set_error("ast_gather_attn: too many keys for the score buffer");
+        return -1;
+    }
+    const dim3 grid(a.n), block(64 * a.H);
+    if (prec == CN_PREC_F32) {
+        if (mode == 0) hipLaunchKernelGGL((ast_gather_attn_kernel<float, 0>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((ast_gather_attn_kernel<float, 1>), grid, block, lds, s, p);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((ast_gather_attn_kernel<bf16, 0>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((ast_gather_attn_kernel<bf16, 1>), grid, block, lds, s, p);
+    }
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CTC side of joint decoding (src/models/transformer.py:135-141, src/utils/ctc_prefix.py).
+// ---------------------------------------------------------------------------------------------
+#define CN_LOGZERO (-1e10f)
+
+// ctc_out.masked_fill_(src_mask^T == 0, logzero); ctc_out[:, :, blank].masked_fill_(src_mask == 0, 0)
+__global__ void ast_ctc_mask_kernel(float* __restrict__ logp, const unsigned char* __restrict__ keymask, int rows, int V,
+                                    int blank) {
+    const int r = blockIdx.x;
+    if (r >= rows || keymask[r]) return;
+    float* p = logp + (long long)r * V;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) p[i] = i == blank ? 0.f : CN_LOGZERO;
+}
+
+// CTCPrefixScore.initial_state: r0[b][t] = (logzero, cumsum_t x[b][t][blank])   (sequential fp32 sum, as torch.cumsum)
+__global__ void ast_ctc_init_kernel(const float* __restrict__ logp, float* __restrict__ r0, int B, int Tp, int V, int blank) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float run = 0.f;
+    for (int t = 0; t < Tp; ++t) {
+        run += logp[((long long)b * Tp + t) * V + blank];
+        r0[((long long)b * Tp + t) * 2 + 0] = CN_LOGZERO;
+        r0[((long long)b * Tp + t) * 2 + 1] = run;
+    }
+}
+
+int launch_ast_ctc_prepare(float* logp, const unsigned char* keymask, float* r0, int B, int Tp, int V, int blank,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(ast_ctc_mask_kernel, dim3(B * Tp), dim3(256), 0, s, logp, keymask, B * Tp, V, blank);
+    hipLaunchKernelGGL(ast_ctc_init_kernel, dim3(cn_ceil_div(B, 64)), dim3(64), 0, s, logp, r0, B, Tp, V, blank);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+__device__ __forceinline__ float lse2(float a, float b) {  // torch.logsumexp over two values
+    const float m = fmaxf(a, b);
+    return m + logf(expf(a - m) + expf(b - m));
+}
+
+// CTCPrefixScore.__call__ (ctc_prefix.py:50-106): one thread per (hypothesis, candidate label), sequential over frames.
+__global__ void ast_ctc_prefix_kernel(CtcPrefixArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n * a.K) return;
+    const int h = i / a.K;
+    const int c = a.cand[i];
+    const int u = a.utt[h];
+    const int Tp = a.Tp;
+    const float* x = a.logp + (long long)u * Tp * a.V;
+    const int ref = a.prev_ref[h];
+    const float* rp = ref < 0 ? a.r0 + (long long)(-1 - ref) * Tp * 2 : a.r_prev + (long long)ref * Tp * 2;
+    float* r = a.r_new + (long long)i * Tp * 2;
+    const bool same = a.last_tok[h] == c;
+    const int L = a.out_len;
+    const int start = L > 1 ? L : 1;
+    for (int t = 0; t < start; ++t) {
+        r[2 * t] = CN_LOGZERO;
+        r[2 * t + 1] = CN_LOGZERO;
+    }
+    if (L == 0) r[0] = x[c];
+    // log_phi(t) = last(g) == c ? r_prev^b(t) : logsumexp(r_prev^n(t), r_prev^b(t))
+    float rn = r[2 * (start - 1)], rb = r[2 * (start - 1) + 1];
+    // log_psi = logsumexp over { r^n(start-1) } U { log_phi(t-1) + x_c(t), t in [start, T) }: streaming max/sum
+    float pm = rn, ps = 1.f;
+    for (int t = start; t < Tp; ++t) {
+        const float p0 = rp[2 * (t - 1)], p1 = rp[2 * (t - 1) + 1];
+        const float phi = same ? p1 : lse2(p0, p1);
+        const float xc = x[(long long)t * a.V + c], xb = x[(long long)t * a.V + a.blank];
+        const float nn = lse2(rn, phi) + xc;
+        const float nb = lse2(rn, rb) + xb;
+        r[2 * t] = nn;
+        r[2 * t + 1] = nb;
+        rn = nn;
+        rb = nb;
+        const float v = phi + xc;
+        if (v > pm) {
+            ps = ps * expf(pm - v) + 1.f;
+            pm = v;
+        } else {
+            ps += expf(v - pm);
+        }
+    }
+    float psi = pm + logf(ps);
+    if (c == a.eos) psi = lse2(rp[2 * (Tp - 1)], rp[2 * (Tp - 1) + 1]);
+    if (c == a.blank) psi = CN_LOGZERO;
+    a.score[i] = psi;
+}
+
+int launch_ast_ctc_prefix(const CtcPrefixArgs& a, hipStream_t s) {
+    if (a.n <= 0 || a.K <= 0) return 0;
+    hipLaunchKernelGGL(ast_ctc_prefix_kernel, dim3(cn_ceil_div(a.n * a.K, 64)), dim3(64), 0, s, a);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -118,3 +118,37 @@ struct GenmaxArgs {
 int launch_genmax(const GenmaxArgs& a, hipStream_t s);
 int genmax_vtw(int V);  // vocabulary tiles per wave; packed sizes: weights 4*vtw*16 KiB, biases 4*vtw*32 floats
 void pack_genmax(const float* w, const float* b, int V, uint16_t* wout, float* bout);
+
+// ---- autoregressive decoder step with KV cache + CTC prefix scorer (BASELINE config 4)             (ast.hip)
+int launch_ast_embed(const int* tok, const float* lut, const float* pe_row, float* x, int n, int d, float scale, hipStream_t s);
+int launch_ast_kv_append(int prec, const void* qkv, void* ck, void* cv, int n, int d, int slots, int pos, hipStream_t s);
+struct GatherAttnArgs {
+    const void* q = nullptr;
+    int ldq = 0;
+    const void* k = nullptr;
+    const void* v = nullptr;
+    void* o = nullptr;
+    int ldo = 0;
+    int n = 0, H = 0, nkeys = 0, slots = 0, d = 0, table_stride = 0;
+    const int* anc = nullptr;
+    const unsigned char* keyok = nullptr;
+    const int* utt = nullptr;
+    const unsigned char* keymask = nullptr;
+    float scale = 0.125f;
+};
+int launch_ast_gather_attn(int prec, int mode, const GatherAttnArgs& a, hipStream_t s);  // mode 0: cache, 1: source memory
+int launch_ast_ctc_prepare(float* logp, const unsigned char* keymask, float* r0, int B, int Tp, int V, int blank, hipStream_t s);
+struct CtcPrefixArgs {
+    const float* logp;   // [B][Tp][V] masked CTC log-posteriors
+    const float* r0;     // [B][Tp][2] initial states
+    const float* r_prev; // [*][Tp][2] states kept from the previous step
+    float* r_new;        // [n*K][Tp][2]
+    const int* utt;      // [n]
+    const int* last_tok; // [n]
+    const int* cand;     // [n][K]
+    const int* prev_ref; // [n]: >= 0 row of r_prev, < 0: initial state of utterance -1-ref
+    float* score;        // [n][K]
+    int n, K, Tp, V, blank, eos, out_len;
+};
+int launch_ast_ctc_prefix(const CtcPrefixArgs& a, hipStream_t s);
+int launch_logsoftmax_temp(float* logits, int M, int V, int ldl, float temperature, int* arg, float* maxlp, hipStream_t s);

@@ -115,6 +115,14 @@ struct cn_model {
 
     int* ymax_pinned = nullptr;  // page-locked host word for the one data-dependent readback per batch
 
+    // autoregressive (AST) decoder state (cn_ast_*): token embedding, per-layer cross K|V, KV cache, CTC prefix states
+    float* tgt_lut = nullptr;  // [V][d] fp32 (view into the blob)
+    int ast_max_len = 0, ast_slots = 0, ast_ctc_beam = 0, ast_Tp_cap = 0, ast_blank = 0;
+    std::vector<void*> ast_kvx, ast_ck, ast_cv;  // per decoder layer
+    float *ast_logits = nullptr, *ast_r0 = nullptr, *ast_r[2] = {nullptr, nullptr}, *ast_maxlp = nullptr;
+    int* ast_arg = nullptr;
+    std::vector<void*> ast_allocs;
+
     // last call
     int B = 0, T = 0, T1 = 0, Tp = 0, U = 0, last_k = 0;
     std::map<std::string, Capture> captures;
@@ -396,6 +404,16 @@ int build_weights(cn_model* m) {
         m->mad.push_back(L);
     }
     m->dec_norm = pk.norm("decoder.norm", d);
+    if (c.ast) {
+        const size_t at = pk.reserve((size_t)V * d * 4);
+        if (pk.fill) {
+            const HostTensor* t = pk.find("tgt_embed.0.lut.weight", {V, d});
+            if (t) std::memcpy(&pk.host[at], t->data.data(), (size_t)V * d * 4);
+        }
+        m->tgt_lut = reinterpret_cast<float*>(at);
+    } else {
+        m->tgt_lut = nullptr;
+    }
     m->ctc_gen = pk.generator("ctc_generator.proj", V, d);
     m->att_gen = pk.generator("att_generator.proj", V, d);
     {
@@ -443,6 +461,7 @@ int build_weights(cn_model* m) {
     rebase_linear(m->ctc_gen, base);
     rebase_linear(m->att_gen, base);
     rebase(m->pe, base);
+    rebase(m->tgt_lut, base);
     return 0;
 }
 
@@ -663,9 +682,40 @@ int check_call(cn_model* m, int B, int T, int F) {
     return 0;
 }
 
+int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_decode_opts* o, hipStream_t s);
+
 // src_embed + encoder + ctc_generator + best_path_align + align_to_mask  (cassnat.py:431-468)
 int stage_encode_align(cn_model* m, const float* feats, const float* ratio, int B, int T, int F,
                        const cn_decode_opts* o, hipStream_t s) {
+    CN_TRY(stage_encode(m, feats, B, T, F, o, s));
+    const cn_config& c = m->cfg;
+    const int Tp = m->Tp, M = B * Tp;
+    const bool cap = o->capture != 0;
+    CN_TRY(run_generator(m, m->ctc_gen, m->enc_h, M, m->best, m->ctc_maxlp, cap, s));
+    if (cap) CN_TRY(capture(m, "ctc_out", m->logits, false, CN_DTYPE_F32, {B, Tp, c.vocab_size}, s));
+    AlignArgs al;
+    al.best = m->best;
+    al.keymask = m->keymask;
+    al.size_ratio = ratio;
+    al.B = B;
+    al.Tp = Tp;
+    al.blank = o->padding_idx;
+    al.left = o->left_trigger;
+    al.right = o->right_trigger;
+    al.shift = m->shift;
+    al.src_size = m->src_size;
+    al.ylen = m->ylen;
+    al.ymax = m->ymax;
+    al.intervals = m->intervals;
+    {
+        ProfScope ps(m, "ctc_align", 0, (double)B * Tp * 9 + (double)B * (Tp + 1) * 16, s);
+        CN_TRY(launch_ctc_align(al, s));
+    }
+    return 0;
+}
+
+// src_embed + encoder (shared by the NAST and AST paths): features -> enc_h (model precision), keymask
+int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_decode_opts* o, hipStream_t s) {
     const cn_config& c = m->cfg;
     const int d = c.d_model;
     const int T1 = (T - 1) / 2 + 1, Tp = (T1 - 1) / 2 + 1, F1 = m->F1, F2 = m->F2;
@@ -735,26 +785,6 @@ int stage_encode_align(cn_model* m, const float* feats, const float* ratio, int 
     }
     if (m->enc.empty()) CN_TRY(run_ln(m, m->enc_norm, m->x, m->enc_h, M, s));
     if (cap) CN_TRY(capture(m, "enc_h", m->enc_h, true, CN_DTYPE_F32, {B, Tp, d}, s));
-    CN_TRY(run_generator(m, m->ctc_gen, m->enc_h, M, m->best, m->ctc_maxlp, cap, s));
-    if (cap) CN_TRY(capture(m, "ctc_out", m->logits, false, CN_DTYPE_F32, {B, Tp, c.vocab_size}, s));
-    AlignArgs al;
-    al.best = m->best;
-    al.keymask = m->keymask;
-    al.size_ratio = ratio;
-    al.B = B;
-    al.Tp = Tp;
-    al.blank = o->padding_idx;
-    al.left = o->left_trigger;
-    al.right = o->right_trigger;
-    al.shift = m->shift;
-    al.src_size = m->src_size;
-    al.ylen = m->ylen;
-    al.ymax = m->ymax;
-    al.intervals = m->intervals;
-    {
-        ProfScope ps(m, "ctc_align", 0, (double)B * Tp * 9 + (double)B * (Tp + 1) * 16, s);
-        CN_TRY(launch_ctc_align(al, s));
-    }
     return 0;
 }
 
@@ -877,6 +907,7 @@ extern "C" void cn_model_destroy(cn_model* m) {
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->ymax_pinned) (void)hipHostFree(m->ymax_pinned);
+    for (void* q : m->ast_allocs) (void)hipFree(q);
     if (m->blob) (void)hipFree(m->blob);
     delete m;
 }
@@ -1289,4 +1320,179 @@ extern "C" int cn_op_genmax(const void* h_dev, const float* w_host, const float*
         rc = -2;
     }
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// AST (autoregressive) path: BASELINE config 4
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+int ast_alloc(cn_model* m, void** p, size_t bytes) {
+    CN_HIP_CHECK(hipMalloc(p, bytes ? bytes : 256));
+    m->ast_allocs.push_back(*p);
+    return 0;
+}
+
+int ast_prepare_buffers(cn_model* m, int max_len, int max_slots, int ctc_beam) {
+    if (m->ast_max_len >= max_len && m->ast_slots >= max_slots && m->ast_ctc_beam >= ctc_beam && m->ast_Tp_cap >= m->maxTp)
+        return 0;
+    for (void* q : m->ast_allocs) (void)hipFree(q);
+    m->ast_allocs.clear();
+    m->ast_kvx.clear();
+    m->ast_ck.clear();
+    m->ast_cv.clear();
+    const size_t d = m->cfg.d_model, V = m->cfg.vocab_size, es = m->es;
+    const size_t Mmem = (size_t)m->maxB * m->maxTp;
+    for (size_t l = 0; l < m->mad.size(); ++l) {
+        void *kvx = nullptr, *ck = nullptr, *cv = nullptr;
+        CN_TRY(ast_alloc(m, &kvx, Mmem * 2 * d * es));
+        CN_TRY(ast_alloc(m, &ck, (size_t)max_len * max_slots * d * es));
+        CN_TRY(ast_alloc(m, &cv, (size_t)max_len * max_slots * d * es));
+        m->ast_kvx.push_back(kvx);
+        m->ast_ck.push_back(ck);
+        m->ast_cv.push_back(cv);
+    }
+    CN_TRY(ast_alloc(m, (void**)&m->ast_logits, (size_t)max_slots * V * 4));
+    CN_TRY(ast_alloc(m, (void**)&m->ast_arg, (size_t)max_slots * 4));
+    CN_TRY(ast_alloc(m, (void**)&m->ast_maxlp, (size_t)max_slots * 4));
+    CN_TRY(ast_alloc(m, (void**)&m->ast_r0, Mmem * 2 * 4));
+    const int kb = ctc_beam > 0 ? ctc_beam : 1;
+    for (int i = 0; i < 2; ++i) CN_TRY(ast_alloc(m, (void**)&m->ast_r[i], (size_t)max_slots * kb * m->maxTp * 2 * 4));
+    m->ast_max_len = max_len;
+    m->ast_slots = max_slots;
+    m->ast_ctc_beam = ctc_beam;
+    m->ast_Tp_cap = m->maxTp;
+    return 0;
+}
+}  // namespace
+
+extern "C" int cn_ast_begin(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts,
+                            int32_t want_ctc, int32_t max_len, int32_t max_slots, int32_t ctc_beam, void* stream) {
+    CN_TRY(check_call(m, B, T, F));
+    if (!m->cfg.ast || !m->tgt_lut) {
+        cn_set_error("cn_ast_begin: the model was not created with cfg.ast = 1");
+        return -1;
+    }
+    if (max_len < 2 || max_slots < 1 || (size_t)max_slots > (size_t)m->maxB * (m->maxTp + 1) || ctc_beam < 0 || ctc_beam > 16) {
+        cn_set_error("cn_ast_begin: bad max_len / max_slots / ctc_beam");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+    CN_TRY(ast_prepare_buffers(m, max_len, max_slots, ctc_beam));
+    m->ast_blank = opts->padding_idx;
+    CN_TRY(stage_encode(m, feats_dev, B, T, F, opts, s));
+    const int d = m->cfg.d_model, Mmem = B * m->Tp, V = m->cfg.vocab_size;
+    for (size_t l = 0; l < m->mad.size(); ++l)  // cross-attention K|V of the memory, once per utterance batch
+        CN_TRY(run_linear(m, "src_kv_proj", m->mad[l].src_kv, m->enc_h, d, m->ast_kvx[l], 2 * d, 0, Mmem, 0, nullptr, 0, s));
+    if (want_ctc) {
+        CN_TRY(run_linear(m, "generator_proj", m->ctc_gen, m->enc_h, d, m->logits, V, 1, Mmem, 0, nullptr, 0, s));
+        CN_TRY(launch_logsoftmax_argmax(m->logits, Mmem, V, V, m->best, m->ctc_maxlp, 1, s));
+        CN_TRY(launch_ast_ctc_prepare(m->logits, m->keymask, m->ast_r0, B, m->Tp, V, opts->padding_idx, s));
+    }
+    return 0;
+}
+
+extern "C" int cn_ast_step(cn_model* m, int32_t n, int32_t pos, const int32_t* tok_dev, const int32_t* utt_dev,
+                           const int32_t* anc_dev, const uint8_t* keyok_dev, int32_t table_stride, float temperature,
+                           int32_t K, int32_t* topk_idx_dev, float* topk_val_dev, void* stream) {
+    if (!m || !m->cfg.ast || m->ast_slots == 0) {
+        cn_set_error("cn_ast_step: call cn_ast_begin first");
+        return -1;
+    }
+    if (n < 1 || n > m->ast_slots || pos < 0 || pos >= m->ast_max_len || pos >= m->pe_rows || K < 1 || K > 16 ||
+        table_stride <= pos) {
+        cn_set_error("cn_ast_step: live rows / position / K outside the configured cache");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+    const cn_config& c = m->cfg;
+    const int d = c.d_model, V = c.vocab_size, H = c.n_head;
+    const float scale = 1.0f / sqrtf((float)(d / H));
+    float* x = m->xd;
+    CN_TRY(launch_ast_embed(tok_dev, m->tgt_lut, m->pe + (size_t)pos * d, x, n, d, sqrtf((float)d), s));
+    for (size_t l = 0; l < m->mad.size(); ++l) {
+        const Layer& L = m->mad[l];
+        // x += O(SelfAttn(LN x)) over the cached prefix
+        CN_TRY(run_ln(m, L.n[0], x, m->xn, n, s));
+        CN_TRY(run_linear(m, "qkv_proj", L.qkv, m->xn, d, m->qkv, 3 * d, 0, n, 0, nullptr, 0, s));
+        CN_TRY(launch_ast_kv_append(m->prec, m->qkv, m->ast_ck[l], m->ast_cv[l], n, d, m->ast_slots, pos, s));
+        GatherAttnArgs a;
+        a.q = m->qkv;
+        a.ldq = 3 * d;
+        a.k = m->ast_ck[l];
+        a.v = m->ast_cv[l];
+        a.o = m->ctx;
+        a.ldo = d;
+        a.n = n;
+        a.H = H;
+        a.nkeys = pos + 1;
+        a.slots = m->ast_slots;
+        a.d = d;
+        a.table_stride = table_stride;
+        a.anc = anc_dev;
+        a.keyok = keyok_dev;
+        a.scale = scale;
+        {
+            ProfScope ps(m, "ast_cache_attention", 4.0 * n * H * (pos + 1) * 64, 2.0 * n * (pos + 1) * d * m->es, s);
+            CN_TRY(launch_ast_gather_attn(m->prec, 0, a, s));
+        }
+        CN_TRY(run_linear(m, "out_proj_resid", L.self_o, m->ctx, d, x, d, 1, n, CN_EPI_RESID, x, d, s));
+        // x += O(SrcAttn(LN x, memory))
+        CN_TRY(run_ln(m, L.n[1], x, m->xn, n, s));
+        CN_TRY(run_linear(m, "src_q_proj", L.src_q, m->xn, d, m->qd, d, 0, n, 0, nullptr, 0, s));
+        GatherAttnArgs b;
+        b.q = m->qd;
+        b.ldq = d;
+        b.k = m->ast_kvx[l];
+        b.v = (const unsigned char*)m->ast_kvx[l] + (size_t)d * m->es;
+        b.o = m->ctx;
+        b.ldo = d;
+        b.n = n;
+        b.H = H;
+        b.nkeys = m->Tp;
+        b.d = d;
+        b.utt = utt_dev;
+        b.keymask = m->keymask;
+        b.scale = scale;
+        {
+            ProfScope ps(m, "ast_src_attention", 4.0 * n * H * m->Tp * 64, 2.0 * n * m->Tp * d * m->es, s);
+            CN_TRY(launch_ast_gather_attn(m->prec, 1, b, s));
+        }
+        CN_TRY(run_linear(m, "out_proj_resid", L.src_o, m->ctx, d, x, d, 1, n, CN_EPI_RESID, x, d, s));
+        CN_TRY(run_ffn(m, L, L.n[2], x, n, nullptr, nullptr, s));
+    }
+    CN_TRY(run_ln(m, m->dec_norm, x, m->dec_h, n, s));
+    CN_TRY(run_linear(m, "generator_proj", m->att_gen, m->dec_h, d, m->ast_logits, V, 1, n, 0, nullptr, 0, s));
+    CN_TRY(launch_logsoftmax_temp(m->ast_logits, n, V, V, temperature, m->ast_arg, m->ast_maxlp, s));
+    CN_TRY(launch_topk(m->ast_logits, n, V, V, K, topk_idx_dev, topk_val_dev, s));
+    return 0;
+}
+
+extern "C" int cn_ast_ctc_score(cn_model* m, int32_t n, int32_t out_len, const int32_t* utt_dev, const int32_t* last_tok_dev,
+                                const int32_t* cand_dev, int32_t K, const int32_t* prev_ref_dev, int32_t parity, int32_t eos,
+                                float* score_dev, void* stream) {
+    if (!m || !m->cfg.ast || !m->ast_r0 || K < 1 || K > m->ast_ctc_beam || n < 1 || n > m->ast_slots) {
+        cn_set_error("cn_ast_ctc_score: call cn_ast_begin with want_ctc and a ctc_beam >= K first");
+        return -1;
+    }
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+    CtcPrefixArgs a;
+    a.logp = m->logits;
+    a.r0 = m->ast_r0;
+    a.r_prev = m->ast_r[(parity & 1) ^ 1];
+    a.r_new = m->ast_r[parity & 1];
+    a.utt = utt_dev;
+    a.last_tok = last_tok_dev;
+    a.cand = cand_dev;
+    a.prev_ref = prev_ref_dev;
+    a.score = score_dev;
+    a.n = n;
+    a.K = K;
+    a.Tp = m->Tp;
+    a.V = m->cfg.vocab_size;
+    a.blank = m->ast_blank;
+    a.eos = eos;
+    a.out_len = out_len;
+    return launch_ast_ctc_prefix(a, (hipStream_t)stream);
 }

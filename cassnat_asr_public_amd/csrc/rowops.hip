@@ -84,14 +84,19 @@ int launch_layernorm(int prec, const float* x, const float* a2, const float* b2,
 // fp32 logits the first-index argmax and its log-probability (x - max) - log(sum exp(x - max));
 // optionally the row is rewritten in place as log-probabilities.  One workgroup per row.
 // ---------------------------------------------------------------------------------------------
+// temperature: Generator.forward(x, T) = log_softmax(proj(x) / T) (src/models/transformer.py:48-51); 1.0 = no division
 __global__ __launch_bounds__(256) void logsoftmax_argmax_kernel(float* __restrict__ logits, int V, int ldl,
                                                                 int* __restrict__ arg, float* __restrict__ maxlp,
-                                                                int write_logp) {
+                                                                int write_logp, float temperature) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     __shared__ float s_sum[4];
     float* p = logits + (long long)blockIdx.x * ldl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (temperature != 1.0f) {
+        for (int i = tid; i < V; i += 256) p[i] = p[i] / temperature;
+        __syncthreads();
+    }
     float best = -INFINITY;
     int bidx = 0x7fffffff;
     for (int i = tid; i < V; i += 256) {
@@ -141,7 +146,14 @@ __global__ __launch_bounds__(256) void logsoftmax_argmax_kernel(float* __restric
 int launch_logsoftmax_argmax(float* logits, int M, int V, int ldl, int* arg, float* maxlp, int write_logp,
                              hipStream_t s) {
     if (M <= 0) return 0;
-    hipLaunchKernelGGL(logsoftmax_argmax_kernel, dim3(M), dim3(256), 0, s, logits, V, ldl, arg, maxlp, write_logp);
+    hipLaunchKernelGGL(logsoftmax_argmax_kernel, dim3(M), dim3(256), 0, s, logits, V, ldl, arg, maxlp, write_logp, 1.0f);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_logsoftmax_temp(float* logits, int M, int V, int ldl, float temperature, int* arg, float* maxlp, hipStream_t s) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(logsoftmax_argmax_kernel, dim3(M), dim3(256), 0, s, logits, V, ldl, arg, maxlp, 1, temperature);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -19,7 +19,7 @@ DTYPES = {0: np.float32, 1: np.int32, 2: np.uint8, 3: np.float64}
 class CnConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "input_size", "d_model", "n_head", "d_encff", "d_decff", "n_enc", "n_extra", "n_self_dec", "n_mix_dec",
-        "vocab_size", "precision", "max_batch", "max_frames", "device")] + [("reserved", C.c_int32 * 8)]
+        "vocab_size", "precision", "max_batch", "max_frames", "device", "ast")] + [("reserved", C.c_int32 * 7)]
 
 
 class CnDecodeOpts(C.Structure):
@@ -85,6 +85,12 @@ def lib():
                            C.POINTER(C.c_int32)]
     L.cn_op_ffn_fused.argtypes = [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     L.cn_op_genmax.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cn_ast_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts), C.c_int32,
+                               C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    L.cn_ast_step.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                              C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cn_ast_ctc_score.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.cn_profile_begin.argtypes = [C.c_void_p, C.c_char_p]
     L.cn_profile_end.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     _lib = L
@@ -113,11 +119,12 @@ class Engine:
 
     def __init__(self, args, precision="bf16", max_batch=32, max_frames=2048, device=0):
         self.L = lib()
+        ast = int(getattr(args, "ast", 0))
         self.cfg = CnConfig(
             input_size=args.input_size, d_model=args.d_model, n_head=args.n_head, d_encff=args.d_encff,
             d_decff=args.d_decff, n_enc=args.N_enc, n_extra=args.N_extra, n_self_dec=args.N_self_dec,
             n_mix_dec=args.N_mix_dec, vocab_size=args.vocab_size, precision=PRECISION[precision],
-            max_batch=max_batch, max_frames=max_frames, device=device)
+            max_batch=max_batch, max_frames=max_frames, device=device, ast=ast)
         self.precision = precision
         self.handle = C.c_void_p()
         check(self.L.cn_model_create(C.byref(self.cfg), C.byref(self.handle)), "cn_model_create")
@@ -175,6 +182,20 @@ class Engine:
         check(self.L.cn_encode_align(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts),
                                      C.byref(ymax), current_stream()), "cn_encode_align")
         return ymax.value
+
+    # ---- autoregressive (AST) path
+    def ast_begin(self, feats, opts, want_ctc, max_len, max_slots, ctc_beam):
+        B, T, F = feats.shape
+        check(self.L.cn_ast_begin(self.handle, _ptr(feats), B, T, F, C.byref(opts), int(want_ctc), max_len, max_slots,
+                                  ctc_beam, current_stream()), "cn_ast_begin")
+
+    def ast_step(self, pos, tok, utt, anc, keyok, temperature, K, topk_idx, topk_val):
+        check(self.L.cn_ast_step(self.handle, tok.shape[0], pos, _ptr(tok), _ptr(utt), _ptr(anc), _ptr(keyok), anc.shape[1],
+                                 float(temperature), K, _ptr(topk_idx), _ptr(topk_val), current_stream()), "cn_ast_step")
+
+    def ast_ctc_score(self, out_len, utt, last_tok, cand, prev_ref, parity, eos, score):
+        check(self.L.cn_ast_ctc_score(self.handle, cand.shape[0], out_len, _ptr(utt), _ptr(last_tok), _ptr(cand), cand.shape[1],
+                                      _ptr(prev_ref), parity, eos, _ptr(score), current_stream()), "cn_ast_ctc_score")
 
     def profile_begin(self, tags=None):
         """Start HIP-event timing of the tagged kernels (None = all) on the launch stream."""

@@ -1,0 +1,149 @@
+"""Drop-in for the inference half of the reference's ``models.transformer`` (src/models/transformer.py): the
+autoregressive (AST) model with joint CTC/attention beam search - BASELINE config 4, SURVEY 8a row a18.
+
+Same surface: ``make_model(input_size, args) -> Transformer`` with the reference's parameter names, and
+``Transformer.beam_decode(src, src_mask, vocab, args, lm_model=None) -> batch_top_seqs``.  The beam bookkeeping stays on
+the host, as in the reference (transformer.py:157-240); every device-side step - token embedding, the decoder layers on
+the NEW position only (keys/values of the prefix come from a KV cache addressed through per-hypothesis ancestor tables,
+the reference re-runs the decoder on the whole prefix), generator + log-softmax + top-k, and the CTC prefix scorer -
+runs as HIP kernels behind ``cn_ast_begin / cn_ast_step / cn_ast_ctc_score``.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import hip
+from .cassnat import _ConvEmbedding, _Generator, _Params, _Stack, create_pe
+
+
+class _Lut(_Params):
+    def __init__(self, vocab, d):
+        super().__init__()
+        self.lut = nn.Embedding(vocab, d)
+
+
+class Transformer(nn.Module):
+    """Attribute names are the checkpoint key prefixes of the reference (src/models/transformer.py:55-60)."""
+
+    def __init__(self, input_size, args):
+        super().__init__()
+        d = args.d_model
+        self.src_embed = _ConvEmbedding(input_size, d)
+        self.tgt_embed = nn.ModuleList([_Lut(args.vocab_size, d)])  # "tgt_embed.0.lut.weight"
+        self.encoder = _Stack(d, args.d_ff, args.N_enc, True, False, True)
+        self.decoder = _Stack(d, args.d_ff, args.N_dec, True, True, True)
+        self.ctc_generator = _Generator(d, args.vocab_size)
+        self.att_generator = _Generator(d, args.vocab_size)
+        self.pe = create_pe(d)
+        self._hyper = dict(input_size=input_size, d_model=d, n_head=args.n_head, d_encff=args.d_ff, d_decff=args.d_ff,
+                           N_enc=args.N_enc, N_extra=0, N_self_dec=0, N_mix_dec=args.N_dec, vocab_size=args.vocab_size, ast=1)
+        self.hip_precision = getattr(args, "hip_precision", "bf16")
+        self.hip_max_batch = getattr(args, "hip_max_batch", 32)
+        self.hip_max_frames = getattr(args, "hip_max_frames", 2048)
+        self._engine = None
+        self._engine_key = None
+
+    def cuda(self, device=None):
+        self._device = 0 if device is None else (device if isinstance(device, int) else torch.device(device).index or 0)
+        return self
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training forward is out of scope; use beam_decode")
+
+    def engine(self, batch, frames):
+        key = (tuple(p._version for p in self.parameters()), self.hip_precision)
+        if (self._engine is None or self._engine_key != key or batch > self._engine.cfg.max_batch
+                or frames > self._engine.cfg.max_frames):
+            if self._engine is not None:
+                self._engine.close()
+            eng = hip.Engine(SimpleNamespace(**self._hyper), precision=self.hip_precision,
+                             max_batch=max(batch, self.hip_max_batch), max_frames=max(frames, self.hip_max_frames),
+                             device=getattr(self, "_device", torch.cuda.current_device()))
+            eng.load_state({k: v.detach() for k, v in self.named_parameters()}, self.pe)
+            self._engine, self._engine_key = eng, key
+        return self._engine
+
+    def beam_decode(self, src, src_mask, vocab, args, lm_model=None):
+        """Same contract as the reference's Transformer.beam_decode (src/models/transformer.py:122-241), lm_weight == 0."""
+        if getattr(args, "lm_weight", 0) > 0:
+            raise NotImplementedError("LM fusion is outside the accelerated path")
+        sos, eos = vocab.word2index["sos"], vocab.word2index["eos"]
+        assert vocab.word2index["blank"] == args.padding_idx
+        dev = torch.device("cuda", getattr(self, "_device", torch.cuda.current_device()))
+        feats = src.to(dev, torch.float32).contiguous()
+        B, T, _ = feats.shape
+        Tp = ((T - 1) // 2 + 1 - 1) // 2 + 1
+        eng = self.engine(B, T)
+        use_ctc = args.ctc_weight > 0
+        bw = int(args.beam_width)
+        K = int(args.ctc_beam) if use_ctc else bw
+        max_step = int(args.max_decode_ratio * Tp) if args.max_decode_ratio > 0 else Tp
+        max_len = max_step + 1
+        opts = hip.CnDecodeOpts(padding_idx=int(args.padding_idx), sos=sos, beam_width=1)
+        eng.ast_begin(feats, opts, use_ctc, max_len, B * bw, K if use_ctc else 0)
+        w32 = np.float32(args.ctc_weight)
+        u32 = np.float32(1 - args.ctc_weight)
+        lp = args.length_penalty
+
+        beams = [[{"score": 0.0, "hyp": [sos], "anc": [], "ctc_ref": -1 - b, "ctc_prev": np.float32(0.0)}] for b in range(B)]
+        idx_d = torch.empty(B * bw, K, dtype=torch.int32, device=dev)
+        val_d = torch.empty(B * bw, K, dtype=torch.float32, device=dev)
+        ctc_d = torch.empty(B * bw, K, dtype=torch.float32, device=dev)
+        for i in range(max_step):
+            live = [(b, s) for b in range(B) for s in beams[b] if s["hyp"][-1] != eos]
+            if not live:
+                break
+            n = len(live)
+            tok = np.array([s["hyp"][-1] for _, s in live], np.int32)
+            utt = np.array([b for b, _ in live], np.int32)
+            anc = np.zeros((n, max_len), np.int32)
+            keyok = np.zeros((n, max_len), np.uint8)
+            for k, (_, s) in enumerate(live):
+                anc[k, :i] = s["anc"]
+                anc[k, i] = k
+                keyok[k, : i + 1] = [t != args.padding_idx for t in s["hyp"]]
+            tok_d, utt_d = torch.from_numpy(tok).to(dev), torch.from_numpy(utt).to(dev)
+            anc_d, keyok_d = torch.from_numpy(anc).to(dev), torch.from_numpy(keyok).to(dev)
+            eng.ast_step(i, tok_d, utt_d, anc_d, keyok_d, args.T, K, idx_d[:n], val_d[:n])
+            if use_ctc:
+                ref_d = torch.from_numpy(np.array([s["ctc_ref"] for _, s in live], np.int32)).to(dev)
+                eng.ast_ctc_score(i, utt_d, tok_d, idx_d[:n], ref_d, i & 1, eos, ctc_d[:n])
+                ctc = ctc_d[:n].cpu().numpy()
+            indices, att = idx_d[:n].cpu().numpy(), val_d[:n].cpu().numpy()
+            if use_ctc:
+                prev = np.array([s["ctc_prev"] for _, s in live], np.float32)[:, None]
+                local = w32 * (ctc - prev) + u32 * att  # float32, same op order as transformer.py:205-206
+                local_idx = np.argsort(-local, axis=1, kind="stable")[:, :bw]
+                local_scores = np.take_along_axis(local, local_idx, 1)
+                tokens = np.take_along_axis(indices, local_idx, 1)
+            else:
+                local_scores, tokens = att[:, :bw], indices[:, :bw]
+            cand = [[s for s in beams[b] if s["hyp"][-1] == eos] for b in range(B)]
+            for k, (b, s) in enumerate(live):
+                for j in range(bw):
+                    new = {"score": s["score"] + float(local_scores[k, j]), "hyp": s["hyp"] + [int(tokens[k, j])],
+                           "anc": s["anc"] + [k]}
+                    if use_ctc:
+                        ti = int(local_idx[k, j])
+                        new["ctc_ref"] = k * K + ti
+                        new["ctc_prev"] = ctc[k, ti]
+                    cand[b].append(new)
+            for b in range(B):
+                if lp is not None:
+                    cand[b].sort(key=lambda x: x["score"] + (len(x["hyp"]) - 1) * lp, reverse=True)
+                else:
+                    cand[b].sort(key=lambda x: x["score"], reverse=True)
+                beams[b] = cand[b][:bw]
+        return [[{"ys": torch.tensor([s["hyp"]], dtype=torch.long), "score": s["score"], "hyp": s["hyp"]} for s in beams[b]]
+                for b in range(B)]
+
+
+def make_model(input_size, args):
+    """Same role as src/models/transformer.py:19-37."""
+    model = Transformer(input_size, args)
+    for p in model.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+    return model

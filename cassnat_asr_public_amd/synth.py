@@ -25,6 +25,14 @@ PRESETS = {
                     N_enc=12, N_extra=1, N_self_dec=3, N_mix_dec=2, vocab_size=5000),
 }
 
+PRESETS_AST = {
+    "tiny_ast": dict(input_size=80, d_model=128, n_head=2, d_ff=256, d_encff=256, N_enc=2, N_dec=2, vocab_size=40),
+    # BASELINE configs[3]: AST beam=10 on the config-2 encoder
+    "config4": dict(input_size=80, d_model=256, n_head=4, d_ff=2048, d_encff=2048, N_enc=12, N_dec=6, vocab_size=5000),
+}
+AST_DECODE_DEFAULTS = dict(ctc_weight=0.3, max_decode_ratio=0.3, T=1.0, ctc_beam=15, beam_width=10, lm_weight=0,
+                           length_penalty=0, ctc_alpha=1, interctc_alpha=0, interctc_layer=0, decode_type="ctc_att")
+
 # Added to the CTC blank logit of the seeded config-2 model: with random weights the argmax is never blank
 # (U ~ 195 of 250 frames); +0.9 gives 39-58 tokens per 10 s utterance, the range real LibriSpeech shows.
 BENCH_BLANK_BIAS = 0.9
@@ -51,6 +59,60 @@ def make_args(preset="tiny", **overrides):
     d.update(PRESETS[preset] if isinstance(preset, str) else preset)
     d.update(overrides)
     return SimpleNamespace(**d)
+
+
+def make_args_ast(preset="tiny_ast", **overrides):
+    d = dict(DECODE_DEFAULTS)
+    d.update(AST_DECODE_DEFAULTS)
+    d.update(PRESETS_AST[preset] if isinstance(preset, str) else preset)
+    d.update(overrides)
+    return SimpleNamespace(**d)
+
+
+def param_shapes_ast(args):
+    """Named parameters of the reference's AST model (src/models/transformer.py:19-37, registration order :55-60)."""
+    d, V, F = args.d_model, args.vocab_size, args.input_size
+    f2 = ((F - 1) // 2) // 2 + 1
+    shapes = OrderedDict()
+
+    def lin(prefix, n_out, n_in):
+        shapes[prefix + ".weight"] = (n_out, n_in)
+        shapes[prefix + ".bias"] = (n_out,)
+
+    def mha(prefix):
+        for i in range(4):
+            lin(f"{prefix}.linears.{i}", d, d)
+
+    def norm(prefix):
+        shapes[prefix + ".a_2"] = (d,)
+        shapes[prefix + ".b_2"] = (d,)
+
+    shapes["src_embed.conv.0.weight"] = (d, 1, 3, 3)
+    shapes["src_embed.conv.0.bias"] = (d,)
+    shapes["src_embed.conv.2.weight"] = (d, d, 3, 3)
+    shapes["src_embed.conv.2.bias"] = (d,)
+    lin("src_embed.linear_out", d, d * f2)
+    shapes["tgt_embed.0.lut.weight"] = (V, d)
+    for n in range(args.N_enc):
+        p = f"encoder.layers.{n}"
+        mha(p + ".self_attn")
+        lin(p + ".feed_forward.w_1", args.d_ff, d)
+        lin(p + ".feed_forward.w_2", d, args.d_ff)
+        norm(p + ".sublayer.0.norm")
+        norm(p + ".sublayer.1.norm")
+    norm("encoder.norm")
+    for n in range(args.N_dec):
+        p = f"decoder.layers.{n}"
+        mha(p + ".self_attn")
+        mha(p + ".src_attn")
+        lin(p + ".feed_forward.w_1", args.d_ff, d)
+        lin(p + ".feed_forward.w_2", d, args.d_ff)
+        for i in range(3):
+            norm(p + f".sublayer.{i}.norm")
+    norm("decoder.norm")
+    lin("ctc_generator.proj", V, d)
+    lin("att_generator.proj", V, d)
+    return shapes
 
 
 def param_shapes(args):
@@ -129,7 +191,8 @@ def make_state(args, seed=0, blank_bias=0.0, gain=1.0):
     """
     rng = np.random.default_rng(seed)
     state = OrderedDict()
-    for name, shape in param_shapes(args).items():
+    shapes = param_shapes_ast(args) if hasattr(args, "N_dec") else param_shapes(args)
+    for name, shape in shapes.items():
         if len(shape) > 1:
             receptive = int(np.prod(shape[2:])) if len(shape) > 2 else 1
             fan_in, fan_out = shape[1] * receptive, shape[0] * receptive

@@ -37,7 +37,8 @@ typedef struct cn_config {
     int32_t max_batch;  /* workspace is sized for max_batch x max_frames */
     int32_t max_frames;
     int32_t device; /* HIP device ordinal */
-    int32_t reserved[8];
+    int32_t ast;    /* 1: autoregressive (AST) model: n_mix_dec = N_dec decoder layers + tgt_embed (src/models/transformer.py) */
+    int32_t reserved[7];
 } cn_config;
 
 /* Decode-time switches read by beam_decode from `args` (src/models/cassnat.py:435-636). */
@@ -82,6 +83,22 @@ int cn_decode_nast(cn_model* m, const float* feats_dev, const float* size_ratio_
 /* stage-level entry: src_embed + encoder + ctc_generator + alignment only (src/models/cassnat.py:431-468) */
 int cn_encode_align(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,
                     const cn_decode_opts* opts, int32_t* ymax_host, void* stream);
+
+/* ---- autoregressive (AST) model, BASELINE config 4: device half of Transformer.beam_decode (src/models/transformer.py:122-241).
+ * The host keeps the beam bookkeeping (as the reference does in Python); per step it passes, for every live hypothesis (row),
+ * its last token, utterance index, ancestor table (slot that wrote each earlier position of its prefix) and the key mask of
+ * its prefix (token != padding_idx), and receives the top-K of log_softmax(att logits / T).  Keys/values of earlier positions
+ * come from a per-layer cache - the decoder is NOT re-run on the whole prefix as the reference does. */
+int cn_ast_begin(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts,
+                 int32_t want_ctc, int32_t max_len, int32_t max_slots, int32_t ctc_beam, void* stream);
+int cn_ast_step(cn_model* m, int32_t n_live, int32_t pos, const int32_t* tok_dev, const int32_t* utt_dev,
+                const int32_t* anc_dev, const uint8_t* keyok_dev, int32_t table_stride, float temperature, int32_t K,
+                int32_t* topk_idx_dev, float* topk_val_dev, void* stream);
+/* CTCPrefixScore.__call__ (src/utils/ctc_prefix.py:50-106) for K candidate labels of every live hypothesis; the new states
+ * of all n_live*K candidates are kept on the device (row h*K+c of the buffer of this step's parity) for the next step. */
+int cn_ast_ctc_score(cn_model* m, int32_t n_live, int32_t out_len, const int32_t* utt_dev, const int32_t* last_tok_dev,
+                     const int32_t* cand_dev, int32_t K, const int32_t* prev_ref_dev, int32_t parity, int32_t eos,
+                     float* score_dev, void* stream);
 
 /* Copy a named internal / captured tensor to the host (synchronous; test + host-beam use).  Activations are
  * returned as fp32 whatever the model precision.  shape_out has room for 4 dims. */

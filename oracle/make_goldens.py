@@ -115,6 +115,36 @@ def run_reference(torch, make_model, args, state, feats, sizes, hooks=True):
     return out
 
 
+def run_reference_ast(torch, args, state, feats):
+    """Reference Transformer.beam_decode (src/models/transformer.py:122-241) -> beams per utterance."""
+    import copy
+
+    from models.transformer import make_model as make_ast
+
+    a = copy.deepcopy(args)
+    model = make_ast(a.input_size, a).eval()
+    named = dict(model.named_parameters())
+    assert list(named.keys()) == list(state.keys()), "AST parameter naming drifted from the reference"
+    with torch.no_grad():
+        for k, p in named.items():
+            p.copy_(torch.from_numpy(state[k]))
+    src = torch.from_numpy(feats)
+    x_mask = (src[:, :, 0] != a.padding_idx).unsqueeze(1)
+    with torch.no_grad():
+        top = model.beam_decode(src, x_mask, _Vocab, a)
+    bw = a.beam_width
+    L = max(len(s["hyp"]) for t in top for s in t)
+    hyp = np.zeros((len(top), bw, L), np.int32)
+    hlen = np.zeros((len(top), bw), np.int32)
+    score = np.full((len(top), bw), -np.inf)
+    for b, t in enumerate(top):
+        for j, s in enumerate(t):
+            hlen[b, j] = len(s["hyp"])
+            hyp[b, j, : hlen[b, j]] = s["hyp"]
+            score[b, j] = s["score"]
+    return dict(beam_hyp=hyp, beam_len=hlen, beam_score=score)
+
+
 def top2_margin(ctc_out):
     s = np.sort(ctc_out, axis=-1)
     return (s[..., -1] - s[..., -2]).astype(np.float32)
@@ -206,6 +236,25 @@ def main():
         hyp=r["hyp"], hyp_len=r["hyp_len"], score=r["score"])
     m = top2_margin(r["ctc_out"])
     print("config2_b32: ymax", r["ymax"], "ylen", r["ylen"], "margin min/p1", m.min(), np.percentile(m, 1))
+
+    # ---- 4c. AST (autoregressive decoder, joint CTC/attention beam search): BASELINE config 4 path
+    a_ast = synth.make_args_ast("tiny_ast", beam_width=3, ctc_beam=5, max_decode_ratio=0.75)
+    st_ast = synth.make_state(a_ast, seed=3, gain=2.0)
+    f_ast, _ = synth.make_feats(3, 61, 80, lengths=[61, 57, 51], seed=11)  # >= 13 valid frames each: no hypothesis outgrows its frames
+    for name, ov in {"ast_tiny_att": dict(ctc_weight=0.0), "ast_tiny_ctc": dict(ctc_weight=0.3),
+                     "ast_tiny_lp": dict(ctc_weight=0.5, length_penalty=0.2, T=1.3)}.items():
+        aa = synth.make_args_ast("tiny_ast", beam_width=3, ctc_beam=5, max_decode_ratio=0.75, **ov)
+        r = run_reference_ast(torch, aa, st_ast, f_ast)
+        np.savez_compressed(os.path.join(gdir, name + ".npz"), **r)
+        print(name, r["beam_len"][:, 0], r["beam_score"][:, 0])
+    a4 = synth.make_args_ast("config4", max_decode_ratio=0.3)
+    st4 = synth.make_state(a4, seed=5)
+    f4, _ = synth.make_feats(2, 400, 80, lengths=[400, 333], seed=31)
+    for name, ov in {"ast_config4_ctc": dict(ctc_weight=0.3), "ast_config4_att": dict(ctc_weight=0.0)}.items():
+        aa = synth.make_args_ast("config4", max_decode_ratio=0.3, **ov)
+        r = run_reference_ast(torch, aa, st4, f4)
+        np.savez_compressed(os.path.join(gdir, name + ".npz"), **r)
+        print(name, r["beam_len"][:, 0], r["beam_score"][:, :2])
 
     # ---- 5. hand-checkable known-answer vector for the alignment helpers,
     #         produced by the reference's own best_path_align/align_to_mask on one-hot log-probs

@@ -61,3 +61,23 @@ def config2_b32_case():
     state = synth.make_state(args, seed=0, blank_bias=synth.BENCH_BLANK_BIAS)
     feats, sizes = synth.make_feats(32, 1000, 80, seed=1234)
     return args, state, feats, sizes
+
+
+def ast_tiny_case(**overrides):
+    from cassnat_asr_public_amd import synth
+
+    args = synth.make_args_ast("tiny_ast", beam_width=3, ctc_beam=5, max_decode_ratio=0.75, **overrides)
+    state = synth.make_state(args, seed=3, gain=2.0)
+    # every utterance keeps >= 13 valid subsampled frames for the 12 decode steps: once a hypothesis has more tokens than
+    # frames its CTC scores are +-1e10 dominated, all candidates tie in float32 and torch.topk's tie order decides
+    feats, _ = synth.make_feats(3, 61, 80, lengths=[61, 57, 51], seed=11)
+    return args, state, feats
+
+
+def ast_config4_case(**overrides):
+    from cassnat_asr_public_amd import synth
+
+    args = synth.make_args_ast("config4", max_decode_ratio=0.3, **overrides)
+    state = synth.make_state(args, seed=5)
+    feats, _ = synth.make_feats(2, 400, 80, lengths=[400, 333], seed=31)
+    return args, state, feats

@@ -1,0 +1,87 @@
+"""GPU parity of the autoregressive (AST) path - BASELINE config 4, SURVEY 8a row a18 - through the drop-in
+``models.transformer`` API and the cn_ast_* C ABI.  Goldens are the reference's own Transformer.beam_decode outputs
+(tests/golden/ast_*.npz, oracle/make_goldens.py).  fp32 engine: every beam token-for-token, scores within 5e-3
+(the KV-cached step must equal the reference's recompute-everything decoder).  bf16 engine: agreement reported."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ast_config4_case, ast_tiny_case, load_golden
+from cassnat_asr_public_amd.models.transformer import make_model
+
+pytestmark = pytest.mark.gpu
+
+
+class Vocab:
+    word2index = {"blank": 0, "sos": 1, "eos": 2, "unk": 3}
+
+
+def run(args, state, feats, precision):
+    args.hip_precision = precision
+    model = make_model(args.input_size, args).cuda()
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.copy_(torch.from_numpy(state[k]))
+    src = torch.from_numpy(feats)
+    mask = (src[:, :, 0] != args.padding_idx).unsqueeze(1)
+    with torch.no_grad():
+        return model.beam_decode(src.cuda(), mask.cuda(), Vocab, args)
+
+
+def agreement(beams, g):
+    exact, total, top1 = 0, 0, 0
+    for b, utt in enumerate(beams):
+        for j, s in enumerate(utt):
+            ok = s["hyp"] == g["beam_hyp"][b, j, : g["beam_len"][b, j]].tolist()
+            exact += ok
+            total += 1
+            top1 += ok and j == 0
+    return exact, total, top1
+
+
+@pytest.mark.parametrize("name,ov", [("ast_tiny_att", dict(ctc_weight=0.0)), ("ast_tiny_ctc", dict(ctc_weight=0.3)),
+                                     ("ast_tiny_lp", dict(ctc_weight=0.5, length_penalty=0.2, T=1.3))])
+def test_ast_tiny_fp32_all_beams(name, ov):
+    g = load_golden(name)
+    args, state, feats = ast_tiny_case(**ov)
+    beams = run(args, state, feats, "fp32")
+    for b, utt in enumerate(beams):
+        assert len(utt) == args.beam_width
+        for j, s in enumerate(utt):
+            assert s["hyp"] == g["beam_hyp"][b, j, : g["beam_len"][b, j]].tolist(), (b, j)
+            assert abs(s["score"] - g["beam_score"][b, j]) < max(5e-3, 1e-6 * abs(g["beam_score"][b, j]))
+            assert s["ys"].tolist() == [s["hyp"]]
+
+
+@pytest.mark.parametrize("name,ov", [("ast_config4_ctc", dict(ctc_weight=0.3)), ("ast_config4_att", dict(ctc_weight=0.0))])
+def test_ast_config4_fp32_beam10(name, ov, capsys):
+    g = load_golden(name)
+    args, state, feats = ast_config4_case(**ov)
+    beams = run(args, state, feats, "fp32")
+    exact, total, top1 = agreement(beams, g)
+    with capsys.disabled():
+        print(f"\n[AST fp32] {name}: {exact}/{total} beams identical, top-1 identical for {top1}/{len(beams)} utterances")
+    # 30 steps x beam 10 with random weights: near-ties between beams can reorder on 1e-6 differences; the best
+    # hypothesis and the bulk of the beam must match the reference exactly.
+    assert top1 == len(beams)
+    assert exact >= total - 2
+    for b, utt in enumerate(beams):
+        assert abs(utt[0]["score"] - g["beam_score"][b, 0]) < 5e-3
+
+
+def test_ast_config4_bf16_report(capsys):
+    g = load_golden("ast_config4_ctc")
+    args, state, feats = ast_config4_case(ctc_weight=0.3)
+    beams = run(args, state, feats, "bf16")
+    exact, total, top1 = agreement(beams, g)
+    prefix = []
+    for b, utt in enumerate(beams):
+        ref = g["beam_hyp"][b, 0, : g["beam_len"][b, 0]].tolist()
+        got = utt[0]["hyp"]
+        k = 0
+        while k < min(len(ref), len(got)) and ref[k] == got[k]:
+            k += 1
+        prefix.append(k)
+        assert len(got) == len(ref) and np.isfinite(utt[0]["score"])
+    with capsys.disabled():
+        print(f"\n[AST bf16] beams identical {exact}/{total}, top-1 identical {top1}/{len(beams)}, common prefix of best {prefix}")

@@ -208,3 +208,12 @@ def test_two_process_gloo_gather_and_broadcast(tmp_path):
         out, _ = pr.communicate(timeout=120)
         assert pr.returncode == 0, out
         assert f"rank {r} ok" in out
+
+
+def test_ast_parameter_names_are_the_reference_checkpoint_keys():
+    from cassnat_asr_public_amd.models.transformer import make_model as make_ast
+
+    args = synth.make_args_ast("tiny_ast")
+    model = make_ast(args.input_size, args)
+    assert {k: tuple(v.shape) for k, v in model.named_parameters()} == dict(synth.param_shapes_ast(args))
+    assert [k for k, _ in model.named_parameters()] == list(synth.param_shapes_ast(args).keys())

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import config1_case, config2_b8_case, config2_b32_case, load_golden, tiny_case
+from conftest import ast_config4_case, ast_tiny_case, config1_case, config2_b8_case, config2_b32_case, load_golden, tiny_case
 from oracle import cassnat_oracle as orc
 
 FTOL = 2e-5
@@ -123,3 +123,28 @@ def test_config2_bench_workload():
     g["margin"] = g["margin"].astype(np.float32)
     _check_big(out, g, 25, 100, 8)
     _close(out["enc_h"][:, ::25, ::16], g["enc_sample"], 1e-4)
+
+
+# ------------------------------------------------------------------------------------------- AST (BASELINE config 4)
+def _check_beams(beams, g, score_tol=2e-3):
+    for b, utt in enumerate(beams):
+        for j, s in enumerate(utt):
+            assert s["hyp"] == g["beam_hyp"][b, j, : g["beam_len"][b, j]].tolist(), (b, j)
+            assert abs(s["score"] - g["beam_score"][b, j]) < score_tol
+
+
+@pytest.mark.parametrize("name,ov", [("ast_tiny_att", dict(ctc_weight=0.0)), ("ast_tiny_ctc", dict(ctc_weight=0.3)),
+                                     ("ast_tiny_lp", dict(ctc_weight=0.5, length_penalty=0.2, T=1.3))])
+def test_ast_tiny_beam_search(name, ov):
+    from oracle import ast_oracle
+
+    args, state, feats = ast_tiny_case(**ov)
+    _check_beams(ast_oracle.decode_ast(state, feats, args), load_golden(name))
+
+
+@pytest.mark.parametrize("name,ov", [("ast_config4_ctc", dict(ctc_weight=0.3)), ("ast_config4_att", dict(ctc_weight=0.0))])
+def test_ast_config4_beam10(name, ov):
+    from oracle import ast_oracle
+
+    args, state, feats = ast_config4_case(**ov)
+    _check_beams(ast_oracle.decode_ast(state, feats, args), load_golden(name))
