@@ -1,0 +1,572 @@
+// Row-chain kernel for gfx950 (bf16 MFMA, d_model = 256): everything of a transformer layer that is not the
+// attention itself, for a block of 128 rows, in ONE launch:
+//
+//     x  <- x + Wo . ctx + bo                      output projection of the attention that just ran + residual
+//     x  <- x + W2 . relu(W1 . LN1(x) + b1) + b2   position-wise feed-forward sublayer + residual
+//     y  <- LNn(x)                                 the NEXT sublayer's pre-norm (or the stack's final norm)
+//     out<- Wt . y + bt                            the NEXT attention's fused Q|K|V (or Q) projection
+//
+// i.e. SublayerConnection / MultiHeadedAttention.linears[3] / PositionwiseFeedForward / LayerNorm /
+// MultiHeadedAttention.linears[0..2] of the reference (src/models/modules/utils.py:23-32, attention.py:44-66,
+// positionff.py:15-16, norm.py:15-18) - six launches and four round trips of the activations in the unfused path.
+//
+// Why this shape.  At B=32 a layer has M = 8000 rows.  The per-layer weights (2.6 MB bf16) stream from L2 into a CU at
+// ~60 GB/s whatever the instruction (LDS-DMA or register loads), so a workgroup that owns few rows is bound by that
+// stream, not by MFMA: the 64-row fused FFN kernel (fused.hip) keeps its CU's matrix pipe ~20 % busy.  Here a
+// workgroup owns 128 rows - each of its four waves a private 32-row block - so every streamed fragment feeds four
+// MFMAs and the pipe is ~80 % busy; a layer then occupies only 63 CUs, which is what lets the four decode pipelines
+// of bench.py run side by side instead of queueing for the whole chip.
+//
+//   * Activations never leave registers.  Every product is computed transposed, Y^T[n][m] = sum_k W[n][k] X^T[k][m],
+//     with the weight fragment as the A operand and the wave's 32 rows on the lane axis; the 32x32 fp32 accumulator
+//     tile (n on registers, m on lanes) is, after a bf16 pack, exactly a B operand of the next product, provided the
+//     next weight is packed in the k-order that implies ("acc order" below).  LayerNorm, bias, ReLU and the residual
+//     are register arithmetic on that layout (one cross-half-wave shuffle per LayerNorm statistic).
+//   * Weights are packed at load time into 16-KiB units (16 fragments of 64 lanes x 16 B) in consumption order and
+//     stream through an 8-slot LDS ring by LDS-DMA (global_load_lds_dwordx4); each wave issues a quarter of every
+//     unit, waits for its own quarter with a counted vmcnt, and ONE s_barrier per unit publishes the slot.  A slot is
+//     refilled as soon as the barrier after its last read has passed, so 5-6 units (~90 KiB) stay in flight per CU;
+//     activations are read and written with the nt policy so that they do not evict the weight stream from L2.
+//   * All LDS reads are issued from inline asm: hipcc drains vmcnt to 0 in front of any LDS access it can see while
+//     an LDS-DMA is outstanding.  Per-channel vectors (biases, LayerNorm gains) ride the same DMA into a 20-KiB table.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "kernels.h"
+
+constexpr int CH_D = 256;
+constexpr int CH_UNIT_BYTES = 16384;
+constexpr int CH_RING = 8;
+constexpr int CH_TAB_FLOATS = 5120;
+constexpr int CH_TAB_BYTES = CH_TAB_FLOATS * 4;  // 20 pieces of 1 KiB, 5 per wave
+constexpr int CH_LDS = CH_TAB_BYTES + CH_RING * CH_UNIT_BYTES;
+static_assert(CH_LDS <= 160 * 1024, "LDS budget");
+// table layout (floats)
+constexpr int CT_BO = 0, CT_LN1A = 256, CT_LN1B = 512, CT_B2 = 768, CT_NLNA = 1024, CT_NLNB = 1280, CT_BT = 1536,
+              CT_B1 = 2304;  // b1: up to 2048 -> 4352 used
+constexpr int CH_MAX_TAIL = 24, CH_MAX_FFN_TILES = 64;
+
+__device__ long long ch_stamps[16];  // phase timestamps of workgroup 0 / wave 0 (investigation aid: CASSNAT_CHAIN_STAMPS)
+
+struct ChainParams {
+    float* x;          // [M][256] fp32 residual stream, updated in place
+    const bf16* ctx;   // [M][ldctx] bf16 (null: no output projection)
+    int ldctx;
+    const uint4* wstream;  // packed units, consumption order
+    const float* tab;      // CH_TAB_FLOATS floats
+    bf16* out;             // tail output [M][ldo] bf16 (tail projection, or LNn(x) itself when tail_tiles == 0)
+    int ldo;
+    int M, ffn_tiles, tail_tiles, has_next;
+    float eps;
+    int stamps;
+};
+
+#define CH_STR2(x) #x
+#define CH_STR(x) CH_STR2(x)
+#define CH_DMA(src, dst)                                                                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),          \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+// eight fragments of a unit: OFFK = 0 (first half) or 8 (second half)
+#define CH_READ8(F, addr, OFFK)                                                                       \
+    asm volatile("ds_read_b128 %0, %8 offset:" CH_STR(((OFFK) + 0) * 1024) "\n\t"                     \
+                 "ds_read_b128 %1, %8 offset:" CH_STR(((OFFK) + 1) * 1024) "\n\t"                     \
+                 "ds_read_b128 %2, %8 offset:" CH_STR(((OFFK) + 2) * 1024) "\n\t"                     \
+                 "ds_read_b128 %3, %8 offset:" CH_STR(((OFFK) + 3) * 1024) "\n\t"                     \
+                 "ds_read_b128 %4, %8 offset:" CH_STR(((OFFK) + 4) * 1024) "\n\t"                     \
+                 "ds_read_b128 %5, %8 offset:" CH_STR(((OFFK) + 5) * 1024) "\n\t"                     \
+                 "ds_read_b128 %6, %8 offset:" CH_STR(((OFFK) + 6) * 1024) "\n\t"                     \
+                 "ds_read_b128 %7, %8 offset:" CH_STR(((OFFK) + 7) * 1024)                            \
+                 : "=&v"(F[0]), "=&v"(F[1]), "=&v"(F[2]), "=&v"(F[3]), "=&v"(F[4]), "=&v"(F[5]),      \
+                   "=&v"(F[6]), "=&v"(F[7])                                                           \
+                 : "v"(addr)                                                                          \
+                 : "memory")
+#define CH_WAIT8(F)                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                               \
+                 : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7]) \
+                 :: "memory")
+// four consecutive-channel quads of a per-channel table for this lane: channels c0 + 8g + 4*half + (0..3), g = 0..3.
+// `dep` is not used by the instructions: it orders the read after the arithmetic that produced it, which keeps the
+// compiler from hoisting every table read of a phase above the phase's arithmetic (and spilling what it read).
+__device__ __forceinline__ void ch_tab4_nowait(unsigned addr, f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("ds_read_b128 %0, %4\n\t"
+                 "ds_read_b128 %1, %4 offset:32\n\t"
+                 "ds_read_b128 %2, %4 offset:64\n\t"
+                 "ds_read_b128 %3, %4 offset:96"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+                 : "v"(addr)
+                 : "memory");
+}
+template <typename D>
+__device__ __forceinline__ void ch_tab4(unsigned addr, const D& dep, f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("ds_read_b128 %0, %4\n\t"
+                 "ds_read_b128 %1, %4 offset:32\n\t"
+                 "ds_read_b128 %2, %4 offset:64\n\t"
+                 "ds_read_b128 %3, %4 offset:96\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+                 : "v"(addr), "v"(dep)
+                 : "memory");
+}
+
+// acc (+ per-channel add from the table) -> LayerNorm over the 256 channels of each row -> bf16 B operands.
+// Row m lives in lanes m and m+32 (128 channels each): statistics need one exchange across the half-waves.
+__device__ __forceinline__ void ch_layernorm_pack(const f32x16 (&acc)[8], unsigned tab_lane, int off_a, int off_b,
+                                                  float eps, bf16x8 (&bop)[16]) {
+    float s = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[nt][r];
+    s += __shfl_xor(s, 32);
+    const float mean = s / (float)CH_D;
+    float ss = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ss = fmaf(acc[nt][r] - mean, acc[nt][r] - mean, ss);
+    ss += __shfl_xor(ss, 32);
+    const float inv = 1.0f / (sqrtf(ss / (float)(CH_D - 1)) + eps);  // the bf16 rounding below dwarfs x/d vs x*(1/d)
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        f32x4 ga[4], be[4];
+        if (nt == 0) {
+            ch_tab4(tab_lane + (off_a + 32 * nt) * 4, inv, ga[0], ga[1], ga[2], ga[3]);
+        } else {
+            ch_tab4(tab_lane + (off_a + 32 * nt) * 4, bop[2 * nt - 1], ga[0], ga[1], ga[2], ga[3]);
+        }
+        ch_tab4(tab_lane + (off_b + 32 * nt) * 4, ga[3], be[0], be[1], be[2], be[3]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                bop[2 * nt + (r >> 3)][r & 7] = (bf16)fmaf(ga[g][e] * (acc[nt][r] - mean), inv, be[g][e]);
+            }
+        // materialise this tile's operands here: without the pin the compiler defers half of the arithmetic to the
+        // operands' first use and spills the table values it still needs (scratch reloads drain the DMA queue)
+        asm volatile("" : "+v"(bop[2 * nt]), "+v"(bop[2 * nt + 1]));
+    }
+}
+
+__device__ __forceinline__ void ch_add_channel(f32x16 (&acc)[8], unsigned tab_lane, int off) {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        f32x4 b[4];
+        ch_tab4(tab_lane + (off + 32 * nt) * 4, acc[nt == 0 ? 0 : nt - 1][15], b[0], b[1], b[2], b[3]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[nt][4 * g + e] += b[g][e];
+        asm volatile("" : "+a"(acc[nt]));
+    }
+}
+
+// ---- hand-scheduled half-unit blocks ------------------------------------------------------------------------
+// One wave per SIMD issues at most one instruction every ~4 cycles and a 32x32x16 MFMA occupies the matrix pipe for
+// 32: everything that is not an MFMA has to be issued in the gaps BETWEEN MFMAs or it runs with the pipe idle.  The
+// compiler clusters; these blocks fix the order by hand: each of the 8 MFMAs of a half-unit is followed by the
+// ds_read of one fragment of the NEXT half-unit, and (second half only) by a quarter of this wave's refill DMAs.
+//   PRE_A : nothing.   PRE_B : own quarter of unit u+1 has landed (counted vmcnt) -> barrier: unit u+1 is published, and
+//   every wave has consumed unit u-1 (its last fragments were waited for by the MFMAs of that unit's second block), so
+//   this block refills that slot with unit u+7 (M0 <- LDS destination of this wave's quarter): ~5-6 units in flight.
+#define CH_MF "v_mfma_f32_32x32x16_bf16 "
+// LDS reads return in order and every MFMA of a block is followed by one read of the next half-unit, so fragment i of
+// the current half-unit is ready exactly when at most 7 younger reads are outstanding: a constant counted wait per MFMA
+// (the read it waits for was issued a whole block earlier - no LDS latency is exposed at block boundaries)
+#define CH_W7 "s_waitcnt lgkmcnt(7)\n\t"
+// The compiler pads its own MFMA -> vector-read sequences with wait states (s_nop 11 for this MFMA) but cannot see into
+// asm: a block whose accumulators the compiler may touch next (copies of "+a" operands included) ends with them itself.
+#define CH_POST_DRAIN "s_nop 13\n\t"
+#define CH_POST_NONE ""
+#define CH_PRE_B_NODMA "s_barrier\n\t"
+// second-half block of a unit, by experiment variant
+#define CH_B1(CC, acc, BO, POST)                                                                               \
+    if constexpr (DBG == 0) { CH_BLK1(CC, acc, Fb, bop, BO, Fa, rn_, 0, CH_PRE_B, CH_D0, CH_D1, CH_D2, CH_D3, POST); } \
+    else if constexpr (DBG == 2) { CH_BLK1(CC, acc, Fb, bop, BO, Fa, rn_, 0, CH_PRE_B_NODMA, "", "", "", "", POST); } \
+    else { asm volatile(CH_PRE_B CH_D0 CH_D1 CH_D2 CH_D3 :: [m0v] "s"(m0v), [vo] "v"(voff), [sb] "s"(sbase) : "memory"); }
+#define CH_A1(CC, acc, BO, PRE, POST)                                                                          \
+    if constexpr (DBG != 3) { CH_BLK1(CC, acc, Fa, bop, BO, Fb, ra_, 8, PRE, "", "", "", "", POST); }
+#define CH_PRE_A ""
+#define CH_PRE_B "s_waitcnt vmcnt(20)\n\ts_barrier\n\ts_mov_b32 m0, %[m0v]\n\t"
+#define CH_D0 "global_load_lds_dwordx4 %[vo], %[sb]\n\t"
+#define CH_D1 "global_load_lds_dwordx4 %[vo], %[sb] offset:1024\n\t"
+#define CH_D2 "global_load_lds_dwordx4 %[vo], %[sb] offset:2048\n\t"
+#define CH_D3 "global_load_lds_dwordx4 %[vo], %[sb] offset:3072\n\t"
+#define CH_RD(n, K) "ds_read_b128 %[" #n "], %[ra] offset:" CH_STR((K) * 1024) "\n\t"
+// single accumulator (constraint CC: "v" or "a"), eight B operands B[BO..BO+7]
+#define CH_BLK1(CC, acc, Fc, B, BO, Fn, raddr, RK, PRE, D0, D1, D2, D3, POST)                                  \
+    asm volatile(PRE                                                                                           \
+                 CH_W7 CH_MF "%[c], %[f0], %[b0], %[c]\n\t" CH_RD(n0, (RK) + 0) D0                                   \
+                 CH_W7 CH_MF "%[c], %[f1], %[b1], %[c]\n\t" CH_RD(n1, (RK) + 1) D1                                   \
+                 CH_W7 CH_MF "%[c], %[f2], %[b2], %[c]\n\t" CH_RD(n2, (RK) + 2) D2                                   \
+                 CH_W7 CH_MF "%[c], %[f3], %[b3], %[c]\n\t" CH_RD(n3, (RK) + 3) D3                                   \
+                 CH_W7 CH_MF "%[c], %[f4], %[b4], %[c]\n\t" CH_RD(n4, (RK) + 4)                                      \
+                 CH_W7 CH_MF "%[c], %[f5], %[b5], %[c]\n\t" CH_RD(n5, (RK) + 5)                                      \
+                 CH_W7 CH_MF "%[c], %[f6], %[b6], %[c]\n\t" CH_RD(n6, (RK) + 6)                                      \
+                 CH_W7 CH_MF "%[c], %[f7], %[b7], %[c]\n\t" CH_RD(n7, (RK) + 7) POST                                 \
+                 : [c] "+" CC(acc), [n0] "=&v"(Fn[0]), [n1] "=&v"(Fn[1]), [n2] "=&v"(Fn[2]), [n3] "=&v"(Fn[3]), \
+                   [n4] "=&v"(Fn[4]), [n5] "=&v"(Fn[5]), [n6] "=&v"(Fn[6]), [n7] "=&v"(Fn[7])                  \
+                 : [f0] "v"(Fc[0]), [f1] "v"(Fc[1]), [f2] "v"(Fc[2]), [f3] "v"(Fc[3]), [f4] "v"(Fc[4]),        \
+                   [f5] "v"(Fc[5]), [f6] "v"(Fc[6]), [f7] "v"(Fc[7]), [b0] "v"(B[(BO) + 0]), [b1] "v"(B[(BO) + 1]), \
+                   [b2] "v"(B[(BO) + 2]), [b3] "v"(B[(BO) + 3]), [b4] "v"(B[(BO) + 4]), [b5] "v"(B[(BO) + 5]), \
+                   [b6] "v"(B[(BO) + 6]), [b7] "v"(B[(BO) + 7]), [ra] "v"(raddr), [m0v] "s"(m0v), [vo] "v"(voff), \
+                   [sb] "s"(sbase)                                                                             \
+                 : "memory")
+// eight accumulators acc[0..7] (AGPRs), one B operand
+#define CH_BLK2(acc, Fc, pbv, Fn, raddr, RK, PRE, D0, D1, D2, D3, LAST)                                        \
+    asm volatile(PRE                                                                                           \
+                 CH_W7 CH_MF "%[c0], %[f0], %[pb], %[c0]\n\t" CH_RD(n0, (RK) + 0) D0                                 \
+                 CH_W7 CH_MF "%[c1], %[f1], %[pb], %[c1]\n\t" CH_RD(n1, (RK) + 1) D1                                 \
+                 CH_W7 CH_MF "%[c2], %[f2], %[pb], %[c2]\n\t" CH_RD(n2, (RK) + 2) D2                                 \
+                 CH_W7 CH_MF "%[c3], %[f3], %[pb], %[c3]\n\t" CH_RD(n3, (RK) + 3) D3                                 \
+                 CH_W7 CH_MF "%[c4], %[f4], %[pb], %[c4]\n\t" CH_RD(n4, (RK) + 4)                                    \
+                 CH_W7 CH_MF "%[c5], %[f5], %[pb], %[c5]\n\t" CH_RD(n5, (RK) + 5)                                    \
+                 CH_W7 CH_MF "%[c6], %[f6], %[pb], %[c6]\n\t" CH_RD(n6, (RK) + 6)                                    \
+                 CH_W7 CH_MF "%[c7], %[f7], %[pb], %[c7]\n\t" CH_RD(n7, (RK) + 7)                                    \
+                 "s_cmp_eq_u32 %[last], 0\n\ts_cbranch_scc1 .Lch_nodrain%=\n\t" CH_POST_DRAIN ".Lch_nodrain%=:\n\t"   \
+                 : [c0] "+a"(acc[0]), [c1] "+a"(acc[1]), [c2] "+a"(acc[2]), [c3] "+a"(acc[3]), [c4] "+a"(acc[4]), \
+                   [c5] "+a"(acc[5]), [c6] "+a"(acc[6]), [c7] "+a"(acc[7]), [n0] "=&v"(Fn[0]), [n1] "=&v"(Fn[1]), \
+                   [n2] "=&v"(Fn[2]), [n3] "=&v"(Fn[3]), [n4] "=&v"(Fn[4]), [n5] "=&v"(Fn[5]), [n6] "=&v"(Fn[6]), \
+                   [n7] "=&v"(Fn[7])                                                                           \
+                 : [f0] "v"(Fc[0]), [f1] "v"(Fc[1]), [f2] "v"(Fc[2]), [f3] "v"(Fc[3]), [f4] "v"(Fc[4]),        \
+                   [f5] "v"(Fc[5]), [f6] "v"(Fc[6]), [f7] "v"(Fc[7]), [pb] "v"(pbv), [ra] "v"(raddr),          \
+                   [m0v] "s"(m0v), [vo] "v"(voff), [sb] "s"(sbase), [last] "s"(LAST)                           \
+                 : "memory", "scc")
+
+// DBG (timing experiments only, results are wrong): 2 = no refill DMAs and no vmcnt waits (compute side alone),
+// 3 = refill DMAs, waits and barriers only (stream side alone)
+template <int DBG>
+__global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m = blockIdx.x * 128 + 32 * wave + l31;
+    const int mc = m < p.M ? m : p.M - 1;
+    const bool live = m < p.M;
+
+#define CH_STAMP(i)                                                                              \
+    if (p.stamps && blockIdx.x == 0 && tid == 0) ch_stamps[i] = (long long)__builtin_amdgcn_s_memtime();
+    CH_STAMP(0)
+    const int U_OUT = p.ctx ? 8 : 0;
+    const int U_FFN = 2 * p.ffn_tiles;
+    const int NU = U_OUT + U_FFN + p.tail_tiles;
+    // every workgroup walks the FFN tiles in its own rotation (the sum over tiles is order-free): the workgroups of a
+    // launch then do not pull the same L2 lines at the same moment
+    const int rot = p.ffn_tiles ? (int)((blockIdx.x * 5u) % (unsigned)p.ffn_tiles) : 0;
+    unsigned char* ring = smem + CH_TAB_BYTES;
+
+#define CH_FFN_TILE(t) (((t) + rot) >= p.ffn_tiles ? (t) + rot - p.ffn_tiles : (t) + rot)
+    // stream unit consumed at position u (positions past the end re-read the last unit: dummy refills keep the DMA
+    // queue depth - and with it every vmcnt in the loop - constant; their slots are never read)
+    auto src_unit = [&](int u) -> int {
+        if (u > NU - 1) u = NU - 1;
+        if (u >= U_OUT && u < U_OUT + U_FFN) {
+            const int k = u - U_OUT;
+            u = U_OUT + 2 * CH_FFN_TILE(k >> 1) + (k & 1);
+        }
+        return u;
+    };
+
+    // ---- prologue: the wave's 32 rows of x (accumulator layout) and ctx (B operands), issued from asm so that the
+    // compiler does not order them against the DMAs below; waited for with a counted vmcnt once the ring is primed
+    f32x4 xr[32];
+    bf16x8 bop[16];
+    {
+        const float* xp = p.x + (long long)mc * CH_D + 4 * half;
+#pragma unroll
+        for (int i = 0; i < 32; ++i)  // i = 4 nt + g : channels 32 nt + 8 g + 4 half + (0..3)
+            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&a"(xr[i]) : "v"(xp + 8 * i) : "memory");
+        if (p.ctx) {
+            const bf16* cp = p.ctx + (long long)mc * p.ldctx + 8 * half;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(bop[ks]) : "v"(cp + 16 * ks) : "memory");
+        }
+    }
+    {
+        const uint4* ts = reinterpret_cast<const uint4*>(p.tab) + 5 * wave * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) CH_DMA(ts + j * 64, smem + (5 * wave + j) * 1024);
+    }
+    if (NU > 0) {
+        for (int u = 0; u < CH_RING - 1; ++u) {  // units 0..6; unit u+7 is requested while unit u is consumed
+            const uint4* src = p.wstream + ((long long)src_unit(u) * 16 + 4 * wave) * 64 + lane;
+            unsigned char* dst = ring + u * CH_UNIT_BYTES + 4 * wave * 1024;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) CH_DMA(src + j * 64, dst + j * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(33)" ::: "memory");  // x, ctx: all but the 5 table + 28 unit DMAs
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("" : "+a"(xr[0]), "+a"(xr[1]), "+a"(xr[2]), "+a"(xr[3]), "+a"(xr[4]), "+a"(xr[5]), "+a"(xr[6]), "+a"(xr[7]),
+                 "+a"(xr[8]), "+a"(xr[9]), "+a"(xr[10]), "+a"(xr[11]), "+a"(xr[12]), "+a"(xr[13]), "+a"(xr[14]), "+a"(xr[15]));
+    asm volatile("" : "+a"(xr[16]), "+a"(xr[17]), "+a"(xr[18]), "+a"(xr[19]), "+a"(xr[20]), "+a"(xr[21]), "+a"(xr[22]),
+                 "+a"(xr[23]), "+a"(xr[24]), "+a"(xr[25]), "+a"(xr[26]), "+a"(xr[27]), "+a"(xr[28]), "+a"(xr[29]),
+                 "+a"(xr[30]), "+a"(xr[31]));
+    if (p.ctx)
+        asm volatile("" : "+v"(bop[0]), "+v"(bop[1]), "+v"(bop[2]), "+v"(bop[3]), "+v"(bop[4]), "+v"(bop[5]), "+v"(bop[6]),
+                     "+v"(bop[7]), "+v"(bop[8]), "+v"(bop[9]), "+v"(bop[10]), "+v"(bop[11]), "+v"(bop[12]), "+v"(bop[13]),
+                     "+v"(bop[14]), "+v"(bop[15]));
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[nt][4 * g + e] = xr[4 * nt + g][e];
+
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
+    const unsigned ring_a = ring_lds + lane * 16;
+    const unsigned tab_lane = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(smem + 16 * half);
+    const unsigned voff = (unsigned)(lane * 16 + wave * 4096);  // this lane's byte offset inside a unit (piece 4 wave + j: + 1024 j)
+    const unsigned m0_wave = __builtin_amdgcn_readfirstlane(ring_lds + wave * 4096);
+
+    CH_STAMP(1)
+    bf16x8 Fa[8], Fb[8];
+    // unit 0 (and the table): own quarter landed -> barrier -> first half into Fa
+    if (NU > 0) {
+        asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+        CH_READ8(Fa, ring_a, 0);
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // per-unit scalars of the second-half block of unit u: where the first half of unit u+1 is read from, and the
+    // refill of unit u+7 into the slot unit u-1 occupied
+#define CH_UNIT_SCALARS(u)                                                                                    \
+    const unsigned ra_ = ring_a + (unsigned)(((u) & 7) * CH_UNIT_BYTES);                                      \
+    const unsigned rn_ = ring_a + (unsigned)((((u) + 1) & 7) * CH_UNIT_BYTES);                                \
+    const unsigned m0v = m0_wave + (unsigned)((((u) + 7) & 7) * CH_UNIT_BYTES);                               \
+    const uint4* sbase = p.wstream + (long long)src_unit((u) + 7) * 1024;
+
+    CH_STAMP(2)
+    // ---- S1: output projection (natural k order; B operands = ctx), accumulating on top of the residual
+    if (p.ctx) {
+#define CH_S1(nt)                                                                                             \
+        {                                                                                                     \
+            CH_UNIT_SCALARS(nt)                                                                               \
+            CH_A1("a", acc[nt], 0, "s_nop 1\n\t", CH_POST_DRAIN)                                            \
+            CH_B1("a", acc[nt], 8, CH_POST_DRAIN)                                                             \
+        }
+        CH_S1(0) CH_S1(1) CH_S1(2) CH_S1(3) CH_S1(4) CH_S1(5) CH_S1(6) CH_S1(7)
+#undef CH_S1
+        ch_add_channel(acc, tab_lane, CT_BO);
+    }
+
+    CH_STAMP(3)
+    // ---- S3: feed-forward sublayer
+    if (p.ffn_tiles) {
+        ch_layernorm_pack(acc, tab_lane, CT_LN1A, CT_LN1B, p.eps, bop);
+        ch_add_channel(acc, tab_lane, CT_B2);  // b2 once; the W2 products accumulate on top of x + b2
+        CH_STAMP(4)
+        for (int t = 0; t < p.ffn_tiles; ++t) {
+            const int u0 = U_OUT + 2 * t;
+            f32x16 xh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xh[r] = 0.f;
+            f32x4 b1v[4];  // b1 of the tile's hidden units: read now, older than every fragment read below, used at the ReLU
+            ch_tab4_nowait(tab_lane + (CT_B1 + 32 * CH_FFN_TILE(t)) * 4, b1v[0], b1v[1], b1v[2], b1v[3]);
+            {
+                CH_UNIT_SCALARS(u0)
+                CH_A1("v", xh, 0, CH_PRE_A, CH_POST_NONE)
+                CH_B1("v", xh, 8, CH_POST_DRAIN)
+            }
+            asm volatile("" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]));  // landed: the blocks above waited past them
+            bf16x8 pb[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {  // ReLU as a signed-integer max on the bits: one instruction, no canonicalising pre-max
+                const float v = xh[r] + b1v[r >> 2][r & 3];
+                const int bits = __float_as_int(v);
+                pb[r >> 3][r & 7] = (bf16)__int_as_float(bits > 0 ? bits : 0);
+            }
+            {
+                CH_UNIT_SCALARS(u0 + 1)
+                const int not_last = __builtin_amdgcn_readfirstlane(0);
+                const int is_last = __builtin_amdgcn_readfirstlane((int)(t + 1 == p.ffn_tiles));
+                if constexpr (DBG != 3) { CH_BLK2(acc, Fa, pb[0], Fb, ra_, 8, CH_PRE_A, "", "", "", "", not_last); }
+                if constexpr (DBG == 0) { CH_BLK2(acc, Fb, pb[1], Fa, rn_, 0, CH_PRE_B, CH_D0, CH_D1, CH_D2, CH_D3, is_last); }
+                else if constexpr (DBG == 2) { CH_BLK2(acc, Fb, pb[1], Fa, rn_, 0, CH_PRE_B_NODMA, "", "", "", "", is_last); }
+                else { asm volatile(CH_PRE_B CH_D0 CH_D1 CH_D2 CH_D3 :: [m0v] "s"(m0v), [vo] "v"(voff), [sb] "s"(sbase) : "memory"); }
+            }
+        }
+    }
+
+    CH_STAMP(5)
+    // ---- S4: the residual stream goes back to memory (row m: 16-byte pieces at channels 32 nt + 8 g + 4 half)
+    if (live && (p.ctx || p.ffn_tiles)) {
+        float* xp = p.x + (long long)m * CH_D + 4 * half;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[nt][4 * g + e];
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(xp + 32 * nt + 8 * g));
+            }
+    }
+    CH_STAMP(6)
+    if (p.has_next) {
+        ch_layernorm_pack(acc, tab_lane, CT_NLNA, CT_NLNB, p.eps, bop);
+        CH_STAMP(7)
+        if (p.tail_tiles == 0) {
+            // y = LNn(x) itself, row-major bf16.  bop[2 nt + s][j] is channel 32 nt + 16 s + 8 (j >> 2) + 4 half + (j & 3)
+            if (live) {
+                bf16* op = p.out + (long long)m * p.ldo + 4 * half;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = bop[k][4 * q + e];
+                        __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(op + 16 * k + 8 * q));
+                    }
+            }
+        }
+        // ---- S5: tail projection (acc-order k; B operands = LNn(x)), written row-major bf16
+        for (int jt = 0; jt < p.tail_tiles; ++jt) {
+            const int u0 = U_OUT + U_FFN + jt;
+            f32x16 q;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[r] = 0.f;
+            f32x4 btv[4];
+            ch_tab4_nowait(tab_lane + (CT_BT + 32 * jt) * 4, btv[0], btv[1], btv[2], btv[3]);
+            {
+                CH_UNIT_SCALARS(u0)
+                CH_A1("v", q, 0, CH_PRE_A, CH_POST_NONE)
+                CH_B1("v", q, 8, CH_POST_DRAIN)
+            }
+            asm volatile("" : "+v"(btv[0]), "+v"(btv[1]), "+v"(btv[2]), "+v"(btv[3]));
+            if (live) {
+                bf16* op = p.out + (long long)m * p.ldo + 32 * jt + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(q[4 * g + e] + btv[g][e]);
+                    __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(op + 8 * g));
+                }
+            }
+        }
+    }
+    CH_STAMP(8)
+    // the dummy refills of the last units may still be writing this workgroup's LDS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    CH_STAMP(9)
+#undef CH_UNIT_SCALARS
+#undef CH_FFN_TILE
+}
+
+template <int DBG> static int launch_chain_variant(const ChainParams& p, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)chain_kernel<DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(chain_kernel<DBG>, dim3(cn_ceil_div(p.M, 128)), dim3(256), CH_LDS, s, p);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int chain_print_stamps() {
+    long long h[16];
+    CN_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(ch_stamps), sizeof(h)));
+    static const char* names[] = {"prologue issue", "x/ctx landed + acc", "first unit visible", "S1 out-proj", "LN1 + b2",
+                                  "S3 ffn loop", "S4 x store", "LNn", "S5 tail", "drain"};
+    for (int i = 1; i < 10; ++i) fprintf(stderr, "[chain stamps] %-20s %8lld ticks\n", names[i], h[i] - h[i - 1]);
+    fprintf(stderr, "[chain stamps] total %lld ticks (s_memtime)\n", h[9] - h[0]);
+    return 0;
+}
+
+int launch_chain(const ChainArgs& a, hipStream_t s) {
+    if (a.d != CH_D || a.dff < 0 || a.dff % 32 != 0 || a.dff / 32 > CH_MAX_FFN_TILES || a.tail_n < 0 || a.tail_n % 32 != 0 ||
+        a.tail_n / 32 > CH_MAX_TAIL || (a.tail_n > 0 && !a.has_next) || (a.has_next && !a.out)) {
+        cn_set_error("chain: needs d_model == 256, d_ff % 32 == 0 <= 2048, tail width % 32 == 0 <= 768");
+        return -1;
+    }
+    if (a.M <= 0) return 0;
+    ChainParams p;
+    p.x = a.x;
+    p.ctx = reinterpret_cast<const bf16*>(a.ctx);
+    p.ldctx = a.ldctx;
+    p.wstream = reinterpret_cast<const uint4*>(a.wstream);
+    p.tab = a.tab;
+    p.out = reinterpret_cast<bf16*>(a.out);
+    p.ldo = a.ldo;
+    p.M = a.M;
+    p.ffn_tiles = a.dff / 32;
+    p.tail_tiles = a.tail_n / 32;
+    p.has_next = a.has_next;
+    p.eps = a.eps;
+    static int stamps = -1;
+    if (stamps < 0) stamps = getenv("CASSNAT_CHAIN_STAMPS") != nullptr;
+    p.stamps = stamps;
+    static int dbg = -1;
+    if (dbg < 0) dbg = getenv("CASSNAT_CHAIN_DEBUG") ? atoi(getenv("CASSNAT_CHAIN_DEBUG")) : 0;
+    if (dbg == 2) return launch_chain_variant<2>(p, s);
+    if (dbg == 3) return launch_chain_variant<3>(p, s);
+    return launch_chain_variant<0>(p, s);
+}
+
+// ---- host-side packing --------------------------------------------------------------------------------------
+static inline uint16_t ch_bf16_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+size_t chain_stream_units(int has_outproj, int dff, int tail_n) { return (has_outproj ? 8 : 0) + 2 * (dff / 32) + tail_n / 32; }
+
+// One unit = rows 32 rt .. +31 of a [N][ld] weight against 256 contraction indices starting at column k0:
+//   natural order : frag ks, lane, j -> W[32 rt + (lane & 31)][k0 + 16 ks + 8 (lane >> 5) + j]
+//   acc order     : frag 2 nt + s   -> W[32 rt + (lane & 31)][k0 + 32 nt + 16 s + 8 (j >> 2) + 4 (lane >> 5) + (j & 3)]
+//   (W2 units use acc order with k0 = 32 t and 32 contraction indices per (s) pair: frag 8 s + nt, rows 32 nt ..)
+static void ch_pack_rows(const float* w, int ld, int rt, bool acc_order, uint16_t* out) {
+    for (int f = 0; f < 16; ++f)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int k = acc_order ? 32 * (f >> 1) + 16 * (f & 1) + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)
+                                        : 16 * f + 8 * (lane >> 5) + j;
+                out[((size_t)f * 64 + lane) * 8 + j] = ch_bf16_bits(w[(size_t)(32 * rt + (lane & 31)) * ld + k]);
+            }
+}
+static void ch_pack_w2(const float* w2, int dff, int t, uint16_t* out) {
+    for (int s = 0; s < 2; ++s)
+        for (int nt = 0; nt < 8; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j)
+                    out[((size_t)(8 * s + nt) * 64 + lane) * 8 + j] = ch_bf16_bits(
+                        w2[(size_t)(32 * nt + (lane & 31)) * dff + 32 * t + 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)]);
+}
+
+void pack_chain(const ChainWeights& w, uint16_t* stream, float* tab) {
+    const size_t unit = CH_UNIT_BYTES / 2;
+    size_t u = 0;
+    if (w.wo)
+        for (int rt = 0; rt < 8; ++rt) ch_pack_rows(w.wo, CH_D, rt, false, stream + unit * u++);
+    for (int t = 0; t < w.dff / 32; ++t) {
+        ch_pack_rows(w.w1, CH_D, t, true, stream + unit * u++);
+        ch_pack_w2(w.w2, w.dff, t, stream + unit * u++);
+    }
+    for (int jt = 0; jt < w.tail_n / 32; ++jt) ch_pack_rows(w.wt, CH_D, jt, true, stream + unit * u++);
+    memset(tab, 0, sizeof(float) * CH_TAB_FLOATS);
+    auto put = [&](int off, const float* src, int n) {
+        if (src) memcpy(tab + off, src, sizeof(float) * n);
+    };
+    put(CT_BO, w.bo, CH_D);
+    put(CT_LN1A, w.ln1_a, CH_D);
+    put(CT_LN1B, w.ln1_b, CH_D);
+    put(CT_B2, w.b2, CH_D);
+    put(CT_NLNA, w.nln_a, CH_D);
+    put(CT_NLNB, w.nln_b, CH_D);
+    put(CT_BT, w.bt, w.tail_n);
+    put(CT_B1, w.b1, w.dff);
+}

@@ -106,6 +106,31 @@ int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s);
 void pack_ffn_w1(const float* w1, int dff, uint16_t* out);  // [dff][256] fp32 -> fragment stream (dff*256 bf16)
 void pack_ffn_w2(const float* w2, int dff, uint16_t* out);  // [256][dff] fp32 -> fragment stream (dff*256 bf16)
 
+// ---- row-chain kernel, bf16 / d_model == 256: out-projection + residual, FFN sublayer + residual, next pre-norm and the
+// next attention's input projection for 128-row blocks, activations in registers, weights streamed once per block (chain.hip)
+constexpr int CHAIN_TAB_FLOATS = 5120;
+constexpr int CHAIN_UNIT_BYTES = 16384;
+struct ChainArgs {
+    float* x = nullptr;          // [M][256] fp32 residual stream, in place
+    const void* ctx = nullptr;   // [M][ldctx] bf16 attention context; null = no output projection
+    int ldctx = 0;
+    const void* wstream = nullptr;  // pack_chain units
+    const float* tab = nullptr;     // pack_chain table (CHAIN_TAB_FLOATS)
+    void* out = nullptr;            // [M][ldo] bf16: tail projection of LNn(x), or LNn(x) itself when tail_n == 0
+    int ldo = 0;
+    int M = 0, d = 0, dff = 0, tail_n = 0, has_next = 0;
+    float eps = 1e-6f;
+};
+int launch_chain(const ChainArgs& a, hipStream_t s);
+int chain_print_stamps();  // investigation aid (CASSNAT_CHAIN_STAMPS): phase times of workgroup 0 of the last launch
+struct ChainWeights {  // host fp32, nn.Linear layout [out][in]; null members = stage absent
+    const float *wo = nullptr, *bo = nullptr, *ln1_a = nullptr, *ln1_b = nullptr, *w1 = nullptr, *b1 = nullptr, *w2 = nullptr,
+                *b2 = nullptr, *nln_a = nullptr, *nln_b = nullptr, *wt = nullptr, *bt = nullptr;
+    int dff = 0, tail_n = 0;
+};
+size_t chain_stream_units(int has_outproj, int dff, int tail_n);
+void pack_chain(const ChainWeights& w, uint16_t* stream, float* tab);
+
 // ---- fused generator tail, bf16 / d_model == 256: per-row argmax and max log-probability of log_softmax(W h + b)   (genmax.hip)
 struct GenmaxArgs {
     const void* h = nullptr;   // [M][256] bf16

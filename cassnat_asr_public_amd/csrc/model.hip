@@ -47,6 +47,11 @@ struct Layer {
     Linear src_q, src_kv, src_o;  // source attention: Q from the stream, K|V from the encoder memory
     Linear w1, w2;
     void *w1p = nullptr, *w2p = nullptr;  // fused-FFN fragment streams (bf16, d_model == 256); then w1/w2 hold biases only
+    // row-chain stream (chain.hip): this layer's attention output projection + FFN + the NEXT sublayer's pre-norm and
+    // input projection (chain_tail_n columns; 0 = the norm itself is the output)
+    void* chain_w = nullptr;
+    float* chain_tab = nullptr;
+    int chain_tail_n = 0;
     bool has_self = false, has_src = false;
 };
 
@@ -281,6 +286,54 @@ struct Packer {
         L.w2.K = (int)dff;
         L.w2.b = vec({p + ".feed_forward.w_2.bias"}, d);
     }
+    // row-chain stream for `L`: out-projection `wo`, FFN under `p` with pre-norm `ln1`, then norm `nln` and the
+    // concatenated projections `tails` (each [d][d]) of whatever consumes the stream next
+    void chain(Layer& L, const std::string& wo, const std::string& ln1, const std::string& p, int64_t dff,
+               const std::string& nln, std::initializer_list<std::string> tails, int64_t d) {
+        if (!(m->prec == CN_PREC_BF16 && d == 256 && dff % 32 == 0 && dff <= 2048 && tails.size() <= 3)) return;
+        const int tail_n = (int)(tails.size() * d);
+        const size_t units = chain_stream_units(1, (int)dff, tail_n);
+        const size_t aw = reserve(units * CHAIN_UNIT_BYTES), at = reserve((size_t)CHAIN_TAB_FLOATS * 4);
+        if (fill) {
+            ChainWeights w;
+            auto get = [&](const std::string& n, std::initializer_list<int64_t> shape) -> const float* {
+                const HostTensor* t = find(n, shape);
+                return t ? t->data.data() : nullptr;
+            };
+            w.wo = get(wo + ".weight", {d, d});
+            w.bo = get(wo + ".bias", {d});
+            w.ln1_a = get(ln1 + ".a_2", {d});
+            w.ln1_b = get(ln1 + ".b_2", {d});
+            w.w1 = get(p + ".feed_forward.w_1.weight", {dff, d});
+            w.b1 = get(p + ".feed_forward.w_1.bias", {dff});
+            w.w2 = get(p + ".feed_forward.w_2.weight", {d, dff});
+            w.b2 = get(p + ".feed_forward.w_2.bias", {d});
+            w.nln_a = get(nln + ".a_2", {d});
+            w.nln_b = get(nln + ".b_2", {d});
+            std::vector<float> tw((size_t)tail_n * d), tb((size_t)tail_n);
+            size_t k = 0;
+            bool ok = w.wo && w.bo && w.ln1_a && w.ln1_b && w.w1 && w.b1 && w.w2 && w.b2 && w.nln_a && w.nln_b;
+            for (auto& tp : tails) {
+                const float* a = get(tp + ".weight", {d, d});
+                const float* b = get(tp + ".bias", {d});
+                if (a && b) {
+                    std::memcpy(&tw[k * d * d], a, (size_t)d * d * 4);
+                    std::memcpy(&tb[k * d], b, (size_t)d * 4);
+                } else {
+                    ok = false;
+                }
+                ++k;
+            }
+            w.wt = tw.data();
+            w.bt = tb.data();
+            w.dff = (int)dff;
+            w.tail_n = tail_n;
+            if (ok) pack_chain(w, reinterpret_cast<uint16_t*>(&host[aw]), reinterpret_cast<float*>(&host[at]));
+        }
+        L.chain_w = reinterpret_cast<void*>(aw);
+        L.chain_tab = reinterpret_cast<float*>(at);
+        L.chain_tail_n = tail_n;
+    }
     // generator: the plain matrix (beam search / capture) plus the fused-argmax fragment stream when it applies
     Linear generator(const std::string& prefix, int64_t V, int64_t d) {
         Linear l = linear({prefix}, V, d);
@@ -386,6 +439,14 @@ int build_weights(cn_model* m) {
     m->mad.clear();
     for (int n = 0; n < c.n_enc; ++n) m->enc.push_back(self_layer("encoder.layers." + std::to_string(n), "self_attn", c.d_encff, 2));
     m->enc_norm = pk.norm("encoder.norm", d);
+    for (int n = 0; n < c.n_enc; ++n) {
+        const std::string p = "encoder.layers." + std::to_string(n), q = "encoder.layers." + std::to_string(n + 1);
+        if (n + 1 < c.n_enc)
+            pk.chain(m->enc[n], p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff, q + ".sublayer.0.norm",
+                     {q + ".self_attn.linears.0", q + ".self_attn.linears.1", q + ".self_attn.linears.2"}, d);
+        else
+            pk.chain(m->enc[n], p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff, "encoder.norm", {}, d);
+    }
     for (int n = 0; n < c.n_extra; ++n) {
         const std::string p = "acembed_extractor.layers." + std::to_string(n);
         Layer L;
@@ -450,6 +511,8 @@ int build_weights(cn_model* m) {
             rebase_linear(L.w2, base);
             rebase(L.w1p, base);
             rebase(L.w2p, base);
+            rebase(L.chain_w, base);
+            rebase(L.chain_tab, base);
         }
     };
     rebase_layers(m->enc);
@@ -584,13 +647,10 @@ int run_ffn(cn_model* m, const Layer& L, const Norm& n, float* x, int M, const N
     return 0;
 }
 
-// x += O(Attn(LN(x) Wq, LN(x) Wk, LN(x) Wv))
-// `pre` == nullptr: m->xn already holds LN(x) (written by the preceding FFN)
-int run_self_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B, int Lseq, const unsigned char* keymask,
-                  const int* klen, int causal, hipStream_t s) {
+// ctx <- Attn(q, k, v) on the fused [M][3d] projection buffer m->qkv
+int run_self_attn_core(cn_model* m, int B, int Lseq, const unsigned char* keymask, const int* klen, int causal,
+                       hipStream_t s) {
     const int d = m->cfg.d_model, M = B * Lseq;
-    if (pre) CN_TRY(run_ln(m, *pre, x, m->xn, M, s));
-    CN_TRY(run_linear(m, "qkv_proj", L.qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
     AttnArgs a;
     const size_t es = m->es;
     a.Q = m->qkv;
@@ -606,13 +666,41 @@ int run_self_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B,
     a.klen = klen;
     a.causal = causal;
     a.scale = 1.0f / sqrtf((float)(d / m->cfg.n_head));
-    {
-        ProfScope ps(m, "self_attention", 4.0 * B * a.H * (double)Lseq * Lseq * 64,
-                     (double)M * 4 * d * m->es, s);
-        CN_TRY(launch_attention(m->prec, a, s));
-    }
+    ProfScope ps(m, "self_attention", 4.0 * B * a.H * (double)Lseq * Lseq * 64, (double)M * 4 * d * m->es, s);
+    return launch_attention(m->prec, a, s);
+}
+
+// x += O(Attn(LN(x) Wq, LN(x) Wk, LN(x) Wv))
+// `pre` == nullptr: m->xn already holds LN(x) (written by the preceding FFN)
+int run_self_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B, int Lseq, const unsigned char* keymask,
+                  const int* klen, int causal, hipStream_t s) {
+    const int d = m->cfg.d_model, M = B * Lseq;
+    if (pre) CN_TRY(run_ln(m, *pre, x, m->xn, M, s));
+    CN_TRY(run_linear(m, "qkv_proj", L.qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
+    CN_TRY(run_self_attn_core(m, B, Lseq, keymask, klen, causal, s));
     CN_TRY(run_linear(m, "out_proj_resid", L.self_o, m->ctx, d, x, d, 1, M, CN_EPI_RESID, x, d, s));
     return 0;
+}
+
+// row-chain launch: x += Wo ctx + bo; x += FFN(LN1 x); out <- tail projection of LNn(x) (or LNn(x) itself)
+int run_chain(cn_model* m, const Layer& L, float* x, int M, void* out, int ldo, hipStream_t s) {
+    const int d = m->cfg.d_model;
+    ProfScope ps(m, "row_chain", 2.0 * M * ((double)d * d + 2.0 * d * L.w1.N + (double)d * L.chain_tail_n),
+                 (double)M * d * (8 + 2) + (double)M * ldo * 2 + 2.0 * ((double)d * d + 2.0 * d * L.w1.N + (double)d * L.chain_tail_n), s);
+    ChainArgs a;
+    a.x = x;
+    a.ctx = m->ctx;
+    a.ldctx = d;
+    a.wstream = L.chain_w;
+    a.tab = L.chain_tab;
+    a.out = out;
+    a.ldo = ldo;
+    a.M = M;
+    a.d = d;
+    a.dff = L.w1.N;
+    a.tail_n = L.chain_tail_n;
+    a.has_next = 1;
+    return launch_chain(a, s);
 }
 
 // x += O(Attn(LN(x) Wq, mem Wk, mem Wv)) with the padding mask and (optionally) trigger intervals
@@ -776,11 +864,22 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         CN_TRY(launch_gemm(m->prec, g, s));
     }
     if (cap) CN_TRY(capture(m, "x_embed", m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
+    static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
+    const bool chain = !m->enc.empty() && m->enc[0].chain_w && !no_chain;
+    if (chain) {  // bf16 / d_model 256: LN + QKV of layer 0, then per layer attention -> row-chain kernel
+        CN_TRY(run_ln(m, m->enc[0].n[0], m->x, m->xn, M, s));
+        CN_TRY(run_linear(m, "qkv_proj", m->enc[0].qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
+    }
     for (size_t n = 0; n < m->enc.size(); ++n) {
         const Layer& L = m->enc[n];
         const bool last = n + 1 == m->enc.size();
-        CN_TRY(run_self_attn(m, L, n == 0 ? &L.n[0] : nullptr, m->x, B, Tp, m->keymask, nullptr, 0, s));
-        CN_TRY(run_ffn(m, L, L.n[1], m->x, M, last ? &m->enc_norm : &m->enc[n + 1].n[0], last ? m->enc_h : m->xn, s));
+        if (chain) {
+            CN_TRY(run_self_attn_core(m, B, Tp, m->keymask, nullptr, 0, s));
+            CN_TRY(run_chain(m, L, m->x, M, last ? m->enc_h : m->qkv, last ? d : 3 * d, s));
+        } else {
+            CN_TRY(run_self_attn(m, L, n == 0 ? &L.n[0] : nullptr, m->x, B, Tp, m->keymask, nullptr, 0, s));
+            CN_TRY(run_ffn(m, L, L.n[1], m->x, M, last ? &m->enc_norm : &m->enc[n + 1].n[0], last ? m->enc_h : m->xn, s));
+        }
         if (cap) CN_TRY(capture(m, ("enc_layer" + std::to_string(n)).c_str(), m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
     }
     if (m->enc.empty()) CN_TRY(run_ln(m, m->enc_norm, m->x, m->enc_h, M, s));
@@ -1282,6 +1381,67 @@ extern "C" int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float*
     (void)hipFree(d2);
     if (rc == 0 && e != hipSuccess) {
         cn_set_error(std::string("cn_op_ffn_fused: ") + hipGetErrorString(e));
+        rc = -2;
+    }
+    return rc;
+}
+
+extern "C" int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, const float* wo_host, const float* bo_host,
+                           const float* ln1_a_host, const float* ln1_b_host, const float* w1_host, const float* b1_host,
+                           const float* w2_host, const float* b2_host, const float* nln_a_host, const float* nln_b_host,
+                           const float* wt_host, const float* bt_host, void* out_dev, int32_t ldo, int32_t M, int32_t dff,
+                           int32_t tail_n, float eps, void* stream) {
+    if (dff < 0 || dff % 32 != 0 || dff > 2048 || tail_n < 0 || tail_n % 32 != 0 || tail_n > 768) {
+        cn_set_error("cn_op_chain: d_ff and the tail width must be multiples of 32 (<= 2048 / <= 768)");
+        return -1;
+    }
+    ChainWeights w;
+    w.wo = ctx_dev ? wo_host : nullptr;
+    w.bo = bo_host;
+    w.ln1_a = ln1_a_host;
+    w.ln1_b = ln1_b_host;
+    w.w1 = w1_host;
+    w.b1 = b1_host;
+    w.w2 = w2_host;
+    w.b2 = b2_host;
+    w.nln_a = nln_a_host;
+    w.nln_b = nln_b_host;
+    w.wt = wt_host;
+    w.bt = bt_host;
+    w.dff = dff;
+    w.tail_n = tail_n;
+    const size_t units = chain_stream_units(ctx_dev != nullptr, dff, tail_n);
+    std::vector<uint16_t> hs(units * (CHAIN_UNIT_BYTES / 2) + 8);
+    std::vector<float> ht(CHAIN_TAB_FLOATS);
+    pack_chain(w, hs.data(), ht.data());
+    void *ds = nullptr, *dt = nullptr;
+    CN_HIP_CHECK(hipMalloc(&ds, hs.size() * 2));
+    CN_HIP_CHECK(hipMalloc(&dt, ht.size() * 4));
+    CN_HIP_CHECK(hipMemcpy(ds, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
+    CN_HIP_CHECK(hipMemcpy(dt, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
+    ChainArgs a;
+    a.x = x_dev;
+    a.ctx = ctx_dev;
+    a.ldctx = ldctx;
+    a.wstream = ds;
+    a.tab = (const float*)dt;
+    a.out = out_dev;
+    a.ldo = ldo;
+    a.M = M;
+    a.d = 256;
+    a.dff = dff;
+    a.tail_n = tail_n;
+    a.has_next = nln_a_host != nullptr;
+    a.eps = eps;
+    int rc = launch_chain(a, (hipStream_t)stream);
+    if (const char* rep = getenv("CASSNAT_CHAIN_REPEAT"))  // timing runs only: x keeps being updated
+        for (int i = 1; i < atoi(rep) && rc == 0; ++i) rc = launch_chain(a, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (getenv("CASSNAT_CHAIN_STAMPS")) (void)chain_print_stamps();
+    (void)hipFree(ds);
+    (void)hipFree(dt);
+    if (rc == 0 && e != hipSuccess) {
+        cn_set_error(std::string("cn_op_chain: ") + hipGetErrorString(e));
         rc = -2;
     }
     return rc;

@@ -111,6 +111,18 @@ int cn_fetch(cn_model* m, const char* name, void* host_dst, int64_t max_bytes, i
 int cn_profile_begin(cn_model* m, const char* tags);
 int cn_profile_end(cn_model* m, char* json_out, int64_t cap);
 
+/* Row-chain kernel (bf16, d_model 256), one launch for the non-attention half of a layer on 128-row blocks:
+ * x += Wo.ctx + bo (skipped when ctx_dev is NULL); x += W2.relu(W1.LN1(x)+b1)+b2 (skipped when dff == 0);
+ * when nln_a_host != NULL: out = Wt.LNn(x)+bt (tail_n columns) or out = LNn(x) itself (tail_n == 0), bf16 [M][ldo].
+ * Replaces linears[3] + SublayerConnection + PositionwiseFeedForward + LayerNorm + linears[0..2]
+ * (src/models/modules/attention.py:44-66, utils.py:23-32, positionff.py:15-16, norm.py:15-18).  Weights are host fp32
+ * in nn.Linear layout and are packed on every call: a test entry point, the model keeps its packed copies. */
+int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, const float* wo_host, const float* bo_host,
+                const float* ln1_a_host, const float* ln1_b_host, const float* w1_host, const float* b1_host,
+                const float* w2_host, const float* b2_host, const float* nln_a_host, const float* nln_b_host,
+                const float* wt_host, const float* bt_host, void* out_dev, int32_t ldo, int32_t M, int32_t dff,
+                int32_t tail_n, float eps, void* stream);
+
 /* ---- single-kernel entry points (parity tests drive each hand-written kernel through the ABI) ---------- */
 /* all pointers device; `precision` selects the element type of activations/weights (fp32 or bf16) */
 int cn_op_gemm(int32_t precision, const void* A, int32_t lda, const void* W, const float* bias, void* C, int32_t ldc,

@@ -381,6 +381,59 @@ def test_ffn_fused_bf16(M, dff, with_next):
         assert relerr(xn_out, layer_norm(xd.cpu(), na, nb)) < 5e-3
 
 
+# ------------------------------------------------------------------------------------------------ row-chain kernel
+def _hp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize("M,dff,tail_n,with_ctx,with_next", [
+    (8000, 2048, 768, True, True),    # encoder layer at config 2: out-proj + FFN + next layer's QKV
+    (8000, 2048, 0, True, True),      # last encoder layer: the stack's final LayerNorm is the output
+    (300, 2048, 256, True, True),     # ragged M (3 workgroups, last one 44 rows), Q-only tail
+    (129, 256, 0, True, False),       # no next norm at all; short FFN (8 tiles)
+    (128, 0, 768, False, True),       # LayerNorm + QKV only (layer-0 entry)
+    (77, 2048, 768, False, True),     # FFN + tail without an output projection
+    (64, 64, 32, True, True),         # fewer units (13) than ring slots + 5
+])
+def test_chain_bf16(M, dff, tail_n, with_ctx, with_next):
+    from oracle.cassnat_oracle import layer_norm
+
+    g = torch.Generator().manual_seed(M + dff + tail_n)
+    d = 256
+    rn = lambda *s: torch.randn(*s, generator=g)
+    x = rn(M, d) * 2 + 0.3
+    ctx = rn(M, d)
+    wo, bo = (rn(d, d) / 16).contiguous(), 0.1 * rn(d)
+    a1, b1n = 1 + 0.1 * rn(d), 0.1 * rn(d)
+    w1, b1 = (rn(max(dff, 1), d) / 16).contiguous(), 0.1 * rn(max(dff, 1))
+    w2, b2 = (rn(d, max(dff, 1)) / math.sqrt(max(dff, 1))).contiguous(), 0.1 * rn(d)
+    na, nb = 1 + 0.1 * rn(d), 0.1 * rn(d)
+    wt, bt = (rn(max(tail_n, 1), d) / 16).contiguous(), 0.1 * rn(max(tail_n, 1))
+    # reference with the kernel's roundings: ctx, LN outputs, weights and hidden activations in bf16, fp32 accumulation
+    ref = x.clone()
+    if with_ctx:
+        ref = ref + F.linear(rounded(ctx, "bf16"), rounded(wo, "bf16"), bo)
+    if dff:
+        xn = rounded(layer_norm(ref, a1, b1n), "bf16")
+        h = rounded(F.relu(F.linear(xn, rounded(w1, "bf16"), b1)), "bf16")
+        ref = ref + F.linear(h, rounded(w2, "bf16"), b2)
+    xd = dev(x)
+    ctxd = dev(ctx, torch.bfloat16) if with_ctx else None
+    ldo = tail_n if tail_n else d
+    out = torch.full((M, ldo), float("nan"), dtype=torch.bfloat16, device="cuda") if with_next else None
+    hip.check(hip.lib().cn_op_chain(p(xd), p(ctxd) if with_ctx else None, d, _hp(wo), _hp(bo), _hp(a1), _hp(b1n), _hp(w1),
+                                    _hp(b1), _hp(w2), _hp(b2), _hp(na) if with_next else None, _hp(nb) if with_next else None,
+                                    _hp(wt), _hp(bt), p(out) if with_next else None, ldo, M, dff, tail_n, 1e-6, stream()))
+    torch.cuda.synchronize()
+    assert relerr(xd, ref) < 2e-3
+    if with_next:
+        y = layer_norm(xd.cpu(), na, nb)
+        if tail_n:
+            assert relerr(out, F.linear(rounded(y, "bf16"), rounded(wt, "bf16"), bt)) < 6e-3
+        else:
+            assert relerr(out, y) < 5e-3
+
+
 # ----------------------------------------------------------------------------------------------- fused generator tail
 @pytest.mark.parametrize("M,V", [(8000, 5000), (37, 5000), (2336, 1028), (32, 40), (100, 4234)])
 def test_generator_argmax_fused_bf16(M, V):
