@@ -165,79 +165,98 @@ __device__ __forceinline__ void ch_add_channel(f32x16 (&acc)[8], unsigned tab_la
 
 // ---- hand-scheduled half-unit blocks ------------------------------------------------------------------------
 // One wave per SIMD issues at most one instruction every ~4 cycles and a 32x32x16 MFMA occupies the matrix pipe for
-// 32: everything that is not an MFMA has to be issued in the gaps BETWEEN MFMAs or it runs with the pipe idle.  The
-// compiler clusters; these blocks fix the order by hand: each of the 8 MFMAs of a half-unit is followed by the
-// ds_read of one fragment of the NEXT half-unit, and (second half only) by a quarter of this wave's refill DMAs.
-//   PRE_A : nothing.   PRE_B : own quarter of unit u+1 has landed (counted vmcnt) -> barrier: unit u+1 is published, and
-//   every wave has consumed unit u-1 (its last fragments were waited for by the MFMAs of that unit's second block), so
-//   this block refills that slot with unit u+7 (M0 <- LDS destination of this wave's quarter): ~5-6 units in flight.
+// 32: everything that is not an MFMA has to be issued in the gaps BETWEEN MFMAs or it runs with the pipe idle (a
+// first version that left address arithmetic, waits and branches between compiler-scheduled MFMA clusters spent
+// 60 cycles per MFMA).  So:
+//   * the stream is consumed in GROUPS of 8 units = one trip round the ring: slot, LDS offsets, DMA destinations and
+//     source offsets of every block are compile-time constants, and the only per-group work is two base pointers;
+//   * a block = 8 MFMAs on the half-unit already in registers; the 8 ds_reads of the NEXT half-unit go two per gap
+//     behind MFMAs 0-3 (so their latency is covered by MFMAs 4-7), the wave's four refill DMAs behind MFMAs 4-7;
+//   * second-half blocks start with: own quarter of unit u+1 landed (counted vmcnt) -> s_barrier (publishes unit
+//     u+1; every wave has consumed unit u-1) -> M0 <- destination of this wave's quarter of unit u+7's slot.
+// The compiler pads its own MFMA -> vector-read sequences with wait states (s_nop 11 for this MFMA) but cannot see
+// into asm: a block whose accumulators the compiler may touch next ends with them itself (CH_DRAIN).
 #define CH_MF "v_mfma_f32_32x32x16_bf16 "
-// LDS reads return in order and every MFMA of a block is followed by one read of the next half-unit, so fragment i of
-// the current half-unit is ready exactly when at most 7 younger reads are outstanding: a constant counted wait per MFMA
-// (the read it waits for was issued a whole block earlier - no LDS latency is exposed at block boundaries)
-#define CH_W7 "s_waitcnt lgkmcnt(7)\n\t"
-// The compiler pads its own MFMA -> vector-read sequences with wait states (s_nop 11 for this MFMA) but cannot see into
-// asm: a block whose accumulators the compiler may touch next (copies of "+a" operands included) ends with them itself.
-#define CH_POST_DRAIN "s_nop 13\n\t"
-#define CH_POST_NONE ""
-#define CH_PRE_B_NODMA "s_barrier\n\t"
-// second-half block of a unit, by experiment variant
-#define CH_B1(CC, acc, BO, POST)                                                                               \
-    if constexpr (DBG == 0) { CH_BLK1(CC, acc, Fb, bop, BO, Fa, rn_, 0, CH_PRE_B, CH_D0, CH_D1, CH_D2, CH_D3, POST); } \
-    else if constexpr (DBG == 2) { CH_BLK1(CC, acc, Fb, bop, BO, Fa, rn_, 0, CH_PRE_B_NODMA, "", "", "", "", POST); } \
-    else { asm volatile(CH_PRE_B CH_D0 CH_D1 CH_D2 CH_D3 :: [m0v] "s"(m0v), [vo] "v"(voff), [sb] "s"(sbase) : "memory"); }
-#define CH_A1(CC, acc, BO, PRE, POST)                                                                          \
-    if constexpr (DBG != 3) { CH_BLK1(CC, acc, Fa, bop, BO, Fb, ra_, 8, PRE, "", "", "", "", POST); }
-#define CH_PRE_A ""
-#define CH_PRE_B "s_waitcnt vmcnt(20)\n\ts_barrier\n\ts_mov_b32 m0, %[m0v]\n\t"
-#define CH_D0 "global_load_lds_dwordx4 %[vo], %[sb]\n\t"
-#define CH_D1 "global_load_lds_dwordx4 %[vo], %[sb] offset:1024\n\t"
-#define CH_D2 "global_load_lds_dwordx4 %[vo], %[sb] offset:2048\n\t"
-#define CH_D3 "global_load_lds_dwordx4 %[vo], %[sb] offset:3072\n\t"
-#define CH_RD(n, K) "ds_read_b128 %[" #n "], %[ra] offset:" CH_STR((K) * 1024) "\n\t"
-// single accumulator (constraint CC: "v" or "a"), eight B operands B[BO..BO+7]
-#define CH_BLK1(CC, acc, Fc, B, BO, Fn, raddr, RK, PRE, D0, D1, D2, D3, POST)                                  \
+#define CH_DRAIN "s_nop 13\n\t"
+#define CH_NODRAIN ""
+#define CH_RD2(n0, n1, K) "ds_read_b128 %[" #n0 "], %[ra] offset:" CH_STR((K) * 1024) "\n\t"                   \
+                          "ds_read_b128 %[" #n1 "], %[ra] offset:" CH_STR(((K) + 1) * 1024) "\n\t"
+#define CH_PRE_A "s_waitcnt lgkmcnt(0)\n\t"
+#define CH_PRE_B(M0OFF) "s_waitcnt vmcnt(20)\n\ts_barrier\n\ts_add_u32 m0, %[m0w], " CH_STR(M0OFF) "\n\ts_waitcnt lgkmcnt(0)\n\t"
+#define CH_DMA0(SOFF) "v_add_u32 %[tv], " CH_STR(SOFF) ", %[vo]\n\tglobal_load_lds_dwordx4 %[tv], %[sb]\n\t"
+#define CH_DMA1 "global_load_lds_dwordx4 %[tv], %[sb] offset:1024\n\t"
+#define CH_DMA2 "global_load_lds_dwordx4 %[tv], %[sb] offset:2048\n\t"
+#define CH_DMA3 "global_load_lds_dwordx4 %[tv], %[sb] offset:3072\n\t"
+// single accumulator (CIO/CC: "+"/"=&" and "v"/"a"; C0 = "0" starts the accumulation, "%[c]" continues it), eight B
+// operands B[BO..BO+7]; reads the next 8 fragments from RA at RK KiB
+#define CH_BLK1(CIO, CC, C0, acc, Fc, B, BO, Fn, RA, RK, PRE, D0, D1, D2, D3, SB, POST)                        \
     asm volatile(PRE                                                                                           \
-                 CH_W7 CH_MF "%[c], %[f0], %[b0], %[c]\n\t" CH_RD(n0, (RK) + 0) D0                                   \
-                 CH_W7 CH_MF "%[c], %[f1], %[b1], %[c]\n\t" CH_RD(n1, (RK) + 1) D1                                   \
-                 CH_W7 CH_MF "%[c], %[f2], %[b2], %[c]\n\t" CH_RD(n2, (RK) + 2) D2                                   \
-                 CH_W7 CH_MF "%[c], %[f3], %[b3], %[c]\n\t" CH_RD(n3, (RK) + 3) D3                                   \
-                 CH_W7 CH_MF "%[c], %[f4], %[b4], %[c]\n\t" CH_RD(n4, (RK) + 4)                                      \
-                 CH_W7 CH_MF "%[c], %[f5], %[b5], %[c]\n\t" CH_RD(n5, (RK) + 5)                                      \
-                 CH_W7 CH_MF "%[c], %[f6], %[b6], %[c]\n\t" CH_RD(n6, (RK) + 6)                                      \
-                 CH_W7 CH_MF "%[c], %[f7], %[b7], %[c]\n\t" CH_RD(n7, (RK) + 7) POST                                 \
-                 : [c] "+" CC(acc), [n0] "=&v"(Fn[0]), [n1] "=&v"(Fn[1]), [n2] "=&v"(Fn[2]), [n3] "=&v"(Fn[3]), \
-                   [n4] "=&v"(Fn[4]), [n5] "=&v"(Fn[5]), [n6] "=&v"(Fn[6]), [n7] "=&v"(Fn[7])                  \
+                 CH_MF "%[c], %[f0], %[b0], " C0 "\n\t" CH_RD2(n0, n1, (RK) + 0)                               \
+                 CH_MF "%[c], %[f1], %[b1], %[c]\n\t" CH_RD2(n2, n3, (RK) + 2)                                 \
+                 CH_MF "%[c], %[f2], %[b2], %[c]\n\t" CH_RD2(n4, n5, (RK) + 4)                                 \
+                 CH_MF "%[c], %[f3], %[b3], %[c]\n\t" CH_RD2(n6, n7, (RK) + 6)                                 \
+                 CH_MF "%[c], %[f4], %[b4], %[c]\n\t" D0                                                       \
+                 CH_MF "%[c], %[f5], %[b5], %[c]\n\t" D1                                                       \
+                 CH_MF "%[c], %[f6], %[b6], %[c]\n\t" D2                                                       \
+                 CH_MF "%[c], %[f7], %[b7], %[c]\n\t" D3 POST                                                  \
+                 : [c] CIO CC(acc), [n0] "=&v"(Fn[0]), [n1] "=&v"(Fn[1]), [n2] "=&v"(Fn[2]), [n3] "=&v"(Fn[3]), \
+                   [n4] "=&v"(Fn[4]), [n5] "=&v"(Fn[5]), [n6] "=&v"(Fn[6]), [n7] "=&v"(Fn[7]), [tv] "=&v"(tv)  \
                  : [f0] "v"(Fc[0]), [f1] "v"(Fc[1]), [f2] "v"(Fc[2]), [f3] "v"(Fc[3]), [f4] "v"(Fc[4]),        \
                    [f5] "v"(Fc[5]), [f6] "v"(Fc[6]), [f7] "v"(Fc[7]), [b0] "v"(B[(BO) + 0]), [b1] "v"(B[(BO) + 1]), \
                    [b2] "v"(B[(BO) + 2]), [b3] "v"(B[(BO) + 3]), [b4] "v"(B[(BO) + 4]), [b5] "v"(B[(BO) + 5]), \
-                   [b6] "v"(B[(BO) + 6]), [b7] "v"(B[(BO) + 7]), [ra] "v"(raddr), [m0v] "s"(m0v), [vo] "v"(voff), \
-                   [sb] "s"(sbase)                                                                             \
-                 : "memory")
-// eight accumulators acc[0..7] (AGPRs), one B operand
-#define CH_BLK2(acc, Fc, pbv, Fn, raddr, RK, PRE, D0, D1, D2, D3, LAST)                                        \
+                   [b6] "v"(B[(BO) + 6]), [b7] "v"(B[(BO) + 7]), [ra] "v"(RA), [m0w] "s"(m0_wave), [vo] "v"(voff), \
+                   [sb] "s"(SB)                                                                                \
+                 : "memory", "scc")
+// single accumulator acc[K] of eight AGPR accumulators that all stay tied in place (no copies around the block)
+#define CH_BLK1A(K, acc, Fc, B, BO, Fn, RA, RK, PRE, D0, D1, D2, D3, SB, POST)                                 \
     asm volatile(PRE                                                                                           \
-                 CH_W7 CH_MF "%[c0], %[f0], %[pb], %[c0]\n\t" CH_RD(n0, (RK) + 0) D0                                 \
-                 CH_W7 CH_MF "%[c1], %[f1], %[pb], %[c1]\n\t" CH_RD(n1, (RK) + 1) D1                                 \
-                 CH_W7 CH_MF "%[c2], %[f2], %[pb], %[c2]\n\t" CH_RD(n2, (RK) + 2) D2                                 \
-                 CH_W7 CH_MF "%[c3], %[f3], %[pb], %[c3]\n\t" CH_RD(n3, (RK) + 3) D3                                 \
-                 CH_W7 CH_MF "%[c4], %[f4], %[pb], %[c4]\n\t" CH_RD(n4, (RK) + 4)                                    \
-                 CH_W7 CH_MF "%[c5], %[f5], %[pb], %[c5]\n\t" CH_RD(n5, (RK) + 5)                                    \
-                 CH_W7 CH_MF "%[c6], %[f6], %[pb], %[c6]\n\t" CH_RD(n6, (RK) + 6)                                    \
-                 CH_W7 CH_MF "%[c7], %[f7], %[pb], %[c7]\n\t" CH_RD(n7, (RK) + 7)                                    \
-                 "s_cmp_eq_u32 %[last], 0\n\ts_cbranch_scc1 .Lch_nodrain%=\n\t" CH_POST_DRAIN ".Lch_nodrain%=:\n\t"   \
+                 CH_MF "%[c" #K "], %[f0], %[b0], %[c" #K "]\n\t" CH_RD2(n0, n1, (RK) + 0)                       \
+                 CH_MF "%[c" #K "], %[f1], %[b1], %[c" #K "]\n\t" CH_RD2(n2, n3, (RK) + 2)                       \
+                 CH_MF "%[c" #K "], %[f2], %[b2], %[c" #K "]\n\t" CH_RD2(n4, n5, (RK) + 4)                       \
+                 CH_MF "%[c" #K "], %[f3], %[b3], %[c" #K "]\n\t" CH_RD2(n6, n7, (RK) + 6)                       \
+                 CH_MF "%[c" #K "], %[f4], %[b4], %[c" #K "]\n\t" D0                                           \
+                 CH_MF "%[c" #K "], %[f5], %[b5], %[c" #K "]\n\t" D1                                           \
+                 CH_MF "%[c" #K "], %[f6], %[b6], %[c" #K "]\n\t" D2                                           \
+                 CH_MF "%[c" #K "], %[f7], %[b7], %[c" #K "]\n\t" D3 POST                                      \
                  : [c0] "+a"(acc[0]), [c1] "+a"(acc[1]), [c2] "+a"(acc[2]), [c3] "+a"(acc[3]), [c4] "+a"(acc[4]), \
                    [c5] "+a"(acc[5]), [c6] "+a"(acc[6]), [c7] "+a"(acc[7]), [n0] "=&v"(Fn[0]), [n1] "=&v"(Fn[1]), \
                    [n2] "=&v"(Fn[2]), [n3] "=&v"(Fn[3]), [n4] "=&v"(Fn[4]), [n5] "=&v"(Fn[5]), [n6] "=&v"(Fn[6]), \
-                   [n7] "=&v"(Fn[7])                                                                           \
+                   [n7] "=&v"(Fn[7]), [tv] "=&v"(tv)                                                           \
                  : [f0] "v"(Fc[0]), [f1] "v"(Fc[1]), [f2] "v"(Fc[2]), [f3] "v"(Fc[3]), [f4] "v"(Fc[4]),        \
-                   [f5] "v"(Fc[5]), [f6] "v"(Fc[6]), [f7] "v"(Fc[7]), [pb] "v"(pbv), [ra] "v"(raddr),          \
-                   [m0v] "s"(m0v), [vo] "v"(voff), [sb] "s"(sbase), [last] "s"(LAST)                           \
+                   [f5] "v"(Fc[5]), [f6] "v"(Fc[6]), [f7] "v"(Fc[7]), [b0] "v"(B[(BO) + 0]), [b1] "v"(B[(BO) + 1]), \
+                   [b2] "v"(B[(BO) + 2]), [b3] "v"(B[(BO) + 3]), [b4] "v"(B[(BO) + 4]), [b5] "v"(B[(BO) + 5]), \
+                   [b6] "v"(B[(BO) + 6]), [b7] "v"(B[(BO) + 7]), [ra] "v"(RA), [m0w] "s"(m0_wave), [vo] "v"(voff), \
+                   [sb] "s"(SB)                                                                                \
                  : "memory", "scc")
+// eight accumulators acc[0..7] (AGPRs), one B operand
+#define CH_BLK2(acc, Fc, pbv, Fn, RA, RK, PRE, D0, D1, D2, D3, SB, POST)                                       \
+    asm volatile(PRE                                                                                           \
+                 CH_MF "%[c0], %[f0], %[pb], %[c0]\n\t" CH_RD2(n0, n1, (RK) + 0)                               \
+                 CH_MF "%[c1], %[f1], %[pb], %[c1]\n\t" CH_RD2(n2, n3, (RK) + 2)                               \
+                 CH_MF "%[c2], %[f2], %[pb], %[c2]\n\t" CH_RD2(n4, n5, (RK) + 4)                               \
+                 CH_MF "%[c3], %[f3], %[pb], %[c3]\n\t" CH_RD2(n6, n7, (RK) + 6)                               \
+                 CH_MF "%[c4], %[f4], %[pb], %[c4]\n\t" D0                                                     \
+                 CH_MF "%[c5], %[f5], %[pb], %[c5]\n\t" D1                                                     \
+                 CH_MF "%[c6], %[f6], %[pb], %[c6]\n\t" D2                                                     \
+                 CH_MF "%[c7], %[f7], %[pb], %[c7]\n\t" D3 POST                                                \
+                 : [c0] "+a"(acc[0]), [c1] "+a"(acc[1]), [c2] "+a"(acc[2]), [c3] "+a"(acc[3]), [c4] "+a"(acc[4]), \
+                   [c5] "+a"(acc[5]), [c6] "+a"(acc[6]), [c7] "+a"(acc[7]), [n0] "=&v"(Fn[0]), [n1] "=&v"(Fn[1]), \
+                   [n2] "=&v"(Fn[2]), [n3] "=&v"(Fn[3]), [n4] "=&v"(Fn[4]), [n5] "=&v"(Fn[5]), [n6] "=&v"(Fn[6]), \
+                   [n7] "=&v"(Fn[7]), [tv] "=&v"(tv)                                                           \
+                 : [f0] "v"(Fc[0]), [f1] "v"(Fc[1]), [f2] "v"(Fc[2]), [f3] "v"(Fc[3]), [f4] "v"(Fc[4]),        \
+                   [f5] "v"(Fc[5]), [f6] "v"(Fc[6]), [f7] "v"(Fc[7]), [pb] "v"(pbv), [ra] "v"(RA),             \
+                   [m0w] "s"(m0_wave), [vo] "v"(voff), [sb] "s"(SB)                                            \
+                 : "memory", "scc")
+// Position k of a group: its second half lives in slot k (first-half blocks read it), the first half of the next unit
+// in slot k+1; while unit k is consumed, unit k+7 of the stream is requested into slot k-1 - i.e. unit 7 of THIS group
+// for k = 0 and unit k-1 of the NEXT group otherwise.  Slots 0-3 are addressed from ra0, 4-7 from ra1 = ra0 + 64 KiB.
+//   X(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB)
+#define CH_POSITIONS(X)                                                                                        \
+    X(0, ra0, 8, ra0, 16, 0x1C000, 0x1C000, sb_cur)  X(1, ra0, 24, ra0, 32, 0x0, 0x0, sb_next)                 \
+    X(2, ra0, 40, ra0, 48, 0x4000, 0x4000, sb_next)  X(3, ra0, 56, ra1, 0, 0x8000, 0x8000, sb_next)            \
+    X(4, ra1, 8, ra1, 16, 0xC000, 0xC000, sb_next)   X(5, ra1, 24, ra1, 32, 0x10000, 0x10000, sb_next)         \
+    X(6, ra1, 40, ra1, 48, 0x14000, 0x14000, sb_next) X(7, ra1, 56, ra0, 0, 0x18000, 0x18000, sb_next)
 
-// DBG (timing experiments only, results are wrong): 2 = no refill DMAs and no vmcnt waits (compute side alone),
-// 3 = refill DMAs, waits and barriers only (stream side alone)
-template <int DBG>
 __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -246,28 +265,23 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     const int m = blockIdx.x * 128 + 32 * wave + l31;
     const int mc = m < p.M ? m : p.M - 1;
     const bool live = m < p.M;
-
 #define CH_STAMP(i)                                                                              \
     if (p.stamps && blockIdx.x == 0 && tid == 0) ch_stamps[i] = (long long)__builtin_amdgcn_s_memtime();
     CH_STAMP(0)
-    const int U_OUT = p.ctx ? 8 : 0;
-    const int U_FFN = 2 * p.ffn_tiles;
-    const int NU = U_OUT + U_FFN + p.tail_tiles;
-    // every workgroup walks the FFN tiles in its own rotation (the sum over tiles is order-free): the workgroups of a
-    // launch then do not pull the same L2 lines at the same moment
-    const int rot = p.ffn_tiles ? (int)((blockIdx.x * 5u) % (unsigned)p.ffn_tiles) : 0;
+    // groups of 8 units in consumption order: [output projection] [FFN: ffn_tiles / 4 groups, walked in a rotation of
+    // its own by every workgroup - the sum over tiles is order-free, and the workgroups of a launch then do not pull the
+    // same L2 lines at the same moment] [tail projection: tail_tiles / 8 groups]
+    const int G_OUT = p.ctx ? 1 : 0, G_FFN = p.ffn_tiles >> 2, G_TAIL = p.tail_tiles >> 3;
+    const int NG = G_OUT + G_FFN + G_TAIL;
+    const int rotg = G_FFN ? (int)((blockIdx.x * 5u) % (unsigned)G_FFN) : 0;
     unsigned char* ring = smem + CH_TAB_BYTES;
-
-#define CH_FFN_TILE(t) (((t) + rot) >= p.ffn_tiles ? (t) + rot - p.ffn_tiles : (t) + rot)
-    // stream unit consumed at position u (positions past the end re-read the last unit: dummy refills keep the DMA
-    // queue depth - and with it every vmcnt in the loop - constant; their slots are never read)
-    auto src_unit = [&](int u) -> int {
-        if (u > NU - 1) u = NU - 1;
-        if (u >= U_OUT && u < U_OUT + U_FFN) {
-            const int k = u - U_OUT;
-            u = U_OUT + 2 * CH_FFN_TILE(k >> 1) + (k & 1);
-        }
-        return u;
+    // stream group consumed at position g (past the end: the last group again - dummy refills keep the DMA queue depth,
+    // and with it every vmcnt of the loop, constant; their slots are never read)
+    auto ffn_group = [&](int g) -> int { return g + rotg >= G_FFN ? g + rotg - G_FFN : g + rotg; };
+    auto group_base = [&](int g) -> const uint4* {
+        if (g > NG - 1) g = NG - 1;
+        if (g >= G_OUT && g < G_OUT + G_FFN) g = G_OUT + ffn_group(g - G_OUT);
+        return p.wstream + (long long)g * 8 * 1024;
     };
 
     // ---- prologue: the wave's 32 rows of x (accumulator layout) and ctx (B operands), issued from asm so that the
@@ -278,12 +292,12 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
         const float* xp = p.x + (long long)mc * CH_D + 4 * half;
 #pragma unroll
         for (int i = 0; i < 32; ++i)  // i = 4 nt + g : channels 32 nt + 8 g + 4 half + (0..3)
-            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&a"(xr[i]) : "v"(xp + 8 * i) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&a"(xr[i]) : "v"(xp + 8 * i) : "memory");
         if (p.ctx) {
             const bf16* cp = p.ctx + (long long)mc * p.ldctx + 8 * half;
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks)
-                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(bop[ks]) : "v"(cp + 16 * ks) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bop[ks]) : "v"(cp + 16 * ks) : "memory");
         }
     }
     {
@@ -291,9 +305,10 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) CH_DMA(ts + j * 64, smem + (5 * wave + j) * 1024);
     }
-    if (NU > 0) {
-        for (int u = 0; u < CH_RING - 1; ++u) {  // units 0..6; unit u+7 is requested while unit u is consumed
-            const uint4* src = p.wstream + ((long long)src_unit(u) * 16 + 4 * wave) * 64 + lane;
+    if (NG > 0) {
+        const uint4* g0 = group_base(0);
+        for (int u = 0; u < CH_RING - 1; ++u) {  // units 0..6 of the first group; unit 7 is requested by position 0
+            const uint4* src = g0 + ((long long)u * 16 + 4 * wave) * 64 + lane;
             unsigned char* dst = ring + u * CH_UNIT_BYTES + 4 * wave * 1024;
 #pragma unroll
             for (int j = 0; j < 4; ++j) CH_DMA(src + j * 64, dst + j * 1024);
@@ -319,84 +334,90 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[nt][4 * g + e] = xr[4 * nt + g][e];
+    CH_STAMP(1)
 
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
-    const unsigned ring_a = ring_lds + lane * 16;
+    const unsigned ra0 = ring_lds + lane * 16, ra1 = ra0 + 4 * CH_UNIT_BYTES;
     const unsigned tab_lane = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(smem + 16 * half);
     const unsigned voff = (unsigned)(lane * 16 + wave * 4096);  // this lane's byte offset inside a unit (piece 4 wave + j: + 1024 j)
     const unsigned m0_wave = __builtin_amdgcn_readfirstlane(ring_lds + wave * 4096);
+    unsigned tv;  // scratch VGPR of the blocks (source offset of a refill)
 
-    CH_STAMP(1)
     bf16x8 Fa[8], Fb[8];
     // unit 0 (and the table): own quarter landed -> barrier -> first half into Fa
-    if (NU > 0) {
+    if (NG > 0) {
         asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
-        CH_READ8(Fa, ring_a, 0);
+        CH_READ8(Fa, ra0, 0);
     } else {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
-
-    // per-unit scalars of the second-half block of unit u: where the first half of unit u+1 is read from, and the
-    // refill of unit u+7 into the slot unit u-1 occupied
-#define CH_UNIT_SCALARS(u)                                                                                    \
-    const unsigned ra_ = ring_a + (unsigned)(((u) & 7) * CH_UNIT_BYTES);                                      \
-    const unsigned rn_ = ring_a + (unsigned)((((u) + 1) & 7) * CH_UNIT_BYTES);                                \
-    const unsigned m0v = m0_wave + (unsigned)((((u) + 7) & 7) * CH_UNIT_BYTES);                               \
-    const uint4* sbase = p.wstream + (long long)src_unit((u) + 7) * 1024;
-
     CH_STAMP(2)
+    int gpos = 0;  // group position in consumption order
+
     // ---- S1: output projection (natural k order; B operands = ctx), accumulating on top of the residual
     if (p.ctx) {
-#define CH_S1(nt)                                                                                             \
-        {                                                                                                     \
-            CH_UNIT_SCALARS(nt)                                                                               \
-            CH_A1("a", acc[nt], 0, "s_nop 1\n\t", CH_POST_DRAIN)                                            \
-            CH_B1("a", acc[nt], 8, CH_POST_DRAIN)                                                             \
-        }
-        CH_S1(0) CH_S1(1) CH_S1(2) CH_S1(3) CH_S1(4) CH_S1(5) CH_S1(6) CH_S1(7)
+        const uint4* sb_cur = group_base(gpos);
+        const uint4* sb_next = group_base(gpos + 1);
+#define CH_S1(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB)                                                     \
+        CH_BLK1A(k, acc, Fa, bop, 0, Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN);                \
+        CH_BLK1A(k, acc, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, CH_DMA3, SB, CH_NODRAIN);
+        asm volatile("s_nop 1" ::: "memory");  // the compiler's copies into the accumulators -> first MFMA
+        CH_POSITIONS(CH_S1)
 #undef CH_S1
+        asm volatile(CH_DRAIN : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]),
+                     "+a"(acc[6]), "+a"(acc[7]));
+        ++gpos;
         ch_add_channel(acc, tab_lane, CT_BO);
     }
-
     CH_STAMP(3)
-    // ---- S3: feed-forward sublayer
+
+    // ---- S3: feed-forward sublayer, four hidden tiles (W1 unit, W2 unit each) per group
     if (p.ffn_tiles) {
         ch_layernorm_pack(acc, tab_lane, CT_LN1A, CT_LN1B, p.eps, bop);
         ch_add_channel(acc, tab_lane, CT_B2);  // b2 once; the W2 products accumulate on top of x + b2
         CH_STAMP(4)
-        for (int t = 0; t < p.ffn_tiles; ++t) {
-            const int u0 = U_OUT + 2 * t;
+        for (int g = 0; g < G_FFN; ++g, ++gpos) {
+            const uint4* sb_cur = group_base(gpos);
+            const uint4* sb_next = group_base(gpos + 1);
+            const unsigned tb = tab_lane + (unsigned)((CT_B1 + 128 * ffn_group(g)) * 4);  // b1 of the group's 128 hidden units
             f32x16 xh;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xh[r] = 0.f;
-            f32x4 b1v[4];  // b1 of the tile's hidden units: read now, older than every fragment read below, used at the ReLU
-            ch_tab4_nowait(tab_lane + (CT_B1 + 32 * CH_FFN_TILE(t)) * 4, b1v[0], b1v[1], b1v[2], b1v[3]);
-            {
-                CH_UNIT_SCALARS(u0)
-                CH_A1("v", xh, 0, CH_PRE_A, CH_POST_NONE)
-                CH_B1("v", xh, 8, CH_POST_DRAIN)
-            }
-            asm volatile("" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]));  // landed: the blocks above waited past them
+            f32x4 b1v[4];
             bf16x8 pb[2];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {  // ReLU as a signed-integer max on the bits: one instruction, no canonicalising pre-max
-                const float v = xh[r] + b1v[r >> 2][r & 3];
-                const int bits = __float_as_int(v);
-                pb[r >> 3][r & 7] = (bf16)__int_as_float(bits > 0 ? bits : 0);
+            ch_tab4_nowait(tb, b1v[0], b1v[1], b1v[2], b1v[3]);
+            // W1 unit at position K0: xh = W1 tile . xn ; then bias + ReLU + pack (next tile's bias read goes out first:
+            // it is older than every fragment read that follows, so the waits of the next blocks cover it)
+#define CH_W1(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB)                                                     \
+            CH_BLK1("=&", "v", "0", xh, Fa, bop, 0, Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN);  \
+            CH_BLK1("+", "v", "%[c]", xh, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, \
+                    CH_DMA3, SB, CH_DRAIN);                                                                    \
+            {                                                                                                 \
+                asm volatile("" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]));                     \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
+                    const float v = xh[r] + b1v[r >> 2][r & 3];                                               \
+                    const int bits = __float_as_int(v);                                                       \
+                    pb[r >> 3][r & 7] = (bf16)__int_as_float(bits > 0 ? bits : 0);                            \
+                }                                                                                             \
+                ch_tab4_nowait(tb + ((k) / 2 + 1 < 4 ? ((k) / 2 + 1) * 128 : 0), b1v[0], b1v[1], b1v[2], b1v[3]); \
             }
-            {
-                CH_UNIT_SCALARS(u0 + 1)
-                const int not_last = __builtin_amdgcn_readfirstlane(0);
-                const int is_last = __builtin_amdgcn_readfirstlane((int)(t + 1 == p.ffn_tiles));
-                if constexpr (DBG != 3) { CH_BLK2(acc, Fa, pb[0], Fb, ra_, 8, CH_PRE_A, "", "", "", "", not_last); }
-                if constexpr (DBG == 0) { CH_BLK2(acc, Fb, pb[1], Fa, rn_, 0, CH_PRE_B, CH_D0, CH_D1, CH_D2, CH_D3, is_last); }
-                else if constexpr (DBG == 2) { CH_BLK2(acc, Fb, pb[1], Fa, rn_, 0, CH_PRE_B_NODMA, "", "", "", "", is_last); }
-                else { asm volatile(CH_PRE_B CH_D0 CH_D1 CH_D2 CH_D3 :: [m0v] "s"(m0v), [vo] "v"(voff), [sb] "s"(sbase) : "memory"); }
-            }
+            // W2 unit at position K1: acc[nt] += W2 tile (s, nt) . relu(xh)
+#define CH_W2(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB, POST)                                               \
+            CH_BLK2(acc, Fa, pb[0], Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN);                  \
+            CH_BLK2(acc, Fb, pb[1], Fa, RA_B, RK_B, CH_PRE_B(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, CH_DMA3, SB, POST);
+            CH_W1(0, ra0, 8, ra0, 16, 0x1C000, 0x1C000, sb_cur)
+            CH_W2(1, ra0, 24, ra0, 32, 0x0, 0x0, sb_next, CH_NODRAIN)
+            CH_W1(2, ra0, 40, ra0, 48, 0x4000, 0x4000, sb_next)
+            CH_W2(3, ra0, 56, ra1, 0, 0x8000, 0x8000, sb_next, CH_NODRAIN)
+            CH_W1(4, ra1, 8, ra1, 16, 0xC000, 0xC000, sb_next)
+            CH_W2(5, ra1, 24, ra1, 32, 0x10000, 0x10000, sb_next, CH_NODRAIN)
+            CH_W1(6, ra1, 40, ra1, 48, 0x14000, 0x14000, sb_next)
+            CH_W2(7, ra1, 56, ra0, 0, 0x18000, 0x18000, sb_next, CH_DRAIN)
+#undef CH_W1
+#undef CH_W2
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]) :: "memory");  // the wrap-around bias read (unused)
         }
     }
-
     CH_STAMP(5)
+
     // ---- S4: the residual stream goes back to memory (row m: 16-byte pieces at channels 32 nt + 8 g + 4 half)
     if (live && (p.ctx || p.ffn_tiles)) {
         float* xp = p.x + (long long)m * CH_D + 4 * half;
@@ -429,49 +450,39 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
                     }
             }
         }
-        // ---- S5: tail projection (acc-order k; B operands = LNn(x)), written row-major bf16
-        for (int jt = 0; jt < p.tail_tiles; ++jt) {
-            const int u0 = U_OUT + U_FFN + jt;
+        // ---- S5: tail projection (acc-order k; B operands = LNn(x)), eight 32-column tiles per group, row-major bf16
+        for (int g = 0; g < G_TAIL; ++g, ++gpos) {
+            const uint4* sb_cur = group_base(gpos);
+            const uint4* sb_next = group_base(gpos + 1);
+            const unsigned tb = tab_lane + (unsigned)((CT_BT + 256 * g) * 4);
+            bf16* op = p.out + (long long)m * p.ldo + 256 * g + 4 * half;
             f32x16 q;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) q[r] = 0.f;
             f32x4 btv[4];
-            ch_tab4_nowait(tab_lane + (CT_BT + 32 * jt) * 4, btv[0], btv[1], btv[2], btv[3]);
-            {
-                CH_UNIT_SCALARS(u0)
-                CH_A1("v", q, 0, CH_PRE_A, CH_POST_NONE)
-                CH_B1("v", q, 8, CH_POST_DRAIN)
+            ch_tab4_nowait(tb, btv[0], btv[1], btv[2], btv[3]);
+#define CH_S5(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB)                                                     \
+            CH_BLK1("=&", "v", "0", q, Fa, bop, 0, Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN);   \
+            CH_BLK1("+", "v", "%[c]", q, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, \
+                    CH_DMA3, SB, CH_DRAIN);                                                                    \
+            {                                                                                                 \
+                asm volatile("" : "+v"(btv[0]), "+v"(btv[1]), "+v"(btv[2]), "+v"(btv[3]));                     \
+                bf16x4 o_[4];                                                                                 \
+                _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                              \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) o_[g_][e] = (bf16)(q[4 * g_ + e] + btv[g_][e]); \
+                ch_tab4_nowait(tb + ((k) + 1 < 8 ? ((k) + 1) * 128 : 0), btv[0], btv[1], btv[2], btv[3]);      \
+                if (live) {                                                                                   \
+                    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                          \
+                        __builtin_nontemporal_store(o_[g_], reinterpret_cast<bf16x4*>(op + 32 * (k) + 8 * g_)); \
+                }                                                                                             \
             }
-            asm volatile("" : "+v"(btv[0]), "+v"(btv[1]), "+v"(btv[2]), "+v"(btv[3]));
-            if (live) {
-                bf16* op = p.out + (long long)m * p.ldo + 32 * jt + 4 * half;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(q[4 * g + e] + btv[g][e]);
-                    __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(op + 8 * g));
-                }
-            }
+            CH_POSITIONS(CH_S5)
+#undef CH_S5
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(btv[0]), "+v"(btv[1]), "+v"(btv[2]), "+v"(btv[3]) :: "memory");
         }
     }
     CH_STAMP(8)
     // the dummy refills of the last units may still be writing this workgroup's LDS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     CH_STAMP(9)
-#undef CH_UNIT_SCALARS
-#undef CH_FFN_TILE
-}
-
-template <int DBG> static int launch_chain_variant(const ChainParams& p, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        CN_HIP_CHECK(hipFuncSetAttribute((const void*)chain_kernel<DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(chain_kernel<DBG>, dim3(cn_ceil_div(p.M, 128)), dim3(256), CH_LDS, s, p);
-    CN_HIP_CHECK(hipGetLastError());
-    return 0;
 }
 
 int chain_print_stamps() {
@@ -485,9 +496,9 @@ int chain_print_stamps() {
 }
 
 int launch_chain(const ChainArgs& a, hipStream_t s) {
-    if (a.d != CH_D || a.dff < 0 || a.dff % 32 != 0 || a.dff / 32 > CH_MAX_FFN_TILES || a.tail_n < 0 || a.tail_n % 32 != 0 ||
+    if (a.d != CH_D || a.dff < 0 || a.dff % 128 != 0 || a.dff / 32 > CH_MAX_FFN_TILES || a.tail_n < 0 || a.tail_n % 256 != 0 ||
         a.tail_n / 32 > CH_MAX_TAIL || (a.tail_n > 0 && !a.has_next) || (a.has_next && !a.out)) {
-        cn_set_error("chain: needs d_model == 256, d_ff % 32 == 0 <= 2048, tail width % 32 == 0 <= 768");
+        cn_set_error("chain: needs d_model == 256, d_ff % 128 == 0 <= 2048, tail width % 256 == 0 <= 768");
         return -1;
     }
     if (a.M <= 0) return 0;
@@ -507,11 +518,14 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
     static int stamps = -1;
     if (stamps < 0) stamps = getenv("CASSNAT_CHAIN_STAMPS") != nullptr;
     p.stamps = stamps;
-    static int dbg = -1;
-    if (dbg < 0) dbg = getenv("CASSNAT_CHAIN_DEBUG") ? atoi(getenv("CASSNAT_CHAIN_DEBUG")) : 0;
-    if (dbg == 2) return launch_chain_variant<2>(p, s);
-    if (dbg == 3) return launch_chain_variant<3>(p, s);
-    return launch_chain_variant<0>(p, s);
+    static bool attr_done = false;
+    if (!attr_done) {
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(chain_kernel, dim3(cn_ceil_div(p.M, 128)), dim3(256), CH_LDS, s, p);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 // ---- host-side packing --------------------------------------------------------------------------------------

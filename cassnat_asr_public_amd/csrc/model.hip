@@ -47,12 +47,24 @@ struct Layer {
     Linear src_q, src_kv, src_o;  // source attention: Q from the stream, K|V from the encoder memory
     Linear w1, w2;
     void *w1p = nullptr, *w2p = nullptr;  // fused-FFN fragment streams (bf16, d_model == 256); then w1/w2 hold biases only
-    // row-chain stream (chain.hip): this layer's attention output projection + FFN + the NEXT sublayer's pre-norm and
-    // input projection (chain_tail_n columns; 0 = the norm itself is the output)
-    void* chain_w = nullptr;
-    float* chain_tab = nullptr;
-    int chain_tail_n = 0;
     bool has_self = false, has_src = false;
+};
+
+// One packed stream of the row-chain kernel (chain.hip): [attention output projection] + [FFN] + [the NEXT sublayer's
+// pre-norm and input projection: tail_n columns, 0 = the norm itself is the output]
+struct ChainRef {
+    void* w = nullptr;
+    float* tab = nullptr;
+    int dff = 0, tail_n = 0;
+    bool has_wo = false, has_next = false;
+};
+// decoder-side sublayers in execution order (extractor: src; SAD: self; MAD: self, src), each followed by its chain
+struct DecStep {
+    int stack = 0;       // 0 extractor, 1 SAD, 2 MAD
+    int layer = 0;
+    bool self = false;   // self attention (else source attention)
+    ChainRef chain;      // after this sublayer's attention
+    ChainRef entry;      // pre-norm + input projection alone (first step; first MAD step when use_unimask shifts the stream)
 };
 
 struct ProfPending {
@@ -100,6 +112,8 @@ struct cn_model {
     Linear conv2;       // [C][9C] (kh,kw,cin)
     Linear linear_out;  // [d][F2*C] (f,c)
     std::vector<Layer> enc, extra, sad, mad;
+    std::vector<ChainRef> enc_chain;  // one per encoder layer when the row-chain path applies, else empty
+    std::vector<DecStep> dec_steps;   // decoder-side sublayers with their chains when the path applies, else empty
     Norm enc_norm, dec_norm;
     Linear ctc_gen, att_gen;
     float* pe = nullptr;  // [pe_rows][d]
@@ -286,41 +300,50 @@ struct Packer {
         L.w2.K = (int)dff;
         L.w2.b = vec({p + ".feed_forward.w_2.bias"}, d);
     }
-    // row-chain stream for `L`: out-projection `wo`, FFN under `p` with pre-norm `ln1`, then norm `nln` and the
-    // concatenated projections `tails` (each [d][d]) of whatever consumes the stream next
-    void chain(Layer& L, const std::string& wo, const std::string& ln1, const std::string& p, int64_t dff,
-               const std::string& nln, std::initializer_list<std::string> tails, int64_t d) {
-        if (!(m->prec == CN_PREC_BF16 && d == 256 && dff % 32 == 0 && dff <= 2048 && tails.size() <= 3)) return;
+    bool chain_ok(int64_t d, int64_t dff) const {
+        return m->prec == CN_PREC_BF16 && d == 256 && dff % 32 == 0 && dff <= 2048;
+    }
+    // row-chain stream: out-projection `wo` ("" = none), FFN under `p` with pre-norm `ln1` (dff 0 = none), then norm
+    // `nln` ("" = nothing follows) and the concatenated projections `tails` (each [d][d]) of whatever consumes the
+    // stream next.  Seven spare units follow the stream: the kernel's dummy refills past the end read them.
+    ChainRef chain(const std::string& wo, const std::string& ln1, const std::string& p, int64_t dff, const std::string& nln,
+                   std::vector<std::string> tails, int64_t d) {
+        ChainRef r;
         const int tail_n = (int)(tails.size() * d);
-        const size_t units = chain_stream_units(1, (int)dff, tail_n);
-        const size_t aw = reserve(units * CHAIN_UNIT_BYTES), at = reserve((size_t)CHAIN_TAB_FLOATS * 4);
+        const size_t units = chain_stream_units(!wo.empty(), (int)dff, tail_n);
+        const size_t aw = reserve((units + 7) * CHAIN_UNIT_BYTES), at = reserve((size_t)CHAIN_TAB_FLOATS * 4);
         if (fill) {
             ChainWeights w;
+            bool ok = true;
             auto get = [&](const std::string& n, std::initializer_list<int64_t> shape) -> const float* {
                 const HostTensor* t = find(n, shape);
+                if (!t) ok = false;
                 return t ? t->data.data() : nullptr;
             };
-            w.wo = get(wo + ".weight", {d, d});
-            w.bo = get(wo + ".bias", {d});
-            w.ln1_a = get(ln1 + ".a_2", {d});
-            w.ln1_b = get(ln1 + ".b_2", {d});
-            w.w1 = get(p + ".feed_forward.w_1.weight", {dff, d});
-            w.b1 = get(p + ".feed_forward.w_1.bias", {dff});
-            w.w2 = get(p + ".feed_forward.w_2.weight", {d, dff});
-            w.b2 = get(p + ".feed_forward.w_2.bias", {d});
-            w.nln_a = get(nln + ".a_2", {d});
-            w.nln_b = get(nln + ".b_2", {d});
+            if (!wo.empty()) {
+                w.wo = get(wo + ".weight", {d, d});
+                w.bo = get(wo + ".bias", {d});
+            }
+            if (dff) {
+                w.ln1_a = get(ln1 + ".a_2", {d});
+                w.ln1_b = get(ln1 + ".b_2", {d});
+                w.w1 = get(p + ".feed_forward.w_1.weight", {dff, d});
+                w.b1 = get(p + ".feed_forward.w_1.bias", {dff});
+                w.w2 = get(p + ".feed_forward.w_2.weight", {d, dff});
+                w.b2 = get(p + ".feed_forward.w_2.bias", {d});
+            }
+            if (!nln.empty()) {
+                w.nln_a = get(nln + ".a_2", {d});
+                w.nln_b = get(nln + ".b_2", {d});
+            }
             std::vector<float> tw((size_t)tail_n * d), tb((size_t)tail_n);
             size_t k = 0;
-            bool ok = w.wo && w.bo && w.ln1_a && w.ln1_b && w.w1 && w.b1 && w.w2 && w.b2 && w.nln_a && w.nln_b;
             for (auto& tp : tails) {
                 const float* a = get(tp + ".weight", {d, d});
                 const float* b = get(tp + ".bias", {d});
                 if (a && b) {
                     std::memcpy(&tw[k * d * d], a, (size_t)d * d * 4);
                     std::memcpy(&tb[k * d], b, (size_t)d * 4);
-                } else {
-                    ok = false;
                 }
                 ++k;
             }
@@ -330,9 +353,13 @@ struct Packer {
             w.tail_n = tail_n;
             if (ok) pack_chain(w, reinterpret_cast<uint16_t*>(&host[aw]), reinterpret_cast<float*>(&host[at]));
         }
-        L.chain_w = reinterpret_cast<void*>(aw);
-        L.chain_tab = reinterpret_cast<float*>(at);
-        L.chain_tail_n = tail_n;
+        r.w = reinterpret_cast<void*>(aw);
+        r.tab = reinterpret_cast<float*>(at);
+        r.dff = (int)dff;
+        r.tail_n = tail_n;
+        r.has_wo = !wo.empty();
+        r.has_next = !nln.empty();
+        return r;
     }
     // generator: the plain matrix (beam search / capture) plus the fused-argmax fragment stream when it applies
     Linear generator(const std::string& prefix, int64_t V, int64_t d) {
@@ -439,14 +466,18 @@ int build_weights(cn_model* m) {
     m->mad.clear();
     for (int n = 0; n < c.n_enc; ++n) m->enc.push_back(self_layer("encoder.layers." + std::to_string(n), "self_attn", c.d_encff, 2));
     m->enc_norm = pk.norm("encoder.norm", d);
-    for (int n = 0; n < c.n_enc; ++n) {
-        const std::string p = "encoder.layers." + std::to_string(n), q = "encoder.layers." + std::to_string(n + 1);
-        if (n + 1 < c.n_enc)
-            pk.chain(m->enc[n], p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff, q + ".sublayer.0.norm",
-                     {q + ".self_attn.linears.0", q + ".self_attn.linears.1", q + ".self_attn.linears.2"}, d);
-        else
-            pk.chain(m->enc[n], p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff, "encoder.norm", {}, d);
-    }
+    m->enc_chain.clear();
+    if (pk.chain_ok(d, c.d_encff))
+        for (int n = 0; n < c.n_enc; ++n) {
+            const std::string p = "encoder.layers." + std::to_string(n), q = "encoder.layers." + std::to_string(n + 1);
+            if (n + 1 < c.n_enc)
+                m->enc_chain.push_back(pk.chain(p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff,
+                                                q + ".sublayer.0.norm",
+                                                {q + ".self_attn.linears.0", q + ".self_attn.linears.1", q + ".self_attn.linears.2"}, d));
+            else
+                m->enc_chain.push_back(
+                    pk.chain(p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff, "encoder.norm", {}, d));
+        }
     for (int n = 0; n < c.n_extra; ++n) {
         const std::string p = "acembed_extractor.layers." + std::to_string(n);
         Layer L;
@@ -465,6 +496,46 @@ int build_weights(cn_model* m) {
         m->mad.push_back(L);
     }
     m->dec_norm = pk.norm("decoder.norm", d);
+    // decoder-side sublayers of the NAT model in execution order, each with the chain that follows its attention
+    m->dec_steps.clear();
+    if (!c.ast && pk.chain_ok(d, c.d_decff)) {
+        struct Sub {
+            int stack, layer;
+            bool self, ffn;
+            std::string p, att, pre, ffn_norm;  // layer prefix, attention module, its pre-norm, the FFN's pre-norm
+        };
+        std::vector<Sub> subs;
+        for (int n = 0; n < c.n_extra; ++n) {
+            const std::string p = "acembed_extractor.layers." + std::to_string(n);
+            subs.push_back({0, n, false, true, p, p + ".src_attn", p + ".sublayer.0.norm", p + ".sublayer.1.norm"});
+        }
+        for (int n = 0; n < c.n_self_dec; ++n) {
+            const std::string p = "embed_mapper.layers." + std::to_string(n);
+            subs.push_back({1, n, true, true, p, p + ".self_attn", p + ".sublayer.0.norm", p + ".sublayer.1.norm"});
+        }
+        for (int n = 0; n < c.n_mix_dec; ++n) {
+            const std::string p = "decoder.layers." + std::to_string(n);
+            subs.push_back({2, n, true, false, p, p + ".self_attn", p + ".sublayer.0.norm", ""});
+            subs.push_back({2, n, false, true, p, p + ".src_attn", p + ".sublayer.1.norm", p + ".sublayer.2.norm"});
+        }
+        auto in_proj = [&](const Sub& u) -> std::vector<std::string> {
+            if (u.self) return {u.att + ".linears.0", u.att + ".linears.1", u.att + ".linears.2"};
+            return {u.att + ".linears.0"};
+        };
+        for (size_t k = 0; k < subs.size(); ++k) {
+            const Sub& u = subs[k];
+            DecStep st;
+            st.stack = u.stack;
+            st.layer = u.layer;
+            st.self = u.self;
+            const bool final = k + 1 == subs.size();
+            st.chain = pk.chain(u.att + ".linears.3", u.ffn_norm, u.p, u.ffn ? c.d_decff : 0,
+                                final ? std::string("decoder.norm") : subs[k + 1].pre,
+                                final ? std::vector<std::string>{} : in_proj(subs[k + 1]), d);
+            if (k == 0 || (u.stack == 2 && u.layer == 0 && u.self)) st.entry = pk.chain("", "", "", 0, u.pre, in_proj(u), d);
+            m->dec_steps.push_back(st);
+        }
+    }
     if (c.ast) {
         const size_t at = pk.reserve((size_t)V * d * 4);
         if (pk.fill) {
@@ -511,10 +582,17 @@ int build_weights(cn_model* m) {
             rebase_linear(L.w2, base);
             rebase(L.w1p, base);
             rebase(L.w2p, base);
-            rebase(L.chain_w, base);
-            rebase(L.chain_tab, base);
         }
     };
+    auto rebase_chain = [&](ChainRef& r) {
+        rebase(r.w, base);
+        rebase(r.tab, base);
+    };
+    for (auto& r : m->enc_chain) rebase_chain(r);
+    for (auto& st : m->dec_steps) {
+        rebase_chain(st.chain);
+        rebase_chain(st.entry);
+    }
     rebase_layers(m->enc);
     rebase_layers(m->extra);
     rebase_layers(m->sad);
@@ -682,33 +760,32 @@ int run_self_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B,
     return 0;
 }
 
-// row-chain launch: x += Wo ctx + bo; x += FFN(LN1 x); out <- tail projection of LNn(x) (or LNn(x) itself)
-int run_chain(cn_model* m, const Layer& L, float* x, int M, void* out, int ldo, hipStream_t s) {
+// row-chain launch: [x += Wo ctx + bo]; [x += FFN(LN1 x)]; [out <- tail projection of LNn(x) (or LNn(x) itself)].
+// `with_next` false drops the norm/projection part of a stream that has one (use_unimask cuts the carry SAD -> MAD).
+int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ldo, bool with_next, hipStream_t s) {
     const int d = m->cfg.d_model;
-    ProfScope ps(m, "row_chain", 2.0 * M * ((double)d * d + 2.0 * d * L.w1.N + (double)d * L.chain_tail_n),
-                 (double)M * d * (8 + 2) + (double)M * ldo * 2 + 2.0 * ((double)d * d + 2.0 * d * L.w1.N + (double)d * L.chain_tail_n), s);
+    const int tail_n = with_next ? r.tail_n : 0;
+    const double macs = (r.has_wo ? (double)d * d : 0.0) + 2.0 * d * r.dff + (double)d * tail_n;
+    ProfScope ps(m, "row_chain", 2.0 * M * macs, (double)M * d * (8 + 2) + (double)M * ldo * 2 + 2.0 * macs, s);
     ChainArgs a;
     a.x = x;
-    a.ctx = m->ctx;
+    a.ctx = r.has_wo ? m->ctx : nullptr;
     a.ldctx = d;
-    a.wstream = L.chain_w;
-    a.tab = L.chain_tab;
+    a.wstream = r.w;
+    a.tab = r.tab;
     a.out = out;
     a.ldo = ldo;
     a.M = M;
     a.d = d;
-    a.dff = L.w1.N;
-    a.tail_n = L.chain_tail_n;
-    a.has_next = 1;
+    a.dff = r.dff;
+    a.tail_n = tail_n;
+    a.has_next = with_next && r.has_next;
     return launch_chain(a, s);
 }
 
-// x += O(Attn(LN(x) Wq, mem Wk, mem Wv)) with the padding mask and (optionally) trigger intervals
-int run_src_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B, int U, int Tp, const int* intervals,
-                 hipStream_t s) {
+// ctx <- Attn(m->qd, enc_h Wk, enc_h Wv) with the padding mask and (optionally) trigger intervals
+int run_src_attn_core(cn_model* m, const Layer& L, int B, int U, int Tp, const int* intervals, hipStream_t s) {
     const int d = m->cfg.d_model;
-    if (pre) CN_TRY(run_ln(m, *pre, x, m->xn, B * U, s));
-    CN_TRY(run_linear(m, "src_q_proj", L.src_q, m->xn, d, m->qd, d, 0, B * U, 0, nullptr, 0, s));
     CN_TRY(run_linear(m, "src_kv_proj", L.src_kv, m->enc_h, d, m->kvm, 2 * d, 0, B * Tp, 0, nullptr, 0, s));
     AttnArgs a;
     a.Q = m->qd;
@@ -726,11 +803,18 @@ int run_src_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B, 
     a.intervals = intervals;
     a.iv_stride = Tp + 1;
     a.scale = 1.0f / sqrtf((float)(d / m->cfg.n_head));
-    {
-        ProfScope ps(m, "src_attention", 4.0 * B * a.H * (double)U * Tp * 64,
-                     ((double)B * U * 2 * d + (double)B * Tp * 2 * d) * m->es, s);
-        CN_TRY(launch_attention(m->prec, a, s));
-    }
+    ProfScope ps(m, "src_attention", 4.0 * B * a.H * (double)U * Tp * 64,
+                 ((double)B * U * 2 * d + (double)B * Tp * 2 * d) * m->es, s);
+    return launch_attention(m->prec, a, s);
+}
+
+// x += O(Attn(LN(x) Wq, mem Wk, mem Wv))
+int run_src_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B, int U, int Tp, const int* intervals,
+                 hipStream_t s) {
+    const int d = m->cfg.d_model;
+    if (pre) CN_TRY(run_ln(m, *pre, x, m->xn, B * U, s));
+    CN_TRY(run_linear(m, "src_q_proj", L.src_q, m->xn, d, m->qd, d, 0, B * U, 0, nullptr, 0, s));
+    CN_TRY(run_src_attn_core(m, L, B, U, Tp, intervals, s));
     CN_TRY(run_linear(m, "out_proj_resid", L.src_o, m->ctx, d, x, d, 1, B * U, CN_EPI_RESID, x, d, s));
     return 0;
 }
@@ -865,7 +949,7 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     }
     if (cap) CN_TRY(capture(m, "x_embed", m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
     static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
-    const bool chain = !m->enc.empty() && m->enc[0].chain_w && !no_chain;
+    const bool chain = !m->enc.empty() && m->enc_chain.size() == m->enc.size() && !no_chain;
     if (chain) {  // bf16 / d_model 256: LN + QKV of layer 0, then per layer attention -> row-chain kernel
         CN_TRY(run_ln(m, m->enc[0].n[0], m->x, m->xn, M, s));
         CN_TRY(run_linear(m, "qkv_proj", m->enc[0].qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
@@ -875,7 +959,7 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         const bool last = n + 1 == m->enc.size();
         if (chain) {
             CN_TRY(run_self_attn_core(m, B, Tp, m->keymask, nullptr, 0, s));
-            CN_TRY(run_chain(m, L, m->x, M, last ? m->enc_h : m->qkv, last ? d : 3 * d, s));
+            CN_TRY(run_chain(m, m->enc_chain[n], m->x, M, last ? m->enc_h : m->qkv, last ? d : 3 * d, true, s));
         } else {
             CN_TRY(run_self_attn(m, L, n == 0 ? &L.n[0] : nullptr, m->x, B, Tp, m->keymask, nullptr, 0, s));
             CN_TRY(run_ffn(m, L, L.n[1], m->x, M, last ? &m->enc_norm : &m->enc[n + 1].n[0], last ? m->enc_h : m->xn, s));
@@ -888,6 +972,9 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
 }
 
 // acembed_extractor + embed_mapper + decoder + att_generator + greedy finish  (cassnat.py:475-497, 574-637)
+int stage_decode_tail(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int hyp_stride, int32_t* hyp_len,
+                      double* score, hipStream_t s);
+
 int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int hyp_stride, int32_t* hyp_len,
                  double* score, hipStream_t s) {
     const cn_config& c = m->cfg;
@@ -910,6 +997,52 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
         if (idx + 1 < m->mad.size()) return &m->mad[idx + 1].n[0];
         return nullptr;
     };
+    static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
+    if (!m->dec_steps.empty() && !no_chain) {
+        // bf16 / d_model 256: every sublayer is [attention] + one row-chain launch that also produces the next
+        // sublayer's input projection (src Q -> m->qd, self Q|K|V -> m->qkv) or, after the last one, dec_h
+        float* xdec = m->xd;
+        const size_t n = m->dec_steps.size();
+        auto proj_out = [&](const DecStep& st, void*& out, int& ldo) {
+            out = st.self ? m->qkv : m->qd;
+            ldo = st.self ? 3 * d : d;
+        };
+        for (size_t k = 0; k < n; ++k) {
+            const DecStep& st = m->dec_steps[k];
+            const Layer& L = st.stack == 0 ? m->extra[st.layer] : st.stack == 1 ? m->sad[st.layer] : m->mad[st.layer];
+            const bool first_mad = st.stack == 2 && st.layer == 0 && st.self;
+            if (first_mad) {
+                if (cap) CN_TRY(capture(m, "pred_embed", m->xd, false, CN_DTYPE_F32, {B, U, d}, s));
+                if (uni) {
+                    CN_TRY(launch_shift_right(m->xd, m->xd2, B, U, d, s));
+                    xdec = m->xd2;
+                }
+            }
+            if (k == 0 || (first_mad && uni)) {
+                void* out;
+                int ldo;
+                proj_out(st, out, ldo);
+                CN_TRY(run_chain(m, st.entry, xdec, MU, out, ldo, true, s));
+            }
+            if (st.self)
+                CN_TRY(run_self_attn_core(m, B, U, nullptr, m->ylen, (st.stack == 2 && uni) ? 1 : 0, s));
+            else
+                CN_TRY(run_src_attn_core(m, L, B, U, Tp,
+                                         st.stack == 0 ? m->intervals : (o->src_trigger ? m->intervals : nullptr), s));
+            const bool final = k + 1 == n;
+            // use_unimask shifts the stream between the last SAD layer and the first MAD layer: nothing carries over
+            const bool carry = final || !(uni && m->dec_steps[k + 1].stack == 2 && m->dec_steps[k + 1].layer == 0 &&
+                                          m->dec_steps[k + 1].self);
+            void* out = m->dec_h;
+            int ldo = d;
+            if (!final) proj_out(m->dec_steps[k + 1], out, ldo);
+            CN_TRY(run_chain(m, st.chain, xdec, MU, out, ldo, carry, s));
+            if (cap && st.stack == 0 && (k + 1 == n || m->dec_steps[k + 1].stack != 0))
+                CN_TRY(capture(m, "ac_embed", m->xd, false, CN_DTYPE_F32, {B, U, d}, s));
+        }
+        if (cap && m->mad.empty()) CN_TRY(capture(m, "pred_embed", m->xd, false, CN_DTYPE_F32, {B, U, d}, s));
+        return stage_decode_tail(m, U, o, hyp, hyp_stride, hyp_len, score, s);
+    }
     bool pending = false;
     for (size_t i = 0; i < m->extra.size(); ++i) {
         const Layer& L = m->extra[i];
@@ -943,6 +1076,15 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
         pending = !last && nx != nullptr;
     }
     if (m->mad.empty()) CN_TRY(run_ln(m, m->dec_norm, xdec, m->dec_h, MU, s));
+    return stage_decode_tail(m, U, o, hyp, hyp_stride, hyp_len, score, s);
+}
+
+// generator + argmax / top-k + hypothesis packing on m->dec_h
+int stage_decode_tail(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int hyp_stride, int32_t* hyp_len,
+                      double* score, hipStream_t s) {
+    const cn_config& c = m->cfg;
+    const int d = c.d_model, B = m->B, MU = B * U;
+    const bool cap = o->capture != 0;
     if (cap) CN_TRY(capture(m, "dec_h", m->dec_h, true, CN_DTYPE_F32, {B, U, d}, s));
     const int k = o->beam_width;
     CN_TRY(run_generator(m, m->att_gen, m->dec_h, MU, m->tok, m->val, cap || k > 1, s));

@@ -393,7 +393,7 @@ def _hp(t):
     (129, 256, 0, True, False),       # no next norm at all; short FFN (8 tiles)
     (128, 0, 768, False, True),       # LayerNorm + QKV only (layer-0 entry)
     (77, 2048, 768, False, True),     # FFN + tail without an output projection
-    (64, 64, 32, True, True),         # fewer units (13) than ring slots + 5
+    (64, 128, 256, True, True),       # short stream: 3 groups
 ])
 def test_chain_bf16(M, dff, tail_n, with_ctx, with_next):
     from oracle.cassnat_oracle import layer_norm
