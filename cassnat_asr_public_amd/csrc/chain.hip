@@ -61,6 +61,7 @@ struct ChainParams {
     int M, ffn_tiles, tail_tiles, has_next;
     float eps;
     int stamps;
+    int x_in_blk, x_out_blk, store_x;
 };
 
 #define CH_STR2(x) #x
@@ -288,11 +289,16 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     // compiler does not order them against the DMAs below; waited for with a counted vmcnt once the ring is primed
     f32x4 xr[32];
     bf16x8 bop[16];
+    const int rb = blockIdx.x * 4 + wave, nrb = (p.M + 31) >> 5;  // this wave's 32-row block; blocks that hold rows
     {
-        const float* xp = p.x + (long long)mc * CH_D + 4 * half;
+        // piece i = 4 nt + g holds channels 32 nt + 8 g + 4 half + (0..3): row-major it sits at float 8 i of the row,
+        // blocked at float 256 i + 4 lane of the row block
+        const float* xp = p.x_in_blk ? p.x + (long long)(rb < nrb ? rb : nrb - 1) * 8192 + 4 * lane
+                                     : p.x + (long long)mc * CH_D + 4 * half;
+        const int step = p.x_in_blk ? 256 : 8;
 #pragma unroll
-        for (int i = 0; i < 32; ++i)  // i = 4 nt + g : channels 32 nt + 8 g + 4 half + (0..3)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&a"(xr[i]) : "v"(xp + 8 * i) : "memory");
+        for (int i = 0; i < 32; ++i)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&a"(xr[i]) : "v"(xp + step * i) : "memory");
         if (p.ctx) {
             const bf16* cp = p.ctx + (long long)mc * p.ldctx + 8 * half;
 #pragma unroll
@@ -419,8 +425,9 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     CH_STAMP(5)
 
     // ---- S4: the residual stream goes back to memory (row m: 16-byte pieces at channels 32 nt + 8 g + 4 half)
-    if (live && (p.ctx || p.ffn_tiles)) {
-        float* xp = p.x + (long long)m * CH_D + 4 * half;
+    if (p.store_x && (p.x_out_blk ? rb < nrb : live)) {  // (blocked: whole tiles, rows past M land in the buffer's padding)
+        float* xp = p.x_out_blk ? p.x + (long long)rb * 8192 + 4 * lane : p.x + (long long)m * CH_D + 4 * half;
+        const int step = p.x_out_blk ? 256 : 8;
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = acc[nt][4 * g + e];
-                __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(xp + 32 * nt + 8 * g));
+                *reinterpret_cast<f32x4*>(xp + step * (4 * nt + g)) = o;
             }
     }
     CH_STAMP(6)
@@ -469,10 +476,10 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
                 _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                              \
                     _Pragma("unroll") for (int e = 0; e < 4; ++e) o_[g_][e] = (bf16)(q[4 * g_ + e] + btv[g_][e]); \
                 ch_tab4_nowait(tb + ((k) + 1 < 8 ? ((k) + 1) * 128 : 0), btv[0], btv[1], btv[2], btv[3]);      \
-                if (live) {                                                                                   \
+                if (live && p.stamps != 2) {                                                                  \
                     _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                          \
                         __builtin_nontemporal_store(o_[g_], reinterpret_cast<bf16x4*>(op + 32 * (k) + 8 * g_)); \
-                }                                                                                             \
+                } else if (p.stamps == 2) { asm volatile("" :: "v"(o_[0]), "v"(o_[1]), "v"(o_[2]), "v"(o_[3])); }                                                                                            \
             }
             CH_POSITIONS(CH_S5)
 #undef CH_S5
@@ -516,8 +523,11 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
     p.has_next = a.has_next;
     p.eps = a.eps;
     static int stamps = -1;
-    if (stamps < 0) stamps = getenv("CASSNAT_CHAIN_STAMPS") != nullptr;
+    if (stamps < 0) stamps = getenv("CASSNAT_CHAIN_STAMPS") ? atoi(getenv("CASSNAT_CHAIN_STAMPS")) : 0;
     p.stamps = stamps;
+    p.x_in_blk = a.x_in_blocked;
+    p.x_out_blk = a.x_out_blocked;
+    p.store_x = a.store_x && (a.ctx || a.dff);
     static bool attr_done = false;
     if (!attr_done) {
         CN_HIP_CHECK(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));

@@ -119,6 +119,10 @@ struct ChainArgs {
     void* out = nullptr;            // [M][ldo] bf16: tail projection of LNn(x), or LNn(x) itself when tail_n == 0
     int ldo = 0;
     int M = 0, d = 0, dff = 0, tail_n = 0, has_next = 0;
+    // x layout: row-major [M][256], or blocked: 32-row blocks of [32 pieces i = 4 nt + g][64 lanes][4 floats] where lane =
+    // (row % 32) + 32 half holds channels 32 nt + 8 g + 4 half + (0..3) - each load/store instruction moves 1 KiB contiguous
+    // (buffer must hold ceil(M / 32) * 32 rows).  store_x = 0: x is not written back (nothing reads it afterwards)
+    int x_in_blocked = 0, x_out_blocked = 0, store_x = 1;
     float eps = 1e-6f;
 };
 int launch_chain(const ChainArgs& a, hipStream_t s);

@@ -616,7 +616,7 @@ int build_workspace(cn_model* m) {
     CN_TRY(dev_alloc(m, (void**)&m->keymask, B * Tp));
     CN_TRY(dev_alloc(m, &m->c1, B * T1 * F1 * d * es));
     CN_TRY(dev_alloc(m, &m->c2, B * Tp * F2 * d * es));
-    CN_TRY(dev_alloc(m, (void**)&m->x, M * d * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->x, (M + 32) * d * 4));  // + one 32-row block: the chain kernel's blocked layout rounds up
     CN_TRY(dev_alloc(m, &m->xn, M * d * es));
     CN_TRY(dev_alloc(m, &m->qkv, M * 3 * d * es));
     CN_TRY(dev_alloc(m, &m->ctx, M * d * es));
@@ -625,8 +625,8 @@ int build_workspace(cn_model* m) {
     CN_TRY(dev_alloc(m, &m->kvm, M * 2 * d * es));
     CN_TRY(dev_alloc(m, &m->qd, M * d * es));
     CN_TRY(dev_alloc(m, &m->dec_h, M * d * es));
-    CN_TRY(dev_alloc(m, (void**)&m->xd, M * d * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->xd2, M * d * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->xd, (M + 32) * d * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->xd2, (M + 32) * d * 4));
     CN_TRY(dev_alloc(m, (void**)&m->logits, M * V * 4));
     CN_TRY(dev_alloc(m, (void**)&m->best, M * 4));
     CN_TRY(dev_alloc(m, (void**)&m->ctc_maxlp, M * 4));
@@ -762,7 +762,10 @@ int run_self_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B,
 
 // row-chain launch: [x += Wo ctx + bo]; [x += FFN(LN1 x)]; [out <- tail projection of LNn(x) (or LNn(x) itself)].
 // `with_next` false drops the norm/projection part of a stream that has one (use_unimask cuts the carry SAD -> MAD).
-int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ldo, bool with_next, hipStream_t s) {
+// x_mode: CHX_* bits - the fp32 stream is read / written row-major or in the kernel's blocked tile layout, or not written
+enum { CHX_IN_BLK = 1, CHX_OUT_BLK = 2, CHX_NO_STORE = 4 };
+int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ldo, bool with_next, int x_mode,
+              hipStream_t s) {
     const int d = m->cfg.d_model;
     const int tail_n = with_next ? r.tail_n : 0;
     const double macs = (r.has_wo ? (double)d * d : 0.0) + 2.0 * d * r.dff + (double)d * tail_n;
@@ -780,6 +783,9 @@ int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ld
     a.dff = r.dff;
     a.tail_n = tail_n;
     a.has_next = with_next && r.has_next;
+    a.x_in_blocked = (x_mode & CHX_IN_BLK) != 0;
+    a.x_out_blocked = (x_mode & CHX_OUT_BLK) != 0;
+    a.store_x = (x_mode & CHX_NO_STORE) == 0;
     return launch_chain(a, s);
 }
 
@@ -959,7 +965,10 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         const bool last = n + 1 == m->enc.size();
         if (chain) {
             CN_TRY(run_self_attn_core(m, B, Tp, m->keymask, nullptr, 0, s));
-            CN_TRY(run_chain(m, m->enc_chain[n], m->x, M, last ? m->enc_h : m->qkv, last ? d : 3 * d, true, s));
+            // between chain launches the residual stream lives in the kernel's blocked layout; the last layer's x is
+            // consumed by nobody (enc_h is the output).  Captures read x row-major.
+            const int xm = cap ? 0 : ((n > 0 ? CHX_IN_BLK : 0) | (last ? CHX_NO_STORE : CHX_OUT_BLK));
+            CN_TRY(run_chain(m, m->enc_chain[n], m->x, M, last ? m->enc_h : m->qkv, last ? d : 3 * d, true, xm, s));
         } else {
             CN_TRY(run_self_attn(m, L, n == 0 ? &L.n[0] : nullptr, m->x, B, Tp, m->keymask, nullptr, 0, s));
             CN_TRY(run_ffn(m, L, L.n[1], m->x, M, last ? &m->enc_norm : &m->enc[n + 1].n[0], last ? m->enc_h : m->xn, s));
@@ -1022,7 +1031,7 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
                 void* out;
                 int ldo;
                 proj_out(st, out, ldo);
-                CN_TRY(run_chain(m, st.entry, xdec, MU, out, ldo, true, s));
+                CN_TRY(run_chain(m, st.entry, xdec, MU, out, ldo, true, CHX_NO_STORE, s));  // reads row-major x, writes none
             }
             if (st.self)
                 CN_TRY(run_self_attn_core(m, B, U, nullptr, m->ylen, (st.stack == 2 && uni) ? 1 : 0, s));
@@ -1036,7 +1045,12 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
             void* out = m->dec_h;
             int ldo = d;
             if (!final) proj_out(m->dec_steps[k + 1], out, ldo);
-            CN_TRY(run_chain(m, st.chain, xdec, MU, out, ldo, carry, s));
+            // blocked between chain launches; row-major where something else touches the stream (queries in, the
+            // use_unimask shift, captures); the last sublayer's x is consumed by nobody
+            const bool in_rm = k == 0 || (first_mad && uni);
+            const bool out_rm = !final && !carry;
+            const int xm = cap ? 0 : ((in_rm ? 0 : CHX_IN_BLK) | (final ? CHX_NO_STORE : (out_rm ? 0 : CHX_OUT_BLK)));
+            CN_TRY(run_chain(m, st.chain, xdec, MU, out, ldo, carry, xm, s));
             if (cap && st.stack == 0 && (k + 1 == n || m->dec_steps[k + 1].stack != 0))
                 CN_TRY(capture(m, "ac_embed", m->xd, false, CN_DTYPE_F32, {B, U, d}, s));
         }
@@ -1532,7 +1546,7 @@ extern "C" int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, con
                            const float* ln1_a_host, const float* ln1_b_host, const float* w1_host, const float* b1_host,
                            const float* w2_host, const float* b2_host, const float* nln_a_host, const float* nln_b_host,
                            const float* wt_host, const float* bt_host, void* out_dev, int32_t ldo, int32_t M, int32_t dff,
-                           int32_t tail_n, float eps, void* stream) {
+                           int32_t tail_n, float eps, int32_t x_mode, void* stream) {
     if (dff < 0 || dff % 32 != 0 || dff > 2048 || tail_n < 0 || tail_n % 32 != 0 || tail_n > 768) {
         cn_set_error("cn_op_chain: d_ff and the tail width must be multiples of 32 (<= 2048 / <= 768)");
         return -1;
@@ -1575,6 +1589,9 @@ extern "C" int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, con
     a.tail_n = tail_n;
     a.has_next = nln_a_host != nullptr;
     a.eps = eps;
+    a.x_in_blocked = (x_mode & 1) != 0;
+    a.x_out_blocked = (x_mode & 2) != 0;
+    a.store_x = (x_mode & 4) == 0;
     int rc = launch_chain(a, (hipStream_t)stream);
     if (const char* rep = getenv("CASSNAT_CHAIN_REPEAT"))  // timing runs only: x keeps being updated
         for (int i = 1; i < atoi(rep) && rc == 0; ++i) rc = launch_chain(a, (hipStream_t)stream);

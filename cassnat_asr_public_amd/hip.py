@@ -85,7 +85,7 @@ def lib():
                            C.POINTER(C.c_int32)]
     L.cn_op_ffn_fused.argtypes = [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     L.cn_op_chain.argtypes = ([C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 13 +
-                              [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p])
+                              [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p])
     L.cn_op_genmax.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_ast_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts), C.c_int32,
                                C.c_int32, C.c_int32, C.c_int32, C.c_void_p]

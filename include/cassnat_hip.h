@@ -116,12 +116,15 @@ int cn_profile_end(cn_model* m, char* json_out, int64_t cap);
  * when nln_a_host != NULL: out = Wt.LNn(x)+bt (tail_n columns) or out = LNn(x) itself (tail_n == 0), bf16 [M][ldo].
  * Replaces linears[3] + SublayerConnection + PositionwiseFeedForward + LayerNorm + linears[0..2]
  * (src/models/modules/attention.py:44-66, utils.py:23-32, positionff.py:15-16, norm.py:15-18).  Weights are host fp32
- * in nn.Linear layout and are packed on every call: a test entry point, the model keeps its packed copies. */
+ * in nn.Linear layout and are packed on every call: a test entry point, the model keeps its packed copies.
+ * x_mode bits: 1 = x_dev is read in the kernel's blocked layout, 2 = written in it, 4 = not written back.  Blocked: 32-row
+ * blocks of [32 pieces i][64 lanes][4 floats], lane = row % 32 + 32 h holding channels 32 (i / 4) + 8 (i % 4) + 4 h + (0..3);
+ * the buffer then holds ceil(M / 32) * 32 rows. */
 int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, const float* wo_host, const float* bo_host,
                 const float* ln1_a_host, const float* ln1_b_host, const float* w1_host, const float* b1_host,
                 const float* w2_host, const float* b2_host, const float* nln_a_host, const float* nln_b_host,
                 const float* wt_host, const float* bt_host, void* out_dev, int32_t ldo, int32_t M, int32_t dff,
-                int32_t tail_n, float eps, void* stream);
+                int32_t tail_n, float eps, int32_t x_mode, void* stream);
 
 /* ---- single-kernel entry points (parity tests drive each hand-written kernel through the ABI) ---------- */
 /* all pointers device; `precision` selects the element type of activations/weights (fp32 or bf16) */

@@ -386,6 +386,22 @@ def _hp(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _to_blocked(x):
+    """[M][256] -> the chain kernel's blocked layout (include/cassnat_hip.h, cn_op_chain), rows padded to 32."""
+    M = x.shape[0]
+    nrb = (M + 31) // 32
+    xp = torch.zeros(nrb * 32, 256, dtype=x.dtype)
+    xp[:M] = x
+    # row = 32 rb + r, channel = 32 nt + 8 g + 4 h + e  ->  [rb][i = 4 nt + g][lane = r + 32 h][e]
+    return xp.view(nrb, 32, 8, 4, 2, 4).permute(0, 2, 3, 4, 1, 5).reshape(nrb, 32, 64, 4).contiguous()
+
+
+def _from_blocked(xb, M):
+    nrb = xb.shape[0]
+    return xb.view(nrb, 8, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(nrb * 32, 256)[:M].contiguous()
+
+
+@pytest.mark.parametrize("x_mode", [0, 3, 1, 2])
 @pytest.mark.parametrize("M,dff,tail_n,with_ctx,with_next", [
     (8000, 2048, 768, True, True),    # encoder layer at config 2: out-proj + FFN + next layer's QKV
     (8000, 2048, 0, True, True),      # last encoder layer: the stack's final LayerNorm is the output
@@ -395,7 +411,7 @@ def _hp(t):
     (77, 2048, 768, False, True),     # FFN + tail without an output projection
     (64, 128, 256, True, True),       # short stream: 3 groups
 ])
-def test_chain_bf16(M, dff, tail_n, with_ctx, with_next):
+def test_chain_bf16(M, dff, tail_n, with_ctx, with_next, x_mode):
     from oracle.cassnat_oracle import layer_norm
 
     g = torch.Generator().manual_seed(M + dff + tail_n)
@@ -417,17 +433,24 @@ def test_chain_bf16(M, dff, tail_n, with_ctx, with_next):
         xn = rounded(layer_norm(ref, a1, b1n), "bf16")
         h = rounded(F.relu(F.linear(xn, rounded(w1, "bf16"), b1)), "bf16")
         ref = ref + F.linear(h, rounded(w2, "bf16"), b2)
-    xd = dev(x)
+    xd = dev(_to_blocked(x) if x_mode & 1 else x)
+    if x_mode & 2 and not x_mode & 1:  # row-major in, blocked out: the buffer must hold whole 32-row blocks
+        xd = torch.cat([xd, torch.zeros(32, d, device="cuda")])
     ctxd = dev(ctx, torch.bfloat16) if with_ctx else None
     ldo = tail_n if tail_n else d
     out = torch.full((M, ldo), float("nan"), dtype=torch.bfloat16, device="cuda") if with_next else None
     hip.check(hip.lib().cn_op_chain(p(xd), p(ctxd) if with_ctx else None, d, _hp(wo), _hp(bo), _hp(a1), _hp(b1n), _hp(w1),
                                     _hp(b1), _hp(w2), _hp(b2), _hp(na) if with_next else None, _hp(nb) if with_next else None,
-                                    _hp(wt), _hp(bt), p(out) if with_next else None, ldo, M, dff, tail_n, 1e-6, stream()))
+                                    _hp(wt), _hp(bt), p(out) if with_next else None, ldo, M, dff, tail_n, 1e-6, x_mode, stream()))
     torch.cuda.synchronize()
-    assert relerr(xd, ref) < 2e-3
+    nrb = (M + 31) // 32
+    xo = xd.cpu().reshape(-1)[: nrb * 32 * d]
+    xo = _from_blocked(xo.view(nrb, 32, 64, 4), M) if x_mode & 2 else xo.view(-1, d)[:M]
+    if not with_ctx and not dff:
+        xo = x  # nothing to store: the kernel leaves x alone (in whatever layout it came)
+    assert relerr(xo, ref) < 2e-3
     if with_next:
-        y = layer_norm(xd.cpu(), na, nb)
+        y = layer_norm(xo, na, nb)
         if tail_n:
             assert relerr(out, F.linear(rounded(y, "bf16"), rounded(wt, "bf16"), bt)) < 6e-3
         else:
