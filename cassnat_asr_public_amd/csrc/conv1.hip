@@ -8,12 +8,15 @@
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
                                                     const float* __restrict__ bias, T* __restrict__ out, int B, int Tn,
-                                                    int F, int T1, int F1, int C) {
+                                                    int F, int T1, int F1, int C, int halo) {
     // A thread keeps its 8 channels for the whole grid-stride loop (the stride is a multiple of C/8), so the
     // 72 tap weights + 8 biases live in registers; per output position it issues 9 (wave-broadcast) loads,
     // 72 FMAs and one 16-byte store.
     const int cg = C >> 3;
-    const long long total = (long long)B * T1 * F1 * cg;
+    // halo = 1: the image is written as [B][T1 + 2][F1 + 2][C] with a border of zeros (the padding of the second
+    // convolution, conv2.hip): the grid then covers the border cells too
+    const int T1p = T1 + 2 * halo, F1p = F1 + 2 * halo;
+    const long long total = (long long)B * T1p * F1p * cg;
     const long long first = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c0 = (int)(first % cg) << 3;
     float w[9][8], bz[8];
@@ -26,9 +29,19 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
     const long long stride = (long long)gridDim.x * 256;  // launcher keeps this a multiple of cg
     for (long long idx = first; idx < total; idx += stride) {
         const long long pos = idx / cg;
-        const int f1 = (int)(pos % F1);
-        const long long bt = pos / F1;
-        const int t1 = (int)(bt % T1), b = (int)(bt / T1);
+        const int f1 = (int)(pos % F1p) - halo;
+        const long long bt = pos / F1p;
+        const int t1 = (int)(bt % T1p) - halo, b = (int)(bt / T1p);
+        T* dst = out + pos * C + c0;
+        if (t1 < 0 || t1 >= T1 || f1 < 0 || f1 >= F1) {  // border cell
+            if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
+            } else {
+                *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(dst + 4) = make_uint4(0, 0, 0, 0);
+            }
+            continue;
+        }
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = bz[j];
@@ -44,7 +57,6 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
                 for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, w[kh * 3 + kw][j], acc[j]);
             }
         }
-        T* dst = out + pos * C + c0;
         if constexpr (sizeof(T) == 2) {
             bf16x8 o;
 #pragma unroll
@@ -64,22 +76,22 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
 }
 
 int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1,
-                 int F1, int C, hipStream_t s) {
+                 int F1, int C, int halo, hipStream_t s) {
     if (C % 8 != 0 || (256 % (C / 8)) != 0) {
         cn_set_error("conv1: channel count must be a multiple of 8 with C/8 dividing 256");
         return -1;
     }
-    const long long total = (long long)B * T1 * F1 * (C / 8);
+    const long long total = (long long)B * (T1 + 2 * halo) * (F1 + 2 * halo) * (C / 8);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;  // 8 workgroups per CU, grid-stride the rest (256 threads % (C/8) == 0)
     if (blocks < 1) blocks = 1;
     const size_t lds = 0;
     if (prec == CN_PREC_F32)
         hipLaunchKernelGGL(conv1_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (float*)out, B, T,
-                           F, T1, F1, C);
+                           F, T1, F1, C, halo);
     else
         hipLaunchKernelGGL(conv1_kernel<bf16>, dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (bf16*)out, B, T,
-                           F, T1, F1, C);
+                           F, T1, F1, C, halo);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,268 @@
+// Second subsampling convolution (Conv2d(256, 256, 3, stride 2, padding 1) + ReLU; reference:
+// src/models/modules/embedding.py:104-108) as an implicit GEMM for gfx950, bf16:
+//     out[m][co] = relu(bias[co] + sum_{tap, ci} in[b][2 t2 - 1 + kh][2 f2 - 1 + kw][ci] . W[co][tap][ci]),
+//     m = (b, t2, f2),  M = B T2 F2 = 160 000 rows at config 2,  N = 256,  K = 9 x 256 = 2304  (188.7 GFLOP).
+//
+// This is the largest single product of the path (34 % of its FLOPs).  The generic GEMM (gemm.hip: 128x128 tiles,
+// operands staged global -> registers -> LDS by the compute waves) reaches 0.6 PFLOP/s on it; what it pays for is
+// exactly the staging (16 ds_write_b128 and their address math per wave and K step) and two-byte output stores.
+//
+//   * Tile 256 rows x all 256 output channels per workgroup, 4 waves (2 x 2, a 128 x 128 sub-tile = 16 accumulators =
+//     256 AGPRs each; two waves per SIMD would leave 128 + 128 registers, which does not hold 128 accumulator
+//     registers plus two fragment sets).  Every K sub-step is one hand-scheduled block of 16 MFMAs with the next
+//     sub-step's 8 fragment reads and a later step's DMA pieces issued in its MFMA gaps.
+//   * Both operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4), 64 KiB per K step (64 channels of one
+//     tap), double buffered; the XOR swizzle that makes the fragment reads conflict-free is applied to the per-lane
+//     SOURCE address (the LDS image of a DMA piece is lane-linear).  conv1 writes its image with a one-cell zero
+//     halo, so the padding taps are ordinary reads and a step's source offset is one scalar.  One s_barrier per K step: it is placed inside the step's last block, where every wave already
+//     holds its last fragments, so the next step's first fragments are prefetched behind it.
+//   * The products are computed transposed (D[co][m]: weights as the A operand) so that a lane ends up with four
+//     consecutive channels of one row; the tile goes through LDS once and leaves as 8-KiB contiguous row runs.
+//   * All LDS reads of the main loop are issued from inline asm (hipcc drains vmcnt before LDS accesses it can see
+//     while an LDS-DMA is in flight).
+#include <cstdlib>
+
+#include "kernels.h"
+
+struct Conv2Params {
+    const unsigned char* A;      // conv1 output with a zero halo [B][T1 + 2][F1 + 2][256] bf16
+    const unsigned char* W;      // [256][9 * 256] bf16, k = (kh * 3 + kw) * 256 + ci
+    const float* bias;
+    bf16* out;                   // [M][256]
+    int M, T1, F1, T2, F2, ntiles;
+};
+
+constexpr int C2_BM = 256, C2_N = 256, C2_C = 256, C2_ROWB = 128;
+constexpr int C2_STAGE = (C2_BM + C2_N) * C2_ROWB;  // 64 KiB: A rows then W rows, 128 bytes (64 channels) each
+constexpr int C2_OSTRIDE = 528;                      // epilogue image: 512-byte rows + 16 (LDS bank spread)
+constexpr int C2_LDS = C2_BM * C2_OSTRIDE > 2 * C2_STAGE ? C2_BM * C2_OSTRIDE : 2 * C2_STAGE;
+static_assert(C2_LDS <= 160 * 1024, "LDS budget");
+constexpr int C2_KSTEPS = 9 * (C2_C / 64);
+
+#define C2_STR2(x) #x
+#define C2_STR(x) C2_STR2(x)
+#define C2_MF "v_mfma_f32_32x32x16_bf16 "
+#define C2_DMA(src, dst)                                                                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),          \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+// One 16-wide k sub-step of a wave's 128 x 128 sub-tile: D[nt][mt] += Wc[nt] (rows = channels) x Ac[mt] (columns =
+// output rows), 16 MFMAs; behind the first eight go the eight fragment reads of the NEXT sub-step (An from address an_:
+// + 4096 mt; Wn from wn_: + 4096 nt), behind the last eight up to eight LDS-DMA pieces of a later K step (DMA = the
+// instruction text; destination M0 = st_ + 4096 i, source = scalar base sb_ + per-piece lane offset vo[i]).
+#define C2_RDA(i) "ds_read_b128 %[na" #i "], %[an] offset:" C2_STR(i * 4096) "\n\t"
+#define C2_RDW(i) "ds_read_b128 %[nw" #i "], %[wn] offset:" C2_STR(i * 4096) "\n\t"
+#define C2_DMA_I(i) "s_add_u32 m0, %[st], " C2_STR(i * 4096) "\n\tglobal_load_lds_dwordx4 %[vo" #i "], %[sb]\n\t"
+#define C2_NODMA(i) ""
+#define C2_M(nt, mt) C2_MF "%[c" #nt #mt "], %[w" #nt "], %[a" #mt "], %[c" #nt #mt "]\n\t"
+#define C2_BLOCK(PRE, Ac, Wc, An, Wn, DMA, vo)                                                                 \
+    asm volatile(PRE "s_waitcnt lgkmcnt(0)\n\t"                                                                \
+                 C2_M(0, 0) C2_RDA(0) C2_M(0, 1) C2_RDA(1) C2_M(0, 2) C2_RDA(2) C2_M(0, 3) C2_RDA(3)           \
+                 C2_M(1, 0) C2_RDW(0) C2_M(1, 1) C2_RDW(1) C2_M(1, 2) C2_RDW(2) C2_M(1, 3) C2_RDW(3)           \
+                 C2_M(2, 0) DMA(0) C2_M(2, 1) DMA(1) C2_M(2, 2) DMA(2) C2_M(2, 3) DMA(3)                       \
+                 C2_M(3, 0) DMA(4) C2_M(3, 1) DMA(5) C2_M(3, 2) DMA(6) C2_M(3, 3) DMA(7)                       \
+                 : [c00] "+a"(acc[0]), [c01] "+a"(acc[1]), [c02] "+a"(acc[2]), [c03] "+a"(acc[3]), [c10] "+a"(acc[4]), \
+                   [c11] "+a"(acc[5]), [c12] "+a"(acc[6]), [c13] "+a"(acc[7]), [c20] "+a"(acc[8]), [c21] "+a"(acc[9]), \
+                   [c22] "+a"(acc[10]), [c23] "+a"(acc[11]), [c30] "+a"(acc[12]), [c31] "+a"(acc[13]),          \
+                   [c32] "+a"(acc[14]), [c33] "+a"(acc[15]), [na0] "=&v"(An[0]), [na1] "=&v"(An[1]),            \
+                   [na2] "=&v"(An[2]), [na3] "=&v"(An[3]), [nw0] "=&v"(Wn[0]), [nw1] "=&v"(Wn[1]),              \
+                   [nw2] "=&v"(Wn[2]), [nw3] "=&v"(Wn[3])                                                      \
+                 : [a0] "v"(Ac[0]), [a1] "v"(Ac[1]), [a2] "v"(Ac[2]), [a3] "v"(Ac[3]), [w0] "v"(Wc[0]),        \
+                   [w1] "v"(Wc[1]), [w2] "v"(Wc[2]), [w3] "v"(Wc[3]), [an] "v"(an_), [wn] "v"(wn_),            \
+                   [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]),   \
+                   [vo5] "v"(vo[5]), [vo6] "v"(vo[6]), [vo7] "v"(vo[7]), [st] "s"(st_), [sb] "s"(sb_)          \
+                 : "memory", "scc")
+
+__global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wnn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    // XCD-aware tile order (as gemm.hip): neighbouring M tiles share conv halo rows; keep them on one XCD's L2
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, rm = nwg & 7;
+    const int tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (blockIdx.x >> 3);
+    const int m0 = tile * C2_BM;
+
+    // ---- DMA sources of this lane: pieces j = wave + 4 i (i = 0..7) of the A slab and of the W slab; a piece is 8 rows
+    // x 128 bytes, lane = 8 (row in piece) + chunk position; the lane fetches chunk (position ^ swizzle(row)).
+    const int r8 = lane >> 3, cp = lane & 7;
+    // (row >> 1) & 7 of row = 8 (wave + 4 i) + r8 does not depend on i: one swizzled chunk offset per lane
+    const unsigned sw = (unsigned)((cp ^ ((4 * wave + (r8 >> 1)) & 7)) << 4);
+    // The input image carries a one-cell zero halo ([B][T1+2][F1+2][256], written by conv1), so no tap is ever out of
+    // range: the source of a row is (its fixed byte offset, a VGPR) + (a per-step, wave-uniform offset, the scalar base
+    // of the DMA): the address arithmetic of a K step is two scalar adds.
+    const int F1p = p.F1 + 2;
+    unsigned pa[8], pw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 8 * (wave + 4 * i) + r8;
+        const int m = m0 + row;
+        const int mc = m < p.M ? m : p.M - 1;  // rows past M compute on the last row's data and are never stored
+        const int f2 = mc % p.F2, bt = mc / p.F2;
+        const int t2 = bt % p.T2, b = bt / p.T2;
+        pa[i] = (unsigned)(((b * (p.T1 + 2) + 2 * t2) * F1p + 2 * f2) * (C2_C * 2)) + sw;
+        pw[i] = (unsigned)(row * (9 * C2_C * 2)) + sw;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned m0_wave = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+    // source bases / destinations of K step kt (channel block outermost, tap innermost), stage kt & 1
+    auto a_base = [&](int kt) -> const unsigned char* {
+        const int cb = kt / 9, tap = kt - 9 * cb;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        return p.A + (long long)((kh * F1p + kw) * (C2_C * 2) + cb * 128);
+    };
+    auto w_base = [&](int kt) -> const unsigned char* {
+        const int cb = kt / 9, tap = kt - 9 * cb;
+        return p.W + (long long)((tap * C2_C + cb * 64) * 2);
+    };
+    auto a_dst = [&](int kt) -> unsigned { return m0_wave + (unsigned)((kt & 1) * C2_STAGE); };
+    auto w_dst = [&](int kt) -> unsigned { return m0_wave + (unsigned)((kt & 1) * C2_STAGE + C2_BM * C2_ROWB); };
+#define C2_ISSUE8(dst, vo, sbase)                                                                             \
+    {                                                                                                         \
+        const unsigned d_ = (dst);                                                                            \
+        const unsigned char* s_ = (sbase);                                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                      \
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d_ + i_ * 4096), "v"(vo[i_]), \
+                         "s"(s_) : "memory");                                                                 \
+    }
+
+    // ---- fragment read addresses: row r of a slab, 16-byte chunk c lives at r * 128 + ((c ^ ((r >> 1) & 7)) << 4); the
+    // swizzle of this lane's rows is the same for every 32-row tile, and chunk 2 ks + half of k sub-step ks sits at
+    // (address of sub-step 0) ^ (ks << 5)
+    const unsigned off0 = (((unsigned)half) ^ (unsigned)((l31 >> 1) & 7)) << 4;
+    const unsigned a_rd0 = lds0 + (unsigned)((wm * 128 + l31) * C2_ROWB) + off0;
+    const unsigned w_rd0 = lds0 + (unsigned)(C2_BM * C2_ROWB + (wnn * 128 + l31) * C2_ROWB) + off0;
+#define C2_RD(base, ks, stage_off) (((base) ^ (unsigned)((ks) << 5)) + (stage_off))
+
+    f32x16 acc[16];  // acc[4 nt + mt]: channels wnn * 128 + 32 nt + (accumulator rows), output rows wm * 128 + 32 mt + (lanes)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    bf16x8 Ax[4], Wx[4], Ay[4], Wy[4];  // fragment sets X / Y alternate between sub-steps (4 per step: a step starts on X)
+
+    C2_ISSUE8(a_dst(0), pa, a_base(0))
+    C2_ISSUE8(w_dst(0), pw, w_base(0))
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    C2_ISSUE8(a_dst(1), pa, a_base(1))
+    {  // fragments of step 0, sub-step 0
+        const unsigned an_ = a_rd0, wn_ = w_rd0;
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:4096\n\tds_read_b128 %2, %8 offset:8192\n\t"
+                     "ds_read_b128 %3, %8 offset:12288\n\tds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:4096\n\t"
+                     "ds_read_b128 %6, %9 offset:8192\n\tds_read_b128 %7, %9 offset:12288"
+                     : "=&v"(Ax[0]), "=&v"(Ax[1]), "=&v"(Ax[2]), "=&v"(Ax[3]), "=&v"(Wx[0]), "=&v"(Wx[1]), "=&v"(Wx[2]),
+                       "=&v"(Wx[3])
+                     : "v"(an_), "v"(wn_)
+                     : "memory");
+    }
+    // K step kt: sub-step blocks 0..2 read on in stage kt & 1; block 0 also requests the W slab of step kt+1 (the other
+    // stage: free since the barrier that closed step kt-1).  Block 3 first waits for this wave's last fragments
+    // (inside the block: lgkmcnt) and for its share of step kt+1 (vmcnt), then the barrier publishes step kt+1 and
+    // frees stage kt & 1, into which the block requests the A slab of step kt+2 while it prefetches the first fragments
+    // of step kt+1.
+#define C2_PRE3 "s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)\n\ts_barrier\n\t"
+    for (int kt = 0; kt < C2_KSTEPS; ++kt) {
+        const unsigned so = (unsigned)((kt & 1) * C2_STAGE), sn = (unsigned)(((kt + 1) & 1) * C2_STAGE);
+        {
+            const unsigned an_ = C2_RD(a_rd0, 1, so), wn_ = C2_RD(w_rd0, 1, so);
+            if (kt + 1 < C2_KSTEPS) {
+                const unsigned st_ = w_dst(kt + 1);
+                const unsigned char* sb_ = w_base(kt + 1);
+                const unsigned* vo = pw;
+                C2_BLOCK("", Ax, Wx, Ay, Wy, C2_DMA_I, vo);
+            } else {
+                const unsigned st_ = 0;
+                const unsigned char* sb_ = p.W;
+                const unsigned* vo = pw;
+                C2_BLOCK("", Ax, Wx, Ay, Wy, C2_NODMA, vo);
+            }
+        }
+        {
+            const unsigned an_ = C2_RD(a_rd0, 2, so), wn_ = C2_RD(w_rd0, 2, so);
+            const unsigned st_ = 0;
+            const unsigned char* sb_ = p.W;
+            const unsigned* vo = pw;
+            C2_BLOCK("", Ay, Wy, Ax, Wx, C2_NODMA, vo);
+        }
+        {
+            const unsigned an_ = C2_RD(a_rd0, 3, so), wn_ = C2_RD(w_rd0, 3, so);
+            const unsigned st_ = 0;
+            const unsigned char* sb_ = p.W;
+            const unsigned* vo = pw;
+            C2_BLOCK("", Ax, Wx, Ay, Wy, C2_NODMA, vo);
+        }
+        {
+            const unsigned an_ = a_rd0 + sn, wn_ = w_rd0 + sn;
+            if (kt + 2 < C2_KSTEPS) {
+                const unsigned st_ = a_dst(kt + 2);
+                const unsigned char* sb_ = a_base(kt + 2);
+                const unsigned* vo = pa;
+                C2_BLOCK(C2_PRE3, Ay, Wy, Ax, Wx, C2_DMA_I, vo);
+            } else {
+                const unsigned st_ = 0;
+                const unsigned char* sb_ = p.W;
+                const unsigned* vo = pa;
+                C2_BLOCK(C2_PRE3, Ay, Wy, Ax, Wx, C2_NODMA, vo);
+            }
+        }
+    }
+    asm volatile("s_nop 13\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // MFMA results -> vector reads below
+
+    // ---- epilogue: + bias, ReLU, bf16, through LDS (row image of the tile), out as contiguous 512-byte rows
+    __syncthreads();
+    {
+        unsigned char* orow = smem + (wm * 128 + l31) * C2_OSTRIDE + (wnn * 128 + 4 * half) * 2;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 bv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(p.bias + wnn * 128 + 32 * nt + 8 * g + 4 * half);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)fmaxf(acc[4 * nt + mt][4 * g + e] + bv[g][e], 0.f);
+                    *reinterpret_cast<bf16x4*>(orow + mt * 32 * C2_OSTRIDE + (32 * nt + 8 * g) * 2) = o;
+                }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+        const int row = 8 * it + (tid >> 5), ch = tid & 31;
+        const int m = m0 + row;
+        if (m < p.M)
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + (long long)m * 512 + ch * 16) =
+                *reinterpret_cast<const uint4*>(smem + row * C2_OSTRIDE + ch * 16);
+    }
+}
+
+// bf16, 256 -> 256 channels only; everything else stays on the generic implicit GEMM (gemm.hip)
+bool conv2_dma_applies(int prec, int C, int N) { return prec == CN_PREC_BF16 && C == C2_C && N == C2_N && !getenv("CASSNAT_NO_CONV2_DMA"); }
+
+// `in`: conv1 output WITH the zero halo, [B][T1 + 2][F1 + 2][256] bf16
+int launch_conv2_dma(const void* in, const void* w, const float* bias, void* out, int B, int T1, int F1, int T2, int F2,
+                     hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS));
+        attr_done = true;
+    }
+    Conv2Params p;
+    p.A = (const unsigned char*)in;
+    p.W = (const unsigned char*)w;
+    p.bias = bias;
+    p.out = (bf16*)out;
+    p.M = B * T2 * F2;
+    p.T1 = T1;
+    p.F1 = F1;
+    p.T2 = T2;
+    p.F2 = F2;
+    p.ntiles = cn_ceil_div(p.M, C2_BM);
+    if (p.M <= 0) return 0;
+    hipLaunchKernelGGL(conv2_kernel, dim3(p.ntiles), dim3(256), C2_LDS, s, p);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -287,5 +287,12 @@ template <typename T> static int dispatch_gemm(const GemmArgs& a, hipStream_t s)
 }
 
 int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
+    if (a.conv && a.conv_halo) {
+        if (!(a.epi == CN_EPI_RELU && a.ldc == a.N && conv2_dma_applies(prec, a.cC, a.N))) {
+            cn_set_error("gemm: a haloed conv input is only understood by the bf16 256-channel conv2 kernel");
+            return -1;
+        }
+        return launch_conv2_dma(a.A, a.W, a.bias, a.C, a.cB, a.cT1, a.cF1, a.cT2, a.cF2, s);
+    }
     return prec == CN_PREC_F32 ? dispatch_gemm<float>(a, s) : dispatch_gemm<bf16>(a, s);
 }

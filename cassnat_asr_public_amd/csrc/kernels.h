@@ -26,6 +26,7 @@ struct GemmArgs {
     // implicit-GEMM A operand for the second 3x3/stride-2 subsampling convolution:
     // A[m=(b,t2,f2)][k=(kh,kw,c)] = conv1[b][2*t2+kh-1][2*f2+kw-1][c] (channels-last), zero outside.
     int conv = 0;
+    int conv_halo = 0;  // the input image carries a one-cell zero halo: [B][T1 + 2][F1 + 2][C] (conv1 with halo = 1)
     int cB = 0, cT1 = 0, cF1 = 0, cC = 0, cT2 = 0, cF2 = 0;
 };
 int launch_gemm(int prec, const GemmArgs& a, hipStream_t s);
@@ -33,7 +34,7 @@ int launch_gemm(int prec, const GemmArgs& a, hipStream_t s);
 // ---- first subsampling convolution, 1 -> C channels, 3x3 stride 2 pad 1, + ReLU   (conv1.hip)
 // x (B,T,F) fp32  ->  out (B,T1,F1,C) channels-last in model precision.  w is [9][C] (tap-major).
 int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1,
-                 int F1, int C, hipStream_t s);
+                 int F1, int C, int halo, hipStream_t s);
 
 // ---- row kernels                                                                  (rowops.hip)
 // y = a_2 * (x - mean) / (std_unbiased + eps) + b_2 ; x fp32 [M][d] ; y model precision (or fp32 if y_f32)
@@ -105,6 +106,11 @@ struct FfnFusedArgs {
 int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s);
 void pack_ffn_w1(const float* w1, int dff, uint16_t* out);  // [dff][256] fp32 -> fragment stream (dff*256 bf16)
 void pack_ffn_w2(const float* w2, int dff, uint16_t* out);  // [256][dff] fp32 -> fragment stream (dff*256 bf16)
+
+// ---- conv2 as an LDS-DMA implicit GEMM, bf16 / 256 -> 256 channels (conv2.hip); launch_gemm dispatches to it
+bool conv2_dma_applies(int prec, int C, int N);
+int launch_conv2_dma(const void* in, const void* w, const float* bias, void* out, int B, int T1, int F1, int T2, int F2,
+                     hipStream_t s);
 
 // ---- row-chain kernel, bf16 / d_model == 256: out-projection + residual, FFN sublayer + residual, next pre-norm and the
 // next attention's input projection for 128-row blocks, activations in registers, weights streamed once per block (chain.hip)

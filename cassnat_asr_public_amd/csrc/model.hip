@@ -614,7 +614,7 @@ int build_workspace(cn_model* m) {
     const size_t M = B * (Tp + 1);  // decoder rows can reach B*(T'+1)
     const size_t dff = std::max(c.d_encff, c.d_decff);
     CN_TRY(dev_alloc(m, (void**)&m->keymask, B * Tp));
-    CN_TRY(dev_alloc(m, &m->c1, B * T1 * F1 * d * es));
+    CN_TRY(dev_alloc(m, &m->c1, B * (T1 + 2) * (F1 + 2) * d * es));  // room for the zero halo the bf16 conv2 kernel wants
     CN_TRY(dev_alloc(m, &m->c2, B * Tp * F2 * d * es));
     CN_TRY(dev_alloc(m, (void**)&m->x, (M + 32) * d * 4));  // + one 32-row block: the chain kernel's blocked layout rounds up
     CN_TRY(dev_alloc(m, &m->xn, M * d * es));
@@ -905,14 +905,17 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     m->Tp = Tp;
     m->U = 0;
     CN_TRY(launch_keymask(feats, B, T, F, Tp, 4, (float)o->padding_idx, m->keymask, s));
+    // conv1 writes its image with a zero halo when the LDS-DMA conv2 kernel consumes it (captures want the plain image)
+    const int halo = (!cap && conv2_dma_applies(m->prec, d, d)) ? 1 : 0;
     {
         ProfScope ps(m, "conv1", 2.0 * 9 * B * T1 * F1 * d, (double)B * T * F * 4 + (double)B * T1 * F1 * d * m->es, s);
-        CN_TRY(launch_conv1(m->prec, feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, s));
+        CN_TRY(launch_conv1(m->prec, feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, halo, s));
     }
     if (cap) CN_TRY(capture(m, "conv1", m->c1, true, CN_DTYPE_F32, {B, T1, F1, d}, s));
     {
         GemmArgs g;
         g.A = m->c1;
+        g.conv_halo = halo;
         g.W = m->conv2.W;
         g.bias = m->conv2.b;
         g.C = m->c2;
@@ -1407,7 +1410,7 @@ extern "C" int cn_op_gemm(int32_t precision, const void* A, int32_t lda, const v
 
 extern "C" int cn_op_conv1(int32_t precision, const float* x, const float* w9c, const float* bias, void* out, int32_t B,
                            int32_t T, int32_t F, int32_t C, void* stream) {
-    return launch_conv1(precision, x, w9c, bias, out, B, T, F, (T - 1) / 2 + 1, (F - 1) / 2 + 1, C, (hipStream_t)stream);
+    return launch_conv1(precision, x, w9c, bias, out, B, T, F, (T - 1) / 2 + 1, (F - 1) / 2 + 1, C, 0, (hipStream_t)stream);
 }
 
 extern "C" int cn_op_conv2(int32_t precision, const void* conv1_out, const void* w_khwc, const float* bias, void* out,
@@ -1430,7 +1433,27 @@ extern "C" int cn_op_conv2(int32_t precision, const void* conv1_out, const void*
     g.cC = C;
     g.cT2 = T2;
     g.cF2 = F2;
-    return launch_gemm(precision, g, (hipStream_t)stream);
+    if (!conv2_dma_applies(precision, C, C)) return launch_gemm(precision, g, (hipStream_t)stream);
+    // bf16, 256 channels: the LDS-DMA kernel reads an image with a one-cell zero halo (the model has conv1 write it that
+    // way); this test entry pads a copy of the plain image
+    const size_t cell = (size_t)C * 2, prow = (size_t)(F1 + 2) * cell;
+    void* padded = nullptr;
+    CN_HIP_CHECK(hipMalloc(&padded, (size_t)B * (T1 + 2) * prow));
+    CN_HIP_CHECK(hipMemsetAsync(padded, 0, (size_t)B * (T1 + 2) * prow, (hipStream_t)stream));
+    for (int b = 0; b < B; ++b)
+        CN_HIP_CHECK(hipMemcpy2DAsync((unsigned char*)padded + ((size_t)b * (T1 + 2) + 1) * prow + cell, prow,
+                                      (const unsigned char*)conv1_out + (size_t)b * T1 * F1 * cell, (size_t)F1 * cell,
+                                      (size_t)F1 * cell, T1, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    g.A = padded;
+    g.conv_halo = 1;
+    int rc = launch_gemm(precision, g, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(padded);
+    if (rc == 0 && e != hipSuccess) {
+        cn_set_error(std::string("cn_op_conv2: ") + hipGetErrorString(e));
+        rc = -2;
+    }
+    return rc;
 }
 
 extern "C" int cn_op_layernorm(int32_t precision, const float* x, const float* a2, const float* b2, void* y, int32_t M,

@@ -104,7 +104,8 @@ def test_gemm_rejects_bad_k():
 
 # ----------------------------------------------------------------------------------------------- convs
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("B,T,Fd,Cc", [(2, 61, 80, 128), (1, 8, 6, 64), (3, 100, 83, 64)])
+@pytest.mark.parametrize("B,T,Fd,Cc", [(2, 61, 80, 128), (1, 8, 6, 64), (3, 100, 83, 64), (2, 61, 80, 256), (1, 9, 7, 256),
+                                       (3, 203, 80, 256)])
 def test_conv1_conv2(prec, B, T, Fd, Cc):
     g = torch.Generator().manual_seed(B * T)
     x = torch.randn(B, T, Fd, generator=g)
