@@ -9,16 +9,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
                                                     const float* __restrict__ bias, T* __restrict__ out, int B, int Tn,
                                                     int F, int T1, int F1, int C, int halo) {
-    // A thread keeps its 8 channels for the whole grid-stride loop (the stride is a multiple of C/8), so the
-    // 72 tap weights + 8 biases live in registers; per output position it issues 9 (wave-broadcast) loads,
-    // 72 FMAs and one 16-byte store.
+    // A thread keeps its 8 channels for the whole kernel, so the 72 tap weights + 8 biases live in registers; per
+    // output position it issues 9 (broadcast) loads, 72 FMAs and one 16-byte store.
     const int cg = C >> 3;
     // halo = 1: the image is written as [B][T1 + 2][F1 + 2][C] with a border of zeros (the padding of the second
-    // convolution, conv2.hip): the grid then covers the border cells too
+    // convolution, conv2.hip): the grid then covers the border cells too.
+    // Work decomposition: a workgroup takes whole image rows (b, t1) in a grid-stride loop (one 32-bit division per
+    // row, not four 64-bit ones per output); inside a row its 256 threads are (256 / cg) positions x cg channel groups.
     const int T1p = T1 + 2 * halo, F1p = F1 + 2 * halo;
-    const long long total = (long long)B * T1p * F1p * cg;
-    const long long first = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int c0 = (int)(first % cg) << 3;
+    const int c0 = (int)(threadIdx.x % cg) << 3;
+    const int p0 = threadIdx.x / cg, pstep = 256 / cg;
     float w[9][8], bz[8];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -26,51 +26,59 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
         for (int j = 0; j < 8; ++j) w[tap][j] = w9c[tap * C + c0 + j];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bz[j] = bias[c0 + j];
-    const long long stride = (long long)gridDim.x * 256;  // launcher keeps this a multiple of cg
-    for (long long idx = first; idx < total; idx += stride) {
-        const long long pos = idx / cg;
-        const int f1 = (int)(pos % F1p) - halo;
-        const long long bt = pos / F1p;
-        const int t1 = (int)(bt % T1p) - halo, b = (int)(bt / T1p);
-        T* dst = out + pos * C + c0;
-        if (t1 < 0 || t1 >= T1 || f1 < 0 || f1 >= F1) {  // border cell
-            if constexpr (sizeof(T) == 2) {
-                *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
-            } else {
-                *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(dst + 4) = make_uint4(0, 0, 0, 0);
-            }
-            continue;
-        }
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = bz[j];
+    const int rows = B * T1p;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int b = row / T1p, t1 = row - b * T1p - halo;
+        T* orow = out + (long long)row * F1p * C + c0;
+        const bool row_in = t1 >= 0 && t1 < T1;
+        // the three input rows of this output row (null = outside the padded input)
+        const float* xr[3];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int t = 2 * t1 - 1 + kh;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int f = 2 * f1 - 1 + kw;
-                float v = 0.f;
-                if (t >= 0 && t < Tn && f >= 0 && f < F) v = x[((long long)b * Tn + t) * F + f];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, w[kh * 3 + kw][j], acc[j]);
-            }
+            xr[kh] = (row_in && t >= 0 && t < Tn) ? x + ((long long)b * Tn + t) * F : nullptr;
         }
-        if constexpr (sizeof(T) == 2) {
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf(acc[j], 0.f);
-            *reinterpret_cast<bf16x8*>(dst) = o;
-        } else {
-            f32x4 o0, o1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o0[j] = fmaxf(acc[j], 0.f);
-                o1[j] = fmaxf(acc[4 + j], 0.f);
+        for (int fp = p0; fp < F1p; fp += pstep) {
+            const int f1 = fp - halo;
+            T* dst = orow + (long long)fp * C;
+            if (!row_in || f1 < 0 || f1 >= F1) {  // border cell
+                if constexpr (sizeof(T) == 2) {
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
+                } else {
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(dst + 4) = make_uint4(0, 0, 0, 0);
+                }
+                continue;
             }
-            *reinterpret_cast<f32x4*>(dst) = o0;
-            *reinterpret_cast<f32x4*>(dst + 4) = o1;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = bz[j];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int f = 2 * f1 - 1 + kw;
+                    float v = 0.f;
+                    if (xr[kh] && f >= 0 && f < F) v = xr[kh][f];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, w[kh * 3 + kw][j], acc[j]);
+                }
+            }
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf(acc[j], 0.f);
+                *reinterpret_cast<bf16x8*>(dst) = o;
+            } else {
+                f32x4 o0, o1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o0[j] = fmaxf(acc[j], 0.f);
+                    o1[j] = fmaxf(acc[4 + j], 0.f);
+                }
+                *reinterpret_cast<f32x4*>(dst) = o0;
+                *reinterpret_cast<f32x4*>(dst + 4) = o1;
+            }
         }
     }
 }
@@ -81,9 +89,8 @@ int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, 
         cn_set_error("conv1: channel count must be a multiple of 8 with C/8 dividing 256");
         return -1;
     }
-    const long long total = (long long)B * (T1 + 2 * halo) * (F1 + 2 * halo) * (C / 8);
-    long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;  // 8 workgroups per CU, grid-stride the rest (256 threads % (C/8) == 0)
+    long long blocks = (long long)B * (T1 + 2 * halo);  // one image row per workgroup pass
+    if (blocks > 256 * 8) blocks = 256 * 8;             // 8 workgroups per CU, grid-stride the rest
     if (blocks < 1) blocks = 1;
     const size_t lds = 0;
     if (prec == CN_PREC_F32)

@@ -1,0 +1,49 @@
+"""Summarise rocprofv3 --pmc passes (separate runs for FETCH_SIZE and WRITE_SIZE, CSV output) into the per-launch HBM
+traffic figures bench.py's roofline objects quote.
+
+    python tools/pmc_summary.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <out dir (profiles/)>
+
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read,
+so it is doubled; WRITE_SIZE is exact.  Both are reported by rocprofv3 in KiB-like units of 1000... no: in KB (x1024 B).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    fdir, wdir, out = sys.argv[1:4]
+    fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
+    targets = {"row_chain": ("chain_kernel", "chain_kernel (all 21 launches of a step: 12 encoder at 8000 rows, 9 decoder-side)"),
+               "conv2": ("conv2_kernel", "conv2_kernel (LDS-DMA implicit GEMM, B=32 x 1000 frames)")}
+    for tag, (needle, label) in targets.items():
+        fk = [v for k, vs in fetch.items() if needle in k for v in vs]
+        wk = [v for k, vs in write.items() if needle in k for v in vs]
+        if not fk or not wk:
+            print("no samples for", needle)
+            continue
+        f_kb, w_kb = sum(fk) / len(fk), sum(wk) / len(wk)
+        rec = {"kernel": label,
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 1 --streams 1",
+               "launches_sampled": len(fk), "FETCH_SIZE_KB_per_launch": round(f_kb), "WRITE_SIZE_KB_per_launch": round(w_kb),
+               "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request for wide (16 B/lane) coalesced reads: doubled "
+                             "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
+               "hbm_bytes_per_launch": round((2 * f_kb + w_kb) * 1024)}
+        json.dump(rec, open(os.path.join(out, f"pmc_{tag}.json"), "w"), indent=2)
+        print(tag, rec)
+
+
+if __name__ == "__main__":
+    main()
