@@ -53,6 +53,17 @@ def config2_b8_case():
     return args, state, feats, sizes
 
 
+def config5_shape_case():
+    """BASELINE configs[4] shape: V = 4230 + 4 characters, same 12L / 1-3-2 model, B=4 ragged."""
+    from cassnat_asr_public_amd import synth
+
+    args = synth.make_args("config2", vocab_size=4234)
+    state = synth.make_state(args, seed=5, blank_bias=0.35)
+    lens = synth.ragged_lengths(4, 600, 300, seed=9)
+    feats, sizes = synth.make_feats(4, 600, 80, lengths=lens, seed=77)
+    return args, state, feats, sizes
+
+
 def config2_b32_case():
     """The benchmark workload (bench.py): B=32 x 1000 frames, blank bias 0.9."""
     from cassnat_asr_public_amd import synth

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import config1_case, config2_b8_case, config2_b32_case, load_golden, tiny_case
+from conftest import config1_case, config2_b8_case, config2_b32_case, config5_shape_case, load_golden, tiny_case
 from cassnat_asr_public_amd import hip, synth
 from cassnat_asr_public_amd.models.cassnat import make_model
 
@@ -131,6 +131,7 @@ def check_against_golden(model, args, feats, sizes, g, st, sv, dt, fp32):
     (config1_case, "config1", (7, 13, 5)),
     (config2_b8_case, "config2_b8", (10, 50, 4)),
     (config2_b32_case, "config2_b32", (25, 100, 8)),
+    (config5_shape_case, "config5_shape", (10, 50, 4)),
 ])
 def test_fp32_parity_gate(case, name, strides, capsys):
     g = load_golden(name)
@@ -144,6 +145,7 @@ def test_fp32_parity_gate(case, name, strides, capsys):
 @pytest.mark.parametrize("case,name,strides", [
     (config2_b8_case, "config2_b8", (10, 50, 4)),
     (config2_b32_case, "config2_b32", (25, 100, 8)),
+    (config5_shape_case, "config5_shape", (10, 50, 4)),
 ])
 def test_bf16_agreement_report(case, name, strides, capsys):
     g = load_golden(name)

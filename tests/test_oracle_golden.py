@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ast_config4_case, ast_tiny_case, config1_case, config2_b8_case, config2_b32_case, load_golden, tiny_case
+from conftest import (ast_config4_case, ast_tiny_case, config1_case, config2_b8_case, config2_b32_case, config5_shape_case,
+                      load_golden, tiny_case)
 from oracle import cassnat_oracle as orc
 
 FTOL = 2e-5
@@ -114,6 +115,14 @@ def test_config2_shape_ragged_batch():
     _check_big(out, g, 10, 50, 4)
     _close(out["enc_h"][:, ::10, ::8], g["enc_sample"], 1e-4)
     _close(out["enc_layers"][0][:, ::10, ::8], g["enc_layer0_sample"], 1e-4)
+
+
+def test_config5_shape_vocab_4234():
+    g = load_golden("config5_shape")
+    args, state, feats, sizes = config5_shape_case()
+    out = orc.decode_nast(state, feats, sizes, args, stages=True)
+    _check_big(out, g, 10, 50, 4)
+    _close(out["enc_h"][:, ::10, ::8], g["enc_sample"], 1e-4)
 
 
 def test_config2_bench_workload():
