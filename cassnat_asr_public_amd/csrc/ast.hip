@@ -254,3 +254,160 @@ int launch_ast_ctc_prefix(const CtcPrefixArgs& a, hipStream_t s) {
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Device-side beam bookkeeping of Transformer.beam_decode (src/models/transformer.py:157-240).  Hypothesis slot s =
+// b * bw + j is also its KV-cache slot; every slot runs every step (finished / unused ones compute on dummies and are
+// ignored), so nothing is compacted and nothing returns to the host inside the loop.  One workgroup per utterance:
+// <= bw finished hypotheses are carried, every live hypothesis contributes its top-bw of K candidates (stable order,
+// like the host path's stable argsort), all candidates are ranked by score + (len - 1) * length_penalty with ties in
+// list order (Python's stable sort), the best bw become the next beam.  Arithmetic follows the reference's types:
+// float32 for the per-candidate combination (no FMA contraction), Python-float (double) score accumulation and keys.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void ast_beam_init_kernel(AstBeamState st, int cur, int B, int bw, int L, int sos, int pad) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B * bw) return;
+    const int b = s / bw, j = s - b * bw;
+    for (int t = 0; t < L; ++t) {
+        st.tok[cur][(long long)s * L + t] = t == 0 ? sos : pad;
+        st.anc[cur][(long long)s * L + t] = s;
+        st.keyok[cur][(long long)s * L + t] = (t == 0 && sos != pad) ? 1 : 0;
+    }
+    st.len[cur][s] = 1;
+    st.score[cur][s] = 0.0;
+    st.valid[cur][s] = j == 0;
+    st.ctc_ref[cur][s] = -1 - b;
+    st.ctc_prev[cur][s] = 0.f;
+    st.cur_tok[s] = sos;
+    st.utt[s] = b;
+    if (s == 0) *st.live = B;
+}
+
+constexpr int BEAM_MAXW = 16, BEAM_MAXC = BEAM_MAXW + BEAM_MAXW * BEAM_MAXW;
+
+__global__ __launch_bounds__(128) void ast_beam_update_kernel(AstBeamState st, AstBeamStep q) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int bw = q.bw, K = q.K, L = q.L, cur = q.cur, nxt = cur ^ 1;
+    __shared__ double ckey[BEAM_MAXC], cscore[BEAM_MAXC];
+    __shared__ int cpar[BEAM_MAXC], ccand[BEAM_MAXC], ctok[BEAM_MAXC], newslot[BEAM_MAXW];
+    __shared__ float cctc[BEAM_MAXC], loc[BEAM_MAXW][BEAM_MAXW];
+    __shared__ int fin_idx[BEAM_MAXW], live_idx[BEAM_MAXW], nf_s, nl_s;
+    if (tid == 0) {
+        int nf = 0, nl = 0;
+        for (int j = 0; j < bw; ++j) {
+            const int s = b * bw + j;
+            if (!st.valid[cur][s]) continue;
+            const int last = st.tok[cur][(long long)s * L + st.len[cur][s] - 1];
+            if (last == q.eos) fin_idx[nf++] = j; else live_idx[nl++] = j;
+        }
+        nf_s = nf;
+        nl_s = nl;
+    }
+    if (tid < BEAM_MAXW) newslot[tid] = -1;
+    __syncthreads();
+    const int nf = nf_s, nl = nl_s;
+    if (tid < nf) {  // finished hypotheses are carried as they are
+        const int s = b * bw + fin_idx[tid];
+        const double sc = st.score[cur][s];
+        cscore[tid] = sc;
+        ckey[tid] = q.use_lp ? sc + (double)(st.len[cur][s] - 1) * q.lp : sc;
+        cpar[tid] = fin_idx[tid];
+        ccand[tid] = -1;
+    }
+    for (int i = tid; i < nl * K; i += 128) {
+        const int li = i / K, c = i - li * K;
+        const int s = b * bw + live_idx[li];
+        const float att = q.att[(long long)s * K + c];
+        // local = ctc_weight * (ctc - prev) + (1 - ctc_weight) * att, float32, one rounding per operation (transformer.py:205-206)
+        loc[li][c] = q.use_ctc ? __fadd_rn(__fmul_rn(q.w, __fsub_rn(q.ctc[(long long)s * K + c], st.ctc_prev[cur][s])), __fmul_rn(q.u, att))
+                               : att;
+    }
+    __syncthreads();
+    for (int i = tid; i < nl * K; i += 128) {
+        const int li = i / K, c = i - li * K;
+        const float v = loc[li][c];
+        int r = 0;
+        for (int c2 = 0; c2 < K; ++c2) r += (loc[li][c2] > v) || (loc[li][c2] == v && c2 < c);
+        if (r < bw) {
+            const int j = live_idx[li], s = b * bw + j, e = nf + li * bw + r;
+            const double sc = st.score[cur][s] + (double)v;
+            cscore[e] = sc;
+            ckey[e] = q.use_lp ? sc + (double)st.len[cur][s] * q.lp : sc;  // new length - 1 = old length
+            cpar[e] = j;
+            ccand[e] = c;
+            ctok[e] = q.idx[(long long)s * K + c];
+            cctc[e] = q.use_ctc ? q.ctc[(long long)s * K + c] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int ncand = nf + nl * (K < bw ? K : bw);
+    for (int e = tid; e < ncand; e += 128) {
+        const double k = ckey[e];
+        int r = 0;
+        for (int e2 = 0; e2 < ncand; ++e2) r += (ckey[e2] > k) || (ckey[e2] == k && e2 < e);
+        if (r < bw) newslot[r] = e;
+    }
+    __syncthreads();
+    int live_new = 0;
+    for (int qn = 0; qn < bw; ++qn) {
+        const int e = newslot[qn];
+        const int sn = b * bw + qn;
+        if (e < 0) {  // fewer candidates than beam slots: an unused slot with harmless inputs for the next step
+            for (int t = tid; t < L; t += 128) st.anc[nxt][(long long)sn * L + t] = sn;
+            if (tid == 0) {
+                st.valid[nxt][sn] = 0;
+                st.len[nxt][sn] = 1;
+                st.score[nxt][sn] = 0.0;
+                st.ctc_ref[nxt][sn] = -1 - b;
+                st.ctc_prev[nxt][sn] = 0.f;
+                st.cur_tok[sn] = q.sos;
+            }
+            continue;
+        }
+        const int so = b * bw + cpar[e];
+        const int len_o = st.len[cur][so];
+        const bool grown = ccand[e] >= 0;
+        for (int t = tid; t < L; t += 128) {
+            int tk = st.tok[cur][(long long)so * L + t], an = st.anc[cur][(long long)so * L + t];
+            unsigned char ko = st.keyok[cur][(long long)so * L + t];
+            if (grown) {
+                if (t == len_o) {
+                    tk = ctok[e];
+                    ko = ctok[e] != q.pad;
+                }
+                if (t == q.pos) an = so;       // position pos was computed in the parent's slot this step
+                if (t == q.pos + 1) an = sn;   // the next position will be computed in this slot
+            }
+            st.tok[nxt][(long long)sn * L + t] = tk;
+            st.anc[nxt][(long long)sn * L + t] = an;
+            st.keyok[nxt][(long long)sn * L + t] = ko;
+        }
+        if (tid == 0) {
+            st.valid[nxt][sn] = 1;
+            st.len[nxt][sn] = len_o + (grown ? 1 : 0);
+            st.score[nxt][sn] = cscore[e];
+            st.ctc_ref[nxt][sn] = grown ? so * K + ccand[e] : st.ctc_ref[cur][so];
+            st.ctc_prev[nxt][sn] = grown ? cctc[e] : st.ctc_prev[cur][so];
+            st.cur_tok[sn] = grown ? ctok[e] : q.eos;
+        }
+        live_new += grown && ctok[e] != q.eos;
+    }
+    if (tid == 0 && live_new) atomicAdd(st.live, live_new);
+}
+
+int launch_ast_beam_init(const AstBeamState& st, int cur, int B, int bw, int L, int sos, int pad, hipStream_t s) {
+    hipLaunchKernelGGL(ast_beam_init_kernel, dim3(cn_ceil_div(B * bw, 64)), dim3(64), 0, s, st, cur, B, bw, L, sos, pad);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_ast_beam_update(const AstBeamState& st, const AstBeamStep& q, int B, hipStream_t s) {
+    if (q.bw < 1 || q.bw > BEAM_MAXW || q.K < 1 || q.K > BEAM_MAXW) {
+        cn_set_error("ast beam: beam_width and candidate count must be in 1..16");
+        return -1;
+    }
+    CN_HIP_CHECK(hipMemsetAsync(st.live, 0, sizeof(int), s));
+    hipLaunchKernelGGL(ast_beam_update_kernel, dim3(B), dim3(128), 0, s, st, q);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}

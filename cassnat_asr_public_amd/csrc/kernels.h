@@ -186,4 +186,28 @@ struct CtcPrefixArgs {
     int n, K, Tp, V, blank, eos, out_len;
 };
 int launch_ast_ctc_prefix(const CtcPrefixArgs& a, hipStream_t s);
+// device-side beam state of the autoregressive search (double buffered: [cur], [cur ^ 1]); S = B * beam_width slots, L = max length
+struct AstBeamState {
+    int* tok[2];              // [S][L] hypothesis tokens (sos first)
+    int* anc[2];              // [S][L] KV-cache slot that produced each position
+    unsigned char* keyok[2];  // [S][L] token != padding_idx
+    int* len[2];              // [S]
+    double* score[2];         // [S]
+    int* valid[2];            // [S]
+    int* ctc_ref[2];          // [S] row of the previous step's CTC states (< 0: initial state of utterance -1-ref)
+    float* ctc_prev[2];       // [S] CTC prefix score of the hypothesis
+    int* cur_tok;             // [S] newest token = the next step's input
+    int* utt;                 // [S] utterance of the slot
+    int* live;                // [1] live hypotheses after the last update
+};
+struct AstBeamStep {
+    const int* idx;    // [S][K] candidate tokens of this step
+    const float* att;  // [S][K] their attention log-probabilities (sorted, best first)
+    const float* ctc;  // [S][K] CTC prefix scores (use_ctc)
+    int cur, pos, bw, K, L, eos, sos, pad, use_ctc, use_lp;
+    float w, u;        // ctc_weight, 1 - ctc_weight as float32
+    double lp;
+};
+int launch_ast_beam_init(const AstBeamState& st, int cur, int B, int bw, int L, int sos, int pad, hipStream_t s);
+int launch_ast_beam_update(const AstBeamState& st, const AstBeamStep& q, int B, hipStream_t s);
 int launch_logsoftmax_temp(float* logits, int M, int V, int ldl, float temperature, int* arg, float* maxlp, hipStream_t s);

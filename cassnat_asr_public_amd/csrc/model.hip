@@ -141,6 +141,10 @@ struct cn_model {
     float *ast_logits = nullptr, *ast_r0 = nullptr, *ast_r[2] = {nullptr, nullptr}, *ast_maxlp = nullptr;
     int* ast_arg = nullptr;
     std::vector<void*> ast_allocs;
+    AstBeamState beam;  // device-side beam search state (cn_decode_ast)
+    int beam_S = 0, beam_L = 0, beam_K = 0;
+    int *beam_idx = nullptr;
+    float *beam_val = nullptr, *beam_ctc = nullptr;
 
     // last call
     int B = 0, T = 0, T1 = 0, Tp = 0, U = 0, last_k = 0;
@@ -1679,6 +1683,7 @@ int ast_prepare_buffers(cn_model* m, int max_len, int max_slots, int ctc_beam) {
         return 0;
     for (void* q : m->ast_allocs) (void)hipFree(q);
     m->ast_allocs.clear();
+    m->beam_S = m->beam_L = m->beam_K = 0;  // the beam-search state lives in the same allocation list
     m->ast_kvx.clear();
     m->ast_ck.clear();
     m->ast_cv.clear();
@@ -1734,20 +1739,11 @@ extern "C" int cn_ast_begin(cn_model* m, const float* feats_dev, int32_t B, int3
     return 0;
 }
 
-extern "C" int cn_ast_step(cn_model* m, int32_t n, int32_t pos, const int32_t* tok_dev, const int32_t* utt_dev,
-                           const int32_t* anc_dev, const uint8_t* keyok_dev, int32_t table_stride, float temperature,
-                           int32_t K, int32_t* topk_idx_dev, float* topk_val_dev, void* stream) {
-    if (!m || !m->cfg.ast || m->ast_slots == 0) {
-        cn_set_error("cn_ast_step: call cn_ast_begin first");
-        return -1;
-    }
-    if (n < 1 || n > m->ast_slots || pos < 0 || pos >= m->ast_max_len || pos >= m->pe_rows || K < 1 || K > 16 ||
-        table_stride <= pos) {
-        cn_set_error("cn_ast_step: live rows / position / K outside the configured cache");
-        return -1;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+namespace {
+// decoder layers on the newest position of n hypotheses -> top-K (token, temperature log-softmax value) per hypothesis
+int ast_step_run(cn_model* m, int n, int pos, const int32_t* tok_dev, const int32_t* utt_dev, const int32_t* anc_dev,
+                 const uint8_t* keyok_dev, int table_stride, float temperature, int K, int32_t* topk_idx_dev,
+                 float* topk_val_dev, hipStream_t s) {
     const cn_config& c = m->cfg;
     const int d = c.d_model, V = c.vocab_size, H = c.n_head;
     const float scale = 1.0f / sqrtf((float)(d / H));
@@ -1810,6 +1806,24 @@ extern "C" int cn_ast_step(cn_model* m, int32_t n, int32_t pos, const int32_t* t
     CN_TRY(launch_topk(m->ast_logits, n, V, V, K, topk_idx_dev, topk_val_dev, s));
     return 0;
 }
+}  // namespace
+
+extern "C" int cn_ast_step(cn_model* m, int32_t n, int32_t pos, const int32_t* tok_dev, const int32_t* utt_dev,
+                           const int32_t* anc_dev, const uint8_t* keyok_dev, int32_t table_stride, float temperature,
+                           int32_t K, int32_t* topk_idx_dev, float* topk_val_dev, void* stream) {
+    if (!m || !m->cfg.ast || m->ast_slots == 0) {
+        cn_set_error("cn_ast_step: call cn_ast_begin first");
+        return -1;
+    }
+    if (n < 1 || n > m->ast_slots || pos < 0 || pos >= m->ast_max_len || pos >= m->pe_rows || K < 1 || K > 16 ||
+        table_stride <= pos) {
+        cn_set_error("cn_ast_step: live rows / position / K outside the configured cache");
+        return -1;
+    }
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+    return ast_step_run(m, n, pos, tok_dev, utt_dev, anc_dev, keyok_dev, table_stride, temperature, K, topk_idx_dev, topk_val_dev,
+                        (hipStream_t)stream);
+}
 
 extern "C" int cn_ast_ctc_score(cn_model* m, int32_t n, int32_t out_len, const int32_t* utt_dev, const int32_t* last_tok_dev,
                                 const int32_t* cand_dev, int32_t K, const int32_t* prev_ref_dev, int32_t parity, int32_t eos,
@@ -1837,4 +1851,86 @@ extern "C" int cn_ast_ctc_score(cn_model* m, int32_t n, int32_t out_len, const i
     a.eos = eos;
     a.out_len = out_len;
     return launch_ast_ctc_prefix(a, (hipStream_t)stream);
+}
+
+// Whole joint CTC/attention beam search on the device (transformer.py:122-241): encoder, then max_step iterations of
+// [decoder step on every slot -> CTC prefix scores -> beam update kernel]; the host only polls the live-hypothesis
+// counter every 8 steps to stop early.  Outputs (device pointers): hyp_out [B][beam_width][max_len] (sos first, padded
+// with padding_idx), hyp_len [B][beam_width], score [B][beam_width] as double; beams best first.
+extern "C" int cn_decode_ast(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts,
+                             const cn_ast_opts* ao, int32_t* hyp_out_dev, int32_t max_len, int32_t* hyp_len_dev,
+                             double* score_dev, void* stream) {
+    if (!m || !opts || !ao || !hyp_out_dev || !hyp_len_dev || !score_dev) {
+        cn_set_error("cn_decode_ast: null argument");
+        return -1;
+    }
+    const int bw = ao->beam_width, want_ctc = ao->ctc_weight > 0.f ? 1 : 0;
+    const int K = want_ctc ? ao->ctc_beam : bw;
+    if (bw < 1 || bw > 16 || K < bw || K > 16 || ao->max_step < 1 || max_len < ao->max_step + 1) {
+        cn_set_error("cn_decode_ast: need 1 <= beam_width <= ctc_beam <= 16 and max_len > max_step");
+        return -1;
+    }
+    const int S = B * bw, L = max_len;
+    CN_TRY(cn_ast_begin(m, feats_dev, B, T, F, opts, want_ctc, L, S, want_ctc ? K : 0, stream));
+    hipStream_t s = (hipStream_t)stream;
+    if (m->beam_S < S || m->beam_L < L || m->beam_K < K) {
+        AstBeamState& st = m->beam;
+        for (int i = 0; i < 2; ++i) {
+            CN_TRY(ast_alloc(m, (void**)&st.tok[i], (size_t)S * L * 4));
+            CN_TRY(ast_alloc(m, (void**)&st.anc[i], (size_t)S * L * 4));
+            CN_TRY(ast_alloc(m, (void**)&st.keyok[i], (size_t)S * L));
+            CN_TRY(ast_alloc(m, (void**)&st.len[i], (size_t)S * 4));
+            CN_TRY(ast_alloc(m, (void**)&st.score[i], (size_t)S * 8));
+            CN_TRY(ast_alloc(m, (void**)&st.valid[i], (size_t)S * 4));
+            CN_TRY(ast_alloc(m, (void**)&st.ctc_ref[i], (size_t)S * 4));
+            CN_TRY(ast_alloc(m, (void**)&st.ctc_prev[i], (size_t)S * 4));
+        }
+        CN_TRY(ast_alloc(m, (void**)&st.cur_tok, (size_t)S * 4));
+        CN_TRY(ast_alloc(m, (void**)&st.utt, (size_t)S * 4));
+        CN_TRY(ast_alloc(m, (void**)&st.live, 64));
+        CN_TRY(ast_alloc(m, (void**)&m->beam_idx, (size_t)S * K * 4));
+        CN_TRY(ast_alloc(m, (void**)&m->beam_val, (size_t)S * K * 4));
+        CN_TRY(ast_alloc(m, (void**)&m->beam_ctc, (size_t)S * K * 4));
+        m->beam_S = S;
+        m->beam_L = L;
+        m->beam_K = K;
+    }
+    const AstBeamState& st = m->beam;
+    int cur = 0;
+    CN_TRY(launch_ast_beam_init(st, cur, B, bw, L, opts->sos, opts->padding_idx, s));
+    for (int pos = 0; pos < ao->max_step; ++pos) {
+        CN_TRY(ast_step_run(m, S, pos, st.cur_tok, st.utt, st.anc[cur], st.keyok[cur], L, ao->temperature, K, m->beam_idx,
+                            m->beam_val, s));
+        if (want_ctc)
+            CN_TRY(cn_ast_ctc_score(m, S, pos, st.utt, st.cur_tok, m->beam_idx, K, st.ctc_ref[cur], pos & 1, ao->eos, m->beam_ctc,
+                                    stream));
+        AstBeamStep q;
+        q.idx = m->beam_idx;
+        q.att = m->beam_val;
+        q.ctc = m->beam_ctc;
+        q.cur = cur;
+        q.pos = pos;
+        q.bw = bw;
+        q.K = K;
+        q.L = L;
+        q.eos = ao->eos;
+        q.sos = opts->sos;
+        q.pad = opts->padding_idx;
+        q.use_ctc = want_ctc;
+        q.use_lp = ao->use_length_penalty;
+        q.w = ao->ctc_weight;
+        q.u = ao->one_minus_ctc_weight;
+        q.lp = ao->length_penalty;
+        CN_TRY(launch_ast_beam_update(st, q, B, s));
+        cur ^= 1;
+        if ((pos & 7) == 7 && pos + 1 < ao->max_step) {  // every 8 steps: anything still alive?
+            CN_HIP_CHECK(hipMemcpyAsync(m->ymax_pinned + 8, st.live, sizeof(int), hipMemcpyDeviceToHost, s));
+            CN_HIP_CHECK(hipStreamSynchronize(s));
+            if (m->ymax_pinned[8] == 0) break;
+        }
+    }
+    CN_HIP_CHECK(hipMemcpyAsync(hyp_out_dev, st.tok[cur], (size_t)S * L * 4, hipMemcpyDeviceToDevice, s));
+    CN_HIP_CHECK(hipMemcpyAsync(hyp_len_dev, st.len[cur], (size_t)S * 4, hipMemcpyDeviceToDevice, s));
+    CN_HIP_CHECK(hipMemcpyAsync(score_dev, st.score[cur], (size_t)S * 8, hipMemcpyDeviceToDevice, s));
+    return 0;
 }

@@ -28,6 +28,12 @@ class CnDecodeOpts(C.Structure):
         "capture")] + [("reserved", C.c_int32 * 8)]
 
 
+class CnAstOpts(C.Structure):
+    _fields_ = [("ctc_weight", C.c_float), ("temperature", C.c_float), ("ctc_beam", C.c_int32), ("beam_width", C.c_int32),
+                ("max_step", C.c_int32), ("eos", C.c_int32), ("use_length_penalty", C.c_int32), ("one_minus_ctc_weight", C.c_float),
+                ("length_penalty", C.c_double), ("reserved", C.c_int32 * 4)]
+
+
 class HipError(RuntimeError):
     pass
 
@@ -91,6 +97,8 @@ def lib():
                                C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.cn_ast_step.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                               C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cn_decode_ast.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts),
+                                C.POINTER(CnAstOpts), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_ast_ctc_score.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.cn_profile_begin.argtypes = [C.c_void_p, C.c_char_p]
@@ -198,6 +206,12 @@ class Engine:
     def ast_ctc_score(self, out_len, utt, last_tok, cand, prev_ref, parity, eos, score):
         check(self.L.cn_ast_ctc_score(self.handle, cand.shape[0], out_len, _ptr(utt), _ptr(last_tok), _ptr(cand), cand.shape[1],
                                       _ptr(prev_ref), parity, eos, _ptr(score), current_stream()), "cn_ast_ctc_score")
+
+    def ast_decode(self, feats, opts, ast_opts, hyp, hyp_len, score):
+        """Whole beam search on the device: hyp int32 (B, beam, max_len), hyp_len int32 (B, beam), score float64 (B, beam)."""
+        B, T, F = feats.shape
+        check(self.L.cn_decode_ast(self.handle, _ptr(feats), B, T, F, C.byref(opts), C.byref(ast_opts), _ptr(hyp),
+                                   hyp.shape[2], _ptr(hyp_len), _ptr(score), current_stream()), "cn_decode_ast")
 
     def profile_begin(self, tags=None):
         """Start HIP-event timing of the tagged kernels (None = all) on the launch stream."""

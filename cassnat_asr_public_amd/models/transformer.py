@@ -2,11 +2,12 @@
 autoregressive (AST) model with joint CTC/attention beam search - BASELINE config 4, SURVEY 8a row a18.
 
 Same surface: ``make_model(input_size, args) -> Transformer`` with the reference's parameter names, and
-``Transformer.beam_decode(src, src_mask, vocab, args, lm_model=None) -> batch_top_seqs``.  The beam bookkeeping stays on
-the host, as in the reference (transformer.py:157-240); every device-side step - token embedding, the decoder layers on
-the NEW position only (keys/values of the prefix come from a KV cache addressed through per-hypothesis ancestor tables,
-the reference re-runs the decoder on the whole prefix), generator + log-softmax + top-k, and the CTC prefix scorer -
-runs as HIP kernels behind ``cn_ast_begin / cn_ast_step / cn_ast_ctc_score``.
+``Transformer.beam_decode(src, src_mask, vocab, args, lm_model=None) -> batch_top_seqs``.  By default the WHOLE search
+runs on the device (``cn_decode_ast``): token embedding, the decoder layers on the NEW position only (keys/values of
+the prefix come from a KV cache addressed through per-hypothesis ancestor tables; the reference re-runs the decoder
+on the whole prefix), generator + log-softmax + top-k, the CTC prefix scorer and the beam bookkeeping
+(transformer.py:157-240) - no host round trip per step.  ``args.hip_host_beam = True`` keeps the bookkeeping in
+Python over ``cn_ast_begin / cn_ast_step / cn_ast_ctc_score`` (same results; used to cross-check the device beam).
 """
 from types import SimpleNamespace
 
@@ -82,10 +83,28 @@ class Transformer(nn.Module):
         max_step = int(args.max_decode_ratio * Tp) if args.max_decode_ratio > 0 else Tp
         max_len = max_step + 1
         opts = hip.CnDecodeOpts(padding_idx=int(args.padding_idx), sos=sos, beam_width=1)
+        lp = args.length_penalty
+        if not getattr(args, "hip_host_beam", False):
+            ao = hip.CnAstOpts(ctc_weight=float(args.ctc_weight) if use_ctc else 0.0, temperature=float(args.T), ctc_beam=K,
+                               beam_width=bw, max_step=max_step, eos=eos, use_length_penalty=int(lp is not None),
+                               one_minus_ctc_weight=float(1 - args.ctc_weight),
+                               length_penalty=float(lp) if lp is not None else 0.0)
+            hyp = torch.empty(B, bw, max_len, dtype=torch.int32, device=dev)
+            hlen = torch.empty(B, bw, dtype=torch.int32, device=dev)
+            score = torch.empty(B, bw, dtype=torch.float64, device=dev)
+            eng.ast_decode(feats, opts, ao, hyp, hlen, score)
+            hyp, hlen, score = hyp.cpu().numpy(), hlen.cpu().numpy(), score.cpu().numpy()
+            out = []
+            for b in range(B):
+                row = []
+                for j in range(bw):
+                    h = hyp[b, j, : hlen[b, j]].tolist()
+                    row.append({"ys": torch.tensor([h], dtype=torch.long), "score": float(score[b, j]), "hyp": h})
+                out.append(row)
+            return out
         eng.ast_begin(feats, opts, use_ctc, max_len, B * bw, K if use_ctc else 0)
         w32 = np.float32(args.ctc_weight)
         u32 = np.float32(1 - args.ctc_weight)
-        lp = args.length_penalty
 
         beams = [[{"score": 0.0, "hyp": [sos], "anc": [], "ctc_ref": -1 - b, "ctc_prev": np.float32(0.0)}] for b in range(B)]
         idx_d = torch.empty(B * bw, K, dtype=torch.int32, device=dev)

@@ -100,6 +100,26 @@ int cn_ast_ctc_score(cn_model* m, int32_t n_live, int32_t out_len, const int32_t
                      const int32_t* cand_dev, int32_t K, const int32_t* prev_ref_dev, int32_t parity, int32_t eos,
                      float* score_dev, void* stream);
 
+/* The whole joint CTC / attention beam search of Transformer.beam_decode (src/models/transformer.py:122-241, lm_weight == 0)
+ * on the device: no host round trip inside the step loop (the host polls a live-hypothesis counter every 8 steps).
+ * hyp_out_dev [B][beam_width][max_len] int32 (sos first, padded with padding_idx), hyp_len_dev [B][beam_width],
+ * score_dev [B][beam_width] double; beams best first, same ordering rules as the reference (stable ties). */
+typedef struct cn_ast_opts {
+    float ctc_weight;            /* > 0: joint scoring with the CTC prefix scorer over ctc_beam candidates */
+    float temperature;           /* args.T */
+    int32_t ctc_beam;
+    int32_t beam_width;
+    int32_t max_step;            /* int(max_decode_ratio * T') or T' */
+    int32_t eos;
+    int32_t use_length_penalty;  /* 0: args.length_penalty is None */
+    float one_minus_ctc_weight;  /* float32(1 - ctc_weight) as the reference computes it (in double, then cast) */
+    double length_penalty;
+    int32_t reserved[4];
+} cn_ast_opts;
+int cn_decode_ast(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts,
+                  const cn_ast_opts* ast_opts, int32_t* hyp_out_dev, int32_t max_len, int32_t* hyp_len_dev, double* score_dev,
+                  void* stream);
+
 /* Copy a named internal / captured tensor to the host (synchronous; test + host-beam use).  Activations are
  * returned as fp32 whatever the model precision.  shape_out has room for 4 dims. */
 int cn_fetch(cn_model* m, const char* name, void* host_dst, int64_t max_bytes, int64_t* shape_out, int32_t* ndim_out,

@@ -16,8 +16,9 @@ class Vocab:
     word2index = {"blank": 0, "sos": 1, "eos": 2, "unk": 3}
 
 
-def run(args, state, feats, precision):
+def run(args, state, feats, precision, host_beam=False):
     args.hip_precision = precision
+    args.hip_host_beam = host_beam
     model = make_model(args.input_size, args).cuda()
     with torch.no_grad():
         for k, p in model.named_parameters():
@@ -85,3 +86,24 @@ def test_ast_config4_bf16_report(capsys):
         assert len(got) == len(ref) and np.isfinite(utt[0]["score"])
     with capsys.disabled():
         print(f"\n[AST bf16] beams identical {exact}/{total}, top-1 identical {top1}/{len(beams)}, common prefix of best {prefix}")
+
+
+@pytest.mark.parametrize("name,ov", [("ast_tiny_lp", dict(ctc_weight=0.5, length_penalty=0.2, T=1.3)), ("ast_tiny_att", dict(ctc_weight=0.0))])
+def test_ast_host_beam_matches_golden(name, ov):
+    """The Python-bookkeeping variant over cn_ast_begin / cn_ast_step / cn_ast_ctc_score (cross-check of the device beam)."""
+    g = load_golden(name)
+    args, state, feats = ast_tiny_case(**ov)
+    beams = run(args, state, feats, "fp32", host_beam=True)
+    for b, utt in enumerate(beams):
+        for j, s in enumerate(utt):
+            assert s["hyp"] == g["beam_hyp"][b, j, : g["beam_len"][b, j]].tolist(), (b, j)
+
+
+def test_ast_device_beam_equals_host_beam_bf16():
+    """Same engine, same kernels: the device-side bookkeeping must reproduce the host bookkeeping bit for bit."""
+    args, state, feats = ast_config4_case(ctc_weight=0.3)
+    dev_b = run(args, state, feats, "bf16")
+    host_b = run(args, state, feats, "bf16", host_beam=True)
+    for u, v in zip(dev_b, host_b):
+        assert [s["hyp"] for s in u] == [s["hyp"] for s in v]
+        assert [s["score"] for s in u] == [s["score"] for s in v]
