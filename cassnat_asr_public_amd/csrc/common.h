@@ -85,4 +85,12 @@ void cn_set_error(const std::string& msg);
         }                                                                                         \
     } while (0)
 
+#ifndef CN_TRY
+#define CN_TRY(expr)                \
+    do {                            \
+        int _rc = (expr);           \
+        if (_rc != 0) return _rc;   \
+    } while (0)
+#endif
+
 static inline int cn_ceil_div(int a, int b) { return (a + b - 1) / b; }

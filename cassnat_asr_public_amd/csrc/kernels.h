@@ -107,6 +107,15 @@ int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s);
 void pack_ffn_w1(const float* w1, int dff, uint16_t* out);  // [dff][256] fp32 -> fragment stream (dff*256 bf16)
 void pack_ffn_w2(const float* w2, int dff, uint16_t* out);  // [256][dff] fp32 -> fragment stream (dff*256 bf16)
 
+// ---- waveform -> log-mel filterbank (+ CMVN), Kaldi compute-fbank-feats semantics with dither 0 (fbank.hip)
+struct FbankOpts {
+    float sample_rate = 16000.f, frame_length_ms = 25.f, frame_shift_ms = 10.f, preemph = 0.97f, low_freq = 20.f, high_freq = 0.f;
+    int num_mel = 80, window_type = 0 /* 0 hamming, 1 povey, 2 hanning, 3 rectangular */, remove_dc = 1, use_power = 1, use_log = 1;
+};
+int fbank_num_frames(const FbankOpts& o, int num_samples);
+int launch_fbank(const FbankOpts& o, const float* wave, const int* num_samples, int B, int max_samples, const float* cmvn_mean,
+                 const float* cmvn_istd, float* out, int Tmax, float pad_value, hipStream_t s);
+
 // ---- conv2 as an LDS-DMA implicit GEMM, bf16 / 256 -> 256 channels (conv2.hip); launch_gemm dispatches to it
 bool conv2_dma_applies(int prec, int C, int N);
 int launch_conv2_dma(const void* in, const void* w, const float* bias, void* out, int B, int T1, int F1, int T2, int F2,

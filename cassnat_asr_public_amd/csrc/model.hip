@@ -1388,6 +1388,54 @@ extern "C" int cn_fetch(cn_model* m, const char* name, void* host_dst, int64_t m
 }
 
 // ---- single-kernel entry points ------------------------------------------------------------------
+static FbankOpts fbank_opts_from(const cn_fbank_opts* o) {
+    FbankOpts f;
+    f.sample_rate = o->sample_rate;
+    f.frame_length_ms = o->frame_length_ms;
+    f.frame_shift_ms = o->frame_shift_ms;
+    f.preemph = o->preemph;
+    f.low_freq = o->low_freq;
+    f.high_freq = o->high_freq;
+    f.num_mel = o->num_mel;
+    f.window_type = o->window_type;
+    f.remove_dc = o->remove_dc;
+    f.use_power = o->use_power;
+    f.use_log = o->use_log;
+    return f;
+}
+
+extern "C" void cn_fbank_default_opts(cn_fbank_opts* o) {
+    if (!o) return;
+    const FbankOpts f;
+    std::memset(o, 0, sizeof(*o));
+    o->sample_rate = f.sample_rate;
+    o->frame_length_ms = f.frame_length_ms;
+    o->frame_shift_ms = f.frame_shift_ms;
+    o->preemph = f.preemph;
+    o->low_freq = f.low_freq;
+    o->high_freq = f.high_freq;
+    o->num_mel = f.num_mel;
+    o->window_type = f.window_type;
+    o->remove_dc = f.remove_dc;
+    o->use_power = f.use_power;
+    o->use_log = f.use_log;
+}
+
+extern "C" int32_t cn_fbank_num_frames(const cn_fbank_opts* o, int32_t num_samples) {
+    return o ? fbank_num_frames(fbank_opts_from(o), num_samples) : 0;
+}
+
+extern "C" int cn_fbank(const cn_fbank_opts* o, const float* wave_dev, const int32_t* num_samples_dev, int32_t B,
+                        int32_t max_samples, const float* cmvn_mean_dev, const float* cmvn_istd_dev, float* feats_dev,
+                        int32_t Tmax, float pad_value, void* stream) {
+    if (!o || !wave_dev || !num_samples_dev || !feats_dev || B < 0 || max_samples < 0 || Tmax < 0) {
+        cn_set_error("cn_fbank: bad argument");
+        return -1;
+    }
+    return launch_fbank(fbank_opts_from(o), wave_dev, num_samples_dev, B, max_samples, cmvn_mean_dev, cmvn_istd_dev, feats_dev,
+                        Tmax, pad_value, (hipStream_t)stream);
+}
+
 extern "C" int cn_op_gemm(int32_t precision, const void* A, int32_t lda, const void* W, const float* bias, void* C,
                           int32_t ldc, int32_t c_is_f32, int32_t M, int32_t N, int32_t K, int32_t relu,
                           const float* resid, int32_t ldr, const float* pe, int32_t pe_period, float scale,

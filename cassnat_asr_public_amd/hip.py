@@ -34,6 +34,12 @@ class CnAstOpts(C.Structure):
                 ("length_penalty", C.c_double), ("reserved", C.c_int32 * 4)]
 
 
+class CnFbankOpts(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("sample_rate", "frame_length_ms", "frame_shift_ms", "preemph", "low_freq", "high_freq")] + \
+               [(n, C.c_int32) for n in ("num_mel", "window_type", "remove_dc", "use_power", "use_log")] + \
+               [("reserved", C.c_int32 * 5)]
+
+
 class HipError(RuntimeError):
     pass
 
@@ -97,6 +103,12 @@ def lib():
                                C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.cn_ast_step.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                               C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cn_fbank_default_opts.argtypes = [C.POINTER(CnFbankOpts)]
+    L.cn_fbank_default_opts.restype = None
+    L.cn_fbank_num_frames.argtypes = [C.POINTER(CnFbankOpts), C.c_int32]
+    L.cn_fbank_num_frames.restype = C.c_int32
+    L.cn_fbank.argtypes = [C.POINTER(CnFbankOpts), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                           C.c_int32, C.c_float, C.c_void_p]
     L.cn_decode_ast.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts),
                                 C.POINTER(CnAstOpts), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_ast_ctc_score.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,

@@ -146,6 +146,25 @@ int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, const float* w
                 const float* wt_host, const float* bt_host, void* out_dev, int32_t ldo, int32_t M, int32_t dff,
                 int32_t tail_n, float eps, int32_t x_mode, void* stream);
 
+/* ---- front-end: waveform -> log-mel filterbank features (+ global CMVN), padded batch out ----------------------
+ * What the reference leaves to Kaldi's compute-fbank-feats (egs/librispeech/conf/fbank.conf:1-6: hamming window, 16 kHz,
+ * 80 mel bins, no energy; other options at Kaldi's defaults, dither = 0) followed by the (feat - mean) / std of
+ * SpeechDataset._load_cmvn (src/data/speech_loader.py:109-115).  wave_dev: [B][max_samples] float32 on the int16 scale
+ * (as Kaldi reads a wav); num_samples_dev: [B]; feats_dev: [B][Tmax][num_mel] float32, frame t of utterance b exists for
+ * t < 1 + (num_samples[b] - frame_len) / frame_shift (snip_edges), later frames are filled with pad_value (the
+ * decoder's padding_idx, so that its mask derivation feats[:,:,0] != padding_idx sees them as padding).
+ * cmvn_mean_dev / cmvn_istd_dev: [num_mel] or NULL.  The output is directly cn_decode_nast's feats_dev. */
+typedef struct cn_fbank_opts {
+    float sample_rate, frame_length_ms, frame_shift_ms, preemph, low_freq, high_freq;
+    int32_t num_mel, window_type /* 0 hamming, 1 povey, 2 hanning, 3 rectangular */, remove_dc, use_power, use_log;
+    int32_t reserved[5];
+} cn_fbank_opts;
+void cn_fbank_default_opts(cn_fbank_opts* o);
+int32_t cn_fbank_num_frames(const cn_fbank_opts* o, int32_t num_samples);
+int cn_fbank(const cn_fbank_opts* o, const float* wave_dev, const int32_t* num_samples_dev, int32_t B, int32_t max_samples,
+             const float* cmvn_mean_dev, const float* cmvn_istd_dev, float* feats_dev, int32_t Tmax, float pad_value,
+             void* stream);
+
 /* ---- single-kernel entry points (parity tests drive each hand-written kernel through the ABI) ---------- */
 /* all pointers device; `precision` selects the element type of activations/weights (fp32 or bf16) */
 int cn_op_gemm(int32_t precision, const void* A, int32_t lda, const void* W, const float* bias, void* C, int32_t ldc,
