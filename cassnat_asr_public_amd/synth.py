@@ -25,6 +25,19 @@ PRESETS = {
                     N_enc=12, N_extra=1, N_self_dec=3, N_mix_dec=2, vocab_size=5000),
 }
 
+# Conformer variants: use_conv_enc / use_conv_dec with relative positions, what the shipped YAMLs
+# configure (egs/librispeech/conf/cassnat_decode.yaml:17-25: relative, enc 20 / kernel 31, dec 8 / kernel 3).
+CONFORMER = dict(use_conv_enc=True, use_conv_dec=True, pos_type="relative", share_ff=False)
+PRESETS_CONF = {
+    "tiny_conf": dict(PRESETS["tiny"], enc_max_relative_len=5, enc_kernel_size=7, dec_max_relative_len=3, dec_kernel_size=3,
+                      **CONFORMER),
+    # the shipped decode YAML's shape at d_model 256 / 4 heads (its commented small-model values), 12-layer encoder
+    "conf_small": dict(input_size=80, d_model=256, n_head=4, d_encff=1024, d_decff=1024, d_ff=2048, N_enc=12, N_extra=1,
+                       N_self_dec=1, N_mix_dec=6, vocab_size=1028, enc_max_relative_len=20, enc_kernel_size=31,
+                       dec_max_relative_len=8, dec_kernel_size=3, **CONFORMER),
+}
+PRESETS.update(PRESETS_CONF)
+
 PRESETS_AST = {
     "tiny_ast": dict(input_size=80, d_model=128, n_head=2, d_ff=256, d_encff=256, N_enc=2, N_dec=2, vocab_size=40),
     # BASELINE configs[3]: AST beam=10 on the config-2 encoder
@@ -180,6 +193,107 @@ def param_shapes(args):
     return shapes
 
 
+def sinusoid_rows(d_model, n):
+    """Rows 0..n-1 of the reference's sinusoid table (src/models/modules/embedding.py:40-46, cassnat.py:91-99)."""
+    pe = np.zeros((n, d_model), np.float32)
+    pos = np.arange(n, dtype=np.float32)[:, None]
+    div = np.exp(np.arange(0, d_model, 2, dtype=np.float32) * np.float32(-(np.log(10000.0) / d_model)))
+    pe[:, 0::2] = np.sin(pos * div)
+    pe[:, 1::2] = np.cos(pos * div)
+    return pe
+
+
+def param_shapes_conformer(args):
+    """Named parameters of the conformer CASS-NAT variants (src/models/cassnat.py:29-57 with use_conv_enc / use_conv_dec),
+    registration order of the reference (checked against the instantiated reference model in oracle/make_goldens.py)."""
+    d, V, F = args.d_model, args.vocab_size, args.input_size
+    f2 = ((F - 1) // 2) // 2 + 1
+    dk = d // args.n_head
+    shapes = OrderedDict()
+
+    def lin(prefix, n_out, n_in):
+        shapes[prefix + ".weight"] = (n_out, n_in)
+        shapes[prefix + ".bias"] = (n_out,)
+
+    def mha(prefix):
+        for i in range(4):
+            lin(f"{prefix}.linears.{i}", d, d)
+
+    def relmha(prefix):
+        shapes[prefix + ".pos_bias_u"] = (args.n_head, dk)
+        shapes[prefix + ".pos_bias_v"] = (args.n_head, dk)
+        mha(prefix)
+        shapes[prefix + ".linear_pos.weight"] = (d, d)
+
+    def ffn(prefix, dff):
+        lin(prefix + ".w_1", dff, d)
+        lin(prefix + ".w_2", d, dff)
+
+    def convm(prefix, k):
+        shapes[prefix + ".pointwise_conv1.weight"] = (2 * d, d, 1)
+        shapes[prefix + ".pointwise_conv1.bias"] = (2 * d,)
+        shapes[prefix + ".depthwise_conv.weight"] = (d, 1, k)
+        shapes[prefix + ".depthwise_conv.bias"] = (d,)
+        shapes[prefix + ".norm.weight"] = (d,)
+        shapes[prefix + ".norm.bias"] = (d,)
+        shapes[prefix + ".pointwise_conv2.weight"] = (d, d, 1)
+        shapes[prefix + ".pointwise_conv2.bias"] = (d,)
+
+    def norm(prefix):
+        shapes[prefix + ".a_2"] = (d,)
+        shapes[prefix + ".b_2"] = (d,)
+
+    shapes["src_embed.conv.0.weight"] = (d, 1, 3, 3)
+    shapes["src_embed.conv.0.bias"] = (d,)
+    shapes["src_embed.conv.2.weight"] = (d, d, 3, 3)
+    shapes["src_embed.conv.2.bias"] = (d,)
+    lin("src_embed.linear_out", d, d * f2)
+    if args.use_conv_enc:
+        shapes["src_embed.pos_enc.embedding.weight"] = (2 * args.enc_max_relative_len + 1, d)
+    for n in range(args.N_enc):
+        p = f"encoder.layers.{n}"
+        if args.use_conv_enc:
+            relmha(p + ".self_attn")
+            ffn(p + ".feed_forward1", args.d_encff)
+            convm(p + ".conv_module", args.enc_kernel_size)
+            ffn(p + ".feed_forward2", args.d_encff)
+            for i in range(4):
+                norm(p + f".sublayer.{i}.norm")
+        else:
+            mha(p + ".self_attn")
+            ffn(p + ".feed_forward", args.d_encff)
+            norm(p + ".sublayer.0.norm")
+            norm(p + ".sublayer.1.norm")
+    norm("encoder.norm")
+    assert args.use_conv_dec, "param_shapes_conformer: the transformer decoder side is param_shapes()"
+    p = "acembed_extractor.layers.0"
+    mha(p + ".src_attn")
+    ffn(p + ".feed_forward", args.d_ff)
+    norm(p + ".sublayer.norm")
+    shapes[p + ".pos_enc.embedding.weight"] = (2 * args.dec_max_relative_len + 1, d)
+    for n in range(args.N_self_dec):
+        p = f"embed_mapper.layers.{n}"
+        relmha(p + ".self_attn")
+        ffn(p + ".feed_forward1", args.d_decff)
+        convm(p + ".conv_module", args.dec_kernel_size)
+        ffn(p + ".feed_forward2", args.d_decff)
+        for i in range(4):
+            norm(p + f".sublayer.{i}.norm")
+    for n in range(args.N_mix_dec):
+        p = f"decoder.layers.{n}"
+        mha(p + ".src_attn")
+        relmha(p + ".self_attn")
+        ffn(p + ".feed_forward1", args.d_decff)
+        convm(p + ".conv_module", args.dec_kernel_size)
+        ffn(p + ".feed_forward2", args.d_decff)
+        for i in range(5):
+            norm(p + f".sublayer.{i}.norm")
+    norm("decoder.norm")
+    lin("ctc_generator.proj", V, d)
+    lin("att_generator.proj", V, d)
+    return shapes
+
+
 def make_state(args, seed=0, blank_bias=0.0, gain=1.0):
     """Seeded float32 state dict (numpy arrays).
 
@@ -191,9 +305,20 @@ def make_state(args, seed=0, blank_bias=0.0, gain=1.0):
     """
     rng = np.random.default_rng(seed)
     state = OrderedDict()
-    shapes = param_shapes_ast(args) if hasattr(args, "N_dec") else param_shapes(args)
+    if hasattr(args, "N_dec"):
+        shapes = param_shapes_ast(args)
+    elif getattr(args, "use_conv_dec", False) or getattr(args, "use_conv_enc", False):
+        shapes = param_shapes_conformer(args)
+    else:
+        shapes = param_shapes(args)
     for name, shape in shapes.items():
-        if len(shape) > 1:
+        if name.endswith("pos_enc.embedding.weight"):  # frozen sinusoid rows (embedding.py:40-47), not a free parameter
+            w = sinusoid_rows(shape[1], shape[0])
+        elif name.endswith(".norm.weight"):  # GroupNorm gain of the convolution module
+            w = 1.0 + 0.1 * rng.uniform(-1, 1, size=shape)
+        elif name.endswith(".norm.bias"):
+            w = 0.1 * rng.uniform(-1, 1, size=shape)
+        elif len(shape) > 1:
             receptive = int(np.prod(shape[2:])) if len(shape) > 2 else 1
             fan_in, fan_out = shape[1] * receptive, shape[0] * receptive
             bound = gain * np.sqrt(6.0 / (fan_in + fan_out))

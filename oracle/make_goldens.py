@@ -60,7 +60,9 @@ def run_reference(torch, make_model, args, state, feats, sizes, hooks=True):
     if hooks:
         def grab(name):
             def fn(mod, inp, out):
-                cap.setdefault(name, []).append((out[0] if isinstance(out, tuple) else out).detach().clone())
+                while isinstance(out, tuple):  # conformer modules return (x, pos_embed) / ((x, pos_embed), mask)
+                    out = out[0]
+                cap.setdefault(name, []).append(out.detach().clone())
             return fn
         model.src_embed.register_forward_hook(grab("x_embed"))
         model.src_embed.conv[1].register_forward_hook(grab("conv1"))
@@ -153,13 +155,71 @@ def top2_margin(ctc_out):
 def main():
     from cassnat_asr_public_amd import synth
 
-    only = sys.argv[1] if len(sys.argv) > 1 else None  # regenerate one fixture only (currently: config5_shape)
+    only = sys.argv[1] if len(sys.argv) > 1 else None  # regenerate one fixture group only: 'conformer' or 'config5_shape'
 
     torch, make_model = import_reference()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     gdir = os.path.join(REPO, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
+
+    # ---- 4a'. conformer variants: use_conv_enc / use_conv_dec, relative positions
+    if only in (None, "conformer"):
+        ac = synth.make_args("tiny_conf")
+        sc = synth.make_state(ac, seed=3, gain=2.0)
+        fc, zc = synth.make_feats(3, 61, 80, lengths=[61, 50, 37], seed=11)
+        r = run_reference(torch, make_model, ac, sc, fc, zc)
+        keep = ["x_embed", "enc_h", "ctc_out", "aligned_seq_shift", "ylen", "ymax", "ac_embed", "pred_embed", "dec_h", "att_out",
+                "hyp", "hyp_len", "score"] + [f"enc_layer{i}" for i in range(ac.N_enc)]
+        np.savez_compressed(os.path.join(gdir, "conf_tiny.npz"), **{k: r[k] for k in keep})
+        print("conf_tiny:", r["hyp_len"], r["score"])
+        for name, ov in {"conf_tiny_dec_only": dict(use_conv_enc=False), "conf_tiny_beam3": dict(beam_width=3, length_penalty=0.1)}.items():
+            a2 = synth.make_args("tiny_conf", **ov)
+            s2 = synth.make_state(a2, seed=4, gain=2.0)
+            r = run_reference(torch, make_model, a2, s2, fc, zc)
+            kk = {k: r[k] for k in ("hyp", "hyp_len", "score", "ylen", "att_out", "dec_h", "enc_h")}
+            for k in ("beam_hyp", "beam_len", "beam_score"):
+                if k in r:
+                    kk[k] = r[k]
+            np.savez_compressed(os.path.join(gdir, f"{name}.npz"), **kk)
+            print(name, r["hyp_len"], r["score"])
+        a3 = synth.make_args("conf_small")
+        s3 = synth.make_state(a3, seed=6, blank_bias=0.35)
+        l3 = synth.ragged_lengths(2, 400, 250, seed=3)
+        f3, z3 = synth.make_feats(2, 400, 80, lengths=l3, seed=99)
+        r = run_reference(torch, make_model, a3, s3, f3, z3)
+        np.savez_compressed(
+            os.path.join(gdir, "conf_small.npz"), lengths=l3,
+            best_paths=r["ctc_out"].argmax(-1).astype(np.int32), margin=top2_margin(r["ctc_out"]),
+            aligned_seq_shift=r["aligned_seq_shift"].astype(np.int32), ylen=r["ylen"], ymax=r["ymax"],
+            ctc_sample=r["ctc_out"][:, ::5, ::13], enc_sample=r["enc_h"][:, ::5, ::8], enc_layer0_sample=r["enc_layer0"][:, ::5, ::8],
+            att_sample=r["att_out"][:, ::3, ::13], dec_sample=r["dec_h"][:, ::3, ::8],
+            att_argmax=r["att_out"].argmax(-1).astype(np.int32), att_margin=top2_margin(r["att_out"]),
+            hyp=r["hyp"], hyp_len=r["hyp_len"], score=r["score"])
+        print("conf_small: ymax", r["ymax"], "ylen", r["ylen"])
+        if only:
+            return
+
+    # ---- 4b'. BASELINE configs[4] shape: Aishell-1 character inventory V = 4230 + 4 (not a multiple of any tile width),
+    # same 12L / 1-3-2 model, B=4 ragged
+    args5 = synth.make_args("config2", vocab_size=4234)
+    state5 = synth.make_state(args5, seed=5, blank_bias=0.35)
+    lens5 = synth.ragged_lengths(4, 600, 300, seed=9)
+    feats5, sizes5 = synth.make_feats(4, 600, 80, lengths=lens5, seed=77)
+    if only in (None, "config5_shape"):
+        r = run_reference(torch, make_model, args5, state5, feats5, sizes5)
+        np.savez_compressed(
+            os.path.join(gdir, "config5_shape.npz"), lengths=lens5,
+            best_paths=r["ctc_out"].argmax(-1).astype(np.int32), margin=top2_margin(r["ctc_out"]),
+            aligned_seq_shift=r["aligned_seq_shift"].astype(np.int32), ylen=r["ylen"], ymax=r["ymax"],
+            ctc_sample=r["ctc_out"][:, ::10, ::50], enc_sample=r["enc_h"][:, ::10, ::8],
+            x_embed_sample=r["x_embed"][:, ::10, ::8], enc_layer0_sample=r["enc_layer0"][:, ::10, ::8],
+            att_sample=r["att_out"][:, ::4, ::50], dec_sample=r["dec_h"][:, ::4, ::8],
+            att_argmax=r["att_out"].argmax(-1).astype(np.int32), att_margin=top2_margin(r["att_out"]),
+            hyp=r["hyp"], hyp_len=r["hyp_len"], score=r["score"])
+        print("config5_shape: ymax", r["ymax"], "ylen", r["ylen"])
+        if only:
+            return
 
     # ---- 1. tiny model, ragged batch, odd frame count: every stage tensor
     args = synth.make_args("tiny")
@@ -238,27 +298,6 @@ def main():
         hyp=r["hyp"], hyp_len=r["hyp_len"], score=r["score"])
     m = top2_margin(r["ctc_out"])
     print("config2_b32: ymax", r["ymax"], "ylen", r["ylen"], "margin min/p1", m.min(), np.percentile(m, 1))
-
-    # ---- 4b'. BASELINE configs[4] shape: Aishell-1 character inventory V = 4230 + 4 (not a multiple of any tile width),
-    # same 12L / 1-3-2 model, B=4 ragged
-    args5 = synth.make_args("config2", vocab_size=4234)
-    state5 = synth.make_state(args5, seed=5, blank_bias=0.35)
-    lens5 = synth.ragged_lengths(4, 600, 300, seed=9)
-    feats5, sizes5 = synth.make_feats(4, 600, 80, lengths=lens5, seed=77)
-    if only in (None, "config5_shape"):
-        r = run_reference(torch, make_model, args5, state5, feats5, sizes5)
-        np.savez_compressed(
-            os.path.join(gdir, "config5_shape.npz"), lengths=lens5,
-            best_paths=r["ctc_out"].argmax(-1).astype(np.int32), margin=top2_margin(r["ctc_out"]),
-            aligned_seq_shift=r["aligned_seq_shift"].astype(np.int32), ylen=r["ylen"], ymax=r["ymax"],
-            ctc_sample=r["ctc_out"][:, ::10, ::50], enc_sample=r["enc_h"][:, ::10, ::8],
-            x_embed_sample=r["x_embed"][:, ::10, ::8], enc_layer0_sample=r["enc_layer0"][:, ::10, ::8],
-            att_sample=r["att_out"][:, ::4, ::50], dec_sample=r["dec_h"][:, ::4, ::8],
-            att_argmax=r["att_out"].argmax(-1).astype(np.int32), att_margin=top2_margin(r["att_out"]),
-            hyp=r["hyp"], hyp_len=r["hyp_len"], score=r["score"])
-        print("config5_shape: ymax", r["ymax"], "ylen", r["ylen"])
-        if only:
-            return
 
     # ---- 4c. AST (autoregressive decoder, joint CTC/attention beam search): BASELINE config 4 path
     a_ast = synth.make_args_ast("tiny_ast", beam_width=3, ctc_beam=5, max_decode_ratio=0.75)

@@ -64,6 +64,27 @@ def config5_shape_case():
     return args, state, feats, sizes
 
 
+def conf_tiny_case(seed=3, **overrides):
+    """Conformer CASS-NAT (use_conv_enc / use_conv_dec, relative positions), tiny, ragged batch."""
+    from cassnat_asr_public_amd import synth
+
+    args = synth.make_args("tiny_conf", **overrides)
+    state = synth.make_state(args, seed=seed, gain=2.0)
+    feats, sizes = synth.make_feats(3, 61, 80, lengths=[61, 50, 37], seed=11)
+    return args, state, feats, sizes
+
+
+def conf_small_case():
+    """The shipped decode YAML's shape at d_model 256: 12 conformer encoder layers, 1 + 1 + 6 conformer decoder blocks."""
+    from cassnat_asr_public_amd import synth
+
+    args = synth.make_args("conf_small")
+    state = synth.make_state(args, seed=6, blank_bias=0.35)
+    lens = synth.ragged_lengths(2, 400, 250, seed=3)
+    feats, sizes = synth.make_feats(2, 400, 80, lengths=lens, seed=99)
+    return args, state, feats, sizes
+
+
 def config2_b32_case():
     """The benchmark workload (bench.py): B=32 x 1000 frames, blank bias 0.9."""
     from cassnat_asr_public_amd import synth

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (ast_config4_case, ast_tiny_case, config1_case, config2_b8_case, config2_b32_case, config5_shape_case,
+from conftest import (conf_small_case, conf_tiny_case, ast_config4_case, ast_tiny_case, config1_case, config2_b8_case, config2_b32_case, config5_shape_case,
                       load_golden, tiny_case)
 from oracle import cassnat_oracle as orc
 
@@ -132,6 +132,53 @@ def test_config2_bench_workload():
     g["margin"] = g["margin"].astype(np.float32)
     _check_big(out, g, 25, 100, 8)
     _close(out["enc_h"][:, ::25, ::16], g["enc_sample"], 1e-4)
+
+
+# ------------------------------------------------------------------------------------------- conformer variants (8f rank 2)
+def test_conformer_tiny_every_stage():
+    from oracle import conformer_oracle as co
+
+    g = load_golden("conf_tiny")
+    args, state, feats, sizes = conf_tiny_case()
+    out = co.decode_nast_conformer(state, feats, sizes, args, stages=True)
+    for i, x in enumerate(out["enc_layers"]):
+        _close(x, g[f"enc_layer{i}"], 2e-5)
+    for k in ("enc_h", "ctc_out", "ac_embed", "pred_embed", "dec_h", "att_out"):
+        _close(out[k], g[k], 3e-5 * max(1.0, float(np.abs(g[k]).max())))  # ac_embed / pred_embed carry the sqrt(d) scale
+    np.testing.assert_array_equal(out["aligned_seq_shift"], g["aligned_seq_shift"])
+    np.testing.assert_array_equal(out["ylen"], g["ylen"])
+    for b, h in enumerate(out["hyps"]):
+        assert h == g["hyp"][b, : g["hyp_len"][b]].tolist()
+    np.testing.assert_allclose(out["scores"], g["score"], atol=1e-4)
+
+
+@pytest.mark.parametrize("name,seed,ov", [("conf_tiny_dec_only", 4, dict(use_conv_enc=False)),
+                                          ("conf_tiny_beam3", 4, dict(beam_width=3, length_penalty=0.1))])
+def test_conformer_tiny_variants(name, seed, ov):
+    from oracle import conformer_oracle as co
+
+    g = load_golden(name)
+    args, state, feats, sizes = conf_tiny_case(seed=seed, **ov)
+    out = co.decode_nast_conformer(state, feats, sizes, args, stages=True)
+    _close(out["att_out"], g["att_out"], 3e-5)
+    for b, h in enumerate(out["hyps"]):
+        assert h == g["hyp"][b, : g["hyp_len"][b]].tolist()
+
+
+def test_conformer_shipped_shape():
+    from oracle import conformer_oracle as co
+
+    g = load_golden("conf_small")
+    args, state, feats, sizes = conf_small_case()
+    out = co.decode_nast_conformer(state, feats, sizes, args, stages=True)
+    clear = g["margin"] > 1e-4
+    assert (out["best_paths"][clear] == g["best_paths"][clear]).all()
+    _close(out["ctc_out"][:, ::5, ::13], g["ctc_sample"], 1e-4)
+    _close(out["enc_h"][:, ::5, ::8], g["enc_sample"], 1e-4)
+    _close(out["dec_h"][:, ::3, ::8], g["dec_sample"], 2e-4)
+    np.testing.assert_array_equal(out["ylen"], g["ylen"])
+    for b, h in enumerate(out["hyps"]):
+        assert h == g["hyp"][b, : g["hyp_len"][b]].tolist()
 
 
 # ------------------------------------------------------------------------------------------- AST (BASELINE config 4)
