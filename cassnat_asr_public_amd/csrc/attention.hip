@@ -34,6 +34,10 @@ struct AttnParams {
     int iv_stride;
     int causal;
     float scale;
+    const float* rel_pos;  // relative-position self attention (see AttnArgs); null otherwise
+    const float* rel_u;
+    const float* rel_v;
+    int rel_R, ld_pos;
 };
 
 template <typename T> struct AttnCfg;
@@ -55,7 +59,9 @@ template <> struct AttnCfg<float> {
 // RES (bf16, Lk <= 256): ALL keys/values of the (batch, head) are brought into LDS at once by LDS-DMA (the XOR swizzles
 // are applied to the per-lane SOURCE address, the LDS image of a DMA piece is lane-linear), then every key tile is
 // processed back to back: one barrier per workgroup instead of two per tile, and a single load round trip.
-template <typename T, int NW, bool RES>
+// REL: relative-position scores (RelMultiHeadedAttention): the query operand is q + u, and a per-query table
+// bd[i][r] = (q_i + v) . P[r] (r = clamp(j - i) + R, at most 63 entries) is built in LDS and added to every raw score.
+template <typename T, int NW, bool RES, bool REL = false>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
     typedef AttnCfg<T> Cfg;
     typedef typename Frag<T>::type frag_t;
@@ -84,6 +90,36 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
         const unsigned char* qp = p.Q + ((long long)b * p.Lq + qc) * p.ldq_b + (long long)h * KROW;
 #pragma unroll
         for (int s = 0; s < NF; ++s) qf[s] = as_frag<T>(ld16(qp + (2 * s + half) * 16));
+    }
+    constexpr int REL_N = REL ? 64 : 1;
+    __shared__ float rel_tab[REL ? 64 * 64 : 1];        // P rows of this head: [2R+1][64]
+    __shared__ float rel_bias[REL ? NW : 1][32][REL_N];  // bd[i][r] per wave
+    if constexpr (REL) {
+        constexpr int E = Frag<T>::ELEMS;
+        const int nr = 2 * p.rel_R + 1;
+        for (int i = tid; i < nr * 64; i += NT) rel_tab[i] = p.rel_pos[(long long)(i >> 6) * p.ld_pos + h * 64 + (i & 63)];
+        __syncthreads();
+        // this lane holds dims {(2s + half) * E + j}: half of the query row; the partner lane (lane ^ 32) holds the rest
+        float qv[NF][E];
+#pragma unroll
+        for (int s = 0; s < NF; ++s)
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const int dim = (2 * s + half) * E + j;
+                const float q = to_f32(qf[s][j]);
+                qv[s][j] = q + p.rel_v[h * 64 + dim];
+                qf[s][j] = from_f32<T>(q + p.rel_u[h * 64 + dim]);
+            }
+        for (int r = 0; r < nr; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < NF; ++s)
+#pragma unroll
+                for (int j = 0; j < E; ++j) acc = fmaf(qv[s][j], rel_tab[r * 64 + (2 * s + half) * E + j], acc);
+            acc += __shfl_xor(acc, 32);
+            if (half == 0) rel_bias[wave][l31][r] = acc;
+        }
+        __syncthreads();
     }
     int iv_s1 = 0, iv_e1 = 0, iv_s2 = 0, iv_e2 = 0;
     if (p.iv) {
@@ -208,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
         }
         // ---- scale + mask + online softmax.  Fast path (wave-uniform): no key of this tile is masked and there are no
         // per-row intervals / causal limit -> one FMA + exp2 per score instead of ~15 VALU ops of mask logic.
-        const bool plain = Mplain[RES ? kt : 0] != 0 && !p.iv && !p.causal;
+        const bool plain = !REL && Mplain[RES ? kt : 0] != 0 && !p.iv && !p.causal;
         float psum = 0.f, alpha;
         if (plain) {
             float tmax = sc[0][0];
@@ -244,7 +280,13 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                         bool ok = code == 1u;
                         if (p.iv) ok = ok && ((key >= iv_s1 && key < iv_e1) || (key >= iv_s2 && key < iv_e2));
                         if (p.causal) ok = ok && key <= q_row;
-                        float v = sc[sub][r] * p.scale;
+                        float v = sc[sub][r];
+                        if constexpr (REL) {
+                            int rd = key - q_row;
+                            rd = rd < -p.rel_R ? -p.rel_R : (rd > p.rel_R ? p.rel_R : rd);
+                            v += rel_bias[wave][l31][rd + p.rel_R];
+                        }
+                        v *= p.scale;
                         v = ok ? v : CN_NEG_FILL;
                         v = code == 2u ? -INFINITY : v;
                         sc[sub][r] = v;
@@ -318,7 +360,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
 
     if (!wave_active) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.f / l_tot;
+    // REL: softmax(...).masked_fill(mask == 0, 0) leaves a row without any allowed key at zero (attention.py:133-134)
+    const float inv = (REL && m_run == CN_NEG_FILL) ? 0.f : 1.f / l_tot;
     if (q_row < p.Lq) {
         T* orow = reinterpret_cast<T*>(p.O) + ((long long)b * p.Lq + q_row) * p.ldo + h * 64;
 #pragma unroll
@@ -361,6 +404,20 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     p.iv_stride = a.iv_stride;
     p.causal = a.causal;
     p.scale = a.scale;
+    p.rel_pos = a.rel_pos;
+    p.rel_u = a.rel_u;
+    p.rel_v = a.rel_v;
+    p.rel_R = a.rel_R;
+    p.ld_pos = a.ld_pos;
+    if (a.rel_pos) {
+        if (a.rel_R < 0 || a.rel_R > 31 || !a.rel_u || !a.rel_v || a.Lq != a.Lk) {
+            cn_set_error("attention: relative positions need self attention and max_relative_len <= 31");
+            return -1;
+        }
+        hipLaunchKernelGGL((attention_kernel<T, 2, false, true>), dim3(cn_ceil_div(a.Lq, 64), a.H, a.B), dim3(128), 0, s, p);
+        CN_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const long long big_grid = (long long)cn_ceil_div(a.Lq, 128) * a.H * a.B;
     if constexpr (sizeof(T) == 2) {
         static int no_res = -1;

@@ -24,7 +24,7 @@ struct GemmParams {
     int M, N, K;
     int epi;
     int pe_period;
-    float scale;
+    float scale, resid_scale;
     int ntn;  // tiles along N
     int cT1, cF1, cC, cT2, cF2;
 };
@@ -209,8 +209,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                 if (m >= p.M) continue;
                 float v = acc[i][j][r] + bias;
                 if (p.epi & CN_EPI_RELU) v = fmaxf(v, 0.f);
-                if (p.epi & CN_EPI_EMBED) v = v * p.scale + p.pe[(long long)(m % p.pe_period) * p.N + n];
-                if (p.epi & CN_EPI_RESID) v = p.resid[(long long)m * p.ldr + n] + v;
+                if (p.epi & CN_EPI_SWISH) v = v * (1.f / (1.f + __expf(-v)));
+                if (p.epi & CN_EPI_EMBED) v = v * p.scale + (p.pe ? p.pe[(long long)(m % p.pe_period) * p.N + n] : 0.f);
+                if (p.epi & CN_EPI_RESID) v = p.resid[(long long)m * p.ldr + n] + p.resid_scale * v;
                 C[(long long)m * p.ldc + n] = from_f32<TC>(v);
             }
         }
@@ -236,6 +237,7 @@ static int run_gemm(const GemmArgs& a, hipStream_t s) {
     p.epi = a.epi;
     p.pe_period = a.pe_period > 0 ? a.pe_period : 1;
     p.scale = a.scale;
+    p.resid_scale = a.resid_scale;
     p.ntn = cn_ceil_div(a.N, BN);
     p.cT1 = a.cT1;
     p.cF1 = a.cF1;

@@ -7,7 +7,7 @@ enum { CN_PREC_F32 = 0, CN_PREC_BF16 = 1 };
 static inline size_t cn_elem_size(int prec) { return prec == CN_PREC_F32 ? 4 : 2; }
 
 // ---- GEMM:  C[M][N] = epi( A[M][K] . W[N][K]^T + bias[N] )            (gemm.hip)
-enum { CN_EPI_RELU = 1, CN_EPI_RESID = 2, CN_EPI_EMBED = 4 };
+enum { CN_EPI_RELU = 1, CN_EPI_RESID = 2, CN_EPI_EMBED = 4, CN_EPI_SWISH = 8 };
 struct GemmArgs {
     const void* A = nullptr;  // activations, model precision, row stride lda (elements)
     int lda = 0;
@@ -18,9 +18,10 @@ struct GemmArgs {
     int c_f32 = 0;
     int M = 0, N = 0, K = 0;
     int epi = 0;
-    const float* resid = nullptr;  // CN_EPI_RESID: C = resid + (acc + bias); fp32 [M][ldr]; may alias C
+    const float* resid = nullptr;  // CN_EPI_RESID: C = resid + resid_scale * (acc + bias); fp32 [M][ldr]; may alias C
+    float resid_scale = 1.0f;      // SublayerConnection's `scale` (0.5 for the conformer's macaron feed-forward halves)
     int ldr = 0;
-    const float* pe = nullptr;  // CN_EPI_EMBED: C = (acc + bias) * scale + pe[m % pe_period][n]
+    const float* pe = nullptr;  // CN_EPI_EMBED: C = (acc + bias) * scale + pe[m % pe_period][n]  (pe may be null: scale only)
     int pe_period = 1;
     float scale = 1.f;
     // implicit-GEMM A operand for the second 3x3/stride-2 subsampling convolution:
@@ -67,8 +68,20 @@ struct AttnArgs {
     int iv_stride = 0;
     int causal = 0;  // key j allowed only if j <= i
     float scale = 0.125f;
+    // relative-position self attention (RelMultiHeadedAttention, attention.py:68-147): score(i, j) = ((q_i + u) . k_j +
+    // (q_i + v) . P[clamp(j - i, -R, R) + R]) * scale; rows with no allowed key yield 0.  rel_pos: [2R+1][ld_pos] fp32
+    // projected position rows (head h at column h*64), rel_u / rel_v: [H*64] fp32
+    const float* rel_pos = nullptr;
+    const float *rel_u = nullptr, *rel_v = nullptr;
+    int rel_R = 0, ld_pos = 0;
 };
 int launch_attention(int prec, const AttnArgs& a, hipStream_t s);
+
+// ---- conformer convolution module pieces (conformer.hip)
+int launch_glu(int prec, const void* in, void* out, int M, int d, hipStream_t s);
+int launch_dwconv(int prec, const void* x, const float* w, const float* bias, float* y, int B, int L, int d, int k, hipStream_t s);
+int launch_groupnorm_swish(int prec, const float* x, double* stats, const float* gw, const float* gb, void* out, int B, int L,
+                           int d, float eps, hipStream_t s);
 
 // ---- CTC greedy alignment -> trigger intervals (integer, exact)                   (ctc_align.hip)
 struct AlignArgs {

@@ -40,8 +40,22 @@ struct Norm {
     float* a = nullptr;
     float* b = nullptr;
 };
+// conformer convolution module (conformer_related.py:15-44)
+struct ConvMod {
+    Linear pw1, pw2;            // pointwise convs as [2d][d] / [d][d] matrices
+    float *dw_w = nullptr, *dw_b = nullptr;  // depthwise [d][k] fp32, bias [d]
+    float *gn_w = nullptr, *gn_b = nullptr;  // GroupNorm(1, d) affine
+    int k = 0;
+};
 struct Layer {
-    Norm n[3];
+    Norm n[5];
+    // conformer blocks: w1/w2 are feed_forward1 (or the extractor's feed_forward), ff2_* feed_forward2; relative-position
+    // self attention keeps the projected position rows P = table . W_pos^T [(2R+1)][d] and the biases u, v [d] in fp32
+    Linear ff2_w1, ff2_w2;
+    ConvMod conv;
+    float *pos_proj = nullptr, *pos_u = nullptr, *pos_v = nullptr;
+    int rel_R = 0;
+    bool conformer = false;
     Linear qkv;       // self-attention: fused Q|K|V projection
     Linear self_o;
     Linear src_q, src_kv, src_o;  // source attention: Q from the stream, K|V from the encoder memory
@@ -132,6 +146,9 @@ struct cn_model {
         *tok = nullptr, *topk_idx = nullptr;
     float *ctc_maxlp = nullptr, *val = nullptr, *topk_val = nullptr;
 
+    void* cv_a = nullptr;      // conformer convolution module scratch
+    float* cv_f = nullptr;
+    double* gn_stats = nullptr;
     int* ymax_pinned = nullptr;  // page-locked host word for the one data-dependent readback per batch
 
     // autoregressive (AST) decoder state (cn_ast_*): token embedding, per-layer cross K|V, KV cache, CTC prefix states
@@ -279,6 +296,83 @@ struct Packer {
         }
         l.b = reinterpret_cast<float*>(bat);
         return l;
+    }
+    // nn.Conv1d(kernel 1) weight [rows][K][1] as a Linear
+    Linear pointwise(const std::string& prefix, int64_t rows, int64_t K) {
+        Linear l;
+        l.N = (int)rows;
+        l.K = (int)K;
+        const size_t at = reserve((size_t)rows * K * m->es);
+        if (fill) {
+            const HostTensor* t = find(prefix + ".weight", {rows, K, 1});
+            if (t)
+                for (int64_t i = 0; i < rows * K; ++i) put_elem(at, i, t->data[i]);
+        }
+        l.W = reinterpret_cast<void*>(at);
+        l.b = vec({prefix + ".bias"}, rows);
+        return l;
+    }
+    // fp32 copy of a named tensor of any shape with n elements
+    float* raw(const std::string& name, std::initializer_list<int64_t> shape, int64_t n) {
+        const size_t at = reserve((size_t)n * 4);
+        if (fill) {
+            const HostTensor* t = find(name, shape);
+            if (t) std::memcpy(&host[at], t->data.data(), (size_t)n * 4);
+        }
+        return reinterpret_cast<float*>(at);
+    }
+    // plain (unfused) feed-forward pair
+    void ffn_plain(Linear& w1, Linear& w2, const std::string& p, int64_t dff, int64_t d) {
+        w1 = linear({p + ".w_1"}, dff, d);
+        w2 = linear({p + ".w_2"}, d, dff);
+    }
+    ConvMod conv_module(const std::string& p, int64_t d, int64_t k) {
+        ConvMod c;
+        c.pw1 = pointwise(p + ".pointwise_conv1", 2 * d, d);
+        c.dw_w = raw(p + ".depthwise_conv.weight", {d, 1, k}, d * k);
+        c.dw_b = vec({p + ".depthwise_conv.bias"}, d);
+        c.gn_w = vec({p + ".norm.weight"}, d);
+        c.gn_b = vec({p + ".norm.bias"}, d);
+        c.pw2 = pointwise(p + ".pointwise_conv2", d, d);
+        c.k = (int)k;
+        return c;
+    }
+    // relative-position self attention: fused Q|K|V, output projection, u / v, and P = table . W_pos^T (the position rows
+    // are a frozen sinusoid table in the checkpoint, so their projection is a constant of the layer)
+    void rel_attn(Layer& L, const std::string& att, const std::string& table, int64_t R, int64_t d, int64_t H) {
+        L.has_self = true;
+        L.qkv = linear({att + ".linears.0", att + ".linears.1", att + ".linears.2"}, d, d);
+        L.self_o = linear({att + ".linears.3"}, d, d);
+        L.pos_u = raw(att + ".pos_bias_u", {H, d / H}, d);
+        L.pos_v = raw(att + ".pos_bias_v", {H, d / H}, d);
+        const int64_t nr = 2 * R + 1;
+        const size_t at = reserve((size_t)nr * d * 4);
+        if (fill) {
+            const HostTensor* tb = find(table, {nr, d});
+            const HostTensor* wp = find(att + ".linear_pos.weight", {d, d});
+            if (tb && wp)
+                for (int64_t r = 0; r < nr; ++r)
+                    for (int64_t o = 0; o < d; ++o) {
+                        double acc = 0.0;
+                        for (int64_t i = 0; i < d; ++i) acc += (double)tb->data[r * d + i] * (double)wp->data[o * d + i];
+                        const float v = (float)acc;
+                        std::memcpy(&host[at + (r * d + o) * 4], &v, 4);
+                    }
+        }
+        L.pos_proj = reinterpret_cast<float*>(at);
+        L.rel_R = (int)R;
+    }
+    // conformer self-attention block (fanat_conformer_blocks.py:9-38): feed_forward1, self_attn, conv_module, feed_forward2
+    Layer conformer_layer(const std::string& p, const std::string& table, int64_t dff, int64_t k, int64_t R, int64_t d, int64_t H,
+                          int nnorm) {
+        Layer L;
+        L.conformer = true;
+        rel_attn(L, p + ".self_attn", table, R, d, H);
+        ffn_plain(L.w1, L.w2, p + ".feed_forward1", dff, d);
+        L.conv = conv_module(p + ".conv_module", d, k);
+        ffn_plain(L.ff2_w1, L.ff2_w2, p + ".feed_forward2", dff, d);
+        for (int i = 0; i < nnorm; ++i) L.n[i] = norm(p + ".sublayer." + std::to_string(i) + ".norm", d);
+        return L;
     }
     // feed-forward weights: fragment streams for the fused kernel when it applies, plain matrices otherwise
     void ffn(Layer& L, const std::string& p, int64_t dff, int64_t d) {
@@ -468,10 +562,17 @@ int build_weights(cn_model* m) {
     m->extra.clear();
     m->sad.clear();
     m->mad.clear();
-    for (int n = 0; n < c.n_enc; ++n) m->enc.push_back(self_layer("encoder.layers." + std::to_string(n), "self_attn", c.d_encff, 2));
+    const int64_t H = c.n_head;
+    for (int n = 0; n < c.n_enc; ++n) {
+        const std::string p = "encoder.layers." + std::to_string(n);
+        if (c.conf_enc)
+            m->enc.push_back(pk.conformer_layer(p, "src_embed.pos_enc.embedding.weight", c.d_encff, c.enc_kernel, c.enc_max_rel, d, H, 4));
+        else
+            m->enc.push_back(self_layer(p, "self_attn", c.d_encff, 2));
+    }
     m->enc_norm = pk.norm("encoder.norm", d);
     m->enc_chain.clear();
-    if (pk.chain_ok(d, c.d_encff))
+    if (!c.conf_enc && pk.chain_ok(d, c.d_encff))
         for (int n = 0; n < c.n_enc; ++n) {
             const std::string p = "encoder.layers." + std::to_string(n), q = "encoder.layers." + std::to_string(n + 1);
             if (n + 1 < c.n_enc)
@@ -482,27 +583,45 @@ int build_weights(cn_model* m) {
                 m->enc_chain.push_back(
                     pk.chain(p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff, "encoder.norm", {}, d));
         }
+    const std::string dec_table = "acembed_extractor.layers.0.pos_enc.embedding.weight";
     for (int n = 0; n < c.n_extra; ++n) {
         const std::string p = "acembed_extractor.layers." + std::to_string(n);
         Layer L;
         add_src(L, p);
-        pk.ffn(L, p, c.d_decff, d);
-        L.n[0] = pk.norm(p + ".sublayer.0.norm", d);
-        L.n[1] = pk.norm(p + ".sublayer.1.norm", d);
+        if (c.conf_dec) {  // SrcAttLayer (fanat_conformer_blocks.py:41-60): one norm, Swish FFN of width d_ff
+            L.conformer = true;
+            pk.ffn_plain(L.w1, L.w2, p + ".feed_forward", c.d_ff, d);
+            L.n[0] = pk.norm(p + ".sublayer.norm", d);
+        } else {
+            pk.ffn(L, p, c.d_decff, d);
+            L.n[0] = pk.norm(p + ".sublayer.0.norm", d);
+            L.n[1] = pk.norm(p + ".sublayer.1.norm", d);
+        }
         m->extra.push_back(L);
     }
-    for (int n = 0; n < c.n_self_dec; ++n)
-        m->sad.push_back(self_layer("embed_mapper.layers." + std::to_string(n), "self_attn", c.d_decff, 2));
+    for (int n = 0; n < c.n_self_dec; ++n) {
+        const std::string p = "embed_mapper.layers." + std::to_string(n);
+        if (c.conf_dec)
+            m->sad.push_back(pk.conformer_layer(p, dec_table, c.d_decff, c.dec_kernel, c.dec_max_rel, d, H, 4));
+        else
+            m->sad.push_back(self_layer(p, "self_attn", c.d_decff, 2));
+    }
     for (int n = 0; n < c.n_mix_dec; ++n) {
         const std::string p = "decoder.layers." + std::to_string(n);
-        Layer L = self_layer(p, "self_attn", c.d_decff, 3);
-        add_src(L, p);
-        m->mad.push_back(L);
+        if (c.conf_dec) {
+            Layer L = pk.conformer_layer(p, dec_table, c.d_decff, c.dec_kernel, c.dec_max_rel, d, H, 5);
+            add_src(L, p);
+            m->mad.push_back(L);
+        } else {
+            Layer L = self_layer(p, "self_attn", c.d_decff, 3);
+            add_src(L, p);
+            m->mad.push_back(L);
+        }
     }
     m->dec_norm = pk.norm("decoder.norm", d);
     // decoder-side sublayers of the NAT model in execution order, each with the chain that follows its attention
     m->dec_steps.clear();
-    if (!c.ast && pk.chain_ok(d, c.d_decff)) {
+    if (!c.ast && !c.conf_dec && pk.chain_ok(d, c.d_decff)) {
         struct Sub {
             int stack, layer;
             bool self, ffn;
@@ -576,7 +695,18 @@ int build_weights(cn_model* m) {
     rebase_linear(m->linear_out, base);
     auto rebase_layers = [&](std::vector<Layer>& v) {
         for (auto& L : v) {
-            for (int i = 0; i < 3; ++i) rebase_norm(L.n[i], base);
+            for (int i = 0; i < 5; ++i) rebase_norm(L.n[i], base);
+            rebase_linear(L.ff2_w1, base);
+            rebase_linear(L.ff2_w2, base);
+            rebase_linear(L.conv.pw1, base);
+            rebase_linear(L.conv.pw2, base);
+            rebase(L.conv.dw_w, base);
+            rebase(L.conv.dw_b, base);
+            rebase(L.conv.gn_w, base);
+            rebase(L.conv.gn_b, base);
+            rebase(L.pos_proj, base);
+            rebase(L.pos_u, base);
+            rebase(L.pos_v, base);
             rebase_linear(L.qkv, base);
             rebase_linear(L.self_o, base);
             rebase_linear(L.src_q, base);
@@ -616,7 +746,7 @@ int build_workspace(cn_model* m) {
     const size_t es = m->es;
     const size_t B = m->maxB, T1 = m->maxT1, Tp = m->maxTp, F1 = m->F1, F2 = m->F2, d = c.d_model, V = c.vocab_size;
     const size_t M = B * (Tp + 1);  // decoder rows can reach B*(T'+1)
-    const size_t dff = std::max(c.d_encff, c.d_decff);
+    const size_t dff = std::max(std::max(c.d_encff, c.d_decff), c.d_ff);  // (d_ff: the conformer extractor's FFN width)
     CN_TRY(dev_alloc(m, (void**)&m->keymask, B * Tp));
     CN_TRY(dev_alloc(m, &m->c1, B * (T1 + 2) * (F1 + 2) * d * es));  // room for the zero halo the bf16 conv2 kernel wants
     CN_TRY(dev_alloc(m, &m->c2, B * Tp * F2 * d * es));
@@ -643,6 +773,11 @@ int build_workspace(cn_model* m) {
     CN_TRY(dev_alloc(m, (void**)&m->val, M * 4));
     CN_TRY(dev_alloc(m, (void**)&m->topk_idx, M * 16 * 4));
     CN_TRY(dev_alloc(m, (void**)&m->topk_val, M * 16 * 4));
+    if (c.conf_enc || c.conf_dec) {  // convolution module: pointwise-conv output [M][2d], depthwise output fp32, GroupNorm sums
+        CN_TRY(dev_alloc(m, &m->cv_a, M * 2 * d * es));
+        CN_TRY(dev_alloc(m, (void**)&m->cv_f, M * d * 4));
+        CN_TRY(dev_alloc(m, (void**)&m->gn_stats, B * 2 * 8));
+    }
     CN_HIP_CHECK(hipHostMalloc((void**)&m->ymax_pinned, 64, hipHostMallocDefault));
     return 0;
 }
@@ -792,6 +927,90 @@ int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ld
     a.store_x = (x_mode & CHX_NO_STORE) == 0;
     return launch_chain(a, s);
 }
+
+// ---- conformer sublayers (fanat_conformer_blocks.py, conformer_related.py, attention.py:68-147) ------------------
+// x += scale * W2 . swish(W1 . LN(x) + b1) + ...   (SublayerConnection with the Swish feed-forward, scale 0.5 in the macaron halves)
+int run_ffn_swish(cn_model* m, const Linear& w1, const Linear& w2, const Norm& n, float* x, int M, float scale, hipStream_t s) {
+    const int d = m->cfg.d_model;
+    CN_TRY(run_ln(m, n, x, m->xn, M, s));
+    CN_TRY(run_linear(m, "ffn_w1_swish", w1, m->xn, d, m->hbuf, w1.N, 0, M, CN_EPI_SWISH, nullptr, 0, s));
+    ProfScope ps(m, "ffn_w2_resid", 2.0 * M * w2.N * w2.K, (double)M * w2.K * m->es + (double)w2.N * w2.K * m->es + (double)M * w2.N * 8, s);
+    GemmArgs g;
+    g.A = m->hbuf;
+    g.lda = w1.N;
+    g.W = w2.W;
+    g.bias = w2.b;
+    g.C = x;
+    g.ldc = d;
+    g.c_f32 = 1;
+    g.M = M;
+    g.N = w2.N;
+    g.K = w2.K;
+    g.epi = CN_EPI_RESID;
+    g.resid = x;
+    g.ldr = d;
+    g.resid_scale = scale;
+    return launch_gemm(m->prec, g, s);
+}
+
+// x += O(RelAttn(LN(x))) with relative-position scores
+int run_rel_self_attn(cn_model* m, const Layer& L, const Norm& n, float* x, int B, int Lseq, const unsigned char* keymask,
+                      const int* klen, hipStream_t s) {
+    const int d = m->cfg.d_model, M = B * Lseq;
+    CN_TRY(run_ln(m, n, x, m->xn, M, s));
+    CN_TRY(run_linear(m, "qkv_proj", L.qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
+    AttnArgs a;
+    const size_t es = m->es;
+    a.Q = m->qkv;
+    a.K = (const unsigned char*)m->qkv + (size_t)d * es;
+    a.V = (const unsigned char*)m->qkv + (size_t)2 * d * es;
+    a.O = m->ctx;
+    a.ldq = a.ldk = a.ldv = 3 * d;
+    a.ldo = d;
+    a.B = B;
+    a.H = m->cfg.n_head;
+    a.Lq = a.Lk = Lseq;
+    a.keymask = keymask;
+    a.klen = klen;
+    a.scale = 1.0f / sqrtf((float)(d / m->cfg.n_head));
+    a.rel_pos = L.pos_proj;
+    a.rel_u = L.pos_u;
+    a.rel_v = L.pos_v;
+    a.rel_R = L.rel_R;
+    a.ld_pos = d;
+    {
+        ProfScope ps(m, "rel_self_attention", 4.0 * B * a.H * (double)Lseq * Lseq * 64, (double)M * 4 * d * m->es, s);
+        CN_TRY(launch_attention(m->prec, a, s));
+    }
+    return run_linear(m, "out_proj_resid", L.self_o, m->ctx, d, x, d, 1, M, CN_EPI_RESID, x, d, s);
+}
+
+// x += ConvModule(LN(x))
+int run_conv_module(cn_model* m, const Layer& L, const Norm& n, float* x, int B, int Lseq, hipStream_t s) {
+    const int d = m->cfg.d_model, M = B * Lseq;
+    CN_TRY(run_ln(m, n, x, m->xn, M, s));
+    CN_TRY(run_linear(m, "conv_pointwise1", L.conv.pw1, m->xn, d, m->cv_a, 2 * d, 0, M, 0, nullptr, 0, s));
+    {
+        ProfScope ps(m, "conv_glu_depthwise_norm", 2.0 * M * d * L.conv.k, (double)M * d * (4 * m->es + 12), s);
+        CN_TRY(launch_glu(m->prec, m->cv_a, m->xn, M, d, s));
+        CN_TRY(launch_dwconv(m->prec, m->xn, L.conv.dw_w, L.conv.dw_b, m->cv_f, B, Lseq, d, L.conv.k, s));
+        CN_TRY(launch_groupnorm_swish(m->prec, m->cv_f, m->gn_stats, L.conv.gn_w, L.conv.gn_b, m->xn, B, Lseq, d, 1e-5f, s));
+    }
+    return run_linear(m, "conv_pointwise2_resid", L.conv.pw2, m->xn, d, x, d, 1, M, CN_EPI_RESID, x, d, s);
+}
+
+// SelfAttLayer, relative branch (fanat_conformer_blocks.py:26-38): ff1 (0.5), attention, convolution, ff2 (0.5)
+int run_conformer_self_layer(cn_model* m, const Layer& L, float* x, int B, int Lseq, const unsigned char* keymask,
+                             const int* klen, hipStream_t s) {
+    const int M = B * Lseq;
+    CN_TRY(run_ffn_swish(m, L.w1, L.w2, L.n[0], x, M, 0.5f, s));
+    CN_TRY(run_rel_self_attn(m, L, L.n[2], x, B, Lseq, keymask, klen, s));
+    CN_TRY(run_conv_module(m, L, L.n[1], x, B, Lseq, s));
+    return run_ffn_swish(m, L.ff2_w1, L.ff2_w2, L.n[3], x, M, 0.5f, s);
+}
+
+int run_src_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B, int U, int Tp, const int* intervals,
+                 hipStream_t s);
 
 // ctx <- Attn(m->qd, enc_h Wk, enc_h Wv) with the padding mask and (optionally) trigger intervals
 int run_src_attn_core(cn_model* m, const Layer& L, int B, int U, int Tp, const int* intervals, hipStream_t s) {
@@ -953,7 +1172,7 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         g.N = d;
         g.K = F2 * d;
         g.epi = CN_EPI_EMBED;
-        g.pe = m->pe;
+        g.pe = c.conf_enc ? nullptr : m->pe;  // relative positions: x * sqrt(d) only (embedding.py:48-58, 119)
         g.pe_period = Tp;
         g.scale = sqrtf((float)d);
         ProfScope ps(m, "linear_out_embed", 2.0 * g.M * g.N * g.K,
@@ -961,6 +1180,15 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         CN_TRY(launch_gemm(m->prec, g, s));
     }
     if (cap) CN_TRY(capture(m, "x_embed", m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
+    if (c.conf_enc) {  // conformer encoder (fanat_conformer_blocks.py:141-170)
+        for (size_t n = 0; n < m->enc.size(); ++n) {
+            CN_TRY(run_conformer_self_layer(m, m->enc[n], m->x, B, Tp, m->keymask, nullptr, s));
+            if (cap) CN_TRY(capture(m, ("enc_layer" + std::to_string(n)).c_str(), m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
+        }
+        CN_TRY(run_ln(m, m->enc_norm, m->x, m->enc_h, M, s));
+        if (cap) CN_TRY(capture(m, "enc_h", m->enc_h, true, CN_DTYPE_F32, {B, Tp, d}, s));
+        return 0;
+    }
     static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
     const bool chain = !m->enc.empty() && m->enc_chain.size() == m->enc.size() && !no_chain;
     if (chain) {  // bf16 / d_model 256: LN + QKV of layer 0, then per layer attention -> row-chain kernel
@@ -1013,6 +1241,53 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
         if (idx + 1 < m->mad.size()) return &m->mad[idx + 1].n[0];
         return nullptr;
     };
+    if (c.conf_dec) {
+        if (uni) {
+            cn_set_error("decode: use_unimask is not defined for the conformer decoder (the reference indexes a tuple there)");
+            return -1;
+        }
+        float* x = m->xd;
+        // ConAcExtra (fanat_conformer_blocks.py:41-60, 172-186): attention on the raw position queries, output projection
+        // WITHOUT residual or pre-norm, scaled by sqrt(d); then x += FFN_swish(LN x)
+        for (size_t i = 0; i < m->extra.size(); ++i) {
+            const Layer& L = m->extra[i];
+            CN_TRY(launch_convert(m->prec, x, m->xn, (size_t)MU * d, s));
+            CN_TRY(run_linear(m, "src_q_proj", L.src_q, m->xn, d, m->qd, d, 0, MU, 0, nullptr, 0, s));
+            CN_TRY(run_src_attn_core(m, L, B, U, Tp, m->intervals, s));
+            {
+                ProfScope ps(m, "out_proj_scaled", 2.0 * MU * d * d, (double)MU * d * (m->es + 4), s);
+                GemmArgs g;
+                g.A = m->ctx;
+                g.lda = d;
+                g.W = L.src_o.W;
+                g.bias = L.src_o.b;
+                g.C = x;
+                g.ldc = d;
+                g.c_f32 = 1;
+                g.M = MU;
+                g.N = d;
+                g.K = d;
+                g.epi = CN_EPI_EMBED;
+                g.pe = nullptr;
+                g.scale = sqrtf((float)d);
+                CN_TRY(launch_gemm(m->prec, g, s));
+            }
+            CN_TRY(run_ffn_swish(m, L.w1, L.w2, L.n[0], x, MU, 1.0f, s));
+        }
+        if (cap) CN_TRY(capture(m, "ac_embed", x, false, CN_DTYPE_F32, {B, U, d}, s));
+        for (size_t i = 0; i < m->sad.size(); ++i) CN_TRY(run_conformer_self_layer(m, m->sad[i], x, B, U, nullptr, m->ylen, s));
+        if (cap) CN_TRY(capture(m, "pred_embed", x, false, CN_DTYPE_F32, {B, U, d}, s));
+        for (size_t i = 0; i < m->mad.size(); ++i) {  // MixAttLayer, relative branch (:85-97)
+            const Layer& L = m->mad[i];
+            CN_TRY(run_ffn_swish(m, L.w1, L.w2, L.n[0], x, MU, 0.5f, s));
+            CN_TRY(run_rel_self_attn(m, L, L.n[2], x, B, U, nullptr, m->ylen, s));
+            CN_TRY(run_conv_module(m, L, L.n[1], x, B, U, s));
+            CN_TRY(run_src_attn(m, L, &L.n[3], x, B, U, Tp, o->src_trigger ? m->intervals : nullptr, s));
+            CN_TRY(run_ffn_swish(m, L.ff2_w1, L.ff2_w2, L.n[4], x, MU, 0.5f, s));
+        }
+        CN_TRY(run_ln(m, m->dec_norm, x, m->dec_h, MU, s));
+        return stage_decode_tail(m, U, o, hyp, hyp_stride, hyp_len, score, s);
+    }
     static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
     if (!m->dec_steps.empty() && !no_chain) {
         // bf16 / d_model 256: every sublayer is [attention] + one row-chain launch that also produces the next

@@ -19,7 +19,8 @@ DTYPES = {0: np.float32, 1: np.int32, 2: np.uint8, 3: np.float64}
 class CnConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "input_size", "d_model", "n_head", "d_encff", "d_decff", "n_enc", "n_extra", "n_self_dec", "n_mix_dec",
-        "vocab_size", "precision", "max_batch", "max_frames", "device", "ast")] + [("reserved", C.c_int32 * 7)]
+        "vocab_size", "precision", "max_batch", "max_frames", "device", "ast", "conf_enc", "conf_dec", "enc_max_rel", "dec_max_rel",
+        "enc_kernel", "dec_kernel", "d_ff")]
 
 
 class CnDecodeOpts(C.Structure):
@@ -146,7 +147,11 @@ class Engine:
             input_size=args.input_size, d_model=args.d_model, n_head=args.n_head, d_encff=args.d_encff,
             d_decff=args.d_decff, n_enc=args.N_enc, n_extra=args.N_extra, n_self_dec=args.N_self_dec,
             n_mix_dec=args.N_mix_dec, vocab_size=args.vocab_size, precision=PRECISION[precision],
-            max_batch=max_batch, max_frames=max_frames, device=device, ast=ast)
+            max_batch=max_batch, max_frames=max_frames, device=device, ast=ast,
+            conf_enc=int(getattr(args, "conf_enc", 0)), conf_dec=int(getattr(args, "conf_dec", 0)),
+            enc_max_rel=int(getattr(args, "enc_max_rel", 0)), dec_max_rel=int(getattr(args, "dec_max_rel", 0)),
+            enc_kernel=int(getattr(args, "enc_kernel", 0)), dec_kernel=int(getattr(args, "dec_kernel", 0)),
+            d_ff=int(getattr(args, "d_ff", 0)))
         self.precision = precision
         self.handle = C.c_void_p()
         check(self.L.cn_model_create(C.byref(self.cfg), C.byref(self.handle)), "cn_model_create")

@@ -98,12 +98,101 @@ class _Stack(_Params):
             self.norm = _Norm(d)
 
 
+# ---- conformer variants (src/models/cassnat.py:29-57; modules/attention.py:68-147, conformer_related.py:15-44) ----
+class _RelPos(_Params):
+    """RelativePositionalEncoding: the frozen sinusoid rows are a (non-trainable) parameter of the checkpoint."""
+
+    def __init__(self, d, max_rel):
+        super().__init__()
+        self.embedding = nn.Embedding.from_pretrained(create_pe(d, 2 * max_rel + 1), freeze=True)
+
+
+class _RelAttention(_Params):
+    def __init__(self, d, h):
+        super().__init__()
+        self.pos_bias_u = nn.Parameter(torch.empty(h, d // h))
+        self.pos_bias_v = nn.Parameter(torch.empty(h, d // h))
+        nn.init.xavier_uniform_(self.pos_bias_u)
+        nn.init.xavier_uniform_(self.pos_bias_v)
+        self.linears = nn.ModuleList([_Linear(d, d) for _ in range(4)])
+        self.linear_pos = nn.Linear(d, d, bias=False)
+
+
+class _Conv1d(_Params):
+    def __init__(self, c_out, c_in_per_group, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(c_out, c_in_per_group, k))
+        self.bias = nn.Parameter(torch.empty(c_out))
+        bound = 1.0 / math.sqrt(c_in_per_group * k)
+        nn.init.uniform_(self.weight, -bound, bound)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _GroupNorm(_Params):
+    def __init__(self, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+
+
+class _ConvModule(_Params):
+    def __init__(self, d, k):
+        super().__init__()
+        self.pointwise_conv1 = _Conv1d(2 * d, d, 1)
+        self.depthwise_conv = _Conv1d(d, 1, k)
+        self.norm = _GroupNorm(d)
+        self.pointwise_conv2 = _Conv1d(d, d, 1)
+
+
+class _ConformerBlock(_Params):
+    """SelfAttLayer / MixAttLayer of fanat_conformer_blocks.py: registration order src_attn?, self_attn, feed_forward1,
+    conv_module, feed_forward2, sublayer."""
+
+    def __init__(self, d, h, d_ff, k, src_attn):
+        super().__init__()
+        if src_attn:
+            self.src_attn = _Attention(d)
+        self.self_attn = _RelAttention(d, h)
+        self.feed_forward1 = _FeedForward(d, d_ff)
+        self.conv_module = _ConvModule(d, k)
+        self.feed_forward2 = _FeedForward(d, d_ff)
+        self.sublayer = nn.ModuleList([_Sublayer(d) for _ in range(5 if src_attn else 4)])
+
+
+class _ConformerStack(_Params):
+    def __init__(self, d, h, d_ff, k, n, src_attn, final_norm):
+        super().__init__()
+        self.layers = nn.ModuleList([_ConformerBlock(d, h, d_ff, k, src_attn) for _ in range(n)])
+        if final_norm:
+            self.norm = _Norm(d)
+
+
+class _ConformerExtractorLayer(_Params):
+    """SrcAttLayer (fanat_conformer_blocks.py:41-60): src_attn, feed_forward, ONE sublayer connection, pos_enc."""
+
+    def __init__(self, d, d_ff, max_rel):
+        super().__init__()
+        self.src_attn = _Attention(d)
+        self.feed_forward = _FeedForward(d, d_ff)
+        self.sublayer = _Sublayer(d)
+        self.pos_enc = _RelPos(d, max_rel)
+
+
+class _ConformerExtractor(_Params):
+    def __init__(self, d, d_ff, max_rel, n):
+        super().__init__()
+        assert n == 1, "the reference's conformer extractor has exactly one layer (fanat_conformer_blocks.py:178)"
+        self.layers = nn.ModuleList([_ConformerExtractorLayer(d, d_ff, max_rel)])
+
+
 class _ConvEmbedding(_Params):
-    def __init__(self, input_size, d):
+    def __init__(self, input_size, d, rel_max=None):
         super().__init__()
         # indices 0 and 2 as in nn.Sequential(conv1, ReLU, conv2, ReLU)  (src/models/modules/embedding.py:102-105)
         self.conv = nn.ModuleDict({"0": _Conv(1, d), "2": _Conv(d, d)})
         self.linear_out = _Linear(d * (((input_size - 1) // 2) // 2 + 1), d)
+        if rel_max is not None:
+            self.pos_enc = _RelPos(d, rel_max)
 
 
 class _Generator(_Params):
@@ -118,19 +207,37 @@ class CassNAT(nn.Module):
     #: engine settings, overridable through ``args`` (hip_precision, hip_max_batch, hip_max_frames)
     def __init__(self, input_size, args):
         super().__init__()
-        d = args.d_model
+        d, h = args.d_model, args.n_head
         self.input_size = input_size
-        self.src_embed = _ConvEmbedding(input_size, d)
-        self.encoder = _Stack(d, args.d_encff, args.N_enc, True, False, True)
-        self.acembed_extractor = _Stack(d, args.d_decff, args.N_extra, False, True, False)
-        self.embed_mapper = _Stack(d, args.d_decff, args.N_self_dec, True, False, False)
-        self.decoder = _Stack(d, args.d_decff, args.N_mix_dec, True, True, True)
+        conf_enc, conf_dec = bool(getattr(args, "use_conv_enc", False)), bool(getattr(args, "use_conv_dec", False))
+        if conf_enc or conf_dec:
+            assert getattr(args, "pos_type", "absolute") == "relative", "conformer must use relative positional encoding"
+        if conf_enc:
+            self.src_embed = _ConvEmbedding(input_size, d, args.enc_max_relative_len)
+            self.encoder = _ConformerStack(d, h, args.d_encff, args.enc_kernel_size, args.N_enc, False, True)
+        else:
+            self.src_embed = _ConvEmbedding(input_size, d)
+            self.encoder = _Stack(d, args.d_encff, args.N_enc, True, False, True)
+        if conf_dec:
+            self.acembed_extractor = _ConformerExtractor(d, args.d_ff, args.dec_max_relative_len, args.N_extra)
+            self.embed_mapper = _ConformerStack(d, h, args.d_decff, args.dec_kernel_size, args.N_self_dec, False, False)
+            self.decoder = _ConformerStack(d, h, args.d_decff, args.dec_kernel_size, args.N_mix_dec, True, True)
+        else:
+            self.acembed_extractor = _Stack(d, args.d_decff, args.N_extra, False, True, False)
+            self.embed_mapper = _Stack(d, args.d_decff, args.N_self_dec, True, False, False)
+            self.decoder = _Stack(d, args.d_decff, args.N_mix_dec, True, True, True)
         self.ctc_generator = _Generator(d, args.vocab_size)
         self.att_generator = _Generator(d, args.vocab_size)
         self.pe = create_pe(d)
         self._hyper = dict(input_size=input_size, d_model=d, n_head=args.n_head, d_encff=args.d_encff,
                            d_decff=args.d_decff, N_enc=args.N_enc, N_extra=args.N_extra, N_self_dec=args.N_self_dec,
-                           N_mix_dec=args.N_mix_dec, vocab_size=args.vocab_size)
+                           N_mix_dec=args.N_mix_dec, vocab_size=args.vocab_size, conf_enc=int(conf_enc), conf_dec=int(conf_dec),
+                           enc_max_rel=getattr(args, "enc_max_relative_len", 0) if conf_enc else 0,
+                           dec_max_rel=getattr(args, "dec_max_relative_len", 0) if conf_dec else 0,
+                           enc_kernel=getattr(args, "enc_kernel_size", 0) if conf_enc else 0,
+                           dec_kernel=getattr(args, "dec_kernel_size", 0) if conf_dec else 0,
+                           d_ff=getattr(args, "d_ff", 0) if conf_dec else 0)
+        self._conf_dec = conf_dec
         self.hip_precision = getattr(args, "hip_precision", "bf16")
         self.hip_max_batch = getattr(args, "hip_max_batch", 32)
         self.hip_max_frames = getattr(args, "hip_max_frames", 2048)
@@ -192,6 +299,9 @@ class CassNAT(nn.Module):
             raise NotImplementedError("LM fusion is outside the accelerated path")
         if getattr(args, "test_hitrate", False):
             raise NotImplementedError("test_hitrate needs the training-time viterbi aligner")
+        if self._conf_dec and getattr(args, "use_unimask", False):
+            raise NotImplementedError("use_unimask with the conformer decoder: the reference itself cannot run it "
+                                      "(cassnat.py:486-488 indexes the (x, pos_embed) tuple)")
 
     def decode_device(self, src, src_size, args, sos=1):
         """The device half of beam_decode: returns cuda tensors (hyp (B,S) int32, hyp_len (B,) int32, score (B,) f64)."""
@@ -255,12 +365,11 @@ class CassNAT(nn.Module):
 
 
 def make_model(input_size, args):
-    """Same role as src/models/cassnat.py:21-89 for ``model_type == 'transformer'`` without conformer blocks."""
-    if getattr(args, "use_conv_enc", False) or getattr(args, "use_conv_dec", False):
-        raise NotImplementedError("conformer encoder/decoder blocks are not on the accelerated path yet")
-    assert args.model_type == "transformer"
+    """Same role as src/models/cassnat.py:21-89: transformer blocks, or conformer blocks with use_conv_enc / use_conv_dec."""
+    if not getattr(args, "use_conv_enc", False):
+        assert args.model_type == "transformer"
     model = CassNAT(input_size, args)
-    for p in model.parameters():  # src/models/cassnat.py:86-88
-        if p.dim() > 1:
+    for name, p in model.named_parameters():  # src/models/cassnat.py:86-88 (the frozen position tables stay as they are)
+        if p.dim() > 1 and p.requires_grad:
             nn.init.xavier_uniform_(p)
     return model

@@ -38,7 +38,12 @@ typedef struct cn_config {
     int32_t max_frames;
     int32_t device; /* HIP device ordinal */
     int32_t ast;    /* 1: autoregressive (AST) model: n_mix_dec = N_dec decoder layers + tgt_embed (src/models/transformer.py) */
-    int32_t reserved[7];
+    /* conformer variants (src/models/cassnat.py:29-57, pos_type "relative"): macaron Swish FFNs, relative-position self
+     * attention, convolution module.  conf_enc / conf_dec = args.use_conv_enc / use_conv_dec. */
+    int32_t conf_enc, conf_dec;
+    int32_t enc_max_rel, dec_max_rel; /* args.enc_max_relative_len / dec_max_relative_len (<= 31) */
+    int32_t enc_kernel, dec_kernel;   /* args.enc_kernel_size / dec_kernel_size (odd) */
+    int32_t d_ff;                     /* args.d_ff: width of the conformer extractor's FFN */
 } cn_config;
 
 /* Decode-time switches read by beam_decode from `args` (src/models/cassnat.py:435-636). */

@@ -64,9 +64,16 @@ def test_positional_table_matches_oracle_closed_form():
     assert torch.equal(create_pe(256), sinusoid_table(256))
 
 
-def test_make_model_refuses_conformer_blocks():
-    with pytest.raises(NotImplementedError):
+def test_make_model_conformer_blocks_hold_the_reference_parameter_names():
+    """use_conv_enc / use_conv_dec build conformer parameter holders whose names and shapes are the reference's checkpoint
+    keys (the list in synth.param_shapes_conformer is checked against the instantiated reference in oracle/make_goldens.py);
+    like the reference (src/models/cassnat.py:31) they insist on relative positions."""
+    with pytest.raises(AssertionError):
         make_model(80, synth.make_args("tiny", use_conv_dec=True))
+    for ov in (dict(), dict(use_conv_enc=False)):
+        args = synth.make_args("tiny_conf", **ov)
+        model = make_model(80, args)
+        assert [(k, tuple(v.shape)) for k, v in model.named_parameters()] == list(synth.param_shapes_conformer(args).items())
 
 
 # ------------------------------------------------------------------------------------------- data side
