@@ -38,6 +38,43 @@ PRESETS_CONF = {
 }
 PRESETS.update(PRESETS_CONF)
 
+# TransformerLM that ranks the ESA samples (src/models/lm.py; egs/librispeech/conf/lm.yaml shape family)
+PRESETS_LM = {
+    "tiny_lm": dict(d_model=128, n_head=2, d_ff=256, N=2, vocab_size=40, dropout=0.0),
+    "lm_small": dict(d_model=256, n_head=4, d_ff=1024, N=4, vocab_size=5000, dropout=0.0),
+}
+
+
+def make_args_lm(preset="tiny_lm", **overrides):
+    d = dict(PRESETS_LM[preset] if isinstance(preset, str) else preset)
+    d.update(overrides)
+    return SimpleNamespace(**d)
+
+
+def param_shapes_lm(args):
+    """Named parameters of the reference's TransformerLM (src/models/lm.py:16-31): text_embed.0.lut, encoder, out_generator."""
+    d = args.d_model
+    shapes = OrderedDict()
+    shapes["text_embed.0.lut.weight"] = (args.vocab_size, d)
+    for n in range(args.N):
+        p = f"encoder.layers.{n}"
+        for i in range(4):
+            shapes[f"{p}.self_attn.linears.{i}.weight"] = (d, d)
+            shapes[f"{p}.self_attn.linears.{i}.bias"] = (d,)
+        shapes[p + ".feed_forward.w_1.weight"] = (args.d_ff, d)
+        shapes[p + ".feed_forward.w_1.bias"] = (args.d_ff,)
+        shapes[p + ".feed_forward.w_2.weight"] = (d, args.d_ff)
+        shapes[p + ".feed_forward.w_2.bias"] = (d,)
+        for i in range(2):
+            shapes[f"{p}.sublayer.{i}.norm.a_2"] = (d,)
+            shapes[f"{p}.sublayer.{i}.norm.b_2"] = (d,)
+    shapes["encoder.norm.a_2"] = (d,)
+    shapes["encoder.norm.b_2"] = (d,)
+    shapes["out_generator.proj.weight"] = (args.vocab_size, d)
+    shapes["out_generator.proj.bias"] = (args.vocab_size,)
+    return shapes
+
+
 PRESETS_AST = {
     "tiny_ast": dict(input_size=80, d_model=128, n_head=2, d_ff=256, d_encff=256, N_enc=2, N_dec=2, vocab_size=40),
     # BASELINE configs[3]: AST beam=10 on the config-2 encoder
@@ -307,6 +344,8 @@ def make_state(args, seed=0, blank_bias=0.0, gain=1.0):
     state = OrderedDict()
     if hasattr(args, "N_dec"):
         shapes = param_shapes_ast(args)
+    elif hasattr(args, "N") and not hasattr(args, "N_enc"):
+        shapes = param_shapes_lm(args)
     elif getattr(args, "use_conv_dec", False) or getattr(args, "use_conv_enc", False):
         shapes = param_shapes_conformer(args)
     else:

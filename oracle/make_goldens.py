@@ -163,6 +163,44 @@ def main():
     gdir = os.path.join(REPO, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
 
+    # ---- 4a''. ESA: error-based sampling of alignments ranked by a TransformerLM, sample_num = 4
+    if only in (None, "esa"):
+        from models.lm import make_model as make_lm
+
+        for name, preset, lmp, bshape, seed in (("esa_tiny", "tiny", "tiny_lm", (3, 61, [61, 50, 37]), 777),
+                                                ("esa_config2", "config2", "lm_small", (2, 300, [300, 231]), 4242)):
+            ae = synth.make_args(preset, sample_num=4, threshold=0.9, rank_model="lm")
+            la = synth.make_args_lm(lmp, vocab_size=ae.vocab_size)
+            se = synth.make_state(ae, seed=0, gain=2.0) if preset == "tiny" else synth.make_state(ae, seed=0, blank_bias=0.35)
+            sl = synth.make_state(la, seed=9, gain=2.0)
+            fe, ze = synth.make_feats(bshape[0], bshape[1], 80, lengths=bshape[2], seed=11)
+            model = make_model(ae.input_size, ae).eval()
+            lm = make_lm(la).eval()
+            assert [k for k, _ in lm.named_parameters()] == list(sl.keys()), "LM parameter naming drifted from the reference"
+            with torch.no_grad():
+                for k, p_ in model.named_parameters():
+                    p_.copy_(torch.from_numpy(se[k]))
+                for k, p_ in lm.named_parameters():
+                    p_.copy_(torch.from_numpy(sl[k]))
+            src = torch.from_numpy(fe)
+            t_sub = ((fe.shape[1] - 1) // 2 + 1 - 1) // 2 + 1
+            torch.manual_seed(seed)
+            select = torch.randint(0, 2, (fe.shape[0] * ae.sample_num, t_sub, 1))  # the draw of cassnat.py:372 under this seed
+            torch.manual_seed(seed)
+            with torch.no_grad():
+                top, _ = model.beam_decode(src, (src[:, :, 0] != 0).unsqueeze(1), torch.from_numpy(ze), _Vocab, ae, lm)
+            U = max(len(t[0]["hyp"]) for t in top)
+            hyp = np.zeros((len(top), U), np.int32)
+            hlen = np.zeros(len(top), np.int32)
+            for b, t in enumerate(top):
+                hlen[b] = len(t[0]["hyp"])
+                hyp[b, : hlen[b]] = t[0]["hyp"]
+            np.savez_compressed(os.path.join(gdir, f"{name}.npz"), hyp=hyp, hyp_len=hlen, select=select.numpy().astype(np.uint8),
+                                score=np.array([t[0]["score"] for t in top], np.float64))
+            print(name, hlen, [t[0]["score"] for t in top])
+        if only:
+            return
+
     # ---- 4a'. conformer variants: use_conv_enc / use_conv_dec, relative positions
     if only in (None, "conformer"):
         ac = synth.make_args("tiny_conf")

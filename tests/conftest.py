@@ -85,6 +85,20 @@ def conf_small_case():
     return args, state, feats, sizes
 
 
+def esa_case(which):
+    """ESA (sample_num = 4) + TransformerLM ranking cases of oracle/make_goldens.py."""
+    from cassnat_asr_public_amd import synth
+
+    preset, lmp, (B, T, lens) = {"esa_tiny": ("tiny", "tiny_lm", (3, 61, [61, 50, 37])),
+                                 "esa_config2": ("config2", "lm_small", (2, 300, [300, 231]))}[which]
+    args = synth.make_args(preset, sample_num=4, threshold=0.9, rank_model="lm")
+    lm_args = synth.make_args_lm(lmp, vocab_size=args.vocab_size)
+    state = synth.make_state(args, seed=0, gain=2.0) if preset == "tiny" else synth.make_state(args, seed=0, blank_bias=0.35)
+    lm_state = synth.make_state(lm_args, seed=9, gain=2.0)
+    feats, sizes = synth.make_feats(B, T, 80, lengths=lens, seed=11)
+    return args, lm_args, state, lm_state, feats, sizes
+
+
 def config2_b32_case():
     """The benchmark workload (bench.py): B=32 x 1000 frames, blank bias 0.9."""
     from cassnat_asr_public_amd import synth

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (conf_small_case, conf_tiny_case, ast_config4_case, ast_tiny_case, config1_case, config2_b8_case, config2_b32_case, config5_shape_case,
+from conftest import (esa_case, conf_small_case, conf_tiny_case, ast_config4_case, ast_tiny_case, config1_case, config2_b8_case, config2_b32_case, config5_shape_case,
                       load_golden, tiny_case)
 from oracle import cassnat_oracle as orc
 
@@ -179,6 +179,22 @@ def test_conformer_shipped_shape():
     np.testing.assert_array_equal(out["ylen"], g["ylen"])
     for b, h in enumerate(out["hyps"]):
         assert h == g["hyp"][b, : g["hyp_len"][b]].tolist()
+
+
+# ------------------------------------------------------------------------------------------- ESA + LM ranking (8f rank 3)
+@pytest.mark.parametrize("which", ["esa_tiny", "esa_config2"])
+def test_esa_sampling_and_lm_ranking(which):
+    """The random 0/1 draws of cassnat.py:372 are an input (stored in the fixture).  A hypothesis shorter than the longest
+    selected one ends with one token read from an all-zero (masked) row: the reference takes torch.topk of equal values
+    there, which is implementation-defined - compared up to that position, scores (unaffected: + 0.0) in full."""
+    g = load_golden(which)
+    args, lm_args, state, lm_state, feats, sizes = esa_case(which)
+    out = orc.decode_nast_esa(state, lm_state, feats, sizes, args, lm_args, torch.from_numpy(g["select"].astype(np.int64)))
+    for b, h in enumerate(out["hyps"]):
+        n = int(out["ylen"][b]) + 1  # sos + ylen tokens are well defined
+        assert len(h) == g["hyp_len"][b]
+        assert h[:n] == g["hyp"][b, :n].tolist()
+    np.testing.assert_allclose(out["scores"], g["score"], atol=1e-4)
 
 
 # ------------------------------------------------------------------------------------------- AST (BASELINE config 4)
