@@ -51,6 +51,11 @@ int launch_keymask(const float* feats, int B, int T, int F, int Tp, int stride, 
 int launch_fill_queries(const float* table, float* out, int B, int U, int d, hipStream_t s);
 // use_unimask: y[b][0] = 0 ; y[b][u] = x[b][u-1]
 int launch_shift_right(const float* x, float* y, int B, int U, int d, hipStream_t s);
+int launch_esa_paths(const int* top2_idx, const float* top2_val, const unsigned char* select, float threshold, int* best, int M,
+                     hipStream_t s);
+int launch_lm_embed(const int* tok, int ld, const float* lut, const float* pe, float* x, int B, int U, int d, float scale,
+                    hipStream_t s);
+int launch_gather_logp(const float* logp, int V, const int* tgt, int ld, float* out, int B, int U, hipStream_t s);
 int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t s);       // fp32 -> model precision
 int launch_convert_back(int prec, const void* src, float* dst, size_t n, hipStream_t s);  // model precision -> fp32
 

@@ -506,9 +506,11 @@ int build_weights(cn_model* m) {
     pk.m = m;
     pk.fill = !m->host.empty();
     const int64_t F2 = m->F2;
+    // cfg.ast == 2: the TransformerLM that ranks ESA samples (src/models/lm.py): token embedding, encoder stack, generator
+    const bool lm = c.ast == 2;
 
     // conv1: (C,1,3,3) -> [tap][C] fp32
-    {
+    if (!lm) {
         const size_t at = pk.reserve(9 * C * 4);
         if (pk.fill) {
             const HostTensor* t = pk.find("src_embed.conv.0.weight", {C, 1, 3, 3});
@@ -521,7 +523,7 @@ int build_weights(cn_model* m) {
         m->conv1_b = pk.vec({"src_embed.conv.0.bias"}, C);
     }
     // conv2: (Co,Ci,3,3) -> [Co][(kh,kw,ci)]
-    {
+    if (!lm) {
         m->conv2.N = (int)C;
         m->conv2.K = (int)(9 * C);
         const size_t at = pk.reserve((size_t)C * 9 * C * m->es);
@@ -537,7 +539,7 @@ int build_weights(cn_model* m) {
         m->conv2.b = pk.vec({"src_embed.conv.2.bias"}, C);
     }
     // linear_out: column c*F2+f of the reference (embedding.py:118) -> column f*C+c (the conv2 GEMM's natural output)
-    {
+    if (!lm) {
         std::vector<int> perm((size_t)(C * F2));
         for (int64_t f = 0; f < F2; ++f)
             for (int64_t ch = 0; ch < C; ++ch) perm[(size_t)(f * C + ch)] = (int)(ch * F2 + f);
@@ -572,7 +574,7 @@ int build_weights(cn_model* m) {
     }
     m->enc_norm = pk.norm("encoder.norm", d);
     m->enc_chain.clear();
-    if (!c.conf_enc && pk.chain_ok(d, c.d_encff))
+    if (!lm && !c.conf_enc && pk.chain_ok(d, c.d_encff))
         for (int n = 0; n < c.n_enc; ++n) {
             const std::string p = "encoder.layers." + std::to_string(n), q = "encoder.layers." + std::to_string(n + 1);
             if (n + 1 < c.n_enc)
@@ -618,7 +620,7 @@ int build_weights(cn_model* m) {
             m->mad.push_back(L);
         }
     }
-    m->dec_norm = pk.norm("decoder.norm", d);
+    if (!lm) m->dec_norm = pk.norm("decoder.norm", d);
     // decoder-side sublayers of the NAT model in execution order, each with the chain that follows its attention
     m->dec_steps.clear();
     if (!c.ast && !c.conf_dec && pk.chain_ok(d, c.d_decff)) {
@@ -662,15 +664,15 @@ int build_weights(cn_model* m) {
     if (c.ast) {
         const size_t at = pk.reserve((size_t)V * d * 4);
         if (pk.fill) {
-            const HostTensor* t = pk.find("tgt_embed.0.lut.weight", {V, d});
+            const HostTensor* t = pk.find(lm ? "text_embed.0.lut.weight" : "tgt_embed.0.lut.weight", {V, d});
             if (t) std::memcpy(&pk.host[at], t->data.data(), (size_t)V * d * 4);
         }
         m->tgt_lut = reinterpret_cast<float*>(at);
     } else {
         m->tgt_lut = nullptr;
     }
-    m->ctc_gen = pk.generator("ctc_generator.proj", V, d);
-    m->att_gen = pk.generator("att_generator.proj", V, d);
+    if (!lm) m->ctc_gen = pk.generator("ctc_generator.proj", V, d);
+    m->att_gen = pk.generator(lm ? "out_generator.proj" : "att_generator.proj", V, d);
     {
         const size_t at = pk.reserve((size_t)m->pe_rows * d * 4);
         if (pk.fill) std::memcpy(&pk.host[at], m->pe_host.data(), (size_t)m->pe_rows * d * 4);
@@ -748,8 +750,10 @@ int build_workspace(cn_model* m) {
     const size_t M = B * (Tp + 1);  // decoder rows can reach B*(T'+1)
     const size_t dff = std::max(std::max(c.d_encff, c.d_decff), c.d_ff);  // (d_ff: the conformer extractor's FFN width)
     CN_TRY(dev_alloc(m, (void**)&m->keymask, B * Tp));
-    CN_TRY(dev_alloc(m, &m->c1, B * (T1 + 2) * (F1 + 2) * d * es));  // room for the zero halo the bf16 conv2 kernel wants
-    CN_TRY(dev_alloc(m, &m->c2, B * Tp * F2 * d * es));
+    if (c.ast != 2) {  // (the LM has no convolutional front-end)
+        CN_TRY(dev_alloc(m, &m->c1, B * (T1 + 2) * (F1 + 2) * d * es));  // room for the zero halo the bf16 conv2 kernel wants
+        CN_TRY(dev_alloc(m, &m->c2, B * Tp * F2 * d * es));
+    }
     CN_TRY(dev_alloc(m, (void**)&m->x, (M + 32) * d * 4));  // + one 32-row block: the chain kernel's blocked layout rounds up
     CN_TRY(dev_alloc(m, &m->xn, M * d * es));
     CN_TRY(dev_alloc(m, &m->qkv, M * 3 * d * es));
@@ -1545,6 +1549,102 @@ extern "C" int cn_decode_nast(cn_model* m, const float* feats_dev, const float* 
     }
     CN_TRY(stage_decode(m, ymax, opts, hyp_out_dev, hyp_stride, hyp_len_dev, score_dev, s));
     return 0;
+}
+
+
+// ---- ESA: error-based sampling of alignments (src/models/cassnat.py:370-376, 441-445) ------------------------------
+// cn_esa_begin runs the encoder and the CTC generator once and keeps the two best labels of every frame; every
+// cn_esa_sample call then builds ONE sampled alignment per utterance - frame t takes the second-best label iff its draw
+// select[b][t] is 1 and the best label's probability is below `threshold` (select == NULL: the best path itself) - and
+// runs the alignment + decoder side on it: tok_out / val_out [B][out_stride] = argmax token and its log-probability per
+// decoder row, ylen_out [B] (EOS row included), *ymax_host = rows of this sample.  Samples are independent, so the caller
+// loops over them on one workspace; the random draws are the caller's (the reference takes them from torch.randint).
+extern "C" int cn_esa_begin(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts,
+                            void* stream) {
+    CN_TRY(check_call(m, B, T, F));
+    if (!opts || m->cfg.ast) {
+        cn_set_error("cn_esa_begin: needs a NAT model and decode options");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+    CN_TRY(stage_encode(m, feats_dev, B, T, F, opts, s));
+    const int d = m->cfg.d_model, V = m->cfg.vocab_size, M = B * m->Tp;
+    CN_TRY(run_linear(m, "generator_proj", m->ctc_gen, m->enc_h, d, m->logits, V, 1, M, 0, nullptr, 0, s));
+    CN_TRY(launch_logsoftmax_argmax(m->logits, M, V, V, m->best, m->ctc_maxlp, 1, s));
+    CN_TRY(launch_topk(m->logits, M, V, V, 2, m->topk_idx, m->topk_val, s));
+    return 0;
+}
+
+extern "C" int cn_esa_sample(cn_model* m, const uint8_t* select_dev, float threshold, const float* size_ratio_dev,
+                             const cn_decode_opts* opts, int32_t* tok_out_dev, float* val_out_dev, int32_t out_stride,
+                             int32_t* ylen_out_dev, int32_t* ymax_host, void* stream) {
+    if (!m || !opts || !tok_out_dev || !val_out_dev || !ylen_out_dev || !ymax_host || m->B < 1 || opts->beam_width != 1) {
+        cn_set_error("cn_esa_sample: call cn_esa_begin first; beam_width must be 1");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+    const int B = m->B, Tp = m->Tp;
+    CN_TRY(launch_esa_paths(m->topk_idx, m->topk_val, select_dev, threshold, m->best, B * Tp, s));
+    AlignArgs al;
+    al.best = m->best;
+    al.keymask = m->keymask;
+    al.size_ratio = size_ratio_dev;
+    al.B = B;
+    al.Tp = Tp;
+    al.blank = opts->padding_idx;
+    al.left = opts->left_trigger;
+    al.right = opts->right_trigger;
+    al.shift = m->shift;
+    al.src_size = m->src_size;
+    al.ylen = m->ylen;
+    al.ymax = m->ymax;
+    al.intervals = m->intervals;
+    CN_TRY(launch_ctc_align(al, s));
+    CN_HIP_CHECK(hipMemcpyAsync(m->ymax_pinned, m->ymax, sizeof(int), hipMemcpyDeviceToHost, s));
+    CN_HIP_CHECK(hipStreamSynchronize(s));
+    const int U = *m->ymax_pinned;
+    if (U < 1 || U > Tp + 1 || U > out_stride) {
+        cn_set_error("cn_esa_sample: token count outside the output stride");
+        return -3;
+    }
+    CN_TRY(stage_decode(m, U, opts, nullptr, 0, nullptr, nullptr, s));
+    CN_HIP_CHECK(hipMemcpy2DAsync(tok_out_dev, (size_t)out_stride * 4, m->tok, (size_t)U * 4, (size_t)U * 4, B, hipMemcpyDeviceToDevice, s));
+    CN_HIP_CHECK(hipMemcpy2DAsync(val_out_dev, (size_t)out_stride * 4, m->val, (size_t)U * 4, (size_t)U * 4, B, hipMemcpyDeviceToDevice, s));
+    CN_HIP_CHECK(hipMemcpyAsync(ylen_out_dev, m->ylen, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    *ymax_host = U;
+    return 0;
+}
+
+// ---- TransformerLM scoring (src/models/lm.py:52-56 as used at cassnat.py:507-523): score[b][u] = log p(tgt[b][u] | tok[b][..u])
+// under the causal + length mask (key j allowed iff j <= u and j < len[b]).  Model created with cfg.ast == 2:
+// n_enc encoder layers of width d_encff, parameters text_embed.0.lut / encoder.* / out_generator.proj.
+extern "C" int cn_lm_score(cn_model* m, const int32_t* tok_dev, const int32_t* tgt_dev, const int32_t* len_dev, int32_t B,
+                           int32_t U, int32_t ld, float* score_dev, void* stream) {
+    if (!m || m->cfg.ast != 2 || !m->finalized || !m->tgt_lut) {
+        cn_set_error("cn_lm_score: the model was not created with cfg.ast = 2 / not finalized");
+        return -1;
+    }
+    if (B < 1 || U < 1 || ld < U || (size_t)B * U > (size_t)m->maxB * (m->maxTp + 1) || U > m->pe_rows) {
+        cn_set_error("cn_lm_score: batch x length exceeds the workspace");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+    CN_TRY(build_workspace(m));
+    const int d = m->cfg.d_model, V = m->cfg.vocab_size, M = B * U;
+    float* x = m->x;
+    CN_TRY(launch_lm_embed(tok_dev, ld, m->tgt_lut, m->pe, x, B, U, d, sqrtf((float)d), s));
+    for (size_t n = 0; n < m->enc.size(); ++n) {
+        const Layer& L = m->enc[n];
+        CN_TRY(run_self_attn(m, L, &L.n[0], x, B, U, nullptr, len_dev, 1, s));
+        CN_TRY(run_ffn(m, L, L.n[1], x, M, nullptr, nullptr, s));
+    }
+    CN_TRY(run_ln(m, m->enc_norm, x, m->enc_h, M, s));
+    CN_TRY(run_linear(m, "generator_proj", m->att_gen, m->enc_h, d, m->logits, V, 1, M, 0, nullptr, 0, s));
+    CN_TRY(launch_logsoftmax_argmax(m->logits, M, V, V, m->best, m->ctc_maxlp, 1, s));
+    return launch_gather_logp(m->logits, V, tgt_dev, ld, score_dev, B, U, s);
 }
 
 extern "C" int cn_profile_begin(cn_model* m, const char* tags) {

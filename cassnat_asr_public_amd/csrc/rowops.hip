@@ -308,3 +308,52 @@ int launch_convert_back(int prec, const void* src, float* dst, size_t n, hipStre
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// ---- ESA sampled alignment: label of frame i = second best iff its draw is 1 and exp(best log-prob) < threshold ----------
+__global__ void esa_paths_kernel(const int* __restrict__ top2_idx, const float* __restrict__ top2_val,
+                                 const unsigned char* __restrict__ select, float threshold, int* __restrict__ best, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int pick = (select && select[i] && expf(top2_val[2 * i]) < threshold) ? 1 : 0;
+    best[i] = top2_idx[2 * i + pick];
+}
+int launch_esa_paths(const int* top2_idx, const float* top2_val, const unsigned char* select, float threshold, int* best, int M,
+                     hipStream_t s) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(esa_paths_kernel, dim3(cn_ceil_div(M, 256)), dim3(256), 0, s, top2_idx, top2_val, select, threshold, best, M);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- TransformerLM input: x[b][u] = lut[tok[b][u]] * sqrt(d) + pe[u]   (embedding.py:71-78, 29-31) -----------------------
+__global__ void lm_embed_kernel(const int* __restrict__ tok, int ld, const float* __restrict__ lut, const float* __restrict__ pe,
+                                float* __restrict__ x, int B, int U, int d, float scale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * U * d) return;
+    const int c = (int)(i % d);
+    const long long bu = i / d;
+    const int u = (int)(bu % U), b = (int)(bu / U);
+    x[i] = lut[(long long)tok[(long long)b * ld + u] * d + c] * scale + pe[(long long)u * d + c];
+}
+int launch_lm_embed(const int* tok, int ld, const float* lut, const float* pe, float* x, int B, int U, int d, float scale,
+                    hipStream_t s) {
+    const long long n = (long long)B * U * d;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(lm_embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tok, ld, lut, pe, x, B, U, d, scale);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ void gather_logp_kernel(const float* __restrict__ logp, int V, const int* __restrict__ tgt, int ld,
+                                   float* __restrict__ out, int B, int U) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * U) return;
+    const int b = i / U, u = i - b * U;
+    out[(long long)b * ld + u] = logp[(long long)i * V + tgt[(long long)b * ld + u]];
+}
+int launch_gather_logp(const float* logp, int V, const int* tgt, int ld, float* out, int B, int U, hipStream_t s) {
+    if (B * U <= 0) return 0;
+    hipLaunchKernelGGL(gather_logp_kernel, dim3(cn_ceil_div(B * U, 256)), dim3(256), 0, s, logp, V, tgt, ld, out, B, U);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}

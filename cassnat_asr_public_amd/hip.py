@@ -110,6 +110,10 @@ def lib():
     L.cn_fbank_num_frames.restype = C.c_int32
     L.cn_fbank.argtypes = [C.POINTER(CnFbankOpts), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_int32, C.c_float, C.c_void_p]
+    L.cn_esa_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts), C.c_void_p]
+    L.cn_esa_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.POINTER(CnDecodeOpts), C.c_void_p, C.c_void_p,
+                                C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
+    L.cn_lm_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.cn_decode_ast.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts),
                                 C.POINTER(CnAstOpts), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_ast_ctc_score.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
@@ -223,6 +227,24 @@ class Engine:
     def ast_ctc_score(self, out_len, utt, last_tok, cand, prev_ref, parity, eos, score):
         check(self.L.cn_ast_ctc_score(self.handle, cand.shape[0], out_len, _ptr(utt), _ptr(last_tok), _ptr(cand), cand.shape[1],
                                       _ptr(prev_ref), parity, eos, _ptr(score), current_stream()), "cn_ast_ctc_score")
+
+    # ---- ESA sampling + LM ranking
+    def esa_begin(self, feats, opts):
+        B, T, F = feats.shape
+        check(self.L.cn_esa_begin(self.handle, _ptr(feats), B, T, F, C.byref(opts), current_stream()), "cn_esa_begin")
+
+    def esa_sample(self, select, threshold, size_ratio, opts, tok, val, ylen):
+        """select: uint8 (B, T') cuda draws or None (best path) -> rows (U) of this sample; tok / val (B, stride), ylen (B,)."""
+        ymax = C.c_int32()
+        check(self.L.cn_esa_sample(self.handle, _ptr(select) if select is not None else None, float(threshold), _ptr(size_ratio),
+                                   C.byref(opts), _ptr(tok), _ptr(val), tok.shape[1], _ptr(ylen), C.byref(ymax), current_stream()),
+              "cn_esa_sample")
+        return ymax.value
+
+    def lm_score(self, tok, tgt, length, U, score):
+        """tok / tgt int32 (N, ld), length int32 (N,), score float32 (N, ld): log p(tgt[n][u] | tok[n][..u]) for u < U."""
+        check(self.L.cn_lm_score(self.handle, _ptr(tok), _ptr(tgt), _ptr(length), tok.shape[0], int(U), tok.shape[1], _ptr(score),
+                                 current_stream()), "cn_lm_score")
 
     def ast_decode(self, feats, opts, ast_opts, hyp, hyp_len, score):
         """Whole beam search on the device: hyp int32 (B, beam, max_len), hyp_len int32 (B, beam), score float64 (B, beam)."""

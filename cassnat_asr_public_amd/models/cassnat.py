@@ -293,10 +293,15 @@ class CassNAT(nn.Module):
     def _check_args(self, args, lm_model):
         if not getattr(args, "use_trigger", True):
             raise NotImplementedError("use_trigger=False is not on the accelerated path")
-        if getattr(args, "sample_num", 0) > 1 or getattr(args, "decode_type", "att_only") not in ("att_only",):
-            raise NotImplementedError("ESA sampling / ctc_att / oracle_att decoding are outside the accelerated path")
+        if getattr(args, "decode_type", "att_only") not in ("att_only",):
+            raise NotImplementedError("ctc_att / oracle_att decoding are outside the accelerated path")
         if getattr(args, "lm_weight", 0) > 0 and lm_model is not None:
-            raise NotImplementedError("LM fusion is outside the accelerated path")
+            raise NotImplementedError("LM shallow fusion in the finish loop is outside the accelerated path")
+        if getattr(args, "sample_num", 0) > 1:
+            if getattr(args, "rank_model", "lm") != "lm" or lm_model is None or not hasattr(lm_model, "score_tokens"):
+                raise NotImplementedError("ESA ranking needs rank_model == 'lm' and a cassnat_asr_public_amd.models.lm.TransformerLM")
+            if args.beam_width != 1 or self._conf_dec or self._hyper.get("conf_enc"):
+                raise NotImplementedError("ESA is implemented for the transformer blocks with beam_width == 1")
         if getattr(args, "test_hitrate", False):
             raise NotImplementedError("test_hitrate needs the training-time viterbi aligner")
         if self._conf_dec and getattr(args, "use_unimask", False):
@@ -331,6 +336,8 @@ class CassNAT(nn.Module):
         self._check_args(args, lm_model)
         sos = vocab.word2index["sos"]
         assert vocab.word2index["blank"] == args.padding_idx, "CTC blank id and padding_idx must agree"
+        if getattr(args, "sample_num", 0) > 1:
+            return self._esa_decode(src, src_size, args, lm_model, sos), args
         hyp, hyp_len, score = self.decode_device(src, src_size, args, sos)
         if args.beam_width > 1:
             return self._host_beam(self._engine, args, sos), args
@@ -340,6 +347,63 @@ class CassNAT(nn.Module):
         for b in range(hyp_h.shape[0]):
             out.append([{"ys": ys, "score": float(score_h[b]), "hyp": hyp_h[b, : len_h[b]].tolist()}])
         return out, args
+
+    def _esa_decode(self, src, src_size, args, lm_model, sos):
+        """Error-based sampling of alignments + LM ranking (src/models/cassnat.py:370-376, 441-445, 499-561; sample_num > 1,
+        rank_model 'lm', lm_weight 0, beam_width 1).  The encoder and the CTC generator run once; every sample (one alignment
+        per utterance, sample 0 = the best path) is a device pass over the same workspace (alignment -> extractor -> decoder ->
+        generator argmax), the TransformerLM scores each sample's tokens on the device, and the ranking - a mean over at
+        most T' numbers per sample - is done here exactly as the reference writes it.  The 0/1 draws come from
+        ``torch.randint(0, 2, (B * sample_num, T', 1))`` like the reference's (same seed, same stream);
+        ``args.esa_select`` overrides them (tests)."""
+        dev = torch.device("cuda", getattr(self, "_device", torch.cuda.current_device()))
+        feats = src.to(dev, torch.float32).contiguous()
+        ratio = src_size.to(dev, torch.float32).contiguous()
+        B, T, _ = feats.shape
+        S = int(args.sample_num)
+        Tp = ((T - 1) // 2 + 1 - 1) // 2 + 1
+        eng = self.engine(B, T)
+        opts = hip.Engine.make_opts(args)
+        opts.sos = sos
+        select = getattr(args, "esa_select", None)
+        if select is None:
+            select = torch.randint(0, 2, (B * S, Tp, 1))
+        select = torch.as_tensor(select).reshape(B, S, Tp).to(torch.uint8)
+        eng.esa_begin(feats, opts)
+        stride = Tp + 2
+        tok = torch.zeros(S, B, stride, dtype=torch.int32, device=dev)
+        val = torch.zeros(S, B, stride, dtype=torch.float32, device=dev)
+        ylen = torch.zeros(S, B, dtype=torch.int32, device=dev)
+        U = 0
+        for s_i in range(S):
+            sel = None if s_i == 0 else select[:, s_i].contiguous().to(dev)  # include_best: sample 0 is the best path
+            U = max(U, eng.esa_sample(sel, args.threshold, ratio, opts, tok[s_i], val[s_i], ylen[s_i]))
+        # LM input = [sos] + predictions shifted right; score of every predicted token under the causal + length mask
+        tokf, ylf = tok.reshape(S * B, stride), ylen.reshape(S * B)
+        lm_in = torch.cat([torch.full((S * B, 1), sos, dtype=torch.int32, device=dev), tokf[:, : stride - 1]], 1).contiguous()
+        lm_score = lm_model.score_tokens(lm_in, tokf.contiguous(), ylf.contiguous(), U, max_frames=max(T, 64))
+        lm_score = lm_score.reshape(S, B, stride)[:, :, :U].transpose(0, 1).cpu()                  # (B, S, U)
+        ylen_h = ylen.transpose(0, 1).cpu().long()                                                # (B, S)
+        tmask = torch.arange(U).view(1, 1, U) < ylen_h.unsqueeze(-1)
+        lm_score = lm_score.masked_fill(tmask == 0, 0)
+        prob_sum = lm_score.sum(-1) / (lm_score != 0).sum(-1).float()                             # cassnat.py:521-522
+        pick = prob_sum.max(-1, keepdim=True)[1]
+        tok_h, val_h = tok.cpu().numpy(), val.cpu().numpy()
+        ylen_sel = ylen_h.gather(1, pick).squeeze(1).numpy()
+        ymax = int(ylen_sel.max())
+        ys = torch.ones(1, 1).fill_(sos).long()
+        out = []
+        for b in range(B):
+            s_b, n = int(pick[b, 0]), int(ylen_sel[b])
+            hyp, score = [sos], 0.0
+            for i in range(min(n + 1, ymax)):  # the greedy finish consumes position i while i <= ylen[b] (cassnat.py:580-637)
+                if i < n:
+                    hyp.append(int(tok_h[s_b, b, i]))
+                    score += float(val_h[s_b, b, i])
+                else:  # one row past the sample's mask: the reference reads an all-zero row there (+ 0.0, arbitrary tie token)
+                    hyp.append(0)
+            out.append([{"ys": ys, "score": score, "hyp": hyp}])
+        return out
 
     @staticmethod
     def _host_beam(eng, args, sos):

@@ -80,9 +80,29 @@ class CassNATTask(BaseTask):
         return cdist.shard_indices(lengths, self.world, self.rank)
 
     def load_lm_model(self, args):
-        if args.lm_weight > 0 or getattr(args, "ctc_lm_weight", 0) > 0:
-            raise NotImplementedError("LM fusion / ESA ranking are outside the accelerated path (SURVEY 8f)")
+        """src/tasks/cassnat_task.py:85-125: the TransformerLM that ranks ESA samples (rank_model 'lm'); the n-gram and
+        at_baseline rankers and LM shallow fusion (lm_weight > 0) are outside the accelerated path."""
         self.lm_model = None
+        if args.lm_weight > 0:
+            raise NotImplementedError("LM shallow fusion (lm_weight > 0) is outside the accelerated path")
+        if getattr(args, "ctc_lm_weight", 0) > 0:
+            if getattr(args, "rank_model", "lm") != "lm":
+                raise NotImplementedError("only rank_model == 'lm' is on the accelerated path")
+            import yaml
+            from types import SimpleNamespace
+
+            from ..models.lm import make_model as make_lm_model
+
+            with open(args.lm_config) as f:
+                lm_args = SimpleNamespace(**yaml.safe_load(f))
+            lm_args.vocab_size = self.vocab.n_words
+            lm_args.hip_precision = getattr(args, "hip_precision", "bf16")
+            lm_model = make_lm_model(lm_args)
+            state = torch.load(args.rnnlm, map_location="cpu")["model_state"]
+            with torch.no_grad():
+                for name, param in lm_model.named_parameters():
+                    param.copy_(state[name if name in state else "module." + name])
+            self.lm_model = lm_model.cuda(self.local_rank) if hasattr(self, "local_rank") else lm_model
 
     def decode(self, args):
         batch_time = util.AverageMeter("Time", ":6.3f")

@@ -37,7 +37,8 @@ typedef struct cn_config {
     int32_t max_batch;  /* workspace is sized for max_batch x max_frames */
     int32_t max_frames;
     int32_t device; /* HIP device ordinal */
-    int32_t ast;    /* 1: autoregressive (AST) model: n_mix_dec = N_dec decoder layers + tgt_embed (src/models/transformer.py) */
+    int32_t ast;    /* 1: autoregressive (AST) model: n_mix_dec = N_dec decoder layers + tgt_embed (src/models/transformer.py);
+                       2: TransformerLM (src/models/lm.py): n_enc layers of width d_encff + text_embed + out_generator */
     /* conformer variants (src/models/cassnat.py:29-57, pos_type "relative"): macaron Swish FFNs, relative-position self
      * attention, convolution module.  conf_enc / conf_dec = args.use_conv_enc / use_conv_dec. */
     int32_t conf_enc, conf_dec;
@@ -124,6 +125,23 @@ typedef struct cn_ast_opts {
 int cn_decode_ast(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts,
                   const cn_ast_opts* ast_opts, int32_t* hyp_out_dev, int32_t max_len, int32_t* hyp_len_dev, double* score_dev,
                   void* stream);
+
+/* ---- ESA: error-based sampling of alignments + TransformerLM ranking (src/models/cassnat.py:370-376, 441-445, 499-561) --
+ * cn_esa_begin: encoder + CTC generator once; the two best labels of every frame are kept.
+ * cn_esa_sample: ONE sampled alignment per utterance (frame t takes the second-best label iff select[b][t] != 0 and the best
+ * label's probability < threshold; select_dev == NULL = the best path), then alignment -> extractor -> decoder -> generator:
+ * tok_out / val_out [B][out_stride] = argmax token and its log-probability per decoder row, ylen_out [B] (EOS row
+ * included), *ymax_host = rows of this sample.  The caller loops over samples (they are independent) and owns the random
+ * draws (the reference takes them from torch.randint).  opts->beam_width must be 1. */
+int cn_esa_begin(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts, void* stream);
+int cn_esa_sample(cn_model* m, const uint8_t* select_dev, float threshold, const float* size_ratio_dev,
+                  const cn_decode_opts* opts, int32_t* tok_out_dev, float* val_out_dev, int32_t out_stride,
+                  int32_t* ylen_out_dev, int32_t* ymax_host, void* stream);
+/* TransformerLM (src/models/lm.py; model created with cfg.ast = 2: n_enc layers of width d_encff, parameters
+ * text_embed.0.lut / encoder.* / out_generator.proj): score[b][u] = log p(tgt[b][u] | tok[b][0..u]) with key j allowed
+ * iff j <= u and j < len[b].  tok / tgt / score are [B][ld] with ld >= U. */
+int cn_lm_score(cn_model* m, const int32_t* tok_dev, const int32_t* tgt_dev, const int32_t* len_dev, int32_t B, int32_t U,
+                int32_t ld, float* score_dev, void* stream);
 
 /* Copy a named internal / captured tensor to the host (synchronous; test + host-beam use).  Activations are
  * returned as fp32 whatever the model precision.  shape_out has room for 4 dims. */

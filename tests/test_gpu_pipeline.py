@@ -275,3 +275,36 @@ def test_bf16_production_path_against_golden(capsys):
     assert rep["ylen_max_abs_diff"] <= 3
     if tok_agree:
         assert rep["token_agreement_on_those"] > 0.9
+
+
+# ------------------------------------------------------------------------------------------- ESA + LM ranking (8f rank 3)
+@pytest.mark.parametrize("which,prec", [("esa_tiny", "fp32"), ("esa_config2", "fp32"), ("esa_config2", "bf16")])
+def test_esa_sampling_with_lm_ranking(which, prec, capsys):
+    """sample_num = 4 alignments per utterance (random draws = the fixture's, i.e. the reference's torch.randint stream),
+    TransformerLM ranking on the device.  fp32: hypotheses (up to the position the reference reads from a masked row, see
+    tests/test_oracle_golden.py) and scores equal the reference's; bf16: reported."""
+    from conftest import esa_case
+    from cassnat_asr_public_amd.models.lm import make_model as make_lm
+
+    g = load_golden(which)
+    args, lm_args, state, lm_state, feats, sizes = esa_case(which)
+    args.esa_select = g["select"]
+    lm_args.hip_precision = prec
+    model = build(args, state, prec)
+    lm = make_lm(lm_args).cuda()
+    with torch.no_grad():
+        for k, p in lm.named_parameters():
+            p.copy_(torch.from_numpy(lm_state[k]))
+    src = torch.from_numpy(feats)
+    with torch.no_grad():
+        out, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, args, lm)
+    same = 0
+    for b, seqs in enumerate(out):
+        h, ref = seqs[0]["hyp"], g["hyp"][b, : g["hyp_len"][b]].tolist()
+        n = len(h) - 1 if len(h) == len(ref) and h[-1] == 0 and ref[-1] != 0 else len(h)  # the masked-row tie token
+        same += h[:n] == ref[:n] and len(h) == len(ref)
+    with capsys.disabled():
+        print(f"\n[ESA {prec}] {which}: {same}/{len(out)} hypotheses identical, scores {[round(s[0]['score'], 3) for s in out]} vs {np.round(g['score'], 3).tolist()}")
+    if prec == "fp32":
+        assert same == len(out)
+        np.testing.assert_allclose([s[0]["score"] for s in out], g["score"], rtol=1e-5, atol=2e-3)
