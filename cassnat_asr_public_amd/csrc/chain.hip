@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
 #define CH_STAMP(i)                                                                              \
     if (p.stamps && blockIdx.x == 0 && tid == 0) ch_stamps[i] = (long long)__builtin_amdgcn_s_memtime();
     CH_STAMP(0)
+    if (p.stamps && blockIdx.x == 0 && tid == 0) ch_stamps[10] = (long long)__builtin_amdgcn_s_memrealtime();
     // groups of 8 units in consumption order: [output projection] [FFN: ffn_tiles / 4 groups, walked in a rotation of
     // its own by every workgroup - the sum over tiles is order-free, and the workgroups of a launch then do not pull the
     // same L2 lines at the same moment] [tail projection: tail_tiles / 8 groups]
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     // the dummy refills of the last units may still be writing this workgroup's LDS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     CH_STAMP(9)
+    if (p.stamps && blockIdx.x == 0 && tid == 0) ch_stamps[11] = (long long)__builtin_amdgcn_s_memrealtime();
 }
 
 int chain_print_stamps() {
@@ -499,6 +501,9 @@ int chain_print_stamps() {
                                   "S3 ffn loop", "S4 x store", "LNn", "S5 tail", "drain"};
     for (int i = 1; i < 10; ++i) fprintf(stderr, "[chain stamps] %-20s %8lld ticks\n", names[i], h[i] - h[i - 1]);
     fprintf(stderr, "[chain stamps] total %lld ticks (s_memtime)\n", h[9] - h[0]);
+    // s_memrealtime runs at a constant 100 MHz: the ratio is the shader clock the workgroup saw
+    fprintf(stderr, "[chain stamps] wall %.2f us (s_memrealtime) -> %.0f MHz\n", (h[11] - h[10]) / 100.0,
+            (double)(h[9] - h[0]) / ((h[11] - h[10]) / 100.0));
     return 0;
 }
 

@@ -30,6 +30,14 @@ struct Conv2Params {
     const float* bias;
     bf16* out;                   // [M][256]
     int M, T1, F1, T2, F2, ntiles;
+    // LINEAR mode (template): a plain [M][K] x [256][K]^T product with the embedding epilogue of linear_out
+    // (embedding.py:118-119): out_f32[m][n] = (acc + bias[n]) * scale + pe[m % pe_period][n] (pe may be null)
+    long long lda_bytes;  // row stride of A
+    int ksteps;           // K / 64
+    float* out_f32;
+    const float* pe;
+    int pe_period;
+    float scale;
 };
 
 constexpr int C2_BM = 256, C2_N = 256, C2_C = 256, C2_ROWB = 128;
@@ -72,6 +80,8 @@ constexpr int C2_KSTEPS = 9 * (C2_C / 64);
                    [vo5] "v"(vo[5]), [vo6] "v"(vo[6]), [vo7] "v"(vo[7]), [st] "s"(st_), [sb] "s"(sb_)          \
                  : "memory", "scc")
 
+// LINEAR = false: the 3x3 / stride-2 convolution; true: a plain K-major GEMM with N = 256 (same tiles, stream and blocks)
+template <bool LINEAR>
 __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -100,18 +110,26 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         const int mc = m < p.M ? m : p.M - 1;  // rows past M compute on the last row's data and are never stored
         const int f2 = mc % p.F2, bt = mc / p.F2;
         const int t2 = bt % p.T2, b = bt / p.T2;
-        pa[i] = (unsigned)(((b * (p.T1 + 2) + 2 * t2) * F1p + 2 * f2) * (C2_C * 2)) + sw;
-        pw[i] = (unsigned)(row * (9 * C2_C * 2)) + sw;
+        if constexpr (LINEAR) {
+            pa[i] = (unsigned)((long long)mc * p.lda_bytes) + sw;
+            pw[i] = (unsigned)(row * (p.ksteps * 128)) + sw;
+        } else {
+            pa[i] = (unsigned)(((b * (p.T1 + 2) + 2 * t2) * F1p + 2 * f2) * (C2_C * 2)) + sw;
+            pw[i] = (unsigned)(row * (9 * C2_C * 2)) + sw;
+        }
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const unsigned m0_wave = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
     // source bases / destinations of K step kt (channel block outermost, tap innermost), stage kt & 1
+    const int KSTEPS = LINEAR ? p.ksteps : C2_KSTEPS;
     auto a_base = [&](int kt) -> const unsigned char* {
+        if constexpr (LINEAR) return p.A + (long long)kt * 128;
         const int cb = kt / 9, tap = kt - 9 * cb;
         const int kh = tap / 3, kw = tap - 3 * kh;
         return p.A + (long long)((kh * F1p + kw) * (C2_C * 2) + cb * 128);
     };
     auto w_base = [&](int kt) -> const unsigned char* {
+        if constexpr (LINEAR) return p.W + (long long)kt * 128;
         const int cb = kt / 9, tap = kt - 9 * cb;
         return p.W + (long long)((tap * C2_C + cb * 64) * 2);
     };
@@ -161,13 +179,13 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
     // frees stage kt & 1, into which the block requests the A slab of step kt+2 while it prefetches the first fragments
     // of step kt+1.
 #define C2_PRE3 "s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)\n\ts_barrier\n\t"
-    for (int kt = 0; kt < C2_KSTEPS; ++kt) {
+    for (int kt = 0; kt < KSTEPS; ++kt) {
         const unsigned so = (unsigned)((kt & 1) * C2_STAGE), sn = (unsigned)(((kt + 1) & 1) * C2_STAGE);
         {
             const unsigned an_ = C2_RD(a_rd0, 1, so), wn_ = C2_RD(w_rd0, 1, so);
-            if (kt + 1 < C2_KSTEPS) {
+            if (LINEAR || kt + 1 < KSTEPS) {  // LINEAR: branch-free, the last steps re-request their own slab
                 const unsigned st_ = w_dst(kt + 1);
-                const unsigned char* sb_ = w_base(kt + 1);
+                const unsigned char* sb_ = w_base(LINEAR ? min(kt + 1, KSTEPS - 1) : kt + 1);
                 const unsigned* vo = pw;
                 C2_BLOCK("", Ax, Wx, Ay, Wy, C2_DMA_I, vo);
             } else {
@@ -193,9 +211,9 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         }
         {
             const unsigned an_ = a_rd0 + sn, wn_ = w_rd0 + sn;
-            if (kt + 2 < C2_KSTEPS) {
+            if (LINEAR || kt + 2 < KSTEPS) {
                 const unsigned st_ = a_dst(kt + 2);
-                const unsigned char* sb_ = a_base(kt + 2);
+                const unsigned char* sb_ = a_base(LINEAR ? min(kt + 2, KSTEPS - 1) : kt + 2);
                 const unsigned* vo = pa;
                 C2_BLOCK(C2_PRE3, Ay, Wy, Ax, Wx, C2_DMA_I, vo);
             } else {
@@ -207,7 +225,35 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         }
     }
     asm volatile("s_nop 13\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // MFMA results -> vector reads below
+    if constexpr (LINEAR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant requests of the last two steps
 
+    if constexpr (LINEAR) {
+        // ---- linear_out epilogue: (acc + bias) * scale + PE row, fp32, four consecutive channels of one row per store
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int mrow = m0 + wm * 128 + 32 * mt + l31;
+            if (mrow >= p.M) continue;
+            float* orow = p.out_f32 + (long long)mrow * C2_N + wnn * 128 + 4 * half;
+            const float* prow = p.pe ? p.pe + (long long)(mrow % p.pe_period) * C2_N + wnn * 128 + 4 * half : nullptr;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + wnn * 128 + 32 * nt + 8 * g + 4 * half);
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (acc[4 * nt + mt][4 * g + e] + bv[e]) * p.scale;
+                    if (prow) {
+                        const f32x4 pv = *reinterpret_cast<const f32x4*>(prow + 32 * nt + 8 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += pv[e];
+                    }
+                    *reinterpret_cast<f32x4*>(orow + 32 * nt + 8 * g) = o;
+                }
+            asm volatile("" ::: "memory");  // one row tile in flight at a time (register pressure)
+        }
+        return;
+    }
     // ---- epilogue: + bias, ReLU, bf16, through LDS (row image of the tile), out as contiguous 512-byte rows
     __syncthreads();
     {
@@ -247,7 +293,7 @@ int launch_conv2_dma(const void* in, const void* w, const float* bias, void* out
                      hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        CN_HIP_CHECK(hipFuncSetAttribute((const void*)conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS));
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)conv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS));
         attr_done = true;
     }
     Conv2Params p;
@@ -262,7 +308,42 @@ int launch_conv2_dma(const void* in, const void* w, const float* bias, void* out
     p.F2 = F2;
     p.ntiles = cn_ceil_div(p.M, C2_BM);
     if (p.M <= 0) return 0;
-    hipLaunchKernelGGL(conv2_kernel, dim3(p.ntiles), dim3(256), C2_LDS, s, p);
+    hipLaunchKernelGGL(conv2_kernel<false>, dim3(p.ntiles), dim3(256), C2_LDS, s, p);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// linear_out (+ sqrt(d) scale + positional rows) on the same tile kernel: A [M][K] bf16 (row stride lda elements), W [256][K]
+// bf16, K % 64 == 0, A and W below 4 GiB.  A launch occupies ceil(M / 256) CUs (32 for the encoder input of config 2) for about
+// as long as the generic GEMM occupies all of them.
+bool linear256_dma_applies(int prec, int N, int K) { return prec == CN_PREC_BF16 && N == C2_N && K % 64 == 0 && K >= 128 && !getenv("CASSNAT_NO_LINEAR_DMA"); }
+
+int launch_linear256_dma(const void* A, int lda, const void* W, const float* bias, float* out, int M, int K, float scale,
+                         const float* pe, int pe_period, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)conv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS));
+        attr_done = true;
+    }
+    if (M <= 0) return 0;
+    if ((long long)M * lda * 2 >= (1ll << 32)) {
+        cn_set_error("linear256: A exceeds the 32-bit lane offsets of the LDS-DMA kernel");
+        return -1;
+    }
+    Conv2Params p = {};
+    p.A = (const unsigned char*)A;
+    p.W = (const unsigned char*)W;
+    p.bias = bias;
+    p.M = M;
+    p.T1 = p.F1 = p.T2 = p.F2 = 1;
+    p.ntiles = cn_ceil_div(M, C2_BM);
+    p.lda_bytes = (long long)lda * 2;
+    p.ksteps = K / 64;
+    p.out_f32 = out;
+    p.pe = pe;
+    p.pe_period = pe_period > 0 ? pe_period : 1;
+    p.scale = scale;
+    hipLaunchKernelGGL(conv2_kernel<true>, dim3(p.ntiles), dim3(256), C2_LDS, s, p);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -296,5 +296,8 @@ int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
         }
         return launch_conv2_dma(a.A, a.W, a.bias, a.C, a.cB, a.cT1, a.cF1, a.cT2, a.cF2, s);
     }
+    // K-deep products onto all 256 output columns with the embedding epilogue (linear_out): the LDS-DMA tile kernel
+    if (!a.conv && a.epi == CN_EPI_EMBED && a.c_f32 && a.ldc == a.N && a.K >= 1024 && linear256_dma_applies(prec, a.N, a.K))
+        return launch_linear256_dma(a.A, a.lda, a.W, a.bias, (float*)a.C, a.M, a.K, a.scale, a.pe, a.pe_period, s);
     return prec == CN_PREC_F32 ? dispatch_gemm<float>(a, s) : dispatch_gemm<bf16>(a, s);
 }

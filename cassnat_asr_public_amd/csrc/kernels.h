@@ -136,6 +136,9 @@ int launch_fbank(const FbankOpts& o, const float* wave, const int* num_samples, 
 
 // ---- conv2 as an LDS-DMA implicit GEMM, bf16 / 256 -> 256 channels (conv2.hip); launch_gemm dispatches to it
 bool conv2_dma_applies(int prec, int C, int N);
+bool linear256_dma_applies(int prec, int N, int K);
+int launch_linear256_dma(const void* A, int lda, const void* W, const float* bias, float* out, int M, int K, float scale,
+                         const float* pe, int pe_period, hipStream_t s);
 int launch_conv2_dma(const void* in, const void* w, const float* bias, void* out, int B, int T1, int F1, int T2, int F2,
                      hipStream_t s);
 

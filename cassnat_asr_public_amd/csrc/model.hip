@@ -2043,8 +2043,19 @@ extern "C" int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, con
     a.x_out_blocked = (x_mode & 2) != 0;
     a.store_x = (x_mode & 4) == 0;
     int rc = launch_chain(a, (hipStream_t)stream);
-    if (const char* rep = getenv("CASSNAT_CHAIN_REPEAT"))  // timing runs only: x keeps being updated
-        for (int i = 1; i < atoi(rep) && rc == 0; ++i) rc = launch_chain(a, (hipStream_t)stream);
+    if (const char* rep = getenv("CASSNAT_CHAIN_REPEAT")) {  // timing runs only: x keeps being updated
+        // CASSNAT_CHAIN_STREAMS = n: the repeats go round-robin onto n private streams (how do concurrent launches share
+        // the chip?); they race on x, which a timing run does not look at
+        const int ns = getenv("CASSNAT_CHAIN_STREAMS") ? atoi(getenv("CASSNAT_CHAIN_STREAMS")) : 0;
+        std::vector<hipStream_t> ss(ns > 0 ? ns : 0);
+        for (auto& q : ss) (void)hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        for (int i = 1; i < atoi(rep) && rc == 0; ++i) rc = launch_chain(a, ns > 0 ? ss[i % ns] : (hipStream_t)stream);
+        for (auto& q : ss) {
+            (void)hipStreamSynchronize(q);
+            (void)hipStreamDestroy(q);
+        }
+    }
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     if (getenv("CASSNAT_CHAIN_STAMPS")) (void)chain_print_stamps();
     (void)hipFree(ds);

@@ -96,6 +96,28 @@ def test_gemm_epilogues(prec):
     assert relerr(out, ref) < RTOL[prec]
 
 
+@pytest.mark.parametrize("M,K,period,lda_pad", [(515, 1024, 103, 0), (8000, 5120, 250, 0), (257, 1280, 257, 64), (31, 2048, 7, 0)])
+def test_gemm_embed_deep_k(M, K, period, lda_pad):
+    # linear_out shape class: bf16, N = 256, K >= 1024 goes to the LDS-DMA tile kernel (conv2.hip, LINEAR variant);
+    # ragged M and a padded row stride included
+    g = torch.Generator().manual_seed(M + K)
+    N, lda = 256, K + lda_pad
+    A = torch.randn(M, lda, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    lin = F.linear(rounded(A[:, :K], "bf16"), rounded(W, "bf16"), bias)
+    Ad, Wd, bd = dev(A, torch.bfloat16), dev(W, torch.bfloat16), dev(bias)
+    out = torch.full((M + 1, N), float("nan"), dtype=torch.float32, device="cuda")
+    pe = torch.randn(period, N, generator=g)
+    ped = dev(pe)
+    ref = lin * 16.0 + pe[torch.arange(M) % period]
+    hip.check(hip.lib().cn_op_gemm(hip.PRECISION["bf16"], p(Ad), lda, p(Wd), p(bd), p(out), N, 1, M, N, K, 0, None, 0,
+                                   p(ped), period, 16.0, stream()))
+    torch.cuda.synchronize()
+    assert relerr(out[:M], ref) < RTOL["bf16"]
+    assert torch.isnan(out[M]).all()  # nothing written past M
+
+
 def test_gemm_rejects_bad_k():
     a = torch.zeros(4, 100, device="cuda")
     rc = hip.lib().cn_op_gemm(0, p(a), 100, p(a), None, p(a), 4, 1, 4, 4, 100, 0, None, 0, None, 1, 1.0, stream())
