@@ -29,6 +29,7 @@ struct AttnParams {
     int ldo;
     int H, Lq, Lk;
     const unsigned char* keymask;
+    int kv_mod;  // > 0: keys / values / keymask of batch entry b live at entry b % kv_mod (several query sets per source)
     const int* klen;
     const int* iv;
     int iv_stride;
@@ -137,8 +138,9 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
 
     // ---- staging registers for the next K/V tile
     uint4 k_reg[ST_IT], v_reg[ST_IT];
-    const unsigned char* kbase = p.K + (long long)b * p.Lk * p.ldk_b + (long long)h * KROW;
-    const unsigned char* vbase = p.V + (long long)b * p.Lk * p.ldv_b + (long long)h * KROW;
+    const int bk = p.kv_mod > 0 ? b % p.kv_mod : b;
+    const unsigned char* kbase = p.K + (long long)bk * p.Lk * p.ldk_b + (long long)h * KROW;
+    const unsigned char* vbase = p.V + (long long)bk * p.Lk * p.ldv_b + (long long)h * KROW;
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < ST_IT; ++i) {
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
             unsigned char code = 2;
             if (key < p.Lk) {
                 bool ok = key < klen;
-                if (p.keymask) ok = ok && p.keymask[(long long)b * p.Lk + key] != 0;
+                if (p.keymask) ok = ok && p.keymask[(long long)bk * p.Lk + key] != 0;
                 code = ok ? 1 : 0;
             }
             reinterpret_cast<unsigned char*>(Ms)[tid] = code;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
             unsigned char code = 2;
             if (i < p.Lk) {
                 bool ok = i < klen;
-                if (p.keymask) ok = ok && p.keymask[(long long)b * p.Lk + i] != 0;
+                if (p.keymask) ok = ok && p.keymask[(long long)bk * p.Lk + i] != 0;
                 code = ok ? 1 : 0;
             }
             reinterpret_cast<unsigned char*>(Ms_all)[i] = code;
@@ -399,6 +401,7 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     p.Lq = a.Lq;
     p.Lk = a.Lk;
     p.keymask = a.keymask;
+    p.kv_mod = a.kv_mod;
     p.klen = a.klen;
     p.iv = a.intervals;
     p.iv_stride = a.iv_stride;

@@ -3,6 +3,8 @@
 //   utterance (padded frames included, as the reference does) -> Swish -> pointwise conv (GEMM).
 // All HBM/latency-bound row work; the GroupNorm statistics are accumulated in double (they are a sum over up to
 // T' x C = 64 000 values per utterance and feed every element of the sublayer).
+#include <cstdlib>
+
 #include "kernels.h"
 
 template <typename T>
@@ -91,8 +93,63 @@ int launch_glu(int prec, const void* in, void* out, int M, int d, hipStream_t s)
     return 0;
 }
 
+// Tiled form for the kernel sizes the recipes use: a thread owns one channel and TT consecutive frames; the K taps sit in
+// registers and every input frame of the window is loaded once (TT + K - 1 loads per TT outputs instead of K per output).
+// Each output still accumulates bias, tap 0, tap 1, ... in that order, so the result equals dwconv_kernel's bit for bit.
+template <typename T, int K, int TT>
+__global__ __launch_bounds__(256) void dwconv_tiled_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int L, int d) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= d) return;
+    const int tiles = (L + TT - 1) / TT;
+    const int b = blockIdx.x / tiles, t0 = (blockIdx.x - b * tiles) * TT;
+    constexpr int pad = (K - 1) / 2;
+    float wk[K], acc[TT];
+#pragma unroll
+    for (int j = 0; j < K; ++j) wk[j] = w[c * K + j];
+    const float bz = bias[c];
+#pragma unroll
+    for (int o = 0; o < TT; ++o) acc[o] = bz;
+    const T* xb = x + (long long)b * L * d + c;
+#pragma unroll
+    for (int tt = 0; tt < TT + K - 1; ++tt) {
+        const int t = t0 + tt - pad;
+        if (t >= 0 && t < L) {  // a frame outside the utterance contributes nothing (and is skipped by dwconv_kernel as well)
+            const float v = to_f32(xb[(long long)t * d]);
+#pragma unroll
+            for (int o = 0; o < TT; ++o) {
+                const int j = tt - o;
+                if (j >= 0 && j < K) acc[o] = fmaf(wk[j], v, acc[o]);
+            }
+        }
+    }
+    float* yb = y + (long long)b * L * d + c;
+#pragma unroll
+    for (int o = 0; o < TT; ++o)
+        if (t0 + o < L) yb[(long long)(t0 + o) * d] = acc[o];
+}
+
+template <typename T, int K>
+static void launch_dwconv_tiled(const void* x, const float* w, const float* bias, float* y, int B, int L, int d, hipStream_t s) {
+    constexpr int TT = 32;
+    const dim3 grid((unsigned)(B * ((L + TT - 1) / TT)), (unsigned)((d + 255) / 256));
+    hipLaunchKernelGGL((dwconv_tiled_kernel<T, K, TT>), grid, dim3(256), 0, s, (const T*)x, w, bias, y, L, d);
+}
+
 int launch_dwconv(int prec, const void* x, const float* w, const float* bias, float* y, int B, int L, int d, int k, hipStream_t s) {
     if (B * L <= 0) return 0;
+    static const bool naive = getenv("CASSNAT_DWCONV_NAIVE") != nullptr;
+#define DW_CASE(KK)                                                                                   \
+    case KK:                                                                                          \
+        if (prec == CN_PREC_F32) launch_dwconv_tiled<float, KK>(x, w, bias, y, B, L, d, s);           \
+        else launch_dwconv_tiled<bf16, KK>(x, w, bias, y, B, L, d, s);                                \
+        CN_HIP_CHECK(hipGetLastError());                                                              \
+        return 0;
+    if (!naive) switch (k) {
+        DW_CASE(3) DW_CASE(7) DW_CASE(15) DW_CASE(31)
+        default: break;
+    }
+#undef DW_CASE
     const long long n = (long long)B * L * d;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (prec == CN_PREC_F32)

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void ctc_align_kernel(AlignArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int Tp = a.Tp;
     const int* best = a.best + (long long)b * Tp;
-    const unsigned char* km = a.keymask + (long long)b * Tp;
+    const int bs = a.src_mod > 0 ? b % a.src_mod : b;
+    const unsigned char* km = a.keymask + (long long)bs * Tp;
     int* shift = a.shift + (long long)b * Tp;
     int* iv = a.intervals + (long long)b * (Tp + 1) * 4;
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void ctc_align_kernel(AlignArgs a) {
     }
     const int ylen0 = s_carry[0];  // number of non-blank entries of shift
     // src_size = (ratio * T').long()  (src/models/cassnat.py:436): fp32 product, truncation toward zero
-    const int ssz = (int)(long long)(a.size_ratio[b] * (float)Tp);
+    const int ssz = (int)(long long)(a.size_ratio[bs] * (float)Tp);
     if (tid == 0) {
         a.src_size[b] = ssz;
         a.ylen[b] = ylen0 + 1;

@@ -52,7 +52,7 @@ int launch_fill_queries(const float* table, float* out, int B, int U, int d, hip
 // use_unimask: y[b][0] = 0 ; y[b][u] = x[b][u-1]
 int launch_shift_right(const float* x, float* y, int B, int U, int d, hipStream_t s);
 int launch_esa_paths(const int* top2_idx, const float* top2_val, const unsigned char* select, float threshold, int* best, int M,
-                     hipStream_t s);
+                     int n, hipStream_t s);
 int launch_lm_embed(const int* tok, int ld, const float* lut, const float* pe, float* x, int B, int U, int d, float scale,
                     hipStream_t s);
 int launch_gather_logp(const float* logp, int V, const int* tgt, int ld, float* out, int B, int U, hipStream_t s);
@@ -68,6 +68,7 @@ struct AttnArgs {
     int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
     int B = 0, H = 0, Lq = 0, Lk = 0;
     const unsigned char* keymask = nullptr;  // [B][Lk] or null (all valid)
+    int kv_mod = 0;  // > 0: K / V / keymask of batch entry b are those of entry b % kv_mod (ESA: many alignments per utterance)
     const int* klen = nullptr;               // [B] or null: key j valid iff j < klen[b]
     const int* intervals = nullptr;          // [B][iv_stride][4] (s1,e1,s2,e2) per query row, or null
     int iv_stride = 0;
@@ -94,6 +95,7 @@ struct AlignArgs {
     const unsigned char* keymask = nullptr;  // [B][Tp]
     const float* size_ratio = nullptr;       // [B] fp32 length ratios
     int B = 0, Tp = 0, blank = 0, left = 0, right = 0;
+    int src_mod = 0;  // > 0: keymask / size_ratio of entry b are those of entry b % src_mod (ESA: best[] holds many paths per utterance)
     int* shift = nullptr;      // [B][Tp]  aligned_seq_shift
     int* src_size = nullptr;   // [B]
     int* ylen = nullptr;       // [B]   (token count + 1)

@@ -165,6 +165,7 @@ struct cn_model {
 
     // last call
     int B = 0, T = 0, T1 = 0, Tp = 0, U = 0, last_k = 0;
+    int dec_group = 1;  // decoder-side batch = B * dec_group (ESA: that many alignments per utterance in one pass), else 1
     std::map<std::string, Capture> captures;
 
     // per-kernel-tag timing with HIP events on the launch stream (cn_profile_begin / cn_profile_end)
@@ -747,7 +748,9 @@ int build_workspace(cn_model* m) {
     const cn_config& c = m->cfg;
     const size_t es = m->es;
     const size_t B = m->maxB, T1 = m->maxT1, Tp = m->maxTp, F1 = m->F1, F2 = m->F2, d = c.d_model, V = c.vocab_size;
-    const size_t M = B * (Tp + 1);  // decoder rows can reach B*(T'+1)
+    const size_t G = (size_t)std::max(1, c.esa_group);  // alignments per utterance the decoder side takes in one pass
+    const size_t M0 = B * (Tp + 1);                     // decoder rows can reach B*(T'+1) per alignment
+    const size_t M = M0 * G;
     const size_t dff = std::max(std::max(c.d_encff, c.d_decff), c.d_ff);  // (d_ff: the conformer extractor's FFN width)
     CN_TRY(dev_alloc(m, (void**)&m->keymask, B * Tp));
     if (c.ast != 2) {  // (the LM has no convolutional front-end)
@@ -759,28 +762,28 @@ int build_workspace(cn_model* m) {
     CN_TRY(dev_alloc(m, &m->qkv, M * 3 * d * es));
     CN_TRY(dev_alloc(m, &m->ctx, M * d * es));
     CN_TRY(dev_alloc(m, &m->hbuf, M * dff * es));
-    CN_TRY(dev_alloc(m, &m->enc_h, M * d * es));
-    CN_TRY(dev_alloc(m, &m->kvm, M * 2 * d * es));
+    CN_TRY(dev_alloc(m, &m->enc_h, M0 * d * es));
+    CN_TRY(dev_alloc(m, &m->kvm, M0 * 2 * d * es));
     CN_TRY(dev_alloc(m, &m->qd, M * d * es));
     CN_TRY(dev_alloc(m, &m->dec_h, M * d * es));
     CN_TRY(dev_alloc(m, (void**)&m->xd, (M + 32) * d * 4));
     CN_TRY(dev_alloc(m, (void**)&m->xd2, (M + 32) * d * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->logits, M * V * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->logits, M0 * V * 4));
     CN_TRY(dev_alloc(m, (void**)&m->best, M * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->ctc_maxlp, M * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->ctc_maxlp, M0 * 4));
     CN_TRY(dev_alloc(m, (void**)&m->shift, M * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->src_size, B * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->ylen, B * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->src_size, B * G * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->ylen, B * G * 4));
     CN_TRY(dev_alloc(m, (void**)&m->ymax, 256));
-    CN_TRY(dev_alloc(m, (void**)&m->intervals, B * (Tp + 1) * 16));
+    CN_TRY(dev_alloc(m, (void**)&m->intervals, B * G * (Tp + 1) * 16));
     CN_TRY(dev_alloc(m, (void**)&m->tok, M * 4));
     CN_TRY(dev_alloc(m, (void**)&m->val, M * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->topk_idx, M * 16 * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->topk_val, M * 16 * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->topk_idx, M0 * 16 * 4));
+    CN_TRY(dev_alloc(m, (void**)&m->topk_val, M0 * 16 * 4));
     if (c.conf_enc || c.conf_dec) {  // convolution module: pointwise-conv output [M][2d], depthwise output fp32, GroupNorm sums
         CN_TRY(dev_alloc(m, &m->cv_a, M * 2 * d * es));
         CN_TRY(dev_alloc(m, (void**)&m->cv_f, M * d * 4));
-        CN_TRY(dev_alloc(m, (void**)&m->gn_stats, B * 2 * 8));
+        CN_TRY(dev_alloc(m, (void**)&m->gn_stats, B * G * 2 * 8));
     }
     CN_HIP_CHECK(hipHostMalloc((void**)&m->ymax_pinned, 64, hipHostMallocDefault));
     return 0;
@@ -1019,8 +1022,10 @@ int run_src_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B, 
 // ctx <- Attn(m->qd, enc_h Wk, enc_h Wv) with the padding mask and (optionally) trigger intervals
 int run_src_attn_core(cn_model* m, const Layer& L, int B, int U, int Tp, const int* intervals, hipStream_t s) {
     const int d = m->cfg.d_model;
-    CN_TRY(run_linear(m, "src_kv_proj", L.src_kv, m->enc_h, d, m->kvm, 2 * d, 0, B * Tp, 0, nullptr, 0, s));
+    // (B counts query sets: dec_group of them share the keys / values of one utterance)
+    CN_TRY(run_linear(m, "src_kv_proj", L.src_kv, m->enc_h, d, m->kvm, 2 * d, 0, m->B * Tp, 0, nullptr, 0, s));
     AttnArgs a;
+    a.kv_mod = m->dec_group > 1 ? m->B : 0;
     a.Q = m->qd;
     a.K = m->kvm;
     a.V = (const unsigned char*)m->kvm + (size_t)d * m->es;
@@ -1127,6 +1132,7 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     const int M = B * Tp;
     const bool cap = o->capture != 0;
     m->B = B;
+    m->dec_group = 1;
     m->T = T;
     m->T1 = T1;
     m->Tp = Tp;
@@ -1226,7 +1232,7 @@ int stage_decode_tail(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp,
 int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int hyp_stride, int32_t* hyp_len,
                  double* score, hipStream_t s) {
     const cn_config& c = m->cfg;
-    const int d = c.d_model, B = m->B, Tp = m->Tp, MU = B * U;
+    const int d = c.d_model, B = m->B * m->dec_group, Tp = m->Tp, MU = B * U;
     const bool cap = o->capture != 0;
     m->U = U;
     if (U > m->pe_rows) {
@@ -1383,7 +1389,7 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
 int stage_decode_tail(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int hyp_stride, int32_t* hyp_len,
                       double* score, hipStream_t s) {
     const cn_config& c = m->cfg;
-    const int d = c.d_model, B = m->B, MU = B * U;
+    const int d = c.d_model, B = m->B * m->dec_group, MU = B * U;
     const bool cap = o->capture != 0;
     if (cap) CN_TRY(capture(m, "dec_h", m->dec_h, true, CN_DTYPE_F32, {B, U, d}, s));
     const int k = o->beam_width;
@@ -1553,12 +1559,14 @@ extern "C" int cn_decode_nast(cn_model* m, const float* feats_dev, const float* 
 
 
 // ---- ESA: error-based sampling of alignments (src/models/cassnat.py:370-376, 441-445) ------------------------------
-// cn_esa_begin runs the encoder and the CTC generator once and keeps the two best labels of every frame; every
-// cn_esa_sample call then builds ONE sampled alignment per utterance - frame t takes the second-best label iff its draw
-// select[b][t] is 1 and the best label's probability is below `threshold` (select == NULL: the best path itself) - and
-// runs the alignment + decoder side on it: tok_out / val_out [B][out_stride] = argmax token and its log-probability per
-// decoder row, ylen_out [B] (EOS row included), *ymax_host = rows of this sample.  Samples are independent, so the caller
-// loops over them on one workspace; the random draws are the caller's (the reference takes them from torch.randint).
+// cn_esa_begin runs the encoder and the CTC generator once and keeps the two best labels of every frame.  Every
+// cn_esa_sample call then builds n_samples sampled alignments per utterance - in alignment g frame t of utterance b takes
+// the second-best label iff its draw select[g][b][t] is 1 and the best label's probability is below `threshold` (all-zero
+// draws, or select == NULL with n_samples == 1: the best path itself) - and runs the alignment + decoder side on all of
+// them in ONE pass of B * n_samples query sets over the B utterances' encoder outputs (n_samples <= cfg.esa_group, which
+// sizes the decoder-side workspace): tok_out / val_out [n_samples][B][out_stride] = argmax token and its log-probability per
+// decoder row, ylen_out [n_samples][B] (EOS row included), *ymax_host = rows of this pass.  The random draws are the
+// caller's (the reference takes them from torch.randint).
 extern "C" int cn_esa_begin(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts,
                             void* stream) {
     CN_TRY(check_call(m, B, T, F));
@@ -1576,22 +1584,27 @@ extern "C" int cn_esa_begin(cn_model* m, const float* feats_dev, int32_t B, int3
     return 0;
 }
 
-extern "C" int cn_esa_sample(cn_model* m, const uint8_t* select_dev, float threshold, const float* size_ratio_dev,
-                             const cn_decode_opts* opts, int32_t* tok_out_dev, float* val_out_dev, int32_t out_stride,
-                             int32_t* ylen_out_dev, int32_t* ymax_host, void* stream) {
+extern "C" int cn_esa_sample(cn_model* m, const uint8_t* select_dev, int32_t n_samples, float threshold,
+                             const float* size_ratio_dev, const cn_decode_opts* opts, int32_t* tok_out_dev, float* val_out_dev,
+                             int32_t out_stride, int32_t* ylen_out_dev, int32_t* ymax_host, void* stream) {
     if (!m || !opts || !tok_out_dev || !val_out_dev || !ylen_out_dev || !ymax_host || m->B < 1 || opts->beam_width != 1) {
         cn_set_error("cn_esa_sample: call cn_esa_begin first; beam_width must be 1");
         return -1;
     }
+    if (n_samples < 1 || n_samples > std::max(1, m->cfg.esa_group) || (n_samples > 1 && !select_dev)) {
+        cn_set_error("cn_esa_sample: n_samples must be in [1, cfg.esa_group] (and needs draws when > 1)");
+        return -1;
+    }
     hipStream_t s = (hipStream_t)stream;
     CN_HIP_CHECK(hipSetDevice(m->cfg.device));
-    const int B = m->B, Tp = m->Tp;
-    CN_TRY(launch_esa_paths(m->topk_idx, m->topk_val, select_dev, threshold, m->best, B * Tp, s));
+    const int B = m->B, Tp = m->Tp, G = n_samples, BG = B * G;
+    CN_TRY(launch_esa_paths(m->topk_idx, m->topk_val, select_dev, threshold, m->best, B * Tp, G, s));
     AlignArgs al;
     al.best = m->best;
     al.keymask = m->keymask;
     al.size_ratio = size_ratio_dev;
-    al.B = B;
+    al.B = BG;
+    al.src_mod = B;  // entry g * B + b reads utterance b's mask and length
     al.Tp = Tp;
     al.blank = opts->padding_idx;
     al.left = opts->left_trigger;
@@ -1609,10 +1622,13 @@ extern "C" int cn_esa_sample(cn_model* m, const uint8_t* select_dev, float thres
         cn_set_error("cn_esa_sample: token count outside the output stride");
         return -3;
     }
-    CN_TRY(stage_decode(m, U, opts, nullptr, 0, nullptr, nullptr, s));
-    CN_HIP_CHECK(hipMemcpy2DAsync(tok_out_dev, (size_t)out_stride * 4, m->tok, (size_t)U * 4, (size_t)U * 4, B, hipMemcpyDeviceToDevice, s));
-    CN_HIP_CHECK(hipMemcpy2DAsync(val_out_dev, (size_t)out_stride * 4, m->val, (size_t)U * 4, (size_t)U * 4, B, hipMemcpyDeviceToDevice, s));
-    CN_HIP_CHECK(hipMemcpyAsync(ylen_out_dev, m->ylen, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    m->dec_group = G;
+    const int rc = stage_decode(m, U, opts, nullptr, 0, nullptr, nullptr, s);
+    m->dec_group = 1;
+    if (rc) return rc;
+    CN_HIP_CHECK(hipMemcpy2DAsync(tok_out_dev, (size_t)out_stride * 4, m->tok, (size_t)U * 4, (size_t)U * 4, BG, hipMemcpyDeviceToDevice, s));
+    CN_HIP_CHECK(hipMemcpy2DAsync(val_out_dev, (size_t)out_stride * 4, m->val, (size_t)U * 4, (size_t)U * 4, BG, hipMemcpyDeviceToDevice, s));
+    CN_HIP_CHECK(hipMemcpyAsync(ylen_out_dev, m->ylen, (size_t)BG * 4, hipMemcpyDeviceToDevice, s));
     *ymax_host = U;
     return 0;
 }

@@ -311,16 +311,19 @@ int launch_convert_back(int prec, const void* src, float* dst, size_t n, hipStre
 
 // ---- ESA sampled alignment: label of frame i = second best iff its draw is 1 and exp(best log-prob) < threshold ----------
 __global__ void esa_paths_kernel(const int* __restrict__ top2_idx, const float* __restrict__ top2_val,
-                                 const unsigned char* __restrict__ select, float threshold, int* __restrict__ best, int M) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    const int pick = (select && select[i] && expf(top2_val[2 * i]) < threshold) ? 1 : 0;
-    best[i] = top2_idx[2 * i + pick];
+                                 const unsigned char* __restrict__ select, float threshold, int* __restrict__ best, int M, int n) {
+    // n paths per frame: best[g][i] for draw set g (select: [n][M], null = the best path)
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (long long)M * n) return;
+    const int i = (int)(j % M);
+    const int pick = (select && select[j] && expf(top2_val[2 * i]) < threshold) ? 1 : 0;
+    best[j] = top2_idx[2 * i + pick];
 }
 int launch_esa_paths(const int* top2_idx, const float* top2_val, const unsigned char* select, float threshold, int* best, int M,
-                     hipStream_t s) {
-    if (M <= 0) return 0;
-    hipLaunchKernelGGL(esa_paths_kernel, dim3(cn_ceil_div(M, 256)), dim3(256), 0, s, top2_idx, top2_val, select, threshold, best, M);
+                     int n, hipStream_t s) {
+    if (M <= 0 || n <= 0) return 0;
+    hipLaunchKernelGGL(esa_paths_kernel, dim3((unsigned)(((long long)M * n + 255) / 256)), dim3(256), 0, s, top2_idx, top2_val, select,
+                       threshold, best, M, n);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

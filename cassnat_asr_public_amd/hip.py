@@ -20,7 +20,7 @@ class CnConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "input_size", "d_model", "n_head", "d_encff", "d_decff", "n_enc", "n_extra", "n_self_dec", "n_mix_dec",
         "vocab_size", "precision", "max_batch", "max_frames", "device", "ast", "conf_enc", "conf_dec", "enc_max_rel", "dec_max_rel",
-        "enc_kernel", "dec_kernel", "d_ff")]
+        "enc_kernel", "dec_kernel", "d_ff", "esa_group")]
 
 
 class CnDecodeOpts(C.Structure):
@@ -111,8 +111,8 @@ def lib():
     L.cn_fbank.argtypes = [C.POINTER(CnFbankOpts), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_int32, C.c_float, C.c_void_p]
     L.cn_esa_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts), C.c_void_p]
-    L.cn_esa_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.POINTER(CnDecodeOpts), C.c_void_p, C.c_void_p,
-                                C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
+    L.cn_esa_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.POINTER(CnDecodeOpts), C.c_void_p,
+                                C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
     L.cn_lm_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.cn_decode_ast.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts),
                                 C.POINTER(CnAstOpts), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -144,7 +144,7 @@ def current_stream():
 class Engine:
     """Owns one ``cn_model`` handle: weights, workspace and the decode pipeline on one GPU."""
 
-    def __init__(self, args, precision="bf16", max_batch=32, max_frames=2048, device=0):
+    def __init__(self, args, precision="bf16", max_batch=32, max_frames=2048, device=0, esa_group=1):
         self.L = lib()
         ast = int(getattr(args, "ast", 0))
         self.cfg = CnConfig(
@@ -155,7 +155,7 @@ class Engine:
             conf_enc=int(getattr(args, "conf_enc", 0)), conf_dec=int(getattr(args, "conf_dec", 0)),
             enc_max_rel=int(getattr(args, "enc_max_rel", 0)), dec_max_rel=int(getattr(args, "dec_max_rel", 0)),
             enc_kernel=int(getattr(args, "enc_kernel", 0)), dec_kernel=int(getattr(args, "dec_kernel", 0)),
-            d_ff=int(getattr(args, "d_ff", 0)))
+            d_ff=int(getattr(args, "d_ff", 0)), esa_group=int(esa_group))
         self.precision = precision
         self.handle = C.c_void_p()
         check(self.L.cn_model_create(C.byref(self.cfg), C.byref(self.handle)), "cn_model_create")
@@ -234,11 +234,13 @@ class Engine:
         check(self.L.cn_esa_begin(self.handle, _ptr(feats), B, T, F, C.byref(opts), current_stream()), "cn_esa_begin")
 
     def esa_sample(self, select, threshold, size_ratio, opts, tok, val, ylen):
-        """select: uint8 (B, T') cuda draws or None (best path) -> rows (U) of this sample; tok / val (B, stride), ylen (B,)."""
+        """One pass over n sampled alignments per utterance (n <= cfg.esa_group): select uint8 (n, B, T') cuda draws (all-zero
+        = the best path) -> rows (U) of this pass; tok / val (n, B, stride), ylen (n, B)."""
         ymax = C.c_int32()
-        check(self.L.cn_esa_sample(self.handle, _ptr(select) if select is not None else None, float(threshold), _ptr(size_ratio),
-                                   C.byref(opts), _ptr(tok), _ptr(val), tok.shape[1], _ptr(ylen), C.byref(ymax), current_stream()),
-              "cn_esa_sample")
+        n = tok.shape[0]
+        assert select.shape[0] == n and select.is_contiguous() and tok.is_contiguous() and val.is_contiguous() and ylen.is_contiguous()
+        check(self.L.cn_esa_sample(self.handle, _ptr(select), n, float(threshold), _ptr(size_ratio), C.byref(opts), _ptr(tok),
+                                   _ptr(val), tok.shape[2], _ptr(ylen), C.byref(ymax), current_stream()), "cn_esa_sample")
         return ymax.value
 
     def lm_score(self, tok, tgt, length, U, score):

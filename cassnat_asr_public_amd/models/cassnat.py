@@ -256,7 +256,7 @@ class CassNAT(nn.Module):
     def _weights_version(self):
         return tuple(p._version for p in self.parameters())
 
-    def build_engine(self, batch, frames, with_weights=True):
+    def build_engine(self, batch, frames, with_weights=True, esa_group=1):
         """Create the HIP engine.  ``with_weights=False`` allocates the (layout-identical) weight blob only: the
         contents then arrive by RCCL broadcast from the rank that read the checkpoint (cassnat_asr_public_amd.dist)."""
         from types import SimpleNamespace
@@ -265,7 +265,7 @@ class CassNAT(nn.Module):
             self._engine.close()
         eng = hip.Engine(SimpleNamespace(**self._hyper), precision=self.hip_precision,
                          max_batch=max(batch, self.hip_max_batch), max_frames=max(frames, self.hip_max_frames),
-                         device=getattr(self, "_device", torch.cuda.current_device()))
+                         device=getattr(self, "_device", torch.cuda.current_device()), esa_group=esa_group)
         if with_weights:
             eng.load_state({k: v.detach() for k, v in self.named_parameters()}, self.pe)
         else:
@@ -281,12 +281,12 @@ class CassNAT(nn.Module):
         self.invalidate_engine()
         return super().load_state_dict(*a, **k)
 
-    def engine(self, batch, frames):
+    def engine(self, batch, frames, esa_group=1):
         """(Re)build the HIP engine when weights changed or the workspace is too small."""
         key = (self._weights_version(), self.hip_precision)
         if (self._engine is None or self._engine_key != key or batch > self._engine.cfg.max_batch
-                or frames > self._engine.cfg.max_frames):
-            self.build_engine(batch, frames)
+                or frames > self._engine.cfg.max_frames or esa_group > max(1, self._engine.cfg.esa_group)):
+            self.build_engine(batch, frames, esa_group=esa_group)
         return self._engine
 
     # ------------------------------------------------------------------------------------------ decode
@@ -350,9 +350,10 @@ class CassNAT(nn.Module):
 
     def _esa_decode(self, src, src_size, args, lm_model, sos):
         """Error-based sampling of alignments + LM ranking (src/models/cassnat.py:370-376, 441-445, 499-561; sample_num > 1,
-        rank_model 'lm', lm_weight 0, beam_width 1).  The encoder and the CTC generator run once; every sample (one alignment
-        per utterance, sample 0 = the best path) is a device pass over the same workspace (alignment -> extractor -> decoder ->
-        generator argmax), the TransformerLM scores each sample's tokens on the device, and the ranking - a mean over at
+        rank_model 'lm', lm_weight 0, beam_width 1).  The encoder and the CTC generator run once; the samples (one alignment
+        per utterance each, sample 0 = the best path) go through the decoder side ``args.hip_esa_group`` (default 16) at a time -
+        one device pass of B * group query sets over the B utterances' encoder outputs (alignment -> extractor -> decoder ->
+        generator argmax); the TransformerLM scores all samples' tokens in one pass, and the ranking - a mean over at
         most T' numbers per sample - is done here exactly as the reference writes it.  The 0/1 draws come from
         ``torch.randint(0, 2, (B * sample_num, T', 1))`` like the reference's (same seed, same stream);
         ``args.esa_select`` overrides them (tests)."""
@@ -362,22 +363,26 @@ class CassNAT(nn.Module):
         B, T, _ = feats.shape
         S = int(args.sample_num)
         Tp = ((T - 1) // 2 + 1 - 1) // 2 + 1
-        eng = self.engine(B, T)
+        # samples per decoder pass: the decoder side runs B * group query sets over the B utterances' encoder outputs
+        group = max(1, min(S, int(getattr(args, "hip_esa_group", 16))))
+        eng = self.engine(B, T, esa_group=group)
         opts = hip.Engine.make_opts(args)
         opts.sos = sos
         select = getattr(args, "esa_select", None)
         if select is None:
             select = torch.randint(0, 2, (B * S, Tp, 1))
-        select = torch.as_tensor(select).reshape(B, S, Tp).to(torch.uint8)
+        select = torch.as_tensor(select).reshape(B, S, Tp).to(torch.uint8).transpose(0, 1).contiguous()  # (S, B, T')
+        select[0] = 0  # include_best: sample 0 is the best path (cassnat.py:441-445)
+        select = select.to(dev)
         eng.esa_begin(feats, opts)
         stride = Tp + 2
         tok = torch.zeros(S, B, stride, dtype=torch.int32, device=dev)
         val = torch.zeros(S, B, stride, dtype=torch.float32, device=dev)
         ylen = torch.zeros(S, B, dtype=torch.int32, device=dev)
         U = 0
-        for s_i in range(S):
-            sel = None if s_i == 0 else select[:, s_i].contiguous().to(dev)  # include_best: sample 0 is the best path
-            U = max(U, eng.esa_sample(sel, args.threshold, ratio, opts, tok[s_i], val[s_i], ylen[s_i]))
+        for g0 in range(0, S, group):
+            g1 = min(S, g0 + group)
+            U = max(U, eng.esa_sample(select[g0:g1], args.threshold, ratio, opts, tok[g0:g1], val[g0:g1], ylen[g0:g1]))
         # LM input = [sos] + predictions shifted right; score of every predicted token under the causal + length mask
         tokf, ylf = tok.reshape(S * B, stride), ylen.reshape(S * B)
         lm_in = torch.cat([torch.full((S * B, 1), sos, dtype=torch.int32, device=dev), tokf[:, : stride - 1]], 1).contiguous()

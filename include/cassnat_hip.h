@@ -45,6 +45,8 @@ typedef struct cn_config {
     int32_t enc_max_rel, dec_max_rel; /* args.enc_max_relative_len / dec_max_relative_len (<= 31) */
     int32_t enc_kernel, dec_kernel;   /* args.enc_kernel_size / dec_kernel_size (odd) */
     int32_t d_ff;                     /* args.d_ff: width of the conformer extractor's FFN */
+    int32_t esa_group;                /* ESA: sampled alignments per utterance one cn_esa_sample pass may take (0/1: one);
+                                         sizes the decoder-side workspace (max_batch x esa_group query sets) */
 } cn_config;
 
 /* Decode-time switches read by beam_decode from `args` (src/models/cassnat.py:435-636). */
@@ -128,13 +130,15 @@ int cn_decode_ast(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int
 
 /* ---- ESA: error-based sampling of alignments + TransformerLM ranking (src/models/cassnat.py:370-376, 441-445, 499-561) --
  * cn_esa_begin: encoder + CTC generator once; the two best labels of every frame are kept.
- * cn_esa_sample: ONE sampled alignment per utterance (frame t takes the second-best label iff select[b][t] != 0 and the best
- * label's probability < threshold; select_dev == NULL = the best path), then alignment -> extractor -> decoder -> generator:
- * tok_out / val_out [B][out_stride] = argmax token and its log-probability per decoder row, ylen_out [B] (EOS row
- * included), *ymax_host = rows of this sample.  The caller loops over samples (they are independent) and owns the random
- * draws (the reference takes them from torch.randint).  opts->beam_width must be 1. */
+ * cn_esa_sample: n_samples (<= cfg.esa_group) sampled alignments per utterance in one pass: in alignment g, frame t of
+ * utterance b takes the second-best label iff select[g][b][t] != 0 and the best label's probability < threshold (all-zero
+ * draws - or select_dev == NULL with n_samples == 1 - give the best path); then alignment -> extractor -> decoder ->
+ * generator over B * n_samples query sets that share the B utterances' encoder outputs: tok_out / val_out
+ * [n_samples][B][out_stride] = argmax token and its log-probability per decoder row, ylen_out [n_samples][B] (EOS row
+ * included), *ymax_host = rows of this pass.  The caller owns the random draws (the reference takes them from
+ * torch.randint) and loops over groups of samples.  opts->beam_width must be 1. */
 int cn_esa_begin(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts, void* stream);
-int cn_esa_sample(cn_model* m, const uint8_t* select_dev, float threshold, const float* size_ratio_dev,
+int cn_esa_sample(cn_model* m, const uint8_t* select_dev, int32_t n_samples, float threshold, const float* size_ratio_dev,
                   const cn_decode_opts* opts, int32_t* tok_out_dev, float* val_out_dev, int32_t out_stride,
                   int32_t* ylen_out_dev, int32_t* ymax_host, void* stream);
 /* TransformerLM (src/models/lm.py; model created with cfg.ast = 2: n_enc layers of width d_encff, parameters

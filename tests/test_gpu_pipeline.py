@@ -308,3 +308,10 @@ def test_esa_sampling_with_lm_ranking(which, prec, capsys):
     if prec == "fp32":
         assert same == len(out)
         np.testing.assert_allclose([s[0]["score"] for s in out], g["score"], rtol=1e-5, atol=2e-3)
+    if which == "esa_tiny":  # the samples go through the decoder side in groups: any group size gives the same answer
+        for group in (1, 3):
+            args.hip_esa_group = group
+            with torch.no_grad():
+                out_g, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, args, lm)
+            assert [s[0]["hyp"] for s in out_g] == [s[0]["hyp"] for s in out]
+            np.testing.assert_allclose([s[0]["score"] for s in out_g], [s[0]["score"] for s in out], rtol=1e-6, atol=1e-5)
