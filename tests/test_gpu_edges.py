@@ -1,0 +1,196 @@
+"""Edge cases of the NAST hot path, HIP fp32 engine against the oracle on the same seeded inputs: smallest legal inputs,
+frame counts around the subsampling boundaries, very ragged batches, utterances that emit no token at all, a batch
+smaller / shorter than the workspace it runs in, and repeated calls on one engine.  Integer results (alignment, token
+counts, hypotheses) must be identical; float stages within the tolerances of test_gpu_pipeline.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from cassnat_asr_public_amd import synth
+from cassnat_asr_public_amd.models.cassnat import make_model
+from oracle.cassnat_oracle import decode_nast
+
+pytestmark = pytest.mark.gpu
+
+
+class Vocab:
+    word2index = {"blank": 0, "sos": 1, "eos": 2, "unk": 3}
+
+
+def build(args, state, capture=True):
+    args.hip_precision = "fp32"
+    args.hip_capture = capture
+    model = make_model(args.input_size, args).cuda()
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.copy_(torch.from_numpy(state[k]))
+    return model
+
+
+def run_both(model, state, args, feats, sizes):
+    src = torch.from_numpy(feats)
+    mask = (src[:, :, 0] != args.padding_idx).unsqueeze(1)
+    with torch.no_grad():
+        out, _ = model.beam_decode(src.cuda(), mask.cuda(), torch.from_numpy(sizes).cuda(), Vocab, args)
+    ref = decode_nast(state, feats, sizes, args, stages=True)
+    return out, ref
+
+
+def assert_same(model, out, ref, clear_margin=True):
+    eng = model._engine
+    ctc = ref["ctc_out"].numpy()
+    top2 = np.sort(ctc, -1)[..., -2:]
+    margin = top2[..., 1] - top2[..., 0]
+    best = eng.fetch("best_paths")
+    flips = best != ref["best_paths"]
+    assert (margin[flips] < 1e-4).all()
+    assert np.abs(eng.fetch("ctc_out") - ctc).max() < 1e-3
+    if flips.any():  # a near-tie frame went the other way: everything downstream may legitimately differ
+        return False
+    np.testing.assert_array_equal(eng.fetch("aligned_seq_shift"), ref["aligned_seq_shift"])
+    np.testing.assert_array_equal(eng.fetch("ylen"), ref["ylen"])
+    assert int(eng.fetch("ymax")[0]) == int(ref["ymax"])
+    att = ref["att_out"].numpy()
+    assert np.abs(eng.fetch("att_out") - att).max() < 1e-3
+    a2 = np.sort(att, -1)[..., -2:]
+    if ((a2[..., 1] - a2[..., 0]) > 1e-4).all():
+        for b, seqs in enumerate(out):
+            assert seqs[0]["hyp"] == list(ref["hyps"][b]), b
+            assert abs(seqs[0]["score"] - ref["scores"][b]) < 1e-3
+    return True
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 5, 7, 8, 9, 62, 63, 64, 65])
+def test_frame_counts_around_the_subsampling_boundaries(T):
+    # T' = ((T - 1) // 2 + 1 - 1) // 2 + 1: one subsampled frame up to T = 4, two up to 8, ...
+    args = synth.make_args("tiny")
+    state = synth.make_state(args, seed=0, gain=2.0)
+    feats, sizes = synth.make_feats(2, T, 80, lengths=[T, max(1, T - 2)], seed=5 + T)
+    model = build(args, state)
+    out, ref = run_both(model, state, args, feats, sizes)
+    assert_same(model, out, ref)
+
+
+def test_single_utterance_single_frame():
+    args = synth.make_args("tiny")
+    state = synth.make_state(args, seed=0, gain=2.0)
+    feats, sizes = synth.make_feats(1, 1, 80, seed=3)
+    model = build(args, state)
+    out, ref = run_both(model, state, args, feats, sizes)
+    assert_same(model, out, ref)
+    assert len(out) == 1 and out[0][0]["hyp"][0] == 1
+
+
+@pytest.mark.parametrize("lengths", [[61, 9, 5, 1], [61, 61, 2, 2], [61, 4, 4, 3]])
+def test_very_ragged_batch(lengths):
+    args = synth.make_args("tiny")
+    state = synth.make_state(args, seed=0, gain=2.0)
+    feats, sizes = synth.make_feats(len(lengths), 61, 80, lengths=lengths, seed=17)
+    model = build(args, state)
+    out, ref = run_both(model, state, args, feats, sizes)
+    assert_same(model, out, ref)
+
+
+def test_utterances_that_emit_no_token():
+    # a huge blank bias makes every frame blank: the token count is 0, ylen = 1 (the EOS row only), one decoder row
+    args = synth.make_args("tiny")
+    state = synth.make_state(args, seed=0, gain=2.0, blank_bias=60.0)
+    feats, sizes = synth.make_feats(3, 61, 80, lengths=[61, 50, 37], seed=11)
+    model = build(args, state)
+    out, ref = run_both(model, state, args, feats, sizes)
+    assert (ref["best_paths"] == 0).all() and int(ref["ymax"]) == 1
+    assert assert_same(model, out, ref)
+    for seqs in out:
+        assert len(seqs[0]["hyp"]) == 1 + min(2, int(ref["ymax"]))
+
+
+def test_mixed_silent_and_speaking_utterances():
+    # utterance 1 is all blank because its features are tiny (the bias decides); the others emit tokens: U comes from them
+    args = synth.make_args("tiny")
+    state = synth.make_state(args, seed=0, gain=2.0, blank_bias=2.5)
+    feats, sizes = synth.make_feats(3, 61, 80, lengths=[61, 61, 40], seed=23)
+    feats[1] *= 1e-3
+    model = build(args, state)
+    out, ref = run_both(model, state, args, feats, sizes)
+    assert_same(model, out, ref)
+    assert int(ref["ylen"].min()) >= 1
+
+
+def test_small_call_inside_a_large_workspace_and_repeated_calls():
+    # one engine sized for (8, 200) serves a (3, 61) call, then a (8, 200) call, then the first again: same answers
+    args = synth.make_args("tiny")
+    args.hip_max_batch, args.hip_max_frames = 8, 200
+    state = synth.make_state(args, seed=0, gain=2.0)
+    model = build(args, state)
+    f1, s1 = synth.make_feats(3, 61, 80, lengths=[61, 50, 37], seed=11)
+    f2, s2 = synth.make_feats(8, 200, 80, lengths=list(synth.ragged_lengths(8, 200, 20, seed=3)), seed=12)
+    out1, ref1 = run_both(model, state, args, f1, s1)
+    eng = model._engine
+    assert_same(model, out1, ref1)
+    out2, ref2 = run_both(model, state, args, f2, s2)
+    assert model._engine is eng  # no rebuild
+    assert_same(model, out2, ref2)
+    out1b, _ = run_both(model, state, args, f1, s1)
+    assert [s[0]["hyp"] for s in out1b] == [s[0]["hyp"] for s in out1]
+    assert [s[0]["score"] for s in out1b] == [s[0]["score"] for s in out1]
+
+
+def test_leading_padding_frames_are_masked_like_the_reference():
+    # the reference derives the mask from feats[:, :, 0] != 0, wherever the zeros are: a zeroed frame in the middle of an
+    # utterance is masked as a key, and size_ratio still counts it
+    args = synth.make_args("tiny")
+    state = synth.make_state(args, seed=0, gain=2.0)
+    feats, sizes = synth.make_feats(2, 61, 80, lengths=[61, 45], seed=29)
+    feats[0, 8:16] = 0.0
+    feats[1, 0:4] = 0.0
+    model = build(args, state)
+    out, ref = run_both(model, state, args, feats, sizes)
+    assert_same(model, out, ref)
+
+
+@pytest.mark.parametrize("B,T,lengths", [(1, 1, [1]), (2, 5, [5, 2]), (3, 64, [64, 9, 1]), (5, 130, [130, 129, 77, 8, 4])])
+def test_bf16_fast_path_on_small_and_ragged_batches(B, T, lengths):
+    """The bf16 engine at d_model 256 runs the fused kernels (row chain, LDS-DMA conv, fused generator); their row tiles are
+    128 / 256 rows, so these batches exercise partial tiles, single rows and masked tails.  Checked against the fp32 engine
+    on the same weights: encoder output within bf16 accumulation error, and - when both engines pick the same CTC path -
+    identical token counts and a decoder output within the same error."""
+    args = synth.make_args("config2", N_enc=2)
+    state = synth.make_state(args, seed=4, blank_bias=0.3)
+    feats, sizes = synth.make_feats(B, T, 80, lengths=lengths, seed=31)
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        args.hip_precision, args.hip_capture = prec, True
+        model = make_model(args.input_size, args).cuda()
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                p.copy_(torch.from_numpy(state[k]))
+            src = torch.from_numpy(feats)
+            out, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, args)
+        e = model._engine
+        outs[prec] = dict(out=out, enc_h=e.fetch("enc_h"), best=e.fetch("best_paths"), ylen=e.fetch("ylen"), dec_h=e.fetch("dec_h"))
+    a, b = outs["fp32"], outs["bf16"]
+    assert np.isfinite(b["enc_h"]).all() and np.isfinite(b["dec_h"]).all()
+    scale = np.abs(a["enc_h"]).max()
+    assert np.abs(a["enc_h"] - b["enc_h"]).max() < 0.06 * scale
+    if (a["best"] == b["best"]).all():
+        np.testing.assert_array_equal(a["ylen"], b["ylen"])
+        # rows u < ylen[b] only: the rest of dec_h is padding the reference never reads
+        for i in range(B):
+            n = int(a["ylen"][i])
+            d = np.abs(a["dec_h"][i, :n] - b["dec_h"][i, :n]).max()
+            assert d < 0.08 * np.abs(a["dec_h"][i, :n]).max(), (i, d)
+    # the production call (no capture: blocked activation layout between chain launches, fused generator + arg-max)
+    args.hip_precision, args.hip_capture = "bf16", False
+    model = make_model(args.input_size, args).cuda()
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.copy_(torch.from_numpy(state[k]))
+        src = torch.from_numpy(feats)
+        prod, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, args)
+    Tp = ((T - 1) // 2 + 1 - 1) // 2 + 1
+    for i, seqs in enumerate(prod):
+        h = seqs[0]["hyp"]
+        assert h[0] == 1 and 2 <= len(h) <= Tp + 2 and all(0 <= t < args.vocab_size for t in h) and np.isfinite(seqs[0]["score"])
+    same = sum(p_[0]["hyp"] == c[0]["hyp"] for p_, c in zip(prod, b["out"]))
+    assert same >= B - 1, (same, B)  # summation order differs between the fused and the captured generator: a near-tie may flip
