@@ -290,6 +290,20 @@ def main():
                "sample": f"{a.cpu_batches} batches of {B} x {T} frames (same workload), median of per-batch wall time "
                          f"{med:.2f} s after 1 warm-up; RTF {med / (B * T * 0.01):.5f}",
                "hyp_agreement_with_gpu": round(float(np.mean([h == r for h, r in zip(hyps[:B], ref["hyps"])])), 3)}
+        # context for that number: the same batch through the fp32 engine (the parity gate; exact-f32 MFMA).  Random-init
+        # weights leave tiny arg-max margins, so bf16 rounding flips frames that a trained model would not
+        a32 = synth.make_args("config2")
+        a32.hip_precision, a32.hip_max_batch, a32.hip_max_frames = "fp32", B, T
+        m32 = make_model(F, a32).cuda(local_rank)
+        with torch.no_grad():
+            for k, p in m32.named_parameters():
+                p.copy_(torch.from_numpy(state[k]))
+        h32, l32, _ = m32.decode_device(feats, sizes, a32)
+        h32, l32 = h32.cpu().numpy(), l32.cpu().numpy()
+        cpu["hyp_agreement_fp32_engine"] = round(float(np.mean([h32[b, : l32[b]].tolist() == list(ref["hyps"][b]) for b in range(B)])), 3)
+        cpu["note"] = ("hyp_agreement_with_gpu is the timed bf16 engine vs this fp32 CPU run, whole hypotheses; "
+                       "hyp_agreement_fp32_engine is the fp32 engine on the same batch")
+        m32._engine.close()
 
     out = {
         "metric": "utterances_per_sec", "value": round(value, 2), "unit": "utt/s", "n_gpus": world, "steps": a.steps,

@@ -4,7 +4,7 @@ traffic figures bench.py's roofline objects quote.
     python tools/pmc_summary.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <out dir (profiles/)>
 
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read,
-so it is doubled; WRITE_SIZE is exact.  Both are reported by rocprofv3 in KiB-like units of 1000... no: in KB (x1024 B).
+so it is doubled; WRITE_SIZE is exact.  Both are reported by rocprofv3 in units of 1024 B.
 """
 import csv
 import glob
@@ -27,7 +27,8 @@ def main():
     fdir, wdir, out = sys.argv[1:4]
     fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
     targets = {"row_chain": ("chain_kernel", "chain_kernel (all 21 launches of a step: 12 encoder at 8000 rows, 9 decoder-side)"),
-               "conv2": ("conv2_kernel", "conv2_kernel (LDS-DMA implicit GEMM, B=32 x 1000 frames)")}
+               "conv2": ("conv2_kernel<false>", "conv2_kernel<false> (LDS-DMA implicit GEMM, B=32 x 1000 frames)"),
+               "linear_out": ("conv2_kernel<true>", "conv2_kernel<true> (linear_out on the LDS-DMA tile kernel, 8000 x 5120 -> 256)")}
     for tag, (needle, label) in targets.items():
         fk = [v for k, vs in fetch.items() if needle in k for v in vs]
         wk = [v for k, vs in write.items() if needle in k for v in vs]
