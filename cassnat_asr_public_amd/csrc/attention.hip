@@ -30,6 +30,7 @@ struct AttnParams {
     int H, Lq, Lk;
     const unsigned char* keymask;
     int kv_mod;  // > 0: keys / values / keymask of batch entry b live at entry b % kv_mod (several query sets per source)
+    const int* kv_index;  // non-null: ... at entry kv_index[b] (beam search: every hypothesis row names its utterance)
     const int* klen;
     const int* iv;
     int iv_stride;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
 
     // ---- staging registers for the next K/V tile
     uint4 k_reg[ST_IT], v_reg[ST_IT];
-    const int bk = p.kv_mod > 0 ? b % p.kv_mod : b;
+    const int bk = p.kv_index ? p.kv_index[b] : (p.kv_mod > 0 ? b % p.kv_mod : b);
     const unsigned char* kbase = p.K + (long long)bk * p.Lk * p.ldk_b + (long long)h * KROW;
     const unsigned char* vbase = p.V + (long long)bk * p.Lk * p.ldv_b + (long long)h * KROW;
     auto load_tile = [&](int kt) {
@@ -402,6 +403,7 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     p.Lk = a.Lk;
     p.keymask = a.keymask;
     p.kv_mod = a.kv_mod;
+    p.kv_index = a.kv_index;
     p.klen = a.klen;
     p.iv = a.intervals;
     p.iv_stride = a.iv_stride;

@@ -37,6 +37,11 @@ struct FfnParams {
     bf16* xn_out;  // [M][256] bf16, written when nln_a != null
     int M, dff;
     float eps;
+    // d_ff split (few rows, e.g. an autoregressive decode step): gridDim.y = nslice workgroups share a row tile, each takes
+    // dff / nslice hidden units and writes its W2 partial products to partial[slice][M][256] (no bias, no residual, x is
+    // not touched); ffn_reduce_kernel adds them up in slice order.  nslice == 1: the whole sublayer in place.
+    int nslice;
+    float* partial;
 };
 
 constexpr int FF_D = 256;
@@ -70,8 +75,8 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     unsigned char* ring = smem + MT * 16384 + wave_u * FF_RING_BYTES;
 
-    const int tiles_per_wave = p.dff / 32 / 4;
-    const int ft0 = wave_u * tiles_per_wave;
+    const int tiles_per_wave = p.dff / 32 / 4 / p.nslice;
+    const int ft0 = ((int)blockIdx.y * 4 + wave_u) * tiles_per_wave;
     // Every workgroup walks its hidden tiles in a different rotation: the sum over tiles is order-free, and the
     // workgroups no longer pull the same L2 lines at the same moment (L2 channel hot-spotting).
     const int rot = (blockIdx.x * 7 + wave_u * 3) % tiles_per_wave;
@@ -316,6 +321,17 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
             const int r = wave + 4 * i;
             const int m = m0 + 32 * mt + r;
             if (m >= p.M) continue;  // wave-uniform
+            if (p.nslice > 1) {  // this slice's share of W2 h only, waves added in a fixed order
+                f32x4 v = *reinterpret_cast<const f32x4*>(part + r * FF_P_STRIDE + 4 * lane);
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(part + (w * 32 + r) * FF_P_STRIDE + 4 * lane);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += q[j];
+                }
+                *reinterpret_cast<f32x4*>(p.partial + ((long long)blockIdx.y * p.M + m) * FF_D + 4 * lane) = v;
+                continue;
+            }
             float* xr = p.x + (long long)m * FF_D + 4 * lane;
             f32x4 v = *reinterpret_cast<const f32x4*>(xr);
 #pragma unroll
@@ -351,7 +367,7 @@ template <int MT, int DBG> static int launch_ffn_variant(const FfnParams& p, hip
         CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_fused_kernel<MT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((ffn_fused_kernel<MT, DBG>), dim3(cn_ceil_div(p.M, 32 * MT)), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((ffn_fused_kernel<MT, DBG>), dim3(cn_ceil_div(p.M, 32 * MT), p.nslice), dim3(256), lds, s, p);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -376,6 +392,12 @@ int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s) {
     p.M = a.M;
     p.dff = a.dff;
     p.eps = a.eps;
+    p.nslice = a.nslice > 1 ? a.nslice : 1;
+    p.partial = a.partial;
+    if (p.nslice > 1 && (a.dff % (128 * p.nslice) != 0 || !a.partial)) {
+        cn_set_error("ffn_fused: a d_ff split needs d_ff % (128 * slices) == 0 and a partial-sum buffer");
+        return -1;
+    }
     static int dbg = -1, force_mt = -1;
     if (dbg < 0) dbg = getenv("CASSNAT_FFN_DEBUG") ? atoi(getenv("CASSNAT_FFN_DEBUG")) : 0;
     if (force_mt < 0) force_mt = getenv("CASSNAT_FFN_MT") ? atoi(getenv("CASSNAT_FFN_MT")) : 0;
@@ -388,6 +410,53 @@ int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s) {
     if (dbg == 2) return launch_ffn_variant<1, 2>(p, s);
     if (dbg == 3) return launch_ffn_variant<1, 3>(p, s);
     return launch_ffn_variant<1, 0>(p, s);
+}
+
+// ---- second half of the d_ff split: x[m] += b2 + sum over slices of partial[slice][m] (slice order: deterministic), then
+// optionally the next LayerNorm of the row in bf16 (the norm the following sublayer would otherwise launch for).
+__global__ __launch_bounds__(256) void ffn_reduce_kernel(float* __restrict__ x, const float* __restrict__ partial, int nslice,
+                                                         const float* __restrict__ b2, const float* __restrict__ nln_a,
+                                                         const float* __restrict__ nln_b, bf16* __restrict__ xn_out, int M,
+                                                         float eps) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float* xr = x + (long long)m * FF_D + 4 * lane;
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr);
+    f32x4 acc = *reinterpret_cast<const f32x4*>(partial + (long long)m * FF_D + 4 * lane);
+    for (int sl = 1; sl < nslice; ++sl) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(partial + ((long long)sl * M + m) * FF_D + 4 * lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += q[j];
+    }
+    const f32x4 b2v = *reinterpret_cast<const f32x4*>(b2 + 4 * lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (v[j] + acc[j]) + b2v[j];
+    *reinterpret_cast<f32x4*>(xr) = v;
+    if (nln_a) {
+        const f32x4 ng = *reinterpret_cast<const f32x4*>(nln_a + 4 * lane);
+        const f32x4 nb = *reinterpret_cast<const f32x4*>(nln_b + 4 * lane);
+        const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)FF_D;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ss = fmaf(v[j] - mean, v[j] - mean, ss);
+        const float denom = sqrtf(wave_sum(ss) / (float)(FF_D - 1)) + eps;
+        float o[4];
+        ln_row_to(v, mean, denom, ng, nb, o);
+        bf16x4 ob;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ob[j] = (bf16)o[j];
+        *reinterpret_cast<bf16x4*>(xn_out + (long long)m * FF_D + 4 * lane) = ob;
+    }
+}
+
+int launch_ffn_reduce(float* x, const float* partial, int nslice, const float* b2, const float* nln_a, const float* nln_b,
+                      void* xn_out, int M, float eps, hipStream_t s) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(ffn_reduce_kernel, dim3(cn_ceil_div(M, 4)), dim3(256), 0, s, x, partial, nslice, b2, nln_a, nln_b,
+                       reinterpret_cast<bf16*>(xn_out), M, eps);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 // ---- host-side packing of nn.Linear weights into the fragment streams above -----------------------------

@@ -69,6 +69,7 @@ struct AttnArgs {
     int B = 0, H = 0, Lq = 0, Lk = 0;
     const unsigned char* keymask = nullptr;  // [B][Lk] or null (all valid)
     int kv_mod = 0;  // > 0: K / V / keymask of batch entry b are those of entry b % kv_mod (ESA: many alignments per utterance)
+    const int* kv_index = nullptr;  // non-null: ... those of entry kv_index[b] (AST beam search: the row's utterance)
     const int* klen = nullptr;               // [B] or null: key j valid iff j < klen[b]
     const int* intervals = nullptr;          // [B][iv_stride][4] (s1,e1,s2,e2) per query row, or null
     int iv_stride = 0;
@@ -122,8 +123,15 @@ struct FfnFusedArgs {
     void* xn_out = nullptr;
     int M = 0, d = 0, dff = 0;
     float eps = 1e-6f;
+    // d_ff split over `nslice` workgroups per row tile (few rows): W2 partial products go to partial[nslice][M][256] and
+    // launch_ffn_reduce finishes the sublayer (x += b2 + sum of slices, optional next LayerNorm); x, b2 and the next norm
+    // are not used by the split launch itself
+    int nslice = 1;
+    float* partial = nullptr;
 };
 int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s);
+int launch_ffn_reduce(float* x, const float* partial, int nslice, const float* b2, const float* nln_a, const float* nln_b,
+                      void* xn_out, int M, float eps, hipStream_t s);
 void pack_ffn_w1(const float* w1, int dff, uint16_t* out);  // [dff][256] fp32 -> fragment stream (dff*256 bf16)
 void pack_ffn_w2(const float* w2, int dff, uint16_t* out);  // [256][dff] fp32 -> fragment stream (dff*256 bf16)
 

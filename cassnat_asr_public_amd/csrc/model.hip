@@ -1968,7 +1968,7 @@ extern "C" int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, in
 extern "C" int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, const float* w1_host,
                                const float* b1_dev, const float* w2_host, const float* b2_dev, const float* nln_a_dev,
                                const float* nln_b_dev, void* xn_out_dev, int32_t M, int32_t dff, float eps,
-                               void* stream) {
+                               int32_t nslice, void* stream) {
     if (dff <= 0 || dff % 128 != 0 || dff > 2048) {
         cn_set_error("cn_op_ffn_fused: d_ff must be a positive multiple of 128, at most 2048");
         return -1;
@@ -1997,10 +1997,19 @@ extern "C" int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float*
     a.d = 256;
     a.dff = dff;
     a.eps = eps;
+    void* part = nullptr;
+    if (nslice > 1) {  // d_ff split + reduce (the decode-step form)
+        CN_HIP_CHECK(hipMalloc(&part, (size_t)nslice * M * 256 * 4));
+        a.nslice = nslice;
+        a.partial = (float*)part;
+    }
     int rc = launch_ffn_fused(a, (hipStream_t)stream);
+    if (rc == 0 && nslice > 1)
+        rc = launch_ffn_reduce(x_dev, a.partial, nslice, b2_dev, nln_a_dev, nln_b_dev, xn_out_dev, M, eps, (hipStream_t)stream);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(d1);
     (void)hipFree(d2);
+    if (part) (void)hipFree(part);
     if (rc == 0 && e != hipSuccess) {
         cn_set_error(std::string("cn_op_ffn_fused: ") + hipGetErrorString(e));
         rc = -2;
@@ -2191,18 +2200,31 @@ extern "C" int cn_ast_begin(cn_model* m, const float* feats_dev, int32_t B, int3
 
 namespace {
 // decoder layers on the newest position of n hypotheses -> top-K (token, temperature log-softmax value) per hypothesis
+// dense_bw > 0: the rows are the dense slots b * dense_bw + j of the device beam (utt[row] = row / dense_bw)
 int ast_step_run(cn_model* m, int n, int pos, const int32_t* tok_dev, const int32_t* utt_dev, const int32_t* anc_dev,
                  const uint8_t* keyok_dev, int table_stride, float temperature, int K, int32_t* topk_idx_dev,
-                 float* topk_val_dev, hipStream_t s) {
+                 float* topk_val_dev, int dense_bw, hipStream_t s) {
     const cn_config& c = m->cfg;
     const int d = c.d_model, V = c.vocab_size, H = c.n_head;
     const float scale = 1.0f / sqrtf((float)(d / H));
     float* x = m->xd;
     CN_TRY(launch_ast_embed(tok_dev, m->tgt_lut, m->pe + (size_t)pos * d, x, n, d, sqrtf((float)d), s));
+    // A decode step has few rows (live hypotheses, <= batch x beam): the fused feed-forward kernel would put them on
+    // ceil(n / 64) workgroups that each stream the whole 2 MB of W1|W2.  Its d_ff split spreads the hidden units over 8
+    // workgroups per row tile; the reduce kernel that adds the slices also writes the LayerNorm the next sublayer starts
+    // with (the next layer's self-attention pre-norm, or decoder.norm after the last layer).
+    static const bool no_split = getenv("CASSNAT_AST_NO_FFN_SPLIT") != nullptr;
+    const int ffn_slices = (m->mad.empty() || !m->mad[0].w1p || no_split) ? 1 : (c.d_decff % (128 * 8) == 0 ? 8 : (c.d_decff % (128 * 4) == 0 ? 4 : 1));
+    bool have_ln = false;  // m->xn already holds LN(x) for the sublayer about to start
+    // (only while the rows are few, and the slices fit the hidden-activation buffer they borrow)
+    const size_t hbuf_bytes = (size_t)m->maxB * (m->maxTp + 1) * std::max(1, c.esa_group) *
+                              (size_t)std::max(std::max(c.d_encff, c.d_decff), c.d_ff) * m->es;
+    const bool split_now = ffn_slices > 1 && n <= 2048 && (size_t)ffn_slices * n * d * 4 <= hbuf_bytes;
     for (size_t l = 0; l < m->mad.size(); ++l) {
         const Layer& L = m->mad[l];
         // x += O(SelfAttn(LN x)) over the cached prefix
-        CN_TRY(run_ln(m, L.n[0], x, m->xn, n, s));
+        if (!have_ln) CN_TRY(run_ln(m, L.n[0], x, m->xn, n, s));
+        have_ln = false;
         CN_TRY(run_linear(m, "qkv_proj", L.qkv, m->xn, d, m->qkv, 3 * d, 0, n, 0, nullptr, 0, s));
         CN_TRY(launch_ast_kv_append(m->prec, m->qkv, m->ast_ck[l], m->ast_cv[l], n, d, m->ast_slots, pos, s));
         GatherAttnArgs a;
@@ -2243,14 +2265,62 @@ int ast_step_run(cn_model* m, int n, int pos, const int32_t* tok_dev, const int3
         b.utt = utt_dev;
         b.keymask = m->keymask;
         b.scale = scale;
-        {
+        static const bool no_fast_src = getenv("CASSNAT_AST_GATHER_SRC") != nullptr;
+        if (m->prec == CN_PREC_BF16 && m->Tp <= 256 && !no_fast_src) {
+            // every hypothesis row is a batch entry of one query whose keys / values are its utterance's: the LDS-resident
+            // attention kernel (K|V of a (row, head) by LDS-DMA, MFMA products) instead of the scalar gather kernel
+            ProfScope ps(m, "ast_src_attention", 4.0 * n * H * m->Tp * 64, 2.0 * n * m->Tp * d * m->es, s);
+            AttnArgs a2;
+            a2.Q = m->qd;
+            a2.K = m->ast_kvx[l];
+            a2.V = (const unsigned char*)m->ast_kvx[l] + (size_t)d * m->es;
+            a2.O = m->ctx;
+            a2.ldq = d;
+            a2.ldk = a2.ldv = 2 * d;
+            a2.ldo = d;
+            a2.H = H;
+            a2.Lk = m->Tp;
+            a2.keymask = m->keymask;
+            if (dense_bw > 0 && n % dense_bw == 0) {  // device beam: utterance b owns rows b * bw .. + bw - 1
+                a2.B = n / dense_bw;
+                a2.Lq = dense_bw;
+            } else {  // caller-managed rows: every row is a batch entry of one query that names its utterance
+                a2.B = n;
+                a2.Lq = 1;
+                a2.kv_index = utt_dev;
+            }
+            a2.scale = scale;
+            CN_TRY(launch_attention(m->prec, a2, s));
+        } else {
             ProfScope ps(m, "ast_src_attention", 4.0 * n * H * m->Tp * 64, 2.0 * n * m->Tp * d * m->es, s);
             CN_TRY(launch_ast_gather_attn(m->prec, 1, b, s));
         }
         CN_TRY(run_linear(m, "out_proj_resid", L.src_o, m->ctx, d, x, d, 1, n, CN_EPI_RESID, x, d, s));
-        CN_TRY(run_ffn(m, L, L.n[2], x, n, nullptr, nullptr, s));
+        if (split_now) {
+            const bool last = l + 1 == m->mad.size();
+            const Norm& nx = last ? m->dec_norm : m->mad[l + 1].n[0];
+            ProfScope ps(m, "ffn_split", 4.0 * n * (double)L.w1.N * d, 2.0 * L.w1.N * d * 2 + (double)n * d * (8 + 4 * ffn_slices), s);
+            FfnFusedArgs a;
+            a.x = x;
+            a.ln_a = L.n[2].a;
+            a.ln_b = L.n[2].b;
+            a.w1p = L.w1p;
+            a.b1 = L.w1.b;
+            a.w2p = L.w2p;
+            a.b2 = L.w2.b;
+            a.M = n;
+            a.d = d;
+            a.dff = L.w1.N;
+            a.nslice = ffn_slices;
+            a.partial = reinterpret_cast<float*>(m->hbuf);  // [slices][n][256] fp32 <= the [rows][d_ff] hidden buffer
+            CN_TRY(launch_ffn_fused(a, s));
+            CN_TRY(launch_ffn_reduce(x, a.partial, ffn_slices, L.w2.b, nx.a, nx.b, last ? m->dec_h : m->xn, n, 1e-6f, s));
+            have_ln = true;
+        } else {
+            CN_TRY(run_ffn(m, L, L.n[2], x, n, nullptr, nullptr, s));
+        }
     }
-    CN_TRY(run_ln(m, m->dec_norm, x, m->dec_h, n, s));
+    if (!have_ln) CN_TRY(run_ln(m, m->dec_norm, x, m->dec_h, n, s));
     CN_TRY(run_linear(m, "generator_proj", m->att_gen, m->dec_h, d, m->ast_logits, V, 1, n, 0, nullptr, 0, s));
     CN_TRY(launch_logsoftmax_temp(m->ast_logits, n, V, V, temperature, m->ast_arg, m->ast_maxlp, s));
     CN_TRY(launch_topk(m->ast_logits, n, V, V, K, topk_idx_dev, topk_val_dev, s));
@@ -2271,7 +2341,7 @@ extern "C" int cn_ast_step(cn_model* m, int32_t n, int32_t pos, const int32_t* t
         return -1;
     }
     CN_HIP_CHECK(hipSetDevice(m->cfg.device));
-    return ast_step_run(m, n, pos, tok_dev, utt_dev, anc_dev, keyok_dev, table_stride, temperature, K, topk_idx_dev, topk_val_dev,
+    return ast_step_run(m, n, pos, tok_dev, utt_dev, anc_dev, keyok_dev, table_stride, temperature, K, topk_idx_dev, topk_val_dev, 0,
                         (hipStream_t)stream);
 }
 
@@ -2350,7 +2420,7 @@ extern "C" int cn_decode_ast(cn_model* m, const float* feats_dev, int32_t B, int
     CN_TRY(launch_ast_beam_init(st, cur, B, bw, L, opts->sos, opts->padding_idx, s));
     for (int pos = 0; pos < ao->max_step; ++pos) {
         CN_TRY(ast_step_run(m, S, pos, st.cur_tok, st.utt, st.anc[cur], st.keyok[cur], L, ao->temperature, K, m->beam_idx,
-                            m->beam_val, s));
+                            m->beam_val, bw, s));
         if (want_ctc)
             CN_TRY(cn_ast_ctc_score(m, S, pos, st.utt, st.cur_tok, m->beam_idx, K, st.ctc_ref[cur], pos & 1, ao->eos, m->beam_ctc,
                                     stream));

@@ -216,10 +216,13 @@ int cn_op_greedy_pack(const int32_t* tok, const float* val, const int32_t* ylen,
                       int32_t hyp_stride, int32_t* hyp, int32_t* hyp_len, double* score, void* stream);
 /* fused LN -> W1 -> ReLU -> W2 -> residual (-> next LN) sublayer, bf16 / d_model 256.  x_dev fp32 [M][256] is updated
  * in place; weights are HOST fp32 nn.Linear matrices (w1 [dff][256], w2 [256][dff]) packed and uploaded by the call
- * (test entry: the model packs once at cn_model_finalize).  xn_out_dev (bf16 [M][256]) may be NULL. */
+ * (test entry: the model packs once at cn_model_finalize).  xn_out_dev (bf16 [M][256]) may be NULL.  nslice > 1: the
+ * hidden units are split over nslice workgroups per row tile and a second kernel adds the slices (the form the
+ * autoregressive decode step uses for its few rows); d_ff % (128 * nslice) == 0. */
 int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, const float* w1_host,
                     const float* b1_dev, const float* w2_host, const float* b2_dev, const float* nln_a_dev,
-                    const float* nln_b_dev, void* xn_out_dev, int32_t M, int32_t dff, float eps, void* stream);
+                    const float* nln_b_dev, void* xn_out_dev, int32_t M, int32_t dff, float eps, int32_t nslice,
+                    void* stream);
 /* fused generator tail, bf16 / d_model 256: arg[m] = argmax_v, maxlp[m] = max_v of log_softmax(W h[m] + b); h_dev bf16 [M][256],
  * W/b HOST fp32 nn.Linear parameters (packed and uploaded by the call; the model packs once at cn_model_finalize). */
 int cn_op_genmax(const void* h_dev, const float* w_host, const float* b_host, int32_t M, int32_t V, int32_t* arg_dev,

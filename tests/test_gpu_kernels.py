@@ -376,8 +376,9 @@ def test_greedy_pack_matches_oracle():
 
 
 # ----------------------------------------------------------------------------------------------- fused FFN sublayer
-@pytest.mark.parametrize("M,dff,with_next", [(8000, 2048, True), (45, 256, False), (2304, 2048, True), (32, 128, True)])
-def test_ffn_fused_bf16(M, dff, with_next):
+@pytest.mark.parametrize("M,dff,with_next,nslice", [(8000, 2048, True, 1), (45, 256, False, 1), (2304, 2048, True, 1), (32, 128, True, 1),
+                                                    (320, 2048, True, 8), (7, 2048, False, 16), (130, 1024, True, 4), (64, 256, True, 2)])
+def test_ffn_fused_bf16(M, dff, with_next, nslice):
     from oracle.cassnat_oracle import layer_norm
 
     g = torch.Generator().manual_seed(M + dff)
@@ -397,7 +398,7 @@ def test_ffn_fused_bf16(M, dff, with_next):
     xn_out = torch.full((M, d), float("nan"), dtype=torch.bfloat16, device="cuda") if with_next else None
     hip.check(hip.lib().cn_op_ffn_fused(p(xd), p(ad), p(bd), C.c_void_p(w1.data_ptr()), p(b1d), C.c_void_p(w2.data_ptr()),
                                         p(b2d), p(nad) if with_next else None, p(nbd) if with_next else None,
-                                        p(xn_out), M, dff, 1e-6, stream()))
+                                        p(xn_out), M, dff, 1e-6, nslice, stream()))
     torch.cuda.synchronize()
     assert relerr(xd, ref) < 2e-3  # fp32 residual stream; error = accumulation order + rare bf16 double-rounding of h
     if with_next:

@@ -1,5 +1,5 @@
 #!/bin/bash
-timeout -k 10 200 python tools/host_gap.py --streams 4 --switch 0.005
-timeout -k 10 200 python tools/host_gap.py --streams 4 --switch 0.0002
-timeout -k 10 200 python tools/host_gap.py --streams 4 --switch 0.00002
-timeout -k 10 200 python tools/host_gap.py --streams 1 --switch 0.005
+timeout -k 10 200 python tools/host_gap.py --streams 4
+timeout -k 10 200 python tools/host_gap.py --streams 6
+timeout -k 10 200 python tools/host_gap.py --streams 8
+GPU_MAX_HW_QUEUES=8 timeout -k 10 200 python tools/host_gap.py --streams 8
