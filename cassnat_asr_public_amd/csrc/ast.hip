@@ -224,22 +224,38 @@ __global__ void ast_ctc_prefix_kernel(CtcPrefixArgs a) {
     float rn = r[2 * (start - 1)], rb = r[2 * (start - 1) + 1];
     // log_psi = logsumexp over { r^n(start-1) } U { log_phi(t-1) + x_c(t), t in [start, T) }: streaming max/sum
     float pm = rn, ps = 1.f;
-    for (int t = start; t < Tp; ++t) {
-        const float p0 = rp[2 * (t - 1)], p1 = rp[2 * (t - 1) + 1];
-        const float phi = same ? p1 : lse2(p0, p1);
-        const float xc = x[(long long)t * a.V + c], xb = x[(long long)t * a.V + a.blank];
-        const float nn = lse2(rn, phi) + xc;
-        const float nb = lse2(rn, rb) + xb;
-        r[2 * t] = nn;
-        r[2 * t + 1] = nb;
-        rn = nn;
-        rb = nb;
-        const float v = phi + xc;
-        if (v > pm) {
-            ps = ps * expf(pm - v) + 1.f;
-            pm = v;
-        } else {
-            ps += expf(v - pm);
+    // The recurrence is sequential in t, its inputs are not: the loads of 8 frames go out together (the one-frame-at-a-time
+    // loop spent 0.7 us per frame waiting for them), then the 8 updates run in the reference's order.
+    for (int t0 = start; t0 < Tp; t0 += 8) {
+        float2 pv[8];
+        float xcv[8], xbv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + j < Tp ? t0 + j : Tp - 1;
+            pv[j] = *reinterpret_cast<const float2*>(rp + 2 * (t - 1));
+            xcv[j] = x[(long long)t * a.V + c];
+            xbv[j] = x[(long long)t * a.V + a.blank];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + j;
+            if (t < Tp) {
+                const float p0 = pv[j].x, p1 = pv[j].y;
+                const float phi = same ? p1 : lse2(p0, p1);
+                const float xc = xcv[j], xb = xbv[j];
+                const float nn = lse2(rn, phi) + xc;
+                const float nb = lse2(rn, rb) + xb;
+                *reinterpret_cast<float2*>(r + 2 * t) = make_float2(nn, nb);
+                rn = nn;
+                rb = nb;
+                const float v = phi + xc;
+                if (v > pm) {
+                    ps = ps * expf(pm - v) + 1.f;
+                    pm = v;
+                } else {
+                    ps += expf(v - pm);
+                }
+            }
         }
     }
     float psi = pm + logf(ps);
