@@ -21,11 +21,16 @@ struct GenmaxParams {
     int* arg;           // [M]
     float* maxlp;       // [M]
     int M, V, vtw;      // vtw = vocabulary tiles per wave (even)
+    // GATHER variant (language-model scoring): instead of the arg-max, the log-probability of a given target per row:
+    // row m = b * tgt_U + u reads tgt[b * tgt_ld + u] and writes tgt_lp[b * tgt_ld + u]
+    const int* tgt;
+    float* tgt_lp;
+    int tgt_U, tgt_ld;
 };
 
 constexpr int GM_RING_BYTES = 32 * 1024;
 
-template <int MT>
+template <int MT, bool GATHER>
 __global__ __launch_bounds__(256) void genmax_kernel(GenmaxParams p) {
     constexpr int BM = 32 * MT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -72,11 +77,20 @@ __global__ __launch_bounds__(256) void genmax_kernel(GenmaxParams p) {
     const unsigned slot_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(ring + lane * 16);
     float m_run[MT], s_run[MT];
     int i_run[MT];
+    int tg[MT];      // GATHER: this lane's rows' target labels and their logits once seen
+    float tv[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         m_run[mt] = CN_NEG_FILL;
         s_run[mt] = 0.f;
         i_run[mt] = 0;
+        tg[mt] = -1;
+        tv[mt] = -INFINITY;
+        if constexpr (GATHER) {
+            int m = m0 + 32 * mt + l31;
+            if (m >= p.M) m = p.M - 1;
+            tg[mt] = p.tgt[(long long)(m / p.tgt_U) * p.tgt_ld + (m % p.tgt_U)];
+        }
     }
 
 #define GM_STR2(x) #x
@@ -122,6 +136,7 @@ __global__ __launch_bounds__(256) void genmax_kernel(GenmaxParams p) {
                 const float v = acc[mt][r] + bv[r];                                                           \
                 acc[mt][r] = v;                                                                               \
                 if (v > tmax) { tmax = v; tidx = vbase + (r & 3) + 8 * (r >> 2); }                            \
+                if constexpr (GATHER) { if (vbase + (r & 3) + 8 * (r >> 2) == tg[mt]) tv[mt] = v; }           \
             }                                                                                                 \
             if (tmax > m_run[mt]) {                                                                           \
                 s_run[mt] *= __expf(m_run[mt] - tmax);                                                        \
@@ -179,6 +194,7 @@ __global__ __launch_bounds__(256) void genmax_kernel(GenmaxParams p) {
         s_run[mt] = s_run[mt] * __expf(m_run[mt] - nm) + os * __expf(om - nm);
         if (om > m_run[mt] || (om == m_run[mt] && oi < i_run[mt])) i_run[mt] = oi;
         m_run[mt] = nm;
+        if constexpr (GATHER) tv[mt] = fmaxf(tv[mt], __shfl_xor(tv[mt], 32));  // exactly one lane half of one wave saw it
     }
     __syncthreads();  // all rings idle (last wait was vmcnt(0)); reuse LDS for the cross-wave merge
     if (half == 0) {
@@ -188,35 +204,43 @@ __global__ __launch_bounds__(256) void genmax_kernel(GenmaxParams p) {
             d[0] = m_run[mt];
             d[1] = s_run[mt];
             d[2] = __int_as_float(i_run[mt]);
+            d[3] = tv[mt];
         }
     }
     __syncthreads();
     if (tid < BM && m0 + tid < p.M) {
         float bm = merge[tid * 4 + 0], bs = merge[tid * 4 + 1];
         int bi = __float_as_int(merge[tid * 4 + 2]);
+        float bt = merge[tid * 4 + 3];
 #pragma unroll
         for (int wv = 1; wv < 4; ++wv) {
             const float* d = merge + (wv * BM + tid) * 4;
             const float om = d[0], os = d[1];
+            bt = fmaxf(bt, d[3]);
             const int oi = __float_as_int(d[2]);
             const float nm = fmaxf(bm, om);
             bs = bs * __expf(bm - nm) + os * __expf(om - nm);
             if (om > bm || (om == bm && oi < bi)) bi = oi;
             bm = nm;
         }
-        p.arg[m0 + tid] = bi;
-        p.maxlp[m0 + tid] = -logf(bs);
+        if constexpr (GATHER) {
+            const int m = m0 + tid;
+            p.tgt_lp[(long long)(m / p.tgt_U) * p.tgt_ld + (m % p.tgt_U)] = (bt - bm) - logf(bs);
+        } else {
+            p.arg[m0 + tid] = bi;
+            p.maxlp[m0 + tid] = -logf(bs);
+        }
     }
 }
 
-template <int MT> static int launch_genmax_variant(const GenmaxParams& p, hipStream_t s) {
+template <int MT, bool GATHER> static int launch_genmax_variant(const GenmaxParams& p, hipStream_t s) {
     constexpr int lds = 4 * GM_RING_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        CN_HIP_CHECK(hipFuncSetAttribute((const void*)genmax_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)genmax_kernel<MT, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((genmax_kernel<MT>), dim3(cn_ceil_div(p.M, 32 * MT)), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((genmax_kernel<MT, GATHER>), dim3(cn_ceil_div(p.M, 32 * MT)), dim3(256), lds, s, p);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -242,7 +266,18 @@ int launch_genmax(const GenmaxArgs& a, hipStream_t s) {
     p.M = a.M;
     p.V = a.V;
     p.vtw = vtw;
-    return a.M > 32 ? launch_genmax_variant<2>(p, s) : launch_genmax_variant<1>(p, s);
+    p.tgt = a.tgt;
+    p.tgt_lp = a.tgt_lp;
+    p.tgt_U = a.tgt_U;
+    p.tgt_ld = a.tgt_ld;
+    if (a.tgt) {
+        if (!a.tgt_lp || a.tgt_U < 1 || a.tgt_ld < a.tgt_U || a.M % a.tgt_U != 0) {
+            cn_set_error("genmax: the target gather needs rows = B x U, an output buffer and ld >= U");
+            return -1;
+        }
+        return a.M > 32 ? launch_genmax_variant<2, true>(p, s) : launch_genmax_variant<1, true>(p, s);
+    }
+    return a.M > 32 ? launch_genmax_variant<2, false>(p, s) : launch_genmax_variant<1, false>(p, s);
 }
 
 static inline uint16_t gm_bf16_bits(float f) {

@@ -189,6 +189,11 @@ struct GenmaxArgs {
     int* arg = nullptr;
     float* maxlp = nullptr;
     int M = 0, V = 0, d = 0;
+    // language-model scoring: tgt != null -> tgt_lp[b * tgt_ld + u] = log_softmax(W h[b * tgt_U + u] + b)[tgt[b * tgt_ld + u]]
+    // (arg / maxlp unused)
+    const int* tgt = nullptr;
+    float* tgt_lp = nullptr;
+    int tgt_U = 0, tgt_ld = 0;
 };
 int launch_genmax(const GenmaxArgs& a, hipStream_t s);
 int genmax_vtw(int V);  // vocabulary tiles per wave; packed sizes: weights 4*vtw*16 KiB, biases 4*vtw*32 floats

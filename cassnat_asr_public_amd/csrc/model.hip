@@ -1658,6 +1658,22 @@ extern "C" int cn_lm_score(cn_model* m, const int32_t* tok_dev, const int32_t* t
         CN_TRY(run_ffn(m, L, L.n[1], x, M, nullptr, nullptr, s));
     }
     CN_TRY(run_ln(m, m->enc_norm, x, m->enc_h, M, s));
+    static const bool no_fused = getenv("CASSNAT_LM_NO_FUSED_TAIL") != nullptr;
+    if (m->att_gen.gm_w && !no_fused) {  // bf16 / d_model 256: generator + log-softmax + gather in one kernel, no (M, V) tensor
+        ProfScope ps(m, "generator_gather_fused", 2.0 * M * V * d, (double)M * d * 2 + (double)V * d * 2, s);
+        GenmaxArgs a;
+        a.h = m->enc_h;
+        a.wp = m->att_gen.gm_w;
+        a.bp = m->att_gen.gm_b;
+        a.M = M;
+        a.V = V;
+        a.d = d;
+        a.tgt = tgt_dev;
+        a.tgt_lp = score_dev;
+        a.tgt_U = U;
+        a.tgt_ld = ld;
+        return launch_genmax(a, s);
+    }
     CN_TRY(run_linear(m, "generator_proj", m->att_gen, m->enc_h, d, m->logits, V, 1, M, 0, nullptr, 0, s));
     CN_TRY(launch_logsoftmax_argmax(m->logits, M, V, V, m->best, m->ctc_maxlp, 1, s));
     return launch_gather_logp(m->logits, V, tgt_dev, ld, score_dev, B, U, s);
@@ -2092,8 +2108,9 @@ extern "C" int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, con
     return rc;
 }
 
-extern "C" int cn_op_genmax(const void* h_dev, const float* w_host, const float* b_host, int32_t M, int32_t V,
-                            int32_t* arg_dev, float* maxlp_dev, void* stream) {
+static int op_genmax_impl(const void* h_dev, const float* w_host, const float* b_host, int32_t M, int32_t V,
+                          int32_t* arg_dev, float* maxlp_dev, const int32_t* tgt_dev, float* tgt_lp_dev, int32_t U, int32_t ld,
+                          void* stream) {
     const int vtw = genmax_vtw(V);
     if (vtw > 48) {
         cn_set_error("cn_op_genmax: V too large");
@@ -2116,6 +2133,10 @@ extern "C" int cn_op_genmax(const void* h_dev, const float* w_host, const float*
     a.M = M;
     a.V = V;
     a.d = 256;
+    a.tgt = tgt_dev;
+    a.tgt_lp = tgt_lp_dev;
+    a.tgt_U = U;
+    a.tgt_ld = ld;
     int rc = launch_genmax(a, (hipStream_t)stream);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(dw);
@@ -2125,6 +2146,16 @@ extern "C" int cn_op_genmax(const void* h_dev, const float* w_host, const float*
         rc = -2;
     }
     return rc;
+}
+
+extern "C" int cn_op_genmax(const void* h_dev, const float* w_host, const float* b_host, int32_t M, int32_t V,
+                            int32_t* arg_dev, float* maxlp_dev, void* stream) {
+    return op_genmax_impl(h_dev, w_host, b_host, M, V, arg_dev, maxlp_dev, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int cn_op_genmax_gather(const void* h_dev, const float* w_host, const float* b_host, int32_t B, int32_t U, int32_t V,
+                                   const int32_t* tgt_dev, int32_t ld, float* tgt_lp_dev, void* stream) {
+    return op_genmax_impl(h_dev, w_host, b_host, B * U, V, nullptr, nullptr, tgt_dev, tgt_lp_dev, U, ld, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

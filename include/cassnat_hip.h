@@ -227,6 +227,10 @@ int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, 
  * W/b HOST fp32 nn.Linear parameters (packed and uploaded by the call; the model packs once at cn_model_finalize). */
 int cn_op_genmax(const void* h_dev, const float* w_host, const float* b_host, int32_t M, int32_t V, int32_t* arg_dev,
                  float* maxlp_dev, void* stream);
+/* the same kernel with a target gather (TransformerLM scoring, src/models/cassnat.py:507-520): h_dev bf16 [B * U][256];
+ * tgt_lp[b * ld + u] = log_softmax(W h[b * U + u] + b)[tgt[b * ld + u]] */
+int cn_op_genmax_gather(const void* h_dev, const float* w_host, const float* b_host, int32_t B, int32_t U, int32_t V,
+                        const int32_t* tgt_dev, int32_t ld, float* tgt_lp_dev, void* stream);
 int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, int32_t* idx, float* val, void* stream);
 
 #ifdef __cplusplus

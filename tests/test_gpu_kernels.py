@@ -375,6 +375,27 @@ def test_greedy_pack_matches_oracle():
         assert sc[b].item() == o_sc[b]  # sequential double sum: bit-identical
 
 
+@pytest.mark.parametrize("B,U,ld,V", [(37, 9, 12, 5000), (3, 1, 1, 40), (1600, 5, 7, 1028), (2, 16, 16, 4234)])
+def test_generator_target_gather_fused_bf16(B, U, ld, V):
+    """TransformerLM scoring tail: log-probability of a given target per row, from the fused generator kernel."""
+    g = torch.Generator().manual_seed(B + U + V)
+    h = torch.randn(B * U, 256, generator=g)
+    w = (torch.randn(V, 256, generator=g) / 16).contiguous()
+    b = (0.1 * torch.randn(V, generator=g)).contiguous()
+    tgt = torch.randint(0, V, (B, ld), generator=g, dtype=torch.int32)
+    tgt[0, 0] = V - 1
+    tgt[-1, U - 1] = 0
+    ref = torch.log_softmax(F.linear(rounded(h, "bf16"), rounded(w, "bf16"), b), -1).view(B, U, V)
+    want = torch.gather(ref, 2, tgt[:, :U].long().unsqueeze(-1)).squeeze(-1)
+    hd, td = dev(h, torch.bfloat16), dev(tgt)
+    out = torch.full((B, ld), float("nan"), dtype=torch.float32, device="cuda")
+    hip.check(hip.lib().cn_op_genmax_gather(p(hd), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), B, U, V, p(td), ld, p(out), stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu()[:, :U] - want).abs().max().item() < 3e-4
+    if ld > U:
+        assert torch.isnan(out.cpu()[:, U:]).all()  # nothing written outside the U scored positions
+
+
 # ----------------------------------------------------------------------------------------------- fused FFN sublayer
 @pytest.mark.parametrize("M,dff,with_next,nslice", [(8000, 2048, True, 1), (45, 256, False, 1), (2304, 2048, True, 1), (32, 128, True, 1),
                                                     (320, 2048, True, 8), (7, 2048, False, 16), (130, 1024, True, 4), (64, 256, True, 2)])

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--samples", type=int, default=50)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--same-seed", action="store_true", help="the same random draws in every repetition")
     a = ap.parse_args()
     args = synth.make_args("config2", sample_num=a.samples, rank_model="lm", threshold=0.9)
     args.hip_precision = a.precision
@@ -47,7 +48,7 @@ def main():
     mask = (src[:, :, 0] != args.padding_idx).unsqueeze(1)
     times = []
     for r in range(a.reps + 1):
-        torch.manual_seed(r)
+        torch.manual_seed(0 if a.same_seed else r)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out, _ = model.beam_decode(src, mask, sizes, Vocab, args, lm)
