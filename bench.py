@@ -46,8 +46,8 @@ def flops_per_batch(B, T, F, U, a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
