@@ -50,6 +50,8 @@ constexpr int CH_MAX_TAIL = 24, CH_MAX_FFN_TILES = 64;
 
 __device__ long long ch_stamps[16];  // phase timestamps of workgroup 0 / wave 0 (investigation aid: CASSNAT_CHAIN_STAMPS)
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 struct ChainParams {
     float* x;          // [M][256] fp32 residual stream, updated in place
     const bf16* ctx;   // [M][ldctx] bf16 (null: no output projection)
@@ -394,14 +396,17 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
             // W1 unit at position K0: xh = W1 tile . xn ; then bias + ReLU + pack (next tile's bias read goes out first:
             // it is older than every fragment read that follows, so the waits of the next blocks cover it)
 #define CH_W1(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB)                                                     \
-            CH_BLK1("=&", "v", "0", xh, Fa, bop, 0, Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN);  \
+            /* the accumulation starts from the tile's bias (the 16 table values ARE the accumulator's initial value) */ \
+            xh = __builtin_shufflevector(__builtin_shufflevector(b1v[0], b1v[1], 0, 1, 2, 3, 4, 5, 6, 7),      \
+                                         __builtin_shufflevector(b1v[2], b1v[3], 0, 1, 2, 3, 4, 5, 6, 7),      \
+                                         0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);               \
+            CH_BLK1("+", "v", "%[c]", xh, Fa, bop, 0, Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN); \
             CH_BLK1("+", "v", "%[c]", xh, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, \
                     CH_DMA3, SB, CH_DRAIN);                                                                    \
             {                                                                                                 \
-                asm volatile("" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]));                     \
+                /* (ReLU as an integer max on the fp32 bits, before the pack: a packed int16 max after it measured slower) */ \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
-                    const float v = xh[r] + b1v[r >> 2][r & 3];                                               \
-                    const int bits = __float_as_int(v);                                                       \
+                    const int bits = __float_as_int(xh[r]);                                                   \
                     pb[r >> 3][r & 7] = (bf16)__int_as_float(bits > 0 ? bits : 0);                            \
                 }                                                                                             \
                 ch_tab4_nowait(tb + ((k) / 2 + 1 < 4 ? ((k) / 2 + 1) * 128 : 0), b1v[0], b1v[1], b1v[2], b1v[3]); \
@@ -463,24 +468,37 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
             const uint4* sb_cur = group_base(gpos);
             const uint4* sb_next = group_base(gpos + 1);
             const unsigned tb = tab_lane + (unsigned)((CT_BT + 256 * g) * 4);
-            bf16* op = p.out + (long long)m * p.ldo + 256 * g + 4 * half;
+            bf16* op16 = p.out + (long long)m * p.ldo + 256 * g + 8 * half;  // after the half-wave exchange (below)
             f32x16 q;
             f32x4 btv[4];
             ch_tab4_nowait(tb, btv[0], btv[1], btv[2], btv[3]);
 #define CH_S5(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB)                                                     \
-            CH_BLK1("=&", "v", "0", q, Fa, bop, 0, Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN);   \
+            q = __builtin_shufflevector(__builtin_shufflevector(btv[0], btv[1], 0, 1, 2, 3, 4, 5, 6, 7),      \
+                                        __builtin_shufflevector(btv[2], btv[3], 0, 1, 2, 3, 4, 5, 6, 7),      \
+                                        0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);  /* bias = initial value */ \
+            CH_BLK1("+", "v", "%[c]", q, Fa, bop, 0, Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN); \
             CH_BLK1("+", "v", "%[c]", q, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, \
                     CH_DMA3, SB, CH_DRAIN);                                                                    \
             {                                                                                                 \
-                asm volatile("" : "+v"(btv[0]), "+v"(btv[1]), "+v"(btv[2]), "+v"(btv[3]));                     \
                 bf16x4 o_[4];                                                                                 \
                 _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                              \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) o_[g_][e] = (bf16)(q[4 * g_ + e] + btv[g_][e]); \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) o_[g_][e] = (bf16)q[4 * g_ + e];             \
                 ch_tab4_nowait(tb + ((k) + 1 < 8 ? ((k) + 1) * 128 : 0), btv[0], btv[1], btv[2], btv[3]);      \
+                /* a lane holds channels 8 g + 4 half + (0..3) of its row: the two half-waves trade their odd / even */ \
+                /* groups (v_permlane32_swap: upper half of the first operand <-> lower half of the second), after    */ \
+                /* which a lane owns 8 consecutive channels of groups (half, half + 2): two 16-byte stores, not four   */ \
+                /* 8-byte ones                                                                                         */ \
+                u32x4 w_[2];                                                                                  \
+                _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                            \
+                    const uint2 lo_ = __builtin_bit_cast(uint2, o_[2 * gp]), hi_ = __builtin_bit_cast(uint2, o_[2 * gp + 1]); \
+                    const auto s0_ = __builtin_amdgcn_permlane32_swap(lo_.x, hi_.x, false, false);            \
+                    const auto s1_ = __builtin_amdgcn_permlane32_swap(lo_.y, hi_.y, false, false);            \
+                    w_[gp] = u32x4{s0_[0], s1_[0], s0_[1], s1_[1]};                                           \
+                }                                                                                             \
                 if (live && p.stamps != 2) {                                                                  \
-                    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                          \
-                        __builtin_nontemporal_store(o_[g_], reinterpret_cast<bf16x4*>(op + 32 * (k) + 8 * g_)); \
-                } else if (p.stamps == 2) { asm volatile("" :: "v"(o_[0]), "v"(o_[1]), "v"(o_[2]), "v"(o_[3])); }                                                                                            \
+                    _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                          \
+                        __builtin_nontemporal_store(w_[gp], reinterpret_cast<u32x4*>(op16 + 32 * (k) + 16 * gp)); \
+                } else if (p.stamps == 2) { asm volatile("" :: "v"(w_[0]), "v"(w_[1])); }                     \
             }
             CH_POSITIONS(CH_S5)
 #undef CH_S5

@@ -1689,6 +1689,13 @@ extern "C" int cn_profile_begin(cn_model* m, const char* tags) {
     m->prof_pending.clear();
     m->prof_stats.clear();
     m->ev_used = 0;
+    // events for a few thousand tagged launches exist before the caller's timed region starts (the pool still grows on
+    // demand past that)
+    while (m->ev_pool.size() < 4096) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        m->ev_pool.push_back(e);
+    }
     return 0;
 }
 
