@@ -109,6 +109,9 @@ int launch_greedy_pack(const int* tok, const float* val, const int* ylen, int B,
                        int* hyp, int* hyp_len, double* score, hipStream_t s);
 // per row top-k (k <= 16) of log-probs [M][V] -> idx/val [M][k], sorted descending (ties: lower index first)
 int launch_topk(const float* logp, int M, int V, int ldl, int k, int* idx, float* val, hipStream_t s);
+// log_softmax(logits / T) and its per-row top-k in one pass (the (M, V) log-probabilities are not written)
+int launch_logsoftmax_topk(const float* logits, int M, int V, int ldl, float temperature, int k, int* idx, float* val,
+                           hipStream_t s);
 
 // ---- fused FFN sublayer, bf16 / d_model == 256                                     (fused.hip)
 //   x <- x + W2 relu(W1 LN(x) + b1) + b2 ;  optionally xn_out <- LN_next(x) in bf16

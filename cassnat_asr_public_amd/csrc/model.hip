@@ -1988,6 +1988,11 @@ extern "C" int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, in
     return launch_topk(logp, M, V, V, k, idx, val, (hipStream_t)stream);
 }
 
+extern "C" int cn_op_logsoftmax_topk(const float* logits, int32_t M, int32_t V, float temperature, int32_t k, int32_t* idx,
+                                     float* val, void* stream) {
+    return launch_logsoftmax_topk(logits, M, V, V, temperature, k, idx, val, (hipStream_t)stream);
+}
+
 extern "C" int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, const float* w1_host,
                                const float* b1_dev, const float* w2_host, const float* b2_dev, const float* nln_a_dev,
                                const float* nln_b_dev, void* xn_out_dev, int32_t M, int32_t dff, float eps,
@@ -2360,8 +2365,7 @@ int ast_step_run(cn_model* m, int n, int pos, const int32_t* tok_dev, const int3
     }
     if (!have_ln) CN_TRY(run_ln(m, m->dec_norm, x, m->dec_h, n, s));
     CN_TRY(run_linear(m, "generator_proj", m->att_gen, m->dec_h, d, m->ast_logits, V, 1, n, 0, nullptr, 0, s));
-    CN_TRY(launch_logsoftmax_temp(m->ast_logits, n, V, V, temperature, m->ast_arg, m->ast_maxlp, s));
-    CN_TRY(launch_topk(m->ast_logits, n, V, V, K, topk_idx_dev, topk_val_dev, s));
+    CN_TRY(launch_logsoftmax_topk(m->ast_logits, n, V, V, temperature, K, topk_idx_dev, topk_val_dev, s));
     return 0;
 }
 }  // namespace

@@ -222,6 +222,105 @@ int launch_topk(const float* logp, int M, int V, int ldl, int k, int* idx, float
     return 0;
 }
 
+// Generator tail of the autoregressive step in one pass per row: log_softmax(logits / T) and its top-k (sorted descending,
+// ties: lower index first).  Same per-element arithmetic as logsoftmax_argmax_kernel followed by topk_kernel - x / T, the
+// row maximum, the sum of expf(x - max) in the same partition and order, (x - max) - lse per entry (in LDS) - without
+// writing the (M, V) log-probabilities back and with the k selection rounds working on cached per-thread maxima (only the
+// thread that owned the previous winner rescans its V / 256 entries).
+__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __restrict__ logits, int V, int ldl, float temperature,
+                                                              int k, int* __restrict__ idx, float* __restrict__ val) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* row = reinterpret_cast<float*>(smem);
+    __shared__ float s_val[4], s_sum[4];
+    __shared__ int s_idx[4];
+    const float* p = logits + (long long)blockIdx.x * ldl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto local_best = [&](float& best, int& bidx) {
+        best = -INFINITY;
+        bidx = 0x7fffffff;
+        for (int i = tid; i < V; i += 256) {
+            const float v = row[i];
+            if (v > best || (v == best && i < bidx)) {
+                best = v;
+                bidx = i;
+            }
+        }
+    };
+    auto block_best = [&](float& best, int& bidx) {  // all threads return the winner
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bidx, o);
+            if (ov > best || (ov == best && oi < bidx)) {
+                best = ov;
+                bidx = oi;
+            }
+        }
+        if (lane == 0) {
+            s_val[wave] = best;
+            s_idx[wave] = bidx;
+        }
+        __syncthreads();
+        best = s_val[0];
+        bidx = s_idx[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bidx)) {
+                best = s_val[w];
+                bidx = s_idx[w];
+            }
+        __syncthreads();  // s_val / s_idx are rewritten by the next round
+    };
+    if (temperature != 1.0f)
+        for (int i = tid; i < V; i += 256) row[i] = p[i] / temperature;
+    else
+        for (int i = tid; i < V; i += 256) row[i] = p[i];
+    // (a thread only ever reads the entries it wrote until the first block_best: no barrier needed before it)
+    float mybest;
+    int myidx;
+    local_best(mybest, myidx);
+    float best = mybest;
+    int bidx = myidx;
+    block_best(best, bidx);
+    const float rmax = best;
+    float sum = 0.f;
+    for (int i = tid; i < V; i += 256) sum += expf(row[i] - rmax);
+    sum = wave_sum(sum);
+    if (lane == 0) s_sum[wave] = sum;
+    __syncthreads();
+    const float lse = logf((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
+    // the selection ranks the LOG-PROBABILITIES, as the two-kernel form and the reference do: two logits one ulp apart can
+    // round to the same log-probability, and the tie then goes to the lower index
+    for (int i = tid; i < V; i += 256) row[i] = (row[i] - rmax) - lse;
+    local_best(mybest, myidx);
+    for (int r = 0; r < k; ++r) {
+        best = mybest;
+        bidx = myidx;
+        block_best(best, bidx);
+        if (tid == 0) {
+            idx[(long long)blockIdx.x * k + r] = bidx;
+            val[(long long)blockIdx.x * k + r] = best;
+        }
+        if (bidx < V && (bidx & 255) == tid) {  // the owner retires the winner and finds its next candidate
+            row[bidx] = -INFINITY;
+            local_best(mybest, myidx);
+        }
+    }
+}
+
+int launch_logsoftmax_topk(const float* logits, int M, int V, int ldl, float temperature, int k, int* idx, float* val,
+                           hipStream_t s) {
+    if (k < 1 || k > 16 || V > 16384) {
+        cn_set_error("logsoftmax_topk: need 1 <= k <= 16 and V <= 16384");
+        return -1;
+    }
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(M), dim3(256), (size_t)V * sizeof(float), s, logits, V, ldl, temperature, k, idx,
+                       val);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Padding mask after 4x subsampling: src/tasks/cassnat_task.py:328 then embedding.py:121-122
 // (mask[:, :, ::2][:, :, ::2]) => keymask[b][j] = feats[b][4j][0] != padding_idx.

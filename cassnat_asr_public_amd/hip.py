@@ -84,6 +84,7 @@ def lib():
     L.cn_op_ctc_align.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 5 + [C.c_void_p] * 6
     L.cn_op_greedy_pack.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p] * 4
     L.cn_op_topk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cn_op_logsoftmax_topk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_model_create.argtypes = [C.POINTER(CnConfig), C.POINTER(C.c_void_p)]
     L.cn_model_destroy.argtypes = [C.c_void_p]
     L.cn_model_load_weights.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]

@@ -232,6 +232,10 @@ int cn_op_genmax(const void* h_dev, const float* w_host, const float* b_host, in
 int cn_op_genmax_gather(const void* h_dev, const float* w_host, const float* b_host, int32_t B, int32_t U, int32_t V,
                         const int32_t* tgt_dev, int32_t ld, float* tgt_lp_dev, void* stream);
 int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, int32_t* idx, float* val, void* stream);
+/* generator tail of the autoregressive step (src/models/transformer.py:48-51, 199-200): log_softmax(logits / T) and its per-row
+ * top-k (sorted descending, ties: lower index) in one pass; the logits [M][V] are left untouched */
+int cn_op_logsoftmax_topk(const float* logits, int32_t M, int32_t V, float temperature, int32_t k, int32_t* idx, float* val,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -296,6 +296,36 @@ def test_topk():
     assert torch.equal(val.cpu(), ref.values)
 
 
+@pytest.mark.parametrize("M,V,k,T", [(320, 5000, 15, 1.0), (7, 40, 10, 1.3), (33, 4234, 16, 0.7), (5, 1028, 1, 1.0)])
+def test_logsoftmax_topk_fused_equals_the_two_kernel_form(M, V, k, T):
+    """The one-pass tail of the autoregressive step must give bit-identical indices and values to log-softmax (row rewritten)
+    followed by top-k, including exact ties (lower index first) and near-ties that collapse after the log-softmax rounding."""
+    g = torch.Generator().manual_seed(M + V + k)
+    x = torch.randn(M, V, generator=g) * 3
+    x[0, 5] = x[0, 9] = x[0].max() + 0.5        # exact tie at the top
+    x[1, 11] = x[1].max() + 2.0
+    x[1, 3] = torch.nextafter(x[1, 11], torch.tensor(float("inf")))  # one ulp apart
+    x[2] = torch.round(x[2] * 4) / 4             # many exact ties down the ranking
+    xd = dev(x)
+    idx_f = torch.empty(M, k, dtype=torch.int32, device="cuda")
+    val_f = torch.empty(M, k, dtype=torch.float32, device="cuda")
+    hip.check(hip.lib().cn_op_logsoftmax_topk(p(xd), M, V, T, k, p(idx_f), p(val_f), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(xd.cpu(), x)  # logits untouched
+    y = (x / T).cuda() if T != 1.0 else x.clone().cuda()
+    arg = torch.empty(M, dtype=torch.int32, device="cuda")
+    mlp = torch.empty(M, dtype=torch.float32, device="cuda")
+    hip.check(hip.lib().cn_op_logsoftmax_argmax(p(y), M, V, p(arg), p(mlp), 1, stream()))
+    idx_2 = torch.empty(M, k, dtype=torch.int32, device="cuda")
+    val_2 = torch.empty(M, k, dtype=torch.float32, device="cuda")
+    hip.check(hip.lib().cn_op_topk(p(y), M, V, k, p(idx_2), p(val_2), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(idx_f.cpu(), idx_2.cpu())
+    assert torch.equal(val_f.cpu(), val_2.cpu())
+    ref = torch.log_softmax(x / T, -1)
+    assert (val_f.cpu() - torch.topk(ref, k, dim=-1).values).abs().max().item() < 3e-6
+
+
 # ----------------------------------------------------------------------------------------------- integer kernels
 def run_align(best, mask, ratio, left=0, right=0):
     B, Tp = best.shape
