@@ -92,49 +92,36 @@ def main():
     args.hip_max_batch, args.hip_max_frames = a.batch, a.frames
     B, T, F = a.batch, a.frames, args.input_size
 
-    # ---- models: rank 0 owns the checkpoint, everyone else receives the packed blob over RCCL.
-    # One engine handle (weights + workspace) per decode pipeline.
-    import threading
+    # ---- model: rank 0 owns the checkpoint, everyone else receives the packed blob over RCCL.
+    # cassnat_asr_public_amd.pipeline.DecodePipelines = NS decode pipelines (engine handle with its weights + workspace, HIP
+    # stream and host thread each): the object the package's own test-set decoder uses.
+    from cassnat_asr_public_amd.pipeline import DecodePipelines
 
     NS = max(1, a.streams)
     state = None
+    model = make_model(F, args).cuda(local_rank)
     if rank == 0:
         state = synth.make_state(args, seed=0, blank_bias=synth.BENCH_BLANK_BIAS)
-    models, engines, groups = [], [], []
-    bcast_ms = None
-    for i in range(NS):
-        model = make_model(F, args).cuda(local_rank)
-        if rank == 0:
-            with torch.no_grad():
-                for k, p in model.named_parameters():
-                    p.copy_(torch.from_numpy(state[k]))
-        eng = model.build_engine(B, T, with_weights=(rank == 0))
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                p.copy_(torch.from_numpy(state[k]))
+    bcast = {"ms": None}
+
+    def receive_weights(eng):
         if world > 1:
             t0 = time.perf_counter()
             cdist.broadcast_weights(eng, src=0)
-            bcast_ms = (time.perf_counter() - t0) * 1e3
-        models.append(model)
-        engines.append(eng)
+            bcast["ms"] = (time.perf_counter() - t0) * 1e3
+
+    pipes = DecodePipelines(model, NS, B, T, with_weights=(rank == 0), after_engine=receive_weights)
+    engines = pipes.engines
+    bcast_ms = bcast["ms"]
     blob_bytes = engines[0].weight_blob()[1]
 
     # ---- synthetic batch, resident in HBM before the timed region (each rank its own shard)
     feats_h, sizes_h = synth.make_feats(B, T, F, seed=1234 + rank)
     feats = torch.from_numpy(feats_h).cuda()
     sizes = torch.from_numpy(sizes_h).cuda()
-
-    def decode_step(i):
-        """device half of one step on pipeline i: returns the packed hypothesis records (still on the GPU)"""
-        hyp, hyp_len, score = models[i].decode_device(feats, sizes, args)
-        return cdist.pack_records(hyp, hyp_len, score)
-
-    def finish_step(rec):
-        """all-gather of the records over the ranks (one collective per batch) + hypotheses to the host"""
-        if world > 1:
-            rec = cdist.all_gather_records(rec)
-        return cdist.unpack_records(rec)
-
-    def step(i=0):
-        return finish_step(decode_step(i))
 
     def fence():
         torch.cuda.synchronize()
@@ -145,36 +132,10 @@ def main():
     last = {}
 
     def run_steps(n_steps):
-        """n_steps batches over NS decode pipelines (host thread + HIP stream + engine handle each).  Collectives are
-        issued by THIS thread only, in step order, so every rank issues the same sequence on one communicator."""
-        if NS == 1:
-            for k in range(n_steps):
-                last[0] = step(0)
-            return
-        import queue
-
-        done = [queue.Queue() for _ in range(NS)]
-
-        def worker(i):
-            torch.cuda.set_device(local_rank)
-            st = torch.cuda.Stream()
-            with torch.cuda.stream(st):
-                for k in range(i, n_steps, NS):
-                    rec = decode_step(i)
-                    ev = torch.cuda.Event()
-                    ev.record(st)
-                    done[i].put((rec, ev))
-                st.synchronize()
-
-        threads = [threading.Thread(target=worker, args=(i,)) for i in range(NS)]
-        for t in threads:
-            t.start()
-        for k in range(n_steps):
-            rec, ev = done[k % NS].get()
-            ev.wait(torch.cuda.current_stream())
-            last[0] = finish_step(rec)
-        for t in threads:
-            t.join()
+        """n_steps batches over the NS decode pipelines.  The per-batch all-gather (N > 1) and the hypotheses' trip to the
+        host happen here, in THIS thread only and in step order, so every rank issues the same sequence of collectives."""
+        for _, hyps_, scores_ in pipes.decode(((feats, sizes, k) for k in range(n_steps)), args, sos=1, gather=world > 1):
+            last[0] = (hyps_, scores_)
 
     run_steps(max(a.warmup, NS))
     hyps, _ = last[0]
@@ -205,8 +166,8 @@ def main():
 
     # ---- per-stage breakdown outside the timed region
     eng.profile_begin(None)
-    for _ in range(3):
-        step()
+    for _ in range(3):  # one pipeline, the GPU to itself
+        cdist.unpack_records(cdist.pack_records(*model.decode_device(feats, sizes, args, engine=eng)))
     stages = eng.profile_end()
     stage_ms = {k: round(v["ms"] / 3, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])}
     if a.stage_profile and rank == 0:

@@ -51,7 +51,7 @@ def pack_records(hyp, hyp_len, score):
 def unpack_records(rec):
     rec = rec.cpu()
     lens = rec[:, 0].numpy()
-    score = rec[:, 1:3].contiguous().view(torch.float64).view(-1).numpy()
+    score = rec[:, 1:3].clone(memory_format=torch.contiguous_format).view(torch.float64).view(-1).numpy()  # (clone: offset 0)
     toks = rec[:, 3:].numpy()
     return [toks[b, : lens[b]].tolist() for b in range(rec.shape[0])], score
 

@@ -273,6 +273,20 @@ class CassNAT(nn.Module):
         self._engine, self._engine_key = eng, (self._weights_version(), self.hip_precision)
         return eng
 
+    def new_engine(self, batch, frames, with_weights=True):
+        """An additional, independent engine handle (own weight blob and workspace) for the same parameters: what a decode
+        pipeline owns (cassnat_asr_public_amd.pipeline).  The model's own engine (``engine()``) is not touched."""
+        from types import SimpleNamespace
+
+        eng = hip.Engine(SimpleNamespace(**self._hyper), precision=self.hip_precision,
+                         max_batch=max(batch, self.hip_max_batch), max_frames=max(frames, self.hip_max_frames),
+                         device=getattr(self, "_device", torch.cuda.current_device()))
+        if with_weights:
+            eng.load_state({k: v.detach() for k, v in self.named_parameters()}, self.pe)
+        else:
+            eng.finalize()
+        return eng
+
     def invalidate_engine(self):
         """Call after changing parameters through ``.data`` (which does not bump tensor versions)."""
         self._engine_key = None
@@ -308,13 +322,14 @@ class CassNAT(nn.Module):
             raise NotImplementedError("use_unimask with the conformer decoder: the reference itself cannot run it "
                                       "(cassnat.py:486-488 indexes the (x, pos_embed) tuple)")
 
-    def decode_device(self, src, src_size, args, sos=1):
-        """The device half of beam_decode: returns cuda tensors (hyp (B,S) int32, hyp_len (B,) int32, score (B,) f64)."""
+    def decode_device(self, src, src_size, args, sos=1, engine=None):
+        """The device half of beam_decode: returns cuda tensors (hyp (B,S) int32, hyp_len (B,) int32, score (B,) f64).
+        ``engine``: run on this handle (a decode pipeline's) instead of the model's own."""
         dev = torch.device("cuda", getattr(self, "_device", torch.cuda.current_device()))
         feats = src.to(dev, torch.float32).contiguous()
         ratio = src_size.to(dev, torch.float32).contiguous()
         B, T, _ = feats.shape
-        eng = self.engine(B, T)
+        eng = engine if engine is not None else self.engine(B, T)
         opts = hip.Engine.make_opts(args, capture=getattr(args, "hip_capture", False))
         opts.sos = sos
         stride = ((T - 1) // 2 + 1 - 1) // 2 + 1 + 2

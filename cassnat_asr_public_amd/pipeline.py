@@ -1,0 +1,147 @@
+"""Decode pipelines: keep one GPU busy with greedy CASS-NAT decoding of many batches.
+
+One ``beam_decode`` call needs the host twice - the token count U of the batch is data dependent (the decoder side is
+launched after it is read back) and the hypotheses themselves have to reach the host - and most of its kernels occupy a
+fraction of the chip (a row-chain launch of a 32-utterance batch sits on 63 of 256 CUs).  So the throughput form of the path
+is N independent pipelines per GPU: each owns an engine handle (its copy of the packed weights and a workspace), a HIP
+stream and a host thread (ctypes releases the GIL inside the C call), pulls the next batch from a shared iterator - so
+feature loading and collation run in the workers too - and hands back device-resident hypothesis records in submission
+order.  ``bench.py`` measures exactly this object; ``tasks.cassnat_task.CassNATTask.decode`` uses it for test sets.
+
+The reference has no counterpart (it decodes batch after batch, src/tasks/cassnat_task.py:317-356); results are the same
+hypotheses in the same order.
+"""
+import queue
+import threading
+
+import torch
+
+from . import dist as cdist
+
+
+class DecodePipelines:
+    def __init__(self, model, n_pipelines, batch, frames, with_weights=True, after_engine=None):
+        """``model``: a CassNAT holding the parameters; ``batch`` / ``frames``: workspace size of every pipeline.
+        ``with_weights=False`` + ``after_engine(engine)``: multi-GPU start-up, where the packed weights arrive by RCCL
+        broadcast (``dist.broadcast_weights``) instead of from the local parameters."""
+        self.model = model
+        self.n = max(1, int(n_pipelines))
+        self.engines = []
+        for _ in range(self.n):
+            eng = model.new_engine(batch, frames, with_weights=with_weights)
+            if after_engine is not None:
+                after_engine(eng)
+            self.engines.append(eng)
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        self.engines = []
+
+    def records(self, batches, args, sos=1):
+        """``batches``: iterable of ``(feats (B,T,F), size_ratio (B,), tag)`` (host or device tensors).  Yields
+        ``(tag, records)`` in the order of the iterable: ``records`` is the device tensor of ``dist.pack_records`` (per
+        utterance: length, float64 score, [sos] + tokens), ready for ``dist.all_gather_records`` / ``unpack_records``.  The
+        consumer's current stream is made to wait for the producing pipeline's work."""
+        it = iter(batches)
+        lock = threading.Lock()
+        slots = {}            # index -> queue of one (tag, records, event) / exception
+        cv = threading.Condition()
+        state = {"next": 0, "done": False, "err": None}
+        ahead = threading.Semaphore(2 * self.n + 2)  # batches decoded but not yet consumed (bounds device memory held by records)
+        device = getattr(self.model, "_device", None)
+        if device is None and torch.cuda.is_available():
+            device = torch.cuda.current_device()
+
+        def slot(i):
+            with cv:
+                if i not in slots:
+                    slots[i] = queue.Queue(1)
+                return slots[i]
+
+        on_gpu = torch.cuda.is_available()  # (False only in the host-logic tests, which drive this class with a stub model)
+
+        class _NoStream:
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *exc):
+                return False
+
+            def synchronize(self):
+                pass
+
+        def worker(k):
+            if on_gpu:
+                torch.cuda.set_device(device)
+            st = torch.cuda.Stream() if on_gpu else _NoStream()
+            try:
+                with (torch.cuda.stream(st) if on_gpu else st), torch.no_grad():
+                    while True:
+                        while not ahead.acquire(timeout=0.05):  # the consumer is behind: wait, but notice a shutdown
+                            if state["done"] or state["err"] is not None:
+                                break
+                        with lock:
+                            if state["done"] or state["err"] is not None:
+                                break
+                            try:
+                                item = next(it)
+                            except StopIteration:
+                                state["done"] = True
+                                break
+                            i = state["next"]
+                            state["next"] += 1
+                        feats, ratio, tag = item
+                        hyp, hyp_len, score = self.model.decode_device(feats, ratio, args, sos, engine=self.engines[k])
+                        rec = cdist.pack_records(hyp, hyp_len, score)
+                        ev = None
+                        if on_gpu:
+                            ev = torch.cuda.Event()
+                            ev.record(st)
+                        slot(i).put((tag, rec, ev))
+                    st.synchronize()
+            except BaseException as e:  # surfaces in the consumer
+                with lock:
+                    state["err"] = e
+                with cv:
+                    cv.notify_all()
+
+        threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(self.n)]
+        for t in threads:
+            t.start()
+        i = 0
+        try:
+            while True:
+                with lock:
+                    finished = state["done"] and i >= state["next"]
+                    err = state["err"]
+                if err is not None:
+                    raise err
+                if finished:
+                    break
+                try:
+                    tag, rec, ev = slot(i).get(timeout=0.05)
+                except queue.Empty:
+                    continue
+                with cv:
+                    slots.pop(i, None)
+                if ev is not None:
+                    ev.wait(torch.cuda.current_stream())
+                ahead.release()
+                yield tag, rec
+                i += 1
+        finally:
+            with lock:
+                state["done"] = True
+            for t in threads:
+                t.join()
+
+    def decode(self, batches, args, sos=1, gather=False):
+        """Hypotheses on the host, in order: yields ``(tag, hyps, scores)`` with ``hyps`` a list of token lists starting
+        with ``sos`` (what ``beam_decode`` returns as ``['hyp']``).  ``gather=True``: every record set goes through the
+        per-batch all-gather of the multi-GPU path first (rank-major concatenation)."""
+        for tag, rec in self.records(batches, args, sos):
+            if gather:
+                rec = cdist.all_gather_records(rec)
+            hyps, scores = cdist.unpack_records(rec)
+            yield tag, hyps, scores

@@ -104,18 +104,9 @@ class CassNATTask(BaseTask):
                     param.copy_(state[name if name in state else "module." + name])
             self.lm_model = lm_model.cuda(self.local_rank) if hasattr(self, "local_rank") else lm_model
 
-    def decode(self, args):
-        batch_time = util.AverageMeter("Time", ":6.3f")
-        progress = util.ProgressMeter(len(self.test_loader), batch_time)
-        results = {}
-        frames = 0
-        if self.world > 1:  # weights travel once over RCCL instead of N checkpoint reads
-            lens = [b[1].shape[1] for b in [next(iter(self.test_loader))]] if len(self.test_loader) else [16]
-            eng = self.model.build_engine(args.batch_size, max(getattr(args, "hip_max_frames", 4096), max(lens)),
-                                          with_weights=(self.rank == 0))
-            cdist.broadcast_weights(eng, src=0)
-        end = time.time()
-        i = -1
+    def _decode_plain(self, args, results, batch_time, progress):
+        """The reference's loop (src/tasks/cassnat_task.py:317-356): one beam_decode call per batch."""
+        frames, i, end = 0, -1, time.time()
         with torch.no_grad():
             self.model.eval()
             for i, (utt_list, feats, labels, feat_sizes, label_sizes) in enumerate(self.test_loader):
@@ -130,6 +121,55 @@ class CassNATTask(BaseTask):
                 end = time.time()
                 if i % args.print_freq == 0 and self.rank == 0:
                     progress.print(i)
+        return frames, i
+
+    def _decode_pipelined(self, args, n_pipes, results, batch_time, progress):
+        """Greedy NAST decoding of a test set through N decode pipelines (pipeline.DecodePipelines: engine handle, HIP stream
+        and host thread each; the workers pull - load and collate - the batches): same hypotheses in the same order, the
+        GPU no longer idles across the two host syncs of a batch."""
+        from ..pipeline import DecodePipelines
+
+        self.model._check_args(args, self.lm_model)
+        sos = self.vocab.word2index["sos"]
+        first = next(iter(self.test_loader))
+        max_frames = max(getattr(args, "hip_max_frames", 4096), first[1].shape[1])
+        pipes = DecodePipelines(self.model, n_pipes, args.batch_size, max_frames, with_weights=(self.rank == 0),
+                                after_engine=(lambda e: cdist.broadcast_weights(e, src=0)) if self.world > 1 else None)
+        meta, frames, i, end = {}, 0, -1, time.time()
+
+        def batches():
+            for j, (utt_list, feats, labels, feat_sizes, label_sizes) in enumerate(self.test_loader):
+                meta[j] = (utt_list, labels, int(feats.shape[0] * feats.shape[1]))
+                yield feats, feat_sizes, j
+
+        for i, hyps, _scores in pipes.decode(batches(), args, sos=sos):
+            utt_list, labels, nfr = meta.pop(i)
+            frames += nfr
+            for utt, hyp, lab in zip(utt_list, hyps, labels):
+                results[utt] = (hyp_to_words(hyp, self.vocab, args.padding_idx), len(hyp) - int((lab != args.padding_idx).sum()))
+            batch_time.update(time.time() - end)
+            end = time.time()
+            if i % args.print_freq == 0 and self.rank == 0:
+                progress.print(i)
+        pipes.close()
+        return frames, i
+
+    def decode(self, args):
+        batch_time = util.AverageMeter("Time", ":6.3f")
+        progress = util.ProgressMeter(len(self.test_loader), batch_time)
+        results = {}
+        # args.hip_pipelines (default 4; 1 = the plain loop): beam search, ESA and capture runs keep the plain loop
+        n_pipes = int(getattr(args, "hip_pipelines", 4))
+        plain_greedy = (args.beam_width == 1 and getattr(args, "sample_num", 0) <= 1 and not getattr(args, "hip_capture", False))
+        if n_pipes > 1 and plain_greedy and len(self.test_loader) > 1:
+            frames, i = self._decode_pipelined(args, n_pipes, results, batch_time, progress)
+        else:
+            if self.world > 1:  # weights travel once over RCCL instead of N checkpoint reads
+                lens = [b[1].shape[1] for b in [next(iter(self.test_loader))]] if len(self.test_loader) else [16]
+                eng = self.model.build_engine(args.batch_size, max(getattr(args, "hip_max_frames", 4096), max(lens)),
+                                              with_weights=(self.rank == 0))
+                cdist.broadcast_weights(eng, src=0)
+            frames, i = self._decode_plain(args, results, batch_time, progress)
         if self.rank == 0 and i >= 0:
             progress.print(i)
         if self.world > 1:

@@ -194,3 +194,34 @@ def test_bf16_fast_path_on_small_and_ragged_batches(B, T, lengths):
         assert h[0] == 1 and 2 <= len(h) <= Tp + 2 and all(0 <= t < args.vocab_size for t in h) and np.isfinite(seqs[0]["score"])
     same = sum(p_[0]["hyp"] == c[0]["hyp"] for p_, c in zip(prod, b["out"]))
     assert same >= B - 1, (same, B)  # summation order differs between the fused and the captured generator: a near-tie may flip
+
+
+def test_decode_pipelines_equal_the_plain_loop():
+    """pipeline.DecodePipelines (what bench.py measures and CassNATTask.decode uses): 11 ragged batches of different shapes
+    through 3 pipelines give, in order, exactly the hypotheses and scores of one beam_decode call per batch."""
+    from cassnat_asr_public_amd.pipeline import DecodePipelines
+
+    args = synth.make_args("tiny")
+    args.hip_max_batch, args.hip_max_frames = 4, 90
+    state = synth.make_state(args, seed=0, gain=2.0)
+    model = build(args, state, capture=False)
+    rng = np.random.default_rng(5)
+    data = []
+    for k in range(11):
+        B, T = int(rng.integers(1, 5)), int(rng.integers(9, 91))
+        lens = sorted((int(x) for x in rng.integers(1, T + 1, size=B)), reverse=True)
+        lens[0] = T
+        data.append(synth.make_feats(B, T, 80, lengths=lens, seed=100 + k))
+    want = []
+    for feats, sizes in data:
+        src = torch.from_numpy(feats)
+        with torch.no_grad():
+            out, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, args)
+        want.append(([s[0]["hyp"] for s in out], [s[0]["score"] for s in out]))
+    pipes = DecodePipelines(model, 3, 4, 90)
+    got = list(pipes.decode(((torch.from_numpy(f), torch.from_numpy(s), k) for k, (f, s) in enumerate(data)), args, sos=1))
+    pipes.close()
+    assert [t for t, _, _ in got] == list(range(11))
+    for (tag, hyps, scores), (wh, ws) in zip(got, want):
+        assert hyps == wh, tag
+        assert list(scores) == ws, tag

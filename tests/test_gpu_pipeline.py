@@ -216,8 +216,10 @@ def test_weight_blob_handoff_reproduces_rank0_engine():
     assert [s[0]["score"] for s in out_a] == [s[0]["score"] for s in out_b]
 
 
-def test_decode_asr_cli_end_to_end(tmp_path):
-    """decode_asr.py --task cassnat on a synthetic Kaldi table: result file == oracle hypotheses as text."""
+@pytest.mark.parametrize("batch_size", [3, 1])
+def test_decode_asr_cli_end_to_end(tmp_path, batch_size):
+    """decode_asr.py --task cassnat on a synthetic Kaldi table: result file == oracle hypotheses as text.  batch_size 3: one
+    batch, the plain loop; batch_size 1: three batches through the decode pipelines (pipeline.DecodePipelines)."""
     import yaml
 
     from cassnat_asr_public_amd.bin import decode_asr
@@ -241,11 +243,15 @@ def test_decode_asr_cli_end_to_end(tmp_path):
     cfg.write_text(yaml.safe_dump(conf))
     result = str(tmp_path / "token_results.txt")
     rc = decode_asr.main(["--task", "cassnat", "--test_config", str(cfg), "--data_path", scp, "--resume_model", ckpt,
-                          "--result_file", result, "--batch_size", "3", "--hip_precision", "fp32", "--load_data_workers", "0"])
+                          "--result_file", result, "--batch_size", str(batch_size), "--hip_precision", "fp32",
+                          "--load_data_workers", "0"])
     assert rc == 0
-    ref = orc.decode_nast(state, feats, sizes, args)
     index2word = {i + 4: f"w{i}" for i in range(args.vocab_size - 4)}
-    expect = [f"spk-utt{b} " + " ".join(orc.hyp_to_text(h, index2word)) for b, h in enumerate(ref["hyps"])]
+    if batch_size == 3:
+        hyps = orc.decode_nast(state, feats, sizes, args)["hyps"]
+    else:  # the reference's greedy finish reads min(ylen + 1, U of the BATCH) rows: an utterance decoded alone ends one token earlier
+        hyps = [orc.decode_nast(state, feats[b : b + 1, :n], np.ones(1, np.float32), args)["hyps"][0] for b, n in enumerate(lengths)]
+    expect = [f"spk-utt{b} " + " ".join(orc.hyp_to_text(h, index2word)) for b, h in enumerate(hyps)]
     assert open(result).read().splitlines() == expect
 
 

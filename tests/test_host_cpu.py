@@ -224,3 +224,58 @@ def test_ast_parameter_names_are_the_reference_checkpoint_keys():
     model = make_ast(args.input_size, args)
     assert {k: tuple(v.shape) for k, v in model.named_parameters()} == dict(synth.param_shapes_ast(args))
     assert [k for k, _ in model.named_parameters()] == list(synth.param_shapes_ast(args).keys())
+
+
+def test_decode_pipelines_keep_submission_order_and_surface_errors():
+    """Host logic of pipeline.DecodePipelines with a stub model (no GPU): results come back in submission order whatever
+    the workers' speeds, every batch is decoded exactly once, a worker's exception reaches the consumer, and an early
+    exit of the consumer stops the workers."""
+    import time as _time
+
+    import torch as _torch
+
+    from cassnat_asr_public_amd.pipeline import DecodePipelines
+
+    class StubEngine:
+        def close(self):
+            pass
+
+    class StubModel:
+        def __init__(self, fail_at=None):
+            self.seen, self.fail_at = [], fail_at
+
+        def new_engine(self, batch, frames, with_weights=True):
+            return StubEngine()
+
+        def decode_device(self, feats, ratio, args, sos, engine=None):
+            k = int(feats[0, 0, 0])
+            if self.fail_at is not None and k == self.fail_at:
+                raise RuntimeError("boom")
+            _time.sleep(0.002 * ((k * 7) % 5))  # uneven pipelines
+            self.seen.append(k)
+            hyp = _torch.tensor([[sos, 10 + k, 0]], dtype=_torch.int32)
+            return hyp, _torch.tensor([2], dtype=_torch.int32), _torch.tensor([float(k)], dtype=_torch.float64)
+
+    def batches(n):
+        for k in range(n):
+            yield _torch.full((1, 4, 2), float(k)), _torch.ones(1), ("tag", k)
+
+    m = StubModel()
+    pipes = DecodePipelines(m, 3, 1, 4)
+    out = list(pipes.decode(batches(25), args=None, sos=1))
+    assert [t for t, _, _ in out] == [("tag", k) for k in range(25)]
+    assert [h for _, h, _ in out] == [[[1, 10 + k]] for k in range(25)]
+    assert [float(s[0]) for _, _, s in out] == [float(k) for k in range(25)]
+    assert sorted(m.seen) == list(range(25))
+    # a failing batch surfaces in the consumer
+    m2 = StubModel(fail_at=6)
+    with pytest.raises(RuntimeError, match="boom"):
+        list(DecodePipelines(m2, 2, 1, 4).decode(batches(20), args=None, sos=1))
+    # early exit of the consumer: the generator closes, the workers stop after the batch they are on
+    m3 = StubModel()
+    gen = DecodePipelines(m3, 2, 1, 4).decode(batches(1000), args=None, sos=1)
+    for n, _ in enumerate(gen):
+        if n == 4:
+            break
+    gen.close()
+    assert len(m3.seen) < 40
