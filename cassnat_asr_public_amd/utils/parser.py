@@ -24,6 +24,8 @@ class DecodeParser(object):
         p.add_argument("--hip_precision", default="bf16", choices=["bf16", "fp32"],
                        help="bf16 MFMA (throughput) or exact-f32 MFMA (parity with the reference CPU path)")
         p.add_argument("--hip_max_frames", default=4096, type=int, help="workspace size in input frames")
+        p.add_argument("--hip_pipelines", default=4, type=int,
+                       help="decode pipelines per GPU for greedy decoding of a test set (1 = batch after batch)")
         self.parser = p
 
     def get_args(self, argv=None):
