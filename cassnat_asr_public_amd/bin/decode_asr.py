@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import yaml
 
-from ..tasks import CassNATTask
+from ..tasks import ArtTask, CassNATTask
 from ..utils.parser import DecodeParser
 
 
@@ -42,9 +42,10 @@ def main(argv=None):
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if args.task != "cassnat":
-        raise NotImplementedError("task '%s' is not on the accelerated path (only 'cassnat')" % args.task)
-    task = CassNATTask("test", args)
+    task_dict = {"cassnat": CassNATTask, "art": ArtTask}  # (the reference's ctc / lmnat* / hubert tasks are out of scope)
+    if args.task not in task_dict:
+        raise NotImplementedError("task '%s' is not on the accelerated path (only %s)" % (args.task, sorted(task_dict)))
+    task = task_dict[args.task]("test", args)
     task.load_lm_model(args)
     task.decode(args)
     if world > 1:

@@ -1,0 +1,131 @@
+"""Decode half of the reference's ArtTask (src/tasks/art_task.py:23-66, 233-277): the autoregressive transformer
+(BASELINE config 4) behind ``decode_asr.py --task art``.
+
+Same constructor / decode surface and result-file lines ("<utt> tok tok ...").  ``decode_type == 'ctc_att'`` (joint
+CTC/attention beam search, src/models/transformer.py:122-241) is the accelerated path; ``ctc_only`` / ``ctc_correct``, LM
+fusion and the conformer AST raise.  A decode step keeps a handful of CUs busy, so a test set goes through
+``args.hip_pipelines`` (default 4) independent model replicas on their own HIP streams and host threads - batches pulled from
+the loader by the workers, result lines written in input order.
+"""
+import threading
+import time
+
+import torch
+import torch.distributed as dist
+
+from ..data.vocab import Vocab
+from ..models import make_transformer
+from ..utils import util
+from .base_task import BaseTask
+from .cassnat_task import hyp_to_words
+
+_DEFAULTS = dict(use_gpu=True, decode_type="ctc_att", use_cmvn=False, dataset_type="SpeechDataset", beam_width=10, ctc_beam=15,
+                 ctc_weight=0.3, max_decode_ratio=0, T=1.0, length_penalty=None, lm_weight=0, left_ctx=0, right_ctx=0,
+                 skip_frame=1, padding_idx=0, model_type="transformer", dropout=0.0, rank=0)
+
+
+class ArtTask(BaseTask):
+    def __init__(self, mode, args):
+        for k, v in _DEFAULTS.items():
+            if not hasattr(args, k):
+                setattr(args, k, v)
+        super(ArtTask, self).__init__(args)
+        if mode != "test":
+            raise NotImplementedError("training is out of scope of the accelerated path")
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise NotImplementedError("--task art decodes on one GPU per process (split the scp file as the reference's recipe does)")
+        self.vocab = Vocab(args.vocab_file, args.rank)
+        args.vocab_size = self.vocab.n_words
+        args.rank = 0
+        for k in ("ctc_alpha", "interctc_alpha", "interctc_layer", "label_smooth"):
+            setattr(args, k, 0)
+        self.set_model(args)
+        self.set_test_dataloader(args)
+        self.load_test_model(args.resume_model)
+        self.model_stats(0, False, False)
+        self.lm_model = None
+
+    def set_model(self, args):
+        assert args.input_size == (args.left_ctx + args.right_ctx + 1) // args.skip_frame * args.n_features
+        if args.model_type != "transformer":
+            raise NotImplementedError("only model_type 'transformer' is on the accelerated AST path")
+        self.model = make_transformer(args.input_size, args)
+
+    def load_lm_model(self, args):
+        if getattr(args, "lm_weight", 0) > 0:
+            raise NotImplementedError("LM shallow fusion (lm_weight > 0) is outside the accelerated path")
+        self.lm_model = None
+
+    def _replicas(self, n):
+        """n models on the same parameters (each builds its own engine handle on first use)."""
+        models = [self.model]
+        state = {k: v.detach() for k, v in self.model.named_parameters()}
+        for _ in range(n - 1):
+            m = make_transformer(self._args.input_size, self._args).cuda(getattr(self.model, "_device", 0))
+            with torch.no_grad():
+                for k, p in m.named_parameters():
+                    p.copy_(state[k])
+            models.append(m)
+        return models
+
+    def decode(self, args):
+        if args.decode_type != "ctc_att":
+            raise NotImplementedError("decode_type '%s' is not on the accelerated path (only 'ctc_att')" % args.decode_type)
+        self._args = args
+        batch_time = util.AverageMeter("Time", ":6.3f")
+        progress = util.ProgressMeter(len(self.test_loader), batch_time)
+        n = max(1, min(int(getattr(args, "hip_pipelines", 4)), len(self.test_loader)))
+        models = self._replicas(n)
+        it = iter(enumerate(self.test_loader))
+        lock = threading.Lock()
+        done = {}
+        cv = threading.Condition()
+        err = []
+
+        def worker(k):
+            try:
+                torch.cuda.set_device(getattr(self.model, "_device", 0))
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st), torch.no_grad():
+                    while not err:
+                        with lock:
+                            try:
+                                i, (utt_list, feats, _, feat_sizes, _) = next(it)
+                            except StopIteration:
+                                break
+                        src_mask = (feats[:, :, 0] != args.padding_idx).unsqueeze(1)
+                        recog = models[k].beam_decode(feats, src_mask, self.vocab, args, self.lm_model)
+                        lines = [utt + " " + " ".join(hyp_to_words(seqs[0]["hyp"], self.vocab, args.padding_idx))
+                                 for utt, seqs in zip(utt_list, recog)]
+                        with cv:
+                            done[i] = lines
+                            cv.notify_all()
+            except BaseException as e:
+                err.append(e)
+                with cv:
+                    cv.notify_all()
+
+        threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(n)]
+        end = time.time()
+        for t in threads:
+            t.start()
+        i = -1
+        with open(args.result_file, "w") as out_file:
+            for i in range(len(self.test_loader)):
+                with cv:
+                    while i not in done and not err:
+                        cv.wait(0.05)
+                    if err:
+                        raise err[0]
+                    lines = done.pop(i)
+                for line in lines:
+                    print(line, flush=True, file=out_file)
+                batch_time.update(time.time() - end)
+                end = time.time()
+                if i % args.print_freq == 0:
+                    progress.print(i)
+        for t in threads:
+            t.join()
+        if i >= 0:
+            progress.print(i)
+        return 0

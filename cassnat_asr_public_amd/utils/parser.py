@@ -10,7 +10,7 @@ class DecodeParser(object):
         p.add_argument("--lm_config")
         p.add_argument("--data_path")
         p.add_argument("--text_label", default="", type=str, help="text label")
-        p.add_argument("--task", default="cassnat", type=str, help="only 'cassnat' runs on the accelerated path")
+        p.add_argument("--task", default="cassnat", type=str, help="'cassnat' (NAT) or 'art' (autoregressive transformer): the tasks on the accelerated path")
         p.add_argument("--batch_size", default=32, type=int)
         p.add_argument("--load_data_workers", default=1, type=int)
         p.add_argument("--resume_model", default="", type=str, help="checkpoint with a 'model_state' dict")

@@ -107,3 +107,49 @@ def test_ast_device_beam_equals_host_beam_bf16():
     for u, v in zip(dev_b, host_b):
         assert [s["hyp"] for s in u] == [s["hyp"] for s in v]
         assert [s["score"] for s in u] == [s["score"] for s in v]
+
+
+@pytest.mark.parametrize("batch_size", [3, 1])
+def test_decode_asr_cli_task_art(tmp_path, batch_size):
+    """decode_asr.py --task art (the reference's ArtTask, decode_type ctc_att) on a synthetic Kaldi table, fp32 engine: the
+    result file holds the best beam of the reference's golden run.  batch_size 1: three batches over the pipelined workers
+    (the tiny fixture's utterances keep their hypotheses when decoded alone: the AST path has no batch-dependent length)."""
+    import yaml
+
+    from cassnat_asr_public_amd.bin import decode_asr
+    from cassnat_asr_public_amd.data import kaldi_io
+
+    g = load_golden("ast_tiny_ctc")
+    args, state, feats = ast_tiny_case(ctc_weight=0.3)
+    lengths = [61, 57, 51]
+    mats = [(f"spk-utt{b}", feats[b, :n]) for b, n in enumerate(lengths)]
+    scp = str(tmp_path / "feats.scp")
+    kaldi_io.write_ark_scp(str(tmp_path / "feats.ark"), scp, mats)
+    vocab_file = tmp_path / "vocab.txt"
+    vocab_file.write_text("".join(f"w{i}\n" for i in range(args.vocab_size - 4)))
+    ckpt = str(tmp_path / "model.mdl")
+    torch.save({"model_state": {"module." + k: torch.from_numpy(v) for k, v in state.items()}}, ckpt)
+    conf = {k: getattr(args, k) for k in ("input_size", "d_model", "n_head", "d_ff", "d_encff", "N_enc", "N_dec", "ctc_weight",
+                                          "max_decode_ratio", "T", "ctc_beam", "beam_width", "length_penalty", "decode_type")}
+    conf.update(vocab_file=str(vocab_file), use_gpu=True, n_features=80, model_type="transformer")
+    cfg = tmp_path / "decode.yaml"
+    cfg.write_text(yaml.safe_dump(conf))
+    result = str(tmp_path / "token_results.txt")
+    rc = decode_asr.main(["--task", "art", "--test_config", str(cfg), "--data_path", scp, "--resume_model", ckpt,
+                          "--result_file", result, "--batch_size", str(batch_size), "--hip_precision", "fp32",
+                          "--load_data_workers", "0"])
+    assert rc == 0
+    lines = open(result).read().splitlines()
+    assert [ln.split()[0] for ln in lines] == [f"spk-utt{b}" for b in range(3)]
+    if batch_size == 3:
+        for b, ln in enumerate(lines):
+            best = g["beam_hyp"][b, 0, : g["beam_len"][b, 0]].tolist()
+            eos_at = best.index(2) if 2 in best else len(best)
+            words = [f"w{t - 4}" for t in best[:eos_at] if t not in (0, 1)]
+            assert ln.split()[1:] == words, b
+    else:  # same utterances one at a time: compare with the in-process model on the same single-utterance batches
+        for b, n in enumerate(lengths):
+            beams = run(ast_tiny_case(ctc_weight=0.3)[0], state, feats[b : b + 1, :n], "fp32")
+            best = beams[0][0]["hyp"]
+            eos_at = best.index(2) if 2 in best else len(best)
+            assert lines[b].split()[1:] == [f"w{t - 4}" for t in best[:eos_at] if t not in (0, 1)], b
