@@ -50,7 +50,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--frames", type=int, default=1000)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="fp8: BASELINE config 5's mode - the bf16 engine with the encoder layers' products on the e4m3fn MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batches", type=int, default=3)
     ap.add_argument("--stage-profile", action="store_true", help="also print a per-kernel-tag table to stderr")
@@ -185,7 +186,8 @@ def main():
     value = utts / elapsed
     audio_s = utts * T * 0.01
     flops = flops_per_batch(B, T, F, U, args)
-    peak = PEAK_BF16_DENSE_TFLOPS if a.precision == "bf16" else 157.3
+    # (the non-scaled fp8 MFMA of gfx950 runs at the bf16 rate: same peak)
+    peak = PEAK_BF16_DENSE_TFLOPS if a.precision in ("bf16", "fp8") else 157.3
 
     def roof(tag, kernel, extra):
         pr = prof.get(tag)
@@ -224,7 +226,7 @@ def main():
                                         "stream is bound per CU, so the remaining CUs are left to the other decode pipelines; "
                                         "'frac' is against the whole chip's peak all the same"})
     roofline_conv2 = roof("conv2", "conv2_kernel (3x3 / stride 2, 256 -> 256 channels, LDS-DMA implicit GEMM, 188.7 GFLOP)"
-                          if a.precision == "bf16" else "gemm_kernel<implicit-conv> (conv2)", {})
+                          if a.precision in ("bf16", "fp8") else "gemm_kernel<implicit-conv> (conv2)", {})
     if roofline is None:
         roofline = roofline_conv2
 

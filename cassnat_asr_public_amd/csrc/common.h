@@ -9,6 +9,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef long i64x2 __attribute__((ext_vector_type(2)));
+// OCP e4m3fn byte (gfx950's fp8 MFMA format; not MI300's fnuz): max 448, no infinities
+struct fp8_t {
+    unsigned char bits;
+};
+#define CN_FP8_MAX 448.0f
 
 #define CN_WAVE 64
 #define CN_NEG_FILL (-3.4028234663852886e38f) /* float32 min: the reference's masked_fill value */
@@ -17,6 +23,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // 16-byte fragment of the GEMM K dimension as one wave lane sees it.
 //   bf16: 8 consecutive k  -> one v_mfma_f32_32x32x16_bf16 (k = 8*(lane>>5) + j)
 //   f32 : 4 consecutive k  -> four v_mfma_f32_32x32x2_f32  (step e uses k = 4*(lane>>5) + e)
+//   fp8 : 16 consecutive k -> two v_mfma_f32_32x32x16_fp8_fp8 (low / high 8 bytes of the fragment)
 // Both operands of a product use the same lane->k map, so the sum over k is complete; only the
 // order of the fp32 additions differs from a sequential loop.
 // ----------------------------------------------------------------------------------------------
@@ -30,6 +37,16 @@ template <> struct Frag<float> {
     static constexpr int ELEMS = 4;
 };
 
+template <> struct Frag<fp8_t> {
+    typedef i64x2 type;
+    static constexpr int ELEMS = 16;
+};
+
+__device__ __forceinline__ f32x16 mfma_frag(i64x2 a, i64x2 b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a[1], b[1], c, 0, 0, 0);
+    return c;
+}
 __device__ __forceinline__ f32x16 mfma_frag(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -48,6 +65,12 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+// float -> e4m3fn, round to nearest even, saturating at +-448 (the value is expected to carry its tensor's scale already)
+__device__ __forceinline__ unsigned char cn_f32_to_fp8(float v) {
+    v = fminf(fmaxf(v, -CN_FP8_MAX), CN_FP8_MAX);
+    return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
+}
+template <> __device__ __forceinline__ fp8_t from_f32<fp8_t>(float v) { return fp8_t{cn_f32_to_fp8(v)}; }
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
 
@@ -58,6 +81,7 @@ __device__ __forceinline__ void st16(void* p, uint4 v) { *reinterpret_cast<uint4
 template <typename T> __device__ __forceinline__ typename Frag<T>::type as_frag(uint4 v);
 template <> __device__ __forceinline__ bf16x8 as_frag<bf16>(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 template <> __device__ __forceinline__ f32x4 as_frag<float>(uint4 v) { return __builtin_bit_cast(f32x4, v); }
+template <> __device__ __forceinline__ i64x2 as_frag<fp8_t>(uint4 v) { return __builtin_bit_cast(i64x2, v); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

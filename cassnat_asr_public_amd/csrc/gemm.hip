@@ -25,6 +25,8 @@ struct GemmParams {
     int epi;
     int pe_period;
     float scale, resid_scale;
+    const float* w_inv_scale;
+    float acc_scale, c_scale;  // fp8 operands: product -> real units; fp8 output: real units -> the consumer's scale
     int ntn;  // tiles along N
     int cT1, cF1, cC, cT2, cF2;
 };
@@ -196,6 +198,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
     // ---- epilogue: lane owns column n, 16 rows per 32x32 accumulator
     TC* C = reinterpret_cast<TC*>(p.C);
+    float deq = 1.f;
+    if constexpr (sizeof(T) == 1) deq = p.acc_scale * (p.w_inv_scale ? *p.w_inv_scale : 1.f);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn * WN + 32 * j + l31;
@@ -207,11 +211,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + 32 * i + acc_row(r, lane);
                 if (m >= p.M) continue;
-                float v = acc[i][j][r] + bias;
+                float v = acc[i][j][r];
+                if constexpr (sizeof(T) == 1) v *= deq;
+                v += bias;
                 if (p.epi & CN_EPI_RELU) v = fmaxf(v, 0.f);
                 if (p.epi & CN_EPI_SWISH) v = v * (1.f / (1.f + __expf(-v)));
                 if (p.epi & CN_EPI_EMBED) v = v * p.scale + (p.pe ? p.pe[(long long)(m % p.pe_period) * p.N + n] : 0.f);
                 if (p.epi & CN_EPI_RESID) v = p.resid[(long long)m * p.ldr + n] + p.resid_scale * v;
+                if constexpr (sizeof(TC) == 1) v *= p.c_scale;
                 C[(long long)m * p.ldc + n] = from_f32<TC>(v);
             }
         }
@@ -238,6 +245,9 @@ static int run_gemm(const GemmArgs& a, hipStream_t s) {
     p.pe_period = a.pe_period > 0 ? a.pe_period : 1;
     p.scale = a.scale;
     p.resid_scale = a.resid_scale;
+    p.acc_scale = a.acc_scale;
+    p.w_inv_scale = a.w_inv_scale;
+    p.c_scale = a.c_scale;
     p.ntn = cn_ceil_div(a.N, BN);
     p.cT1 = a.cT1;
     p.cF1 = a.cF1;
@@ -288,7 +298,21 @@ template <typename T> static int dispatch_gemm(const GemmArgs& a, hipStream_t s)
     return fullk ? run_gemm<T, T, 64, 64, false, true>(a, s) : run_gemm<T, T, 64, 64, false>(a, s);
 }
 
+// fp8 operands (the encoder products of config 5): bf16 / fp32 / fp8 output, no implicit-GEMM form
+static int dispatch_gemm_fp8(const GemmArgs& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return 0;
+    if (a.conv || a.K <= 0 || a.K % 128 != 0 || a.lda % 16 != 0) {
+        cn_set_error("gemm(fp8): K must be a positive multiple of 128 and rows 16-byte aligned; no convolution form");
+        return -1;
+    }
+    const bool use_big = (long long)cn_ceil_div(a.M, 128) * cn_ceil_div(a.N, 128) >= 512;
+    if (a.c_f32) return use_big ? run_gemm<fp8_t, float, 128, 128, false>(a, s) : run_gemm<fp8_t, float, 64, 64, false>(a, s);
+    if (a.c_fp8) return use_big ? run_gemm<fp8_t, fp8_t, 128, 128, false>(a, s) : run_gemm<fp8_t, fp8_t, 64, 64, false>(a, s);
+    return use_big ? run_gemm<fp8_t, bf16, 128, 128, false>(a, s) : run_gemm<fp8_t, bf16, 64, 64, false>(a, s);
+}
+
 int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
+    if (a.ab_fp8) return dispatch_gemm_fp8(a, s);
     if (a.conv && a.conv_halo) {
         if (!(a.epi == CN_EPI_RELU && a.ldc == a.N && conv2_dma_applies(prec, a.cC, a.N))) {
             cn_set_error("gemm: a haloed conv input is only understood by the bf16 256-channel conv2 kernel");

@@ -26,6 +26,13 @@ struct GemmArgs {
     float scale = 1.f;
     // implicit-GEMM A operand for the second 3x3/stride-2 subsampling convolution:
     // A[m=(b,t2,f2)][k=(kh,kw,c)] = conv1[b][2*t2+kh-1][2*f2+kw-1][c] (channels-last), zero outside.
+    // fp8 operands (BASELINE config 5): A and W are e4m3fn bytes carrying per-tensor scales; acc_scale = 1 / (scale_A * scale_W)
+    // restores the product.  c_fp8: the output is e4m3fn too, scaled by c_scale after the epilogue (feeds the next fp8 product)
+    int ab_fp8 = 0;
+    float acc_scale = 1.f;
+    const float* w_inv_scale = nullptr;  // device: 1 / (the weights' scale), multiplied into acc_scale (may be null)
+    int c_fp8 = 0;
+    float c_scale = 1.f;
     int conv = 0;
     int conv_halo = 0;  // the input image carries a one-cell zero halo: [B][T1 + 2][F1 + 2][C] (conv1 with halo = 1)
     int cB = 0, cT1 = 0, cF1 = 0, cC = 0, cT2 = 0, cF2 = 0;
@@ -41,6 +48,10 @@ int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, 
 // y = a_2 * (x - mean) / (std_unbiased + eps) + b_2 ; x fp32 [M][d] ; y model precision (or fp32 if y_f32)
 int launch_layernorm(int prec, const float* x, const float* a2, const float* b2, void* y, int y_f32, int M, int d,
                      float eps, hipStream_t s);
+// fp8 operands of config 5: LayerNorm straight into e4m3fn at a per-tensor scale; bf16 -> e4m3fn of a finished tensor
+int launch_layernorm_fp8(const float* x, const float* a2, const float* b2, void* y, int M, int d, float eps, float scale,
+                         hipStream_t s);
+int launch_quantize_fp8(const void* src_bf16, int ld, void* dst, int M, int K, float scale, hipStream_t s);
 // per row of logits [M][V] (fp32): first-index argmax, max log-prob; optionally rewrites the row as log-softmax.
 int launch_logsoftmax_argmax(float* logits, int M, int V, int ldl, int* arg, float* maxlp, int write_logp,
                              hipStream_t s);

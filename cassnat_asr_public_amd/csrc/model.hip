@@ -33,6 +33,8 @@ struct Linear {
     void* W = nullptr;  // [N][K] model precision
     float* b = nullptr;
     int N = 0, K = 0;
+    void* W8 = nullptr;          // fp8 encoder mode (config 5): e4m3fn copy [N][K] at a per-tensor power-of-two scale ...
+    float* w8_inv = nullptr;     // ... and 1 / scale (one float in the blob: it travels with a weight broadcast)
     void* gm_w = nullptr;   // generators only (bf16, d_model 256): pack_genmax fragment stream ...
     float* gm_b = nullptr;  // ... and padded biases for the fused argmax kernel
 };
@@ -111,6 +113,7 @@ inline uint16_t f32_to_bf16_host(float f) {
 struct cn_model {
     cn_config cfg;
     int prec = 0;
+    bool fp8_enc = false;  // CN_PRECISION_FP8: bf16 engine whose encoder-layer products run on the fp8 MFMA (BASELINE config 5)
     size_t es = 4;
     std::map<std::string, HostTensor> host;
     std::vector<float> pe_host;
@@ -265,6 +268,54 @@ struct Packer {
         return reinterpret_cast<float*>(at);
     }
     // [sum rows][K] matrix in model precision from several [rows][K] matrices, optional column permutation
+    // float -> OCP e4m3fn byte, round to nearest even, saturating at +-448 (what v_cvt_pk_fp8_f32 produces on gfx950)
+    static unsigned char f32_to_e4m3(float f) {
+        const unsigned char sign = std::signbit(f) ? 0x80 : 0;
+        float a = std::fabs(f);
+        if (a != a) return 0x7f;
+        if (a >= 448.f) return sign | 0x7e;
+        if (a < 0.0009765625f) return sign;  // below half of the smallest subnormal (2^-9): zero (the tie goes to even = 0)
+        int e;
+        (void)std::frexp(a, &e);
+        int E = e - 1;  // a = 1.xxx * 2^E
+        if (E < -6) {   // subnormal: multiples of 2^-9
+            const int r = (int)std::nearbyint(a * 512.f);
+            return sign | (unsigned char)(r >= 8 ? 0x08 : r);
+        }
+        int r = (int)std::nearbyint((a / std::ldexp(1.f, E) - 1.f) * 8.f);
+        if (r == 8) {
+            r = 0;
+            ++E;
+        }
+        const int bits = ((E + 7) << 3) | r;
+        return sign | (unsigned char)(bits > 0x7e ? 0x7e : bits);
+    }
+    // fp8 copy of a packed Linear (same row order as `linear` built it from `prefixes`): one power-of-two scale per tensor,
+    // the largest that keeps max|w| * scale <= 448
+    void quant8(Linear& l, std::initializer_list<std::string> prefixes, int64_t rows_each) {
+        const size_t at = reserve((size_t)l.N * l.K);
+        const size_t sat = reserve(4);
+        if (fill) {
+            float mx = 0.f;
+            for (auto& pfx : prefixes) {
+                const HostTensor* t = find(pfx + ".weight", {rows_each, (int64_t)l.K});
+                if (t)
+                    for (float v : t->data) mx = std::max(mx, std::fabs(v));
+            }
+            const float scale = mx > 0.f ? std::ldexp(1.f, (int)std::floor(std::log2(448.f / mx))) : 1.f;
+            size_t r0 = 0;
+            for (auto& pfx : prefixes) {
+                const HostTensor* t = find(pfx + ".weight", {rows_each, (int64_t)l.K});
+                if (t)
+                    for (int64_t i = 0; i < rows_each * l.K; ++i) host[at + r0 * l.K + i] = f32_to_e4m3(t->data[i] * scale);
+                r0 += rows_each;
+            }
+            const float inv = 1.f / scale;
+            std::memcpy(&host[sat], &inv, 4);
+        }
+        l.W8 = reinterpret_cast<void*>(at);
+        l.w8_inv = reinterpret_cast<float*>(sat);
+    }
     Linear linear(std::initializer_list<std::string> prefixes, int64_t rows_each, int64_t K,
                   const std::vector<int>* colperm = nullptr) {
         Linear l;
@@ -494,6 +545,8 @@ void rebase_linear(Linear& l, unsigned char* base) {
     rebase(l.b, base);
     rebase(l.gm_w, base);
     rebase(l.gm_b, base);
+    rebase(l.W8, base);
+    rebase(l.w8_inv, base);
 }
 void rebase_norm(Norm& n, unsigned char* base) {
     rebase(n.a, base);
@@ -570,12 +623,20 @@ int build_weights(cn_model* m) {
         const std::string p = "encoder.layers." + std::to_string(n);
         if (c.conf_enc)
             m->enc.push_back(pk.conformer_layer(p, "src_embed.pos_enc.embedding.weight", c.d_encff, c.enc_kernel, c.enc_max_rel, d, H, 4));
-        else
-            m->enc.push_back(self_layer(p, "self_attn", c.d_encff, 2));
+        else {
+            Layer L = self_layer(p, "self_attn", c.d_encff, 2);
+            if (m->fp8_enc) {  // config 5: e4m3fn copies of the four products of an encoder layer
+                pk.quant8(L.qkv, {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"}, d);
+                pk.quant8(L.self_o, {p + ".self_attn.linears.3"}, d);
+                pk.quant8(L.w1, {p + ".feed_forward.w_1"}, c.d_encff);
+                pk.quant8(L.w2, {p + ".feed_forward.w_2"}, d);
+            }
+            m->enc.push_back(L);
+        }
     }
     m->enc_norm = pk.norm("encoder.norm", d);
     m->enc_chain.clear();
-    if (!lm && !c.conf_enc && pk.chain_ok(d, c.d_encff))
+    if (!lm && !c.conf_enc && !m->fp8_enc && pk.chain_ok(d, c.d_encff))
         for (int n = 0; n < c.n_enc; ++n) {
             const std::string p = "encoder.layers." + std::to_string(n), q = "encoder.layers." + std::to_string(n + 1);
             if (n + 1 < c.n_enc)
@@ -935,6 +996,62 @@ int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ld
     return launch_chain(a, s);
 }
 
+// ---- encoder layer with e4m3fn products (BASELINE config 5; the layer of encoder.py / transformer_blocks.py) -------------
+// Operands carry per-tensor power-of-two scales: the weights' is chosen at pack time (largest that keeps max|w| in range,
+// stored beside them), the activations' are fixed - LayerNorm outputs and attention contexts x16 (saturating at 28), the
+// ReLU hidden activations x8 (saturating at 56).  Accumulation, bias, residual and LayerNorm stay fp32; attention runs
+// on the bf16 Q|K|V the first product writes.  LayerNorm and the first FFN product write their fp8 outputs directly; only
+// the attention context needs a quantisation pass.
+constexpr float FP8_S_LN = 16.f, FP8_S_CTX = 16.f, FP8_S_HID = 8.f;
+int run_linear_fp8(cn_model* m, const char* tag, const Linear& l, const void* a8, float a_scale, void* C, int ldc, int c_f32,
+                   int c_fp8, float c_scale, int M, int epi, const float* resid, int ldr, hipStream_t s) {
+    ProfScope ps(m, tag, 2.0 * M * l.N * l.K, (double)M * l.K + (double)l.N * l.K + (double)M * l.N * (c_f32 ? 4 : (c_fp8 ? 1 : 2)), s);
+    GemmArgs g;
+    g.A = a8;
+    g.lda = l.K;
+    g.W = l.W8;
+    g.bias = l.b;
+    g.C = C;
+    g.ldc = ldc;
+    g.c_f32 = c_f32;
+    g.c_fp8 = c_fp8;
+    g.c_scale = c_scale;
+    g.M = M;
+    g.N = l.N;
+    g.K = l.K;
+    g.epi = epi;
+    g.resid = resid;
+    g.ldr = ldr;
+    g.ab_fp8 = 1;
+    g.acc_scale = 1.f / a_scale;
+    g.w_inv_scale = l.w8_inv;
+    return launch_gemm(CN_PREC_BF16, g, s);
+}
+
+int run_enc_layer_fp8(cn_model* m, const Layer& L, float* x, int B, int Tp, hipStream_t s) {
+    const int d = m->cfg.d_model, M = B * Tp;
+    void* q8 = m->xn;    // [M][d] e4m3fn (the bf16 buffer is twice as large)
+    void* h8 = m->hbuf;  // [M][d_ff] e4m3fn
+    {
+        ProfScope ps(m, "layernorm_fp8", 0, (double)M * d * 5, s);
+        CN_TRY(launch_layernorm_fp8(x, L.n[0].a, L.n[0].b, q8, M, d, 1e-6f, FP8_S_LN, s));
+    }
+    CN_TRY(run_linear_fp8(m, "qkv_proj_fp8", L.qkv, q8, FP8_S_LN, m->qkv, 3 * d, 0, 0, 1.f, M, 0, nullptr, 0, s));
+    CN_TRY(run_self_attn_core(m, B, Tp, m->keymask, nullptr, 0, s));
+    {
+        ProfScope ps(m, "quantize_fp8", 0, (double)M * d * 3, s);
+        CN_TRY(launch_quantize_fp8(m->ctx, d, q8, M, d, FP8_S_CTX, s));
+    }
+    CN_TRY(run_linear_fp8(m, "out_proj_fp8", L.self_o, q8, FP8_S_CTX, x, d, 1, 0, 1.f, M, CN_EPI_RESID, x, d, s));
+    {
+        ProfScope ps(m, "layernorm_fp8", 0, (double)M * d * 5, s);
+        CN_TRY(launch_layernorm_fp8(x, L.n[1].a, L.n[1].b, q8, M, d, 1e-6f, FP8_S_LN, s));
+    }
+    CN_TRY(run_linear_fp8(m, "ffn_w1_fp8", L.w1, q8, FP8_S_LN, h8, L.w1.N, 0, 1, FP8_S_HID, M, CN_EPI_RELU, nullptr, 0, s));
+    CN_TRY(run_linear_fp8(m, "ffn_w2_fp8", L.w2, h8, FP8_S_HID, x, d, 1, 0, 1.f, M, CN_EPI_RESID, x, d, s));
+    return 0;
+}
+
 // ---- conformer sublayers (fanat_conformer_blocks.py, conformer_related.py, attention.py:68-147) ------------------
 // x += scale * W2 . swish(W1 . LN(x) + b1) + ...   (SublayerConnection with the Swish feed-forward, scale 0.5 in the macaron halves)
 int run_ffn_swish(cn_model* m, const Linear& w1, const Linear& w2, const Norm& n, float* x, int M, float scale, hipStream_t s) {
@@ -1199,6 +1316,15 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         if (cap) CN_TRY(capture(m, "enc_h", m->enc_h, true, CN_DTYPE_F32, {B, Tp, d}, s));
         return 0;
     }
+    if (m->fp8_enc) {  // BASELINE config 5: the four products of every encoder layer on the fp8 MFMA
+        for (size_t n = 0; n < m->enc.size(); ++n) {
+            CN_TRY(run_enc_layer_fp8(m, m->enc[n], m->x, B, Tp, s));
+            if (cap) CN_TRY(capture(m, ("enc_layer" + std::to_string(n)).c_str(), m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
+        }
+        CN_TRY(run_ln(m, m->enc_norm, m->x, m->enc_h, M, s));
+        if (cap) CN_TRY(capture(m, "enc_h", m->enc_h, true, CN_DTYPE_F32, {B, Tp, d}, s));
+        return 0;
+    }
     static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
     const bool chain = !m->enc.empty() && m->enc_chain.size() == m->enc.size() && !no_chain;
     if (chain) {  // bf16 / d_model 256: LN + QKV of layer 0, then per layer attention -> row-chain kernel
@@ -1423,8 +1549,12 @@ extern "C" int cn_model_create(const cn_config* cfg, cn_model** out) {
         cn_set_error("cn_model_create: feed-forward widths must be multiples of 64 and d_model <= 1024");
         return -1;
     }
-    if (c.precision != CN_PRECISION_F32 && c.precision != CN_PRECISION_BF16) {
+    if (c.precision != CN_PRECISION_F32 && c.precision != CN_PRECISION_BF16 && c.precision != CN_PRECISION_FP8) {
         cn_set_error("cn_model_create: unknown precision");
+        return -1;
+    }
+    if (c.precision == CN_PRECISION_FP8 && (c.ast || c.conf_enc || c.d_model % 128 != 0 || c.d_encff % 128 != 0)) {
+        cn_set_error("cn_model_create: the fp8 encoder mode covers the transformer-block NAT model with d_model, d_encff % 128 == 0");
         return -1;
     }
     if (c.input_size < 4 || c.vocab_size < 4 || c.max_batch < 1 || c.max_frames < 4 || c.n_enc < 0 || c.n_extra < 0 ||
@@ -1435,8 +1565,10 @@ extern "C" int cn_model_create(const cn_config* cfg, cn_model** out) {
     CN_HIP_CHECK(hipSetDevice(c.device));
     cn_model* m = new cn_model();
     m->cfg = c;
-    m->prec = c.precision;
-    m->es = cn_elem_size(c.precision);
+    // fp8: a bf16 engine (storage, decoder side, conv front-end) whose encoder-layer products take e4m3fn operands
+    m->fp8_enc = c.precision == CN_PRECISION_FP8;
+    m->prec = m->fp8_enc ? CN_PREC_BF16 : c.precision;
+    m->es = cn_elem_size(m->prec);
     m->maxB = c.max_batch;
     m->maxT = c.max_frames;
     m->maxT1 = (c.max_frames - 1) / 2 + 1;
@@ -1986,6 +2118,58 @@ extern "C" int cn_op_greedy_pack(const int32_t* tok, const float* val, const int
 
 extern "C" int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, int32_t* idx, float* val, void* stream) {
     return launch_topk(logp, M, V, V, k, idx, val, (hipStream_t)stream);
+}
+
+// fp8 product through the ABI (config 5): A bf16 on the device is quantised at a_scale, W (HOST fp32 [N][K]) at the largest
+// power-of-two scale that fits e4m3fn (as cn_model_finalize does); C = relu?(A_q . W_q^T / scales + bias), fp32 [M][N]
+extern "C" int cn_op_gemm_fp8(const void* a_bf16_dev, int32_t lda, const float* w_host, const float* bias_dev, float* c_dev,
+                              int32_t M, int32_t N, int32_t K, float a_scale, int32_t relu, float* w_scale_out, void* stream) {
+    if (M < 1 || N < 1 || K < 128 || K % 128 != 0) {
+        cn_set_error("cn_op_gemm_fp8: K must be a positive multiple of 128");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)N * K; ++i) mx = std::max(mx, std::fabs(w_host[i]));
+    const float ws = mx > 0.f ? std::ldexp(1.f, (int)std::floor(std::log2(448.f / mx))) : 1.f;
+    if (w_scale_out) *w_scale_out = ws;
+    std::vector<unsigned char> w8((size_t)N * K);
+    for (size_t i = 0; i < w8.size(); ++i) w8[i] = Packer::f32_to_e4m3(w_host[i] * ws);
+    void *dw = nullptr, *da = nullptr;
+    CN_HIP_CHECK(hipMalloc(&dw, w8.size()));
+    CN_HIP_CHECK(hipMalloc(&da, (size_t)M * K));
+    CN_HIP_CHECK(hipMemcpy(dw, w8.data(), w8.size(), hipMemcpyHostToDevice));
+    int rc = launch_quantize_fp8(a_bf16_dev, lda, da, M, K, a_scale, s);
+    if (rc == 0) {
+        GemmArgs g;
+        g.A = da;
+        g.lda = K;
+        g.W = dw;
+        g.bias = bias_dev;
+        g.C = c_dev;
+        g.ldc = N;
+        g.c_f32 = 1;
+        g.M = M;
+        g.N = N;
+        g.K = K;
+        g.epi = relu ? CN_EPI_RELU : 0;
+        g.ab_fp8 = 1;
+        g.acc_scale = 1.f / (a_scale * ws);
+        rc = launch_gemm(CN_PREC_BF16, g, s);
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    (void)hipFree(da);
+    if (rc == 0 && e != hipSuccess) {
+        cn_set_error(std::string("cn_op_gemm_fp8: ") + hipGetErrorString(e));
+        rc = -2;
+    }
+    return rc;
+}
+
+extern "C" int cn_op_quantize_fp8(const void* src_bf16_dev, int32_t ld, void* dst_dev, int32_t M, int32_t K, float scale,
+                                  void* stream) {
+    return launch_quantize_fp8(src_bf16_dev, ld, dst_dev, M, K, scale, (hipStream_t)stream);
 }
 
 extern "C" int cn_op_logsoftmax_topk(const float* logits, int32_t M, int32_t V, float temperature, int32_t k, int32_t* idx,

@@ -9,7 +9,7 @@
 template <typename TY>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ a2,
                                                         const float* __restrict__ b2, TY* __restrict__ y, int M, int d,
-                                                        float eps) {
+                                                        float eps, float out_scale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -48,7 +48,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[i][j] - mean) / denom + bb[j];
-            if constexpr (sizeof(TY) == 2) {
+            if constexpr (sizeof(TY) == 1) {  // e4m3fn at the consumer's per-tensor scale (config 5)
+                unsigned int w = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w |= (unsigned int)cn_f32_to_fp8(o[j] * out_scale) << (8 * j);
+                *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(yr) + idx) = w;
+            } else if constexpr (sizeof(TY) == 2) {
                 bf16x4 ob;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ob[j] = (bf16)o[j];
@@ -72,9 +77,50 @@ int launch_layernorm(int prec, const float* x, const float* a2, const float* b2,
     if (M <= 0) return 0;
     const dim3 grid(cn_ceil_div(M, 4));
     if (y_f32 || prec == CN_PREC_F32)
-        hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, a2, b2, (float*)y, M, d, eps);
+        hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, a2, b2, (float*)y, M, d, eps, 1.f);
     else
-        hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, dim3(256), 0, s, x, a2, b2, (bf16*)y, M, d, eps);
+        hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, dim3(256), 0, s, x, a2, b2, (bf16*)y, M, d, eps, 1.f);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// LayerNorm straight into e4m3fn at `scale` (the A operand of an fp8 product)
+int launch_layernorm_fp8(const float* x, const float* a2, const float* b2, void* y, int M, int d, float eps, float scale,
+                         hipStream_t s) {
+    if (d % 4 != 0 || d > 1024 || d < 2) {
+        cn_set_error("layernorm: d must be a multiple of 4 in [4, 1024]");
+        return -1;
+    }
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(layernorm_kernel<fp8_t>, dim3(cn_ceil_div(M, 4)), dim3(256), 0, s, x, a2, b2, (fp8_t*)y, M, d, eps, scale);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// bf16 [M][K] (row stride ld) -> e4m3fn [M][K] at `scale`, saturating: the A operand of an fp8 product whose producer
+// writes bf16 (the attention context)
+__global__ void quantize_fp8_kernel(const bf16* __restrict__ src, int ld, unsigned char* __restrict__ dst, int M, int K, float scale) {
+    const long long n4 = (long long)M * (K / 4);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / (K / 4);
+        const int c = (int)(i - m * (K / 4)) * 4;
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(src + m * ld + c);
+        unsigned int w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w |= (unsigned int)cn_f32_to_fp8((float)v[j] * scale) << (8 * j);
+        *reinterpret_cast<unsigned int*>(dst + m * K + c) = w;
+    }
+}
+int launch_quantize_fp8(const void* src_bf16, int ld, void* dst, int M, int K, float scale, hipStream_t s) {
+    if (M <= 0 || K <= 0) return 0;
+    if (K % 4 != 0 || ld % 4 != 0) {
+        cn_set_error("quantize_fp8: K and the row stride must be multiples of 4");
+        return -1;
+    }
+    const long long n4 = (long long)M * (K / 4);
+    long long g = (n4 + 255) / 256;
+    if (g > 65536) g = 65536;
+    hipLaunchKernelGGL(quantize_fp8_kernel, dim3((unsigned)g), dim3(256), 0, s, (const bf16*)src_bf16, ld, (unsigned char*)dst, M, K, scale);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

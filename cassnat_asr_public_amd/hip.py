@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcassnat_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cassnat_hip.h")
 
-PRECISION = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+PRECISION = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp8": 2}
 DTYPES = {0: np.float32, 1: np.int32, 2: np.uint8, 3: np.float64}
 
 
@@ -84,6 +84,9 @@ def lib():
     L.cn_op_ctc_align.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 5 + [C.c_void_p] * 6
     L.cn_op_greedy_pack.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p] * 4
     L.cn_op_topk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cn_op_gemm_fp8.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                 C.c_int32, C.POINTER(C.c_float), C.c_void_p]
+    L.cn_op_quantize_fp8.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     L.cn_op_logsoftmax_topk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_model_create.argtypes = [C.POINTER(CnConfig), C.POINTER(C.c_void_p)]
     L.cn_model_destroy.argtypes = [C.c_void_p]

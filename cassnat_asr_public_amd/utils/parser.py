@@ -21,7 +21,7 @@ class DecodeParser(object):
         p.add_argument("--lm_weight", type=float, default=0.0)
         p.add_argument("--seed", default=1, type=int)
         # engine switches (not in the reference)
-        p.add_argument("--hip_precision", default="bf16", choices=["bf16", "fp32"],
+        p.add_argument("--hip_precision", default="bf16", choices=["bf16", "fp32", "fp8"],
                        help="bf16 MFMA (throughput) or exact-f32 MFMA (parity with the reference CPU path)")
         p.add_argument("--hip_max_frames", default=4096, type=int, help="workspace size in input frames")
         p.add_argument("--hip_pipelines", default=4, type=int,

@@ -23,7 +23,7 @@ extern "C" {
 
 typedef struct cn_model cn_model;
 
-enum { CN_PRECISION_F32 = 0, CN_PRECISION_BF16 = 1 };
+enum { CN_PRECISION_F32 = 0, CN_PRECISION_BF16 = 1, CN_PRECISION_FP8 = 2 };
 enum { CN_DTYPE_F32 = 0, CN_DTYPE_I32 = 1, CN_DTYPE_U8 = 2, CN_DTYPE_F64 = 3 };
 
 /* Model hyper-parameters: the subset of the flat `args` bag that make_model reads for the transformer
@@ -33,7 +33,8 @@ typedef struct cn_config {
     int32_t d_model, n_head, d_encff, d_decff;
     int32_t n_enc, n_extra, n_self_dec, n_mix_dec;
     int32_t vocab_size;
-    int32_t precision;  /* CN_PRECISION_F32: exact-f32 MFMA (parity gate); CN_PRECISION_BF16: throughput */
+    int32_t precision;  /* CN_PRECISION_F32: exact-f32 MFMA (parity gate); CN_PRECISION_BF16: throughput; CN_PRECISION_FP8:
+                           the bf16 engine with the encoder layers' products on the e4m3fn MFMA (BASELINE config 5) */
     int32_t max_batch;  /* workspace is sized for max_batch x max_frames */
     int32_t max_frames;
     int32_t device; /* HIP device ordinal */
@@ -232,6 +233,13 @@ int cn_op_genmax(const void* h_dev, const float* w_host, const float* b_host, in
 int cn_op_genmax_gather(const void* h_dev, const float* w_host, const float* b_host, int32_t B, int32_t U, int32_t V,
                         const int32_t* tgt_dev, int32_t ld, float* tgt_lp_dev, void* stream);
 int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, int32_t* idx, float* val, void* stream);
+/* e4m3fn product (BASELINE config 5): A bf16 [M][lda] on the device is quantised at a_scale (saturating at 448 / a_scale),
+ * W = HOST fp32 [N][K] at the largest power-of-two scale that fits (returned in *w_scale_out), as cn_model_finalize does for
+ * the encoder layers of a CN_PRECISION_FP8 model; C fp32 [M][N] = relu?(A_q . W_q^T / (a_scale * w_scale) + bias) */
+int cn_op_gemm_fp8(const void* a_bf16_dev, int32_t lda, const float* w_host, const float* bias_dev, float* c_dev, int32_t M,
+                   int32_t N, int32_t K, float a_scale, int32_t relu, float* w_scale_out, void* stream);
+/* bf16 [M][ld] -> e4m3fn bytes [M][K] at `scale` (round to nearest even, saturating at +-448): the activation quantiser */
+int cn_op_quantize_fp8(const void* src_bf16_dev, int32_t ld, void* dst_dev, int32_t M, int32_t K, float scale, void* stream);
 /* generator tail of the autoregressive step (src/models/transformer.py:48-51, 199-200): log_softmax(logits / T) and its per-row
  * top-k (sorted descending, ties: lower index) in one pass; the logits [M][V] are left untouched */
 int cn_op_logsoftmax_topk(const float* logits, int32_t M, int32_t V, float temperature, int32_t k, int32_t* idx, float* val,

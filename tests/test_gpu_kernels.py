@@ -68,6 +68,53 @@ def test_gemm_bias(prec, M, N, K):
         assert relerr(out, ref) < RTOL[prec] * (1 if c_f32 or prec == "fp32" else 1.5)
 
 
+def test_quantize_fp8_matches_torch_e4m3fn():
+    g = torch.Generator().manual_seed(2)
+    x = torch.cat([torch.randn(4096, generator=g) * s for s in (1e-4, 1e-3, 1e-2, 0.1, 1.0, 10.0, 40.0)]).view(-1, 256)
+    x[0, :8] = torch.tensor([0.0, -0.0, 28.0, -28.0, 29.0, 0.001953125 / 16, 0.0009765625 / 16, 0.0146484375 / 16])
+    xb = x.to(torch.bfloat16)
+    out = torch.zeros(x.shape, dtype=torch.uint8, device="cuda")
+    hip.check(hip.lib().cn_op_quantize_fp8(p(xb.cuda()), 256, p(out), x.shape[0], 256, 16.0, stream()))
+    torch.cuda.synchronize()
+    ref = (xb.float() * 16.0).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    bad = (out.cpu() != ref).nonzero()
+    assert len(bad) == 0, [(xb[i, j].item(), hex(out[i, j].item()), hex(ref[i, j].item())) for i, j in bad[:8].tolist()]
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(300, 768, 256, 0), (8000, 2048, 256, 1), (515, 256, 2048, 0), (1, 256, 128, 0)])
+def test_gemm_fp8_matches_an_e4m3_emulation(M, N, K, relu):
+    """BASELINE config 5's product: both operands rounded to OCP e4m3fn (torch.float8_e4m3fn on the CPU is the emulation:
+    round to nearest even; the kernel side saturates at 448) at per-tensor power-of-two scales, fp32 accumulation.  Also pins
+    the host-side weight quantiser and the device-side activation quantiser against torch's conversion."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * 1.5
+    A[0, :4] = torch.tensor([40.0, -40.0, 27.9, 1e-4])  # beyond the range at scale 16 (saturates at 28), near it, tiny
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    a_scale = 16.0
+    Ab = A.to(torch.bfloat16)
+    Ad, bd = Ab.cuda(), dev(bias)
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ws = C.c_float()
+    hip.check(hip.lib().cn_op_gemm_fp8(p(Ad), K, C.c_void_p(W.data_ptr()), p(bd), p(out), M, N, K, a_scale, relu, C.byref(ws), stream()))
+    torch.cuda.synchronize()
+    w_scale = ws.value
+    assert w_scale == 2.0 ** math.floor(math.log2(448.0 / W.abs().max().item()))
+    q = lambda t: t.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    ref = F.linear(q(Ab.float() * a_scale), q(W * w_scale)) / (a_scale * w_scale) + bias
+    if relu:
+        ref = F.relu(ref)
+    # identical operands (the quantisers are byte-exact, see test_quantize_fp8_...): what is left is the matrix core's own
+    # summation of the 16 products of an fp8 MFMA, which is not a chain of fp32 adds (measured 3e-5 of the output range)
+    assert relerr(out, ref) < 1e-4
+    # and the whole thing is a sane approximation of the unquantised product where nothing saturates
+    full = F.linear(Ab.float(), W) + bias
+    if relu:
+        full = F.relu(full)
+    if M > 1:
+        assert relerr(out[1:], full[1:]) < 0.08
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_gemm_epilogues(prec):
     g = torch.Generator().manual_seed(3)

@@ -321,3 +321,26 @@ def test_esa_sampling_with_lm_ranking(which, prec, capsys):
                 out_g, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, args, lm)
             assert [s[0]["hyp"] for s in out_g] == [s[0]["hyp"] for s in out]
             np.testing.assert_allclose([s[0]["score"] for s in out_g], [s[0]["score"] for s in out], rtol=1e-6, atol=1e-5)
+
+
+def test_config5_fp8_encoder_products(capsys):
+    """BASELINE config 5 (Aishell-1-sized vocabulary, e4m3fn encoder products with per-tensor scales): no 1e-3 gate exists for
+    it - the run reports its alignment agreement and logit error against the reference's fp32 golden, next to
+    the bf16 engine's on the same weights, and is gated loosely (finite, most frames agree, error of the fp8 order)."""
+    g = load_golden("config5_shape")
+    args, state, feats, sizes = config5_shape_case()
+    st, sv = 10, 50  # strides of the golden's log-posterior sample
+    rows = {}
+    for prec in ("bf16", "fp8"):
+        model = build(args, state, prec, capture=True)
+        out = decode(model, args, feats, sizes)
+        eng = model._engine
+        best, ctc = eng.fetch("best_paths"), eng.fetch("ctc_out")
+        assert np.isfinite(ctc).all() and all(np.isfinite(s[0]["score"]) for s in out)
+        rows[prec] = dict(flips=float((best != g["best_paths"]).mean()), err=maxerr(ctc[:, ::st, ::sv], g["ctc_sample"]),
+                          hyp=sum(s[0]["hyp"] == g["hyp"][b, : g["hyp_len"][b]].tolist() for b, s in enumerate(out)))
+    with capsys.disabled():
+        print(f"\n[config 5] V={args.vocab_size}, {g['best_paths'].size} frames, against the fp32 reference: "
+              + "; ".join(f"{k}: argmax flips {v['flips']:.4f}, max |d log-posterior| {v['err']:.4f}, hypotheses identical "
+                          f"{v['hyp']}/{len(g['hyp'])}" for k, v in rows.items()))
+    assert rows["fp8"]["flips"] < 0.25 and rows["fp8"]["err"] < 0.5
