@@ -636,7 +636,7 @@ int build_weights(cn_model* m) {
     }
     m->enc_norm = pk.norm("encoder.norm", d);
     m->enc_chain.clear();
-    if (!lm && !c.conf_enc && !m->fp8_enc && pk.chain_ok(d, c.d_encff))
+    if (!c.conf_enc && !m->fp8_enc && pk.chain_ok(d, c.d_encff))  // (the TransformerLM's layers are encoder layers: same chains)
         for (int n = 0; n < c.n_enc; ++n) {
             const std::string p = "encoder.layers." + std::to_string(n), q = "encoder.layers." + std::to_string(n + 1);
             if (n + 1 < c.n_enc)
@@ -1784,12 +1784,25 @@ extern "C" int cn_lm_score(cn_model* m, const int32_t* tok_dev, const int32_t* t
     const int d = m->cfg.d_model, V = m->cfg.vocab_size, M = B * U;
     float* x = m->x;
     CN_TRY(launch_lm_embed(tok_dev, ld, m->tgt_lut, m->pe, x, B, U, d, sqrtf((float)d), s));
-    for (size_t n = 0; n < m->enc.size(); ++n) {
-        const Layer& L = m->enc[n];
-        CN_TRY(run_self_attn(m, L, &L.n[0], x, B, U, nullptr, len_dev, 1, s));
-        CN_TRY(run_ffn(m, L, L.n[1], x, M, nullptr, nullptr, s));
+    static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
+    if (!m->enc.empty() && m->enc_chain.size() == m->enc.size() && !no_chain) {
+        // bf16 / d_model 256: per layer [causal + length-masked attention] + one row-chain launch, as in stage_encode
+        CN_TRY(run_ln(m, m->enc[0].n[0], x, m->xn, M, s));
+        CN_TRY(run_linear(m, "qkv_proj", m->enc[0].qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
+        for (size_t n = 0; n < m->enc.size(); ++n) {
+            const bool last = n + 1 == m->enc.size();
+            CN_TRY(run_self_attn_core(m, B, U, nullptr, len_dev, 1, s));
+            const int xm = (n > 0 ? CHX_IN_BLK : 0) | (last ? CHX_NO_STORE : CHX_OUT_BLK);
+            CN_TRY(run_chain(m, m->enc_chain[n], x, M, last ? m->enc_h : m->qkv, last ? d : 3 * d, true, xm, s));
+        }
+    } else {
+        for (size_t n = 0; n < m->enc.size(); ++n) {
+            const Layer& L = m->enc[n];
+            CN_TRY(run_self_attn(m, L, &L.n[0], x, B, U, nullptr, len_dev, 1, s));
+            CN_TRY(run_ffn(m, L, L.n[1], x, M, nullptr, nullptr, s));
+        }
+        CN_TRY(run_ln(m, m->enc_norm, x, m->enc_h, M, s));
     }
-    CN_TRY(run_ln(m, m->enc_norm, x, m->enc_h, M, s));
     static const bool no_fused = getenv("CASSNAT_LM_NO_FUSED_TAIL") != nullptr;
     if (m->att_gen.gm_w && !no_fused) {  // bf16 / d_model 256: generator + log-softmax + gather in one kernel, no (M, V) tensor
         ProfScope ps(m, "generator_gather_fused", 2.0 * M * V * d, (double)M * d * 2 + (double)V * d * 2, s);

@@ -225,3 +225,32 @@ def test_decode_pipelines_equal_the_plain_loop():
     for (tag, hyps, scores), (wh, ws) in zip(got, want):
         assert hyps == wh, tag
         assert list(scores) == ws, tag
+
+
+def test_lm_scoring_bf16_fast_path_against_the_fp32_engine():
+    """TransformerLM scoring (ESA ranking): the bf16 engine runs attention + row chain per layer and the fused generator with
+    a target gather; the fp32 engine runs the generic kernels and a full log-softmax.  Same tokens, ragged lengths, rows that
+    do not fill a 128-row tile: scores of the positions the ranking reads (u < length) agree within bf16 error."""
+    from cassnat_asr_public_amd.models.lm import make_model as make_lm
+
+    lm_args = synth.make_args_lm("lm_small")
+    lm_state = synth.make_state(lm_args, seed=9, gain=2.0)
+    g = torch.Generator().manual_seed(3)
+    N, U, ld = 37, 23, 26
+    tok = torch.randint(4, lm_args.vocab_size, (N, ld), generator=g, dtype=torch.int32)
+    tok[:, 0] = 1
+    tgt = torch.randint(4, lm_args.vocab_size, (N, ld), generator=g, dtype=torch.int32)
+    length = torch.randint(1, U + 1, (N,), generator=g, dtype=torch.int32)
+    length[0], length[1] = U, 1
+    got = {}
+    for prec in ("fp32", "bf16"):
+        lm_args.hip_precision = prec
+        lm = make_lm(lm_args).cuda()
+        with torch.no_grad():
+            for k, p in lm.named_parameters():
+                p.copy_(torch.from_numpy(lm_state[k]))
+        got[prec] = lm.score_tokens(tok.cuda(), tgt.cuda(), length.cuda(), U, max_frames=256).cpu()  # (workspace: rows <= N * (frames / 4 + 1))
+    mask = torch.arange(ld).view(1, ld) < length.view(N, 1).long()
+    a, b = got["fp32"][mask], got["bf16"][mask]
+    assert torch.isfinite(b).all()
+    assert (a - b).abs().max().item() < 0.12 and (a - b).abs().mean().item() < 0.02
