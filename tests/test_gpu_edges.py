@@ -149,7 +149,8 @@ def test_leading_padding_frames_are_masked_like_the_reference():
     assert_same(model, out, ref)
 
 
-@pytest.mark.parametrize("B,T,lengths", [(1, 1, [1]), (2, 5, [5, 2]), (3, 64, [64, 9, 1]), (5, 130, [130, 129, 77, 8, 4])])
+@pytest.mark.parametrize("B,T,lengths", [(1, 1, [1]), (2, 5, [5, 2]), (3, 64, [64, 9, 1]), (5, 130, [130, 129, 77, 8, 4]),
+                                          (2, 1530, [1530, 1100])])  # (T' = 383 > 256: keys no longer resident in one LDS tile set)
 def test_bf16_fast_path_on_small_and_ragged_batches(B, T, lengths):
     """The bf16 engine at d_model 256 runs the fused kernels (row chain, LDS-DMA conv, fused generator); their row tiles are
     128 / 256 rows, so these batches exercise partial tiles, single rows and masked tails.  Checked against the fp32 engine
