@@ -18,6 +18,9 @@
 //     ds_read_b32 (f32 path, v_mfma_f32_32x32x2_f32).
 #include <cstdlib>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "kernels.h"
 
 struct AttnParams {
@@ -30,6 +33,7 @@ struct AttnParams {
     int H, Lq, Lk;
     const unsigned char* keymask;
     int kv_mod;  // > 0: keys / values / keymask of batch entry b live at entry b % kv_mod (several query sets per source)
+    int stamps;  // investigation aid (CASSNAT_ATTN_STAMPS): workgroup 0 / thread 0 records s_memtime at its phase boundaries
     const int* kv_index;  // non-null: ... at entry kv_index[b] (beam search: every hypothesis row names its utterance)
     const int* klen;
     const int* iv;
@@ -63,6 +67,9 @@ template <> struct AttnCfg<float> {
 // processed back to back: one barrier per workgroup instead of two per tile, and a single load round trip.
 // REL: relative-position scores (RelMultiHeadedAttention): the query operand is q + u, and a per-query table
 // bd[i][r] = (q_i + v) . P[r] (r = clamp(j - i) + R, at most 63 entries) is built in LDS and added to every raw score.
+__device__ long long attn_stamps[8];
+#define AT_STAMP(i) if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) attn_stamps[i] = (long long)__builtin_amdgcn_s_memtime();
+
 template <typename T, int NW, bool RES, bool REL = false>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
     typedef AttnCfg<T> Cfg;
@@ -82,6 +89,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y;
+    AT_STAMP(0)
     const int q_row = blockIdx.x * (32 * NW) + wave * 32 + l31;
     const bool wave_active = (blockIdx.x * (32 * NW) + wave * 32) < p.Lq;
     const int qc = q_row < p.Lq ? q_row : p.Lq - 1;
@@ -201,6 +209,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
+        AT_STAMP(1)
         if (tid < NRES) Mplain[tid] = 1;
         __syncthreads();
         for (int i = tid; i < nkt * 64; i += NT) {
@@ -215,6 +224,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        AT_STAMP(2)
     } else {
         load_tile(0);
     }
@@ -361,6 +371,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
         }
     }
 
+    AT_STAMP(3)
     if (!wave_active) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     // REL: softmax(...).masked_fill(mask == 0, 0) leaves a row without any allowed key at zero (attention.py:133-134)
@@ -386,6 +397,16 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
             }
         }
     }
+    AT_STAMP(4)
+}
+
+int attention_print_stamps() {
+    long long h[8];
+    CN_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(attn_stamps), sizeof(h)));
+    static const char* names[] = {"", "Q fragments + K/V requests", "K/V landed + mask codes", "key-tile loop", "normalise + store"};
+    for (int i = 1; i < 5; ++i) fprintf(stderr, "[attention stamps] %-28s %8lld ticks\n", names[i], h[i] - h[i - 1]);
+    fprintf(stderr, "[attention stamps] total %lld ticks (s_memtime)\n", h[4] - h[0]);
+    return 0;
 }
 
 template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s) {
@@ -403,6 +424,8 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     p.Lk = a.Lk;
     p.keymask = a.keymask;
     p.kv_mod = a.kv_mod;
+    static const int stamps = getenv("CASSNAT_ATTN_STAMPS") ? 1 : 0;
+    p.stamps = stamps;
     p.kv_index = a.kv_index;
     p.klen = a.klen;
     p.iv = a.intervals;

@@ -94,6 +94,7 @@ struct AttnArgs {
     int rel_R = 0, ld_pos = 0;
 };
 int launch_attention(int prec, const AttnArgs& a, hipStream_t s);
+int attention_print_stamps();  // CASSNAT_ATTN_STAMPS: phase timestamps of the last launch's workgroup 0
 
 // ---- conformer convolution module pieces (conformer.hip)
 int launch_glu(int prec, const void* in, void* out, int M, int d, hipStream_t s);

@@ -2095,7 +2095,12 @@ extern "C" int cn_op_attention(int32_t precision, const void* Q, int32_t ldq, co
     a.iv_stride = iv_stride;
     a.causal = causal;
     a.scale = scale;
-    return launch_attention(precision, a, (hipStream_t)stream);
+    int rc = launch_attention(precision, a, (hipStream_t)stream);
+    if (rc == 0 && getenv("CASSNAT_ATTN_STAMPS")) {
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)attention_print_stamps();
+    }
+    return rc;
 }
 
 extern "C" int cn_op_logsoftmax_argmax(float* logits, int32_t M, int32_t V, int32_t* arg, float* maxlp,
