@@ -135,11 +135,13 @@ def main():
     def run_steps(n_steps):
         """n_steps batches over the NS decode pipelines.  The per-batch all-gather (N > 1) and the hypotheses' trip to the
         host happen here, in THIS thread only and in step order, so every rank issues the same sequence of collectives."""
-        for _, hyps_, scores_ in pipes.decode(((feats, sizes, k) for k in range(n_steps)), args, sos=1, gather=world > 1):
+        # (hypotheses reach the host as arrays - tokens, lengths, scores of all ranks' utterances - without per-utterance Python
+        # work: at 8 ranks a step carries 256 of them)
+        for _, hyps_, scores_ in pipes.decode(((feats, sizes, k) for k in range(n_steps)), args, sos=1, gather=world > 1,
+                                              as_lists=False):
             last[0] = (hyps_, scores_)
 
     run_steps(max(a.warmup, NS))
-    hyps, _ = last[0]
     U = int(engines[0].fetch("ymax")[0])
     eng = engines[0]
     fence()
@@ -159,7 +161,8 @@ def main():
             if got.get(t):
                 for k in prof[t]:
                     prof[t][k] += got[t][k]
-    hyps, scores = last[0]
+    (toks_, lens_), scores = last[0]
+    hyps = [toks_[b, : lens_[b]].tolist() for b in range(toks_.shape[0])]  # the last step's hypotheses, as token lists
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

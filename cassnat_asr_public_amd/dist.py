@@ -48,11 +48,16 @@ def pack_records(hyp, hyp_len, score):
     return torch.cat([hyp_len.view(-1, 1), sc, hyp], dim=1).contiguous()
 
 
-def unpack_records(rec):
+def unpack_records(rec, as_lists=True):
+    """Records -> host.  ``as_lists``: ([tokens of utterance b ...], scores) as ``beam_decode`` reports them; otherwise the
+    arrays themselves ``((tokens (N, S) int32, lengths (N,) int32), scores (N,) float64)`` - one device-to-host copy and no
+    per-utterance Python work (what a throughput loop over many ranks' records wants)."""
     rec = rec.cpu()
     lens = rec[:, 0].numpy()
     score = rec[:, 1:3].clone(memory_format=torch.contiguous_format).view(torch.float64).view(-1).numpy()  # (clone: offset 0)
     toks = rec[:, 3:].numpy()
+    if not as_lists:
+        return (toks, lens), score
     return [toks[b, : lens[b]].tolist() for b in range(rec.shape[0])], score
 
 

@@ -136,12 +136,13 @@ class DecodePipelines:
             for t in threads:
                 t.join()
 
-    def decode(self, batches, args, sos=1, gather=False):
+    def decode(self, batches, args, sos=1, gather=False, as_lists=True):
         """Hypotheses on the host, in order: yields ``(tag, hyps, scores)`` with ``hyps`` a list of token lists starting
-        with ``sos`` (what ``beam_decode`` returns as ``['hyp']``).  ``gather=True``: every record set goes through the
-        per-batch all-gather of the multi-GPU path first (rank-major concatenation)."""
+        with ``sos`` (what ``beam_decode`` returns as ``['hyp']``), or with ``as_lists=False`` the arrays ``(tokens (N, S),
+        lengths (N,))`` of ``dist.unpack_records``.  ``gather=True``: every record set goes through the per-batch all-gather
+        of the multi-GPU path first (rank-major concatenation)."""
         for tag, rec in self.records(batches, args, sos):
             if gather:
                 rec = cdist.all_gather_records(rec)
-            hyps, scores = cdist.unpack_records(rec)
+            hyps, scores = cdist.unpack_records(rec, as_lists=as_lists)
             yield tag, hyps, scores
