@@ -73,6 +73,10 @@ struct GatherAttnParams {
     const int* utt;              // MODE 1: [n]
     const unsigned char* keymask;  // MODE 1: [B][nkeys]
     float scale;
+    // MODE 0, append_pos >= 0: this step's K and V of hypothesis h are still in the projection buffer (columns d.. and 2d.. of
+    // q's row): the workgroup writes them to cache row (append_pos, slot h) for the steps to come and reads key append_pos
+    // from the projection buffer itself (no separate append launch, no read-after-write through the cache)
+    int append_pos;
 };
 
 template <typename T, int MODE>
@@ -90,9 +94,17 @@ __global__ void ast_gather_attn_kernel(GatherAttnParams p) {
         return (long long)u * p.nkeys + j;
     };
     const int kstride = MODE == 0 ? p.d : 2 * p.d;
+    const bool append = MODE == 0 && p.append_pos >= 0;
+    const T* new_k = qrow + p.d;      // (head hd of this row's K | V in the fused projection)
+    const T* new_v = qrow + 2 * p.d;
+    if (append) {
+        const long long crow = ((long long)p.append_pos * p.slots + h) * p.d + hd * 64 + lane;
+        const_cast<T*>(reinterpret_cast<const T*>(p.k))[crow] = new_k[lane];
+        const_cast<T*>(reinterpret_cast<const T*>(p.v))[crow] = new_v[lane];
+    }
     float lmax = -INFINITY;
     for (int j = lane; j < p.nkeys; j += 64) {
-        const T* kr = reinterpret_cast<const T*>(p.k) + row_of(j) * kstride + hd * 64;
+        const T* kr = (append && j == p.append_pos) ? new_k : reinterpret_cast<const T*>(p.k) + row_of(j) * kstride + hd * 64;
         float dot = 0.f;
 #pragma unroll
         for (int i = 0; i < 64; ++i) dot = fmaf(q[i], to_f32(kr[i]), dot);
@@ -114,7 +126,7 @@ __global__ void ast_gather_attn_kernel(GatherAttnParams p) {
     const float inv = 1.f / lsum;
     float acc = 0.f;
     for (int j = 0; j < p.nkeys; ++j) {
-        const T* vr = reinterpret_cast<const T*>(p.v) + row_of(j) * kstride + hd * 64;
+        const T* vr = (append && j == p.append_pos) ? new_v : reinterpret_cast<const T*>(p.v) + row_of(j) * kstride + hd * 64;
         acc = fmaf(sc[j], to_f32(vr[lane]), acc);
     }
     reinterpret_cast<T*>(p.o)[(long long)h * p.ldo + hd * 64 + lane] = from_f32<T>(acc * inv);
@@ -144,6 +156,7 @@ int launch_ast_gather_attn(int prec, int mode, const GatherAttnArgs& a, hipStrea
     p.utt = a.utt;
     p.keymask = a.keymask;
     p.scale = a.scale;
+    p.append_pos = mode == 0 ? a.append_pos : -1;
     const size_t lds = (size_t)a.H * a.nkeys * sizeof(float);
     if (lds > 64 * 1024) {
         cn_set_error("ast_gather_attn: too many keys for the score buffer");

@@ -230,6 +230,7 @@ struct GatherAttnArgs {
     const int* utt = nullptr;
     const unsigned char* keymask = nullptr;
     float scale = 0.125f;
+    int append_pos = -1;  // mode 0: >= 0 appends this step's K | V (columns d.. / 2d.. of q's rows) to the cache at that position
 };
 int launch_ast_gather_attn(int prec, int mode, const GatherAttnArgs& a, hipStream_t s);  // mode 0: cache, 1: source memory
 int launch_ast_ctc_prepare(float* logp, const unsigned char* keymask, float* r0, int B, int Tp, int V, int blank, hipStream_t s);

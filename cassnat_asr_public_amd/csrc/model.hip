@@ -2471,8 +2471,8 @@ int ast_step_run(cn_model* m, int n, int pos, const int32_t* tok_dev, const int3
         if (!have_ln) CN_TRY(run_ln(m, L.n[0], x, m->xn, n, s));
         have_ln = false;
         CN_TRY(run_linear(m, "qkv_proj", L.qkv, m->xn, d, m->qkv, 3 * d, 0, n, 0, nullptr, 0, s));
-        CN_TRY(launch_ast_kv_append(m->prec, m->qkv, m->ast_ck[l], m->ast_cv[l], n, d, m->ast_slots, pos, s));
         GatherAttnArgs a;
+        a.append_pos = pos;  // the cache attention appends this position's K | V itself (it is the only reader of that row now)
         a.q = m->qkv;
         a.ldq = 3 * d;
         a.k = m->ast_ck[l];
