@@ -30,7 +30,8 @@ struct GenmaxParams {
 
 constexpr int GM_RING_BYTES = 32 * 1024;
 
-template <int MT, bool GATHER>
+// LSE = false: the arg-max alone (no exponentials, no log-sum-exp): what the CTC alignment of the greedy path needs
+template <int MT, bool GATHER, bool LSE = true>
 __global__ __launch_bounds__(256) void genmax_kernel(GenmaxParams p) {
     constexpr int BM = 32 * MT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -139,13 +140,15 @@ __global__ __launch_bounds__(256) void genmax_kernel(GenmaxParams p) {
                 if constexpr (GATHER) { if (vbase + (r & 3) + 8 * (r >> 2) == tg[mt]) tv[mt] = v; }           \
             }                                                                                                 \
             if (tmax > m_run[mt]) {                                                                           \
-                s_run[mt] *= __expf(m_run[mt] - tmax);                                                        \
+                if constexpr (LSE) s_run[mt] *= __expf(m_run[mt] - tmax);                                     \
                 m_run[mt] = tmax;                                                                             \
                 i_run[mt] = tidx;                                                                             \
             }                                                                                                 \
-            float ps = 0.f;                                                                                   \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) ps += __expf(acc[mt][r] - m_run[mt]);              \
-            s_run[mt] += ps;                                                                                  \
+            if constexpr (LSE) {                                                                              \
+                float ps = 0.f;                                                                               \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) ps += __expf(acc[mt][r] - m_run[mt]);          \
+                s_run[mt] += ps;                                                                              \
+            }                                                                                                 \
         }                                                                                                     \
     }
 
@@ -228,19 +231,19 @@ __global__ __launch_bounds__(256) void genmax_kernel(GenmaxParams p) {
             p.tgt_lp[(long long)(m / p.tgt_U) * p.tgt_ld + (m % p.tgt_U)] = (bt - bm) - logf(bs);
         } else {
             p.arg[m0 + tid] = bi;
-            p.maxlp[m0 + tid] = -logf(bs);
+            if constexpr (LSE) p.maxlp[m0 + tid] = -logf(bs);
         }
     }
 }
 
-template <int MT, bool GATHER> static int launch_genmax_variant(const GenmaxParams& p, hipStream_t s) {
+template <int MT, bool GATHER, bool LSE> static int launch_genmax_variant(const GenmaxParams& p, hipStream_t s) {
     constexpr int lds = 4 * GM_RING_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        CN_HIP_CHECK(hipFuncSetAttribute((const void*)genmax_kernel<MT, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)genmax_kernel<MT, GATHER, LSE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((genmax_kernel<MT, GATHER>), dim3(cn_ceil_div(p.M, 32 * MT)), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((genmax_kernel<MT, GATHER, LSE>), dim3(cn_ceil_div(p.M, 32 * MT)), dim3(256), lds, s, p);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -275,9 +278,11 @@ int launch_genmax(const GenmaxArgs& a, hipStream_t s) {
             cn_set_error("genmax: the target gather needs rows = B x U, an output buffer and ld >= U");
             return -1;
         }
-        return a.M > 32 ? launch_genmax_variant<2, true>(p, s) : launch_genmax_variant<1, true>(p, s);
+        return a.M > 32 ? launch_genmax_variant<2, true, true>(p, s) : launch_genmax_variant<1, true, true>(p, s);
     }
-    return a.M > 32 ? launch_genmax_variant<2, false>(p, s) : launch_genmax_variant<1, false>(p, s);
+    if (!a.maxlp)  // arg-max only
+        return a.M > 32 ? launch_genmax_variant<2, false, false>(p, s) : launch_genmax_variant<1, false, false>(p, s);
+    return a.M > 32 ? launch_genmax_variant<2, false, true>(p, s) : launch_genmax_variant<1, false, true>(p, s);
 }
 
 static inline uint16_t gm_bf16_bits(float f) {

@@ -148,6 +148,7 @@ struct cn_model {
     int *best = nullptr, *shift = nullptr, *src_size = nullptr, *ylen = nullptr, *ymax = nullptr, *intervals = nullptr,
         *tok = nullptr, *topk_idx = nullptr;
     float *ctc_maxlp = nullptr, *val = nullptr, *topk_val = nullptr;
+    bool ctc_maxlp_valid = false;  // the fused arg-max-only CTC generator does not produce it
 
     void* cv_a = nullptr;      // conformer convolution module scratch
     float* cv_f = nullptr;
@@ -1218,7 +1219,9 @@ int stage_encode_align(cn_model* m, const float* feats, const float* ratio, int 
     const cn_config& c = m->cfg;
     const int Tp = m->Tp, M = B * Tp;
     const bool cap = o->capture != 0;
-    CN_TRY(run_generator(m, m->ctc_gen, m->enc_h, M, m->best, m->ctc_maxlp, cap, s));
+    // the alignment needs the arg-max only; the best path's log-probabilities are produced when a capture asks for rows
+    m->ctc_maxlp_valid = cap || !m->ctc_gen.gm_w;
+    CN_TRY(run_generator(m, m->ctc_gen, m->enc_h, M, m->best, m->ctc_maxlp_valid ? m->ctc_maxlp : nullptr, cap, s));
     if (cap) CN_TRY(capture(m, "ctc_out", m->logits, false, CN_DTYPE_F32, {B, Tp, c.vocab_size}, s));
     AlignArgs al;
     al.best = m->best;
@@ -1712,6 +1715,7 @@ extern "C" int cn_esa_begin(cn_model* m, const float* feats_dev, int32_t B, int3
     const int d = m->cfg.d_model, V = m->cfg.vocab_size, M = B * m->Tp;
     CN_TRY(run_linear(m, "generator_proj", m->ctc_gen, m->enc_h, d, m->logits, V, 1, M, 0, nullptr, 0, s));
     CN_TRY(launch_logsoftmax_argmax(m->logits, M, V, V, m->best, m->ctc_maxlp, 1, s));
+    m->ctc_maxlp_valid = true;
     CN_TRY(launch_topk(m->logits, M, V, V, 2, m->topk_idx, m->topk_val, s));
     return 0;
 }
@@ -1821,6 +1825,7 @@ extern "C" int cn_lm_score(cn_model* m, const int32_t* tok_dev, const int32_t* t
     }
     CN_TRY(run_linear(m, "generator_proj", m->att_gen, m->enc_h, d, m->logits, V, 1, M, 0, nullptr, 0, s));
     CN_TRY(launch_logsoftmax_argmax(m->logits, M, V, V, m->best, m->ctc_maxlp, 1, s));
+    m->ctc_maxlp_valid = true;
     return launch_gather_logp(m->logits, V, tgt_dev, ld, score_dev, B, U, s);
 }
 
@@ -1900,7 +1905,12 @@ extern "C" int cn_fetch(cn_model* m, const char* name, void* host_dst, int64_t m
         dtype = it->second.dtype;
         shape = it->second.shape;
     } else if (n == "best_paths") { src = m->best; dtype = CN_DTYPE_I32; shape = {B, Tp};
-    } else if (n == "ctc_maxlp") { src = m->ctc_maxlp; shape = {B, Tp};
+    } else if (n == "ctc_maxlp") {
+        if (!m->ctc_maxlp_valid) {
+            cn_set_error("cn_fetch: ctc_maxlp is only produced by capture runs (the fused CTC generator computes the arg-max alone)");
+            return -1;
+        }
+        src = m->ctc_maxlp; shape = {B, Tp};
     } else if (n == "aligned_seq_shift") { src = m->shift; dtype = CN_DTYPE_I32; shape = {B, Tp};
     } else if (n == "keymask") { src = m->keymask; dtype = CN_DTYPE_U8; shape = {B, Tp};
     } else if (n == "src_size") { src = m->src_size; dtype = CN_DTYPE_I32; shape = {B};
@@ -2438,6 +2448,7 @@ extern "C" int cn_ast_begin(cn_model* m, const float* feats_dev, int32_t B, int3
     if (want_ctc) {
         CN_TRY(run_linear(m, "generator_proj", m->ctc_gen, m->enc_h, d, m->logits, V, 1, Mmem, 0, nullptr, 0, s));
         CN_TRY(launch_logsoftmax_argmax(m->logits, Mmem, V, V, m->best, m->ctc_maxlp, 1, s));
+    m->ctc_maxlp_valid = true;
         CN_TRY(launch_ast_ctc_prepare(m->logits, m->keymask, m->ast_r0, B, m->Tp, V, opts->padding_idx, s));
     }
     return 0;
