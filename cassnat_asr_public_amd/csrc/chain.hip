@@ -45,8 +45,8 @@ constexpr int CH_LDS = CH_TAB_BYTES + CH_RING * CH_UNIT_BYTES;
 static_assert(CH_LDS <= 160 * 1024, "LDS budget");
 // table layout (floats)
 constexpr int CT_BO = 0, CT_LN1A = 256, CT_LN1B = 512, CT_B2 = 768, CT_NLNA = 1024, CT_NLNB = 1280, CT_BT = 1536,
-              CT_B1 = 2304;  // b1: up to 2048 -> 4352 used
-constexpr int CH_MAX_TAIL = 24, CH_MAX_FFN_TILES = 64;
+              CT_B1 = 3072;  // tail biases: up to 1536; b1: up to 2048 -> 5120 = the whole table
+constexpr int CH_MAX_TAIL = 48, CH_MAX_FFN_TILES = 64;
 
 __device__ long long ch_stamps[16];  // phase timestamps of workgroup 0 / wave 0 (investigation aid: CASSNAT_CHAIN_STAMPS)
 
@@ -58,8 +58,10 @@ struct ChainParams {
     int ldctx;
     const uint4* wstream;  // packed units, consumption order
     const float* tab;      // CH_TAB_FLOATS floats
-    bf16* out;             // tail output [M][ldo] bf16 (tail projection, or LNn(x) itself when tail_tiles == 0)
+    bf16* out;             // tail projection [M][ldo] bf16
     int ldo;
+    bf16* ln_out;          // LNn(x) itself [M][ld_ln] bf16, or null (both may be asked for: the last encoder layer writes enc_h
+    int ld_ln;             // and the cross-attention K|V of every decoder-side layer)
     int M, ffn_tiles, tail_tiles, has_next;
     float eps;
     int stamps;
@@ -448,10 +450,10 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     if (p.has_next) {
         ch_layernorm_pack(acc, tab_lane, CT_NLNA, CT_NLNB, p.eps, bop);
         CH_STAMP(7)
-        if (p.tail_tiles == 0) {
+        if (p.ln_out) {
             // y = LNn(x) itself, row-major bf16.  bop[2 nt + s][j] is channel 32 nt + 16 s + 8 (j >> 2) + 4 half + (j & 3)
             if (live) {
-                bf16* op = p.out + (long long)m * p.ldo + 4 * half;
+                bf16* op = p.ln_out + (long long)m * p.ld_ln + 4 * half;
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
 #pragma unroll
@@ -527,8 +529,8 @@ int chain_print_stamps() {
 
 int launch_chain(const ChainArgs& a, hipStream_t s) {
     if (a.d != CH_D || a.dff < 0 || a.dff % 128 != 0 || a.dff / 32 > CH_MAX_FFN_TILES || a.tail_n < 0 || a.tail_n % 256 != 0 ||
-        a.tail_n / 32 > CH_MAX_TAIL || (a.tail_n > 0 && !a.has_next) || (a.has_next && !a.out)) {
-        cn_set_error("chain: needs d_model == 256, d_ff % 128 == 0 <= 2048, tail width % 256 == 0 <= 768");
+        a.tail_n / 32 > CH_MAX_TAIL || (a.tail_n > 0 && (!a.has_next || !a.out)) || (a.has_next && !a.out && !a.ln_out)) {
+        cn_set_error("chain: needs d_model == 256, d_ff % 128 == 0 <= 2048, tail width % 256 == 0 <= 1536");
         return -1;
     }
     if (a.M <= 0) return 0;
@@ -540,6 +542,9 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
     p.tab = a.tab;
     p.out = reinterpret_cast<bf16*>(a.out);
     p.ldo = a.ldo;
+    // (no tail: `out` is where LNn(x) goes, as before)
+    p.ln_out = reinterpret_cast<bf16*>(a.ln_out ? a.ln_out : (a.tail_n == 0 ? a.out : nullptr));
+    p.ld_ln = a.ln_out ? a.ld_ln : a.ldo;
     p.M = a.M;
     p.ffn_tiles = a.dff / 32;
     p.tail_tiles = a.tail_n / 32;

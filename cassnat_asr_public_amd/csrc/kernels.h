@@ -179,6 +179,8 @@ struct ChainArgs {
     const float* tab = nullptr;     // pack_chain table (CHAIN_TAB_FLOATS)
     void* out = nullptr;            // [M][ldo] bf16: tail projection of LNn(x), or LNn(x) itself when tail_n == 0
     int ldo = 0;
+    void* ln_out = nullptr;         // optional: LNn(x) itself [M][ld_ln] bf16 IN ADDITION to a tail projection
+    int ld_ln = 0;
     int M = 0, d = 0, dff = 0, tail_n = 0, has_next = 0;
     // x layout: row-major [M][256], or blocked: 32-row blocks of [32 pieces i = 4 nt + g][64 lanes][4 floats] where lane =
     // (row % 32) + 32 half holds channels 32 nt + 8 g + 4 half + (0..3) - each load/store instruction moves 1 KiB contiguous

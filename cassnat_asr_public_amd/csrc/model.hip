@@ -58,6 +58,7 @@ struct Layer {
     float *pos_proj = nullptr, *pos_u = nullptr, *pos_v = nullptr;
     int rel_R = 0;
     bool conformer = false;
+    int kv_slot = -1;  // >= 0: this layer's cross-attention K|V are columns kv_slot * 2d.. of m->kv_all (written by the last encoder chain)
     Linear qkv;       // self-attention: fused Q|K|V projection
     Linear self_o;
     Linear src_q, src_kv, src_o;  // source attention: Q from the stream, K|V from the encoder memory
@@ -148,6 +149,9 @@ struct cn_model {
     int *best = nullptr, *shift = nullptr, *src_size = nullptr, *ylen = nullptr, *ymax = nullptr, *intervals = nullptr,
         *tok = nullptr, *topk_idx = nullptr;
     float *ctc_maxlp = nullptr, *val = nullptr, *topk_val = nullptr;
+    void* kv_all = nullptr;   // [M][kv_cols] bf16: cross-attention K|V of every decoder-side layer, projected by the last encoder
+    int kv_cols = 0;          // chain launch's tail (0: each layer projects its own into kvm)
+    bool kv_ready = false;    // ... and that launch ran for the current batch
     bool ctc_maxlp_valid = false;  // the fused arg-max-only CTC generator does not produce it
 
     void* cv_a = nullptr;      // conformer convolution module scratch
@@ -637,6 +641,7 @@ int build_weights(cn_model* m) {
     }
     m->enc_norm = pk.norm("encoder.norm", d);
     m->enc_chain.clear();
+    m->kv_cols = 0;
     if (!c.conf_enc && !m->fp8_enc && pk.chain_ok(d, c.d_encff))  // (the TransformerLM's layers are encoder layers: same chains)
         for (int n = 0; n < c.n_enc; ++n) {
             const std::string p = "encoder.layers." + std::to_string(n), q = "encoder.layers." + std::to_string(n + 1);
@@ -644,9 +649,23 @@ int build_weights(cn_model* m) {
                 m->enc_chain.push_back(pk.chain(p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff,
                                                 q + ".sublayer.0.norm",
                                                 {q + ".self_attn.linears.0", q + ".self_attn.linears.1", q + ".self_attn.linears.2"}, d));
-            else
+            else {
+                // the last launch also projects enc_h = encoder.norm(x) onto the cross-attention K|V of every decoder-side
+                // layer (extractor, then mixed-attention decoder): three 8000-row GEMM launches per batch become the tail of
+                // a launch that already holds enc_h in registers
+                std::vector<std::string> kv_tails;
+                if (!lm && !c.ast && !c.conf_dec && pk.chain_ok(d, c.d_decff) && (c.n_extra + c.n_mix_dec) * 2 * d <= 1536) {
+                    for (int j = 0; j < c.n_extra; ++j)
+                        for (int w = 1; w <= 2; ++w)
+                            kv_tails.push_back("acembed_extractor.layers." + std::to_string(j) + ".src_attn.linears." + std::to_string(w));
+                    for (int j = 0; j < c.n_mix_dec; ++j)
+                        for (int w = 1; w <= 2; ++w)
+                            kv_tails.push_back("decoder.layers." + std::to_string(j) + ".src_attn.linears." + std::to_string(w));
+                }
+                m->kv_cols = (int)kv_tails.size() * (int)d;
                 m->enc_chain.push_back(
-                    pk.chain(p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff, "encoder.norm", {}, d));
+                    pk.chain(p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff, "encoder.norm", kv_tails, d));
+            }
         }
     const std::string dec_table = "acembed_extractor.layers.0.pos_enc.embedding.weight";
     for (int n = 0; n < c.n_extra; ++n) {
@@ -682,6 +701,10 @@ int build_weights(cn_model* m) {
             add_src(L, p);
             m->mad.push_back(L);
         }
+    }
+    if (m->kv_cols > 0) {
+        for (size_t j = 0; j < m->extra.size(); ++j) m->extra[j].kv_slot = (int)j;
+        for (size_t j = 0; j < m->mad.size(); ++j) m->mad[j].kv_slot = (int)(m->extra.size() + j);
     }
     if (!lm) m->dec_norm = pk.norm("decoder.norm", d);
     // decoder-side sublayers of the NAT model in execution order, each with the chain that follows its attention
@@ -826,6 +849,7 @@ int build_workspace(cn_model* m) {
     CN_TRY(dev_alloc(m, &m->hbuf, M * dff * es));
     CN_TRY(dev_alloc(m, &m->enc_h, M0 * d * es));
     CN_TRY(dev_alloc(m, &m->kvm, M0 * 2 * d * es));
+    if (m->kv_cols > 0) CN_TRY(dev_alloc(m, &m->kv_all, M0 * (size_t)m->kv_cols * es));
     CN_TRY(dev_alloc(m, &m->qd, M * d * es));
     CN_TRY(dev_alloc(m, &m->dec_h, M * d * es));
     CN_TRY(dev_alloc(m, (void**)&m->xd, (M + 32) * d * 4));
@@ -973,7 +997,7 @@ int run_self_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B,
 // x_mode: CHX_* bits - the fp32 stream is read / written row-major or in the kernel's blocked tile layout, or not written
 enum { CHX_IN_BLK = 1, CHX_OUT_BLK = 2, CHX_NO_STORE = 4 };
 int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ldo, bool with_next, int x_mode,
-              hipStream_t s) {
+              hipStream_t s, void* ln_out = nullptr, int ld_ln = 0) {
     const int d = m->cfg.d_model;
     const int tail_n = with_next ? r.tail_n : 0;
     const double macs = (r.has_wo ? (double)d * d : 0.0) + 2.0 * d * r.dff + (double)d * tail_n;
@@ -986,6 +1010,8 @@ int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ld
     a.tab = r.tab;
     a.out = out;
     a.ldo = ldo;
+    a.ln_out = ln_out;
+    a.ld_ln = ld_ln;
     a.M = M;
     a.d = d;
     a.dff = r.dff;
@@ -1141,15 +1167,20 @@ int run_src_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B, 
 int run_src_attn_core(cn_model* m, const Layer& L, int B, int U, int Tp, const int* intervals, hipStream_t s) {
     const int d = m->cfg.d_model;
     // (B counts query sets: dec_group of them share the keys / values of one utterance)
-    CN_TRY(run_linear(m, "src_kv_proj", L.src_kv, m->enc_h, d, m->kvm, 2 * d, 0, m->B * Tp, 0, nullptr, 0, s));
     AttnArgs a;
+    if (m->kv_ready && L.kv_slot >= 0) {  // projected by the last encoder chain launch
+        a.K = (const unsigned char*)m->kv_all + (size_t)L.kv_slot * 2 * d * m->es;
+        a.ldk = a.ldv = m->kv_cols;
+    } else {
+        CN_TRY(run_linear(m, "src_kv_proj", L.src_kv, m->enc_h, d, m->kvm, 2 * d, 0, m->B * Tp, 0, nullptr, 0, s));
+        a.K = m->kvm;
+        a.ldk = a.ldv = 2 * d;
+    }
+    a.V = (const unsigned char*)a.K + (size_t)d * m->es;
     a.kv_mod = m->dec_group > 1 ? m->B : 0;
     a.Q = m->qd;
-    a.K = m->kvm;
-    a.V = (const unsigned char*)m->kvm + (size_t)d * m->es;
     a.O = m->ctx;
     a.ldq = d;
-    a.ldk = a.ldv = 2 * d;
     a.ldo = d;
     a.B = B;
     a.H = m->cfg.n_head;
@@ -1253,6 +1284,7 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     const bool cap = o->capture != 0;
     m->B = B;
     m->dec_group = 1;
+    m->kv_ready = false;
     m->T = T;
     m->T1 = T1;
     m->Tp = Tp;
@@ -1342,7 +1374,12 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
             // between chain launches the residual stream lives in the kernel's blocked layout; the last layer's x is
             // consumed by nobody (enc_h is the output).  Captures read x row-major.
             const int xm = cap ? 0 : ((n > 0 ? CHX_IN_BLK : 0) | (last ? CHX_NO_STORE : CHX_OUT_BLK));
-            CN_TRY(run_chain(m, m->enc_chain[n], m->x, M, last ? m->enc_h : m->qkv, last ? d : 3 * d, true, xm, s));
+            if (last && m->kv_cols > 0) {  // enc_h and, from the same registers, every decoder-side layer's K|V
+                CN_TRY(run_chain(m, m->enc_chain[n], m->x, M, m->kv_all, m->kv_cols, true, xm, s, m->enc_h, d));
+                m->kv_ready = true;
+            } else {
+                CN_TRY(run_chain(m, m->enc_chain[n], m->x, M, last ? m->enc_h : m->qkv, last ? d : 3 * d, true, xm, s));
+            }
         } else {
             CN_TRY(run_self_attn(m, L, n == 0 ? &L.n[0] : nullptr, m->x, B, Tp, m->keymask, nullptr, 0, s));
             CN_TRY(run_ffn(m, L, L.n[1], m->x, M, last ? &m->enc_norm : &m->enc[n + 1].n[0], last ? m->enc_h : m->xn, s));
@@ -2262,8 +2299,8 @@ extern "C" int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, con
                            const float* w2_host, const float* b2_host, const float* nln_a_host, const float* nln_b_host,
                            const float* wt_host, const float* bt_host, void* out_dev, int32_t ldo, int32_t M, int32_t dff,
                            int32_t tail_n, float eps, int32_t x_mode, void* stream) {
-    if (dff < 0 || dff % 32 != 0 || dff > 2048 || tail_n < 0 || tail_n % 32 != 0 || tail_n > 768) {
-        cn_set_error("cn_op_chain: d_ff and the tail width must be multiples of 32 (<= 2048 / <= 768)");
+    if (dff < 0 || dff % 32 != 0 || dff > 2048 || tail_n < 0 || tail_n % 32 != 0 || tail_n > 1536) {
+        cn_set_error("cn_op_chain: d_ff and the tail width must be multiples of 32 (<= 2048 / <= 1536)");
         return -1;
     }
     ChainWeights w;

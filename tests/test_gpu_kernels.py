@@ -532,6 +532,7 @@ def _from_blocked(xb, M):
     (128, 0, 768, False, True),       # LayerNorm + QKV only (layer-0 entry)
     (77, 2048, 768, False, True),     # FFN + tail without an output projection
     (64, 128, 256, True, True),       # short stream: 3 groups
+    (300, 2048, 1536, True, True),    # the last encoder layer's tail: K|V of three decoder-side layers (6 groups)
 ])
 def test_chain_bf16(M, dff, tail_n, with_ctx, with_next, x_mode):
     from oracle.cassnat_oracle import layer_norm
