@@ -131,6 +131,7 @@ struct cn_model {
     Linear linear_out;  // [d][F2*C] (f,c)
     std::vector<Layer> enc, extra, sad, mad;
     std::vector<ChainRef> enc_chain;  // one per encoder layer when the row-chain path applies, else empty
+    ChainRef enc_entry;               // LayerNorm + Q|K|V projection of encoder layer 0 (the rows come from linear_out)
     std::vector<DecStep> dec_steps;   // decoder-side sublayers with their chains when the path applies, else empty
     Norm enc_norm, dec_norm;
     Linear ctc_gen, att_gen;
@@ -667,6 +668,11 @@ int build_weights(cn_model* m) {
                     pk.chain(p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff, "encoder.norm", kv_tails, d));
             }
         }
+    m->enc_entry = ChainRef();
+    if (!m->enc_chain.empty())
+        m->enc_entry = pk.chain("", "", "", 0, "encoder.layers.0.sublayer.0.norm",
+                                {"encoder.layers.0.self_attn.linears.0", "encoder.layers.0.self_attn.linears.1",
+                                 "encoder.layers.0.self_attn.linears.2"}, d);
     const std::string dec_table = "acembed_extractor.layers.0.pos_enc.embedding.weight";
     for (int n = 0; n < c.n_extra; ++n) {
         const std::string p = "acembed_extractor.layers." + std::to_string(n);
@@ -811,6 +817,7 @@ int build_weights(cn_model* m) {
         rebase(r.tab, base);
     };
     for (auto& r : m->enc_chain) rebase_chain(r);
+    rebase_chain(m->enc_entry);
     for (auto& st : m->dec_steps) {
         rebase_chain(st.chain);
         rebase_chain(st.entry);
@@ -1362,9 +1369,14 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     }
     static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
     const bool chain = !m->enc.empty() && m->enc_chain.size() == m->enc.size() && !no_chain;
-    if (chain) {  // bf16 / d_model 256: LN + QKV of layer 0, then per layer attention -> row-chain kernel
-        CN_TRY(run_ln(m, m->enc[0].n[0], m->x, m->xn, M, s));
-        CN_TRY(run_linear(m, "qkv_proj", m->enc[0].qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
+    if (chain) {  // bf16 / d_model 256: LN + QKV of layer 0 (an entry chain launch: no FFN, x left alone), then per layer
+                  // attention -> row-chain kernel
+        if (m->enc_entry.w) {
+            CN_TRY(run_chain(m, m->enc_entry, m->x, M, m->qkv, 3 * d, true, CHX_NO_STORE, s));
+        } else {
+            CN_TRY(run_ln(m, m->enc[0].n[0], m->x, m->xn, M, s));
+            CN_TRY(run_linear(m, "qkv_proj", m->enc[0].qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
+        }
     }
     for (size_t n = 0; n < m->enc.size(); ++n) {
         const Layer& L = m->enc[n];
@@ -1828,8 +1840,12 @@ extern "C" int cn_lm_score(cn_model* m, const int32_t* tok_dev, const int32_t* t
     static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
     if (!m->enc.empty() && m->enc_chain.size() == m->enc.size() && !no_chain) {
         // bf16 / d_model 256: per layer [causal + length-masked attention] + one row-chain launch, as in stage_encode
-        CN_TRY(run_ln(m, m->enc[0].n[0], x, m->xn, M, s));
-        CN_TRY(run_linear(m, "qkv_proj", m->enc[0].qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
+        if (m->enc_entry.w) {
+            CN_TRY(run_chain(m, m->enc_entry, x, M, m->qkv, 3 * d, true, CHX_NO_STORE, s));
+        } else {
+            CN_TRY(run_ln(m, m->enc[0].n[0], x, m->xn, M, s));
+            CN_TRY(run_linear(m, "qkv_proj", m->enc[0].qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
+        }
         for (size_t n = 0; n < m->enc.size(); ++n) {
             const bool last = n + 1 == m->enc.size();
             CN_TRY(run_self_attn_core(m, B, U, nullptr, len_dev, 1, s));
