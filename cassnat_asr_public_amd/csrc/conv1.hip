@@ -16,6 +16,10 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
     // convolution, conv2.hip): the grid then covers the border cells too.
     // Work decomposition: a workgroup takes whole image rows (b, t1) in a grid-stride loop (one 32-bit division per
     // row, not four 64-bit ones per output); inside a row its 256 threads are (256 / cg) positions x cg channel groups.
+    // halo = 2: the same bordered layout, but the border cells hold their zeros already (same shape as the previous image
+    // in this buffer): they are skipped instead of rewritten
+    const bool skip_border = halo == 2;
+    halo = halo ? 1 : 0;
     const int T1p = T1 + 2 * halo, F1p = F1 + 2 * halo;
     const int c0 = (int)(threadIdx.x % cg) << 3;
     const int p0 = threadIdx.x / cg, pstep = 256 / cg;
@@ -42,6 +46,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
             const int f1 = fp - halo;
             T* dst = orow + (long long)fp * C;
             if (!row_in || f1 < 0 || f1 >= F1) {  // border cell
+                if (skip_border) continue;
                 if constexpr (sizeof(T) == 2) {
                     *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
                 } else {
@@ -89,7 +94,7 @@ int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, 
         cn_set_error("conv1: channel count must be a multiple of 8 with C/8 dividing 256");
         return -1;
     }
-    long long blocks = (long long)B * (T1 + 2 * halo);  // one image row per workgroup pass
+    long long blocks = (long long)B * (T1 + 2 * (halo ? 1 : 0));  // one image row per workgroup pass
     if (blocks > 256 * 8) blocks = 256 * 8;             // 8 workgroups per CU, grid-stride the rest
     if (blocks < 1) blocks = 1;
     const size_t lds = 0;

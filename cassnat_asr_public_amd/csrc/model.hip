@@ -153,6 +153,7 @@ struct cn_model {
     void* kv_all = nullptr;   // [M][kv_cols] bf16: cross-attention K|V of every decoder-side layer, projected by the last encoder
     int kv_cols = 0;          // chain launch's tail (0: each layer projects its own into kvm)
     bool kv_ready = false;    // ... and that launch ran for the current batch
+    int c1_halo_B = -1, c1_halo_T1 = -1;  // shape of the haloed conv1 image the buffer currently holds (-1: none)
     bool ctc_maxlp_valid = false;  // the fused arg-max-only CTC generator does not produce it
 
     void* cv_a = nullptr;      // conformer convolution module scratch
@@ -1300,8 +1301,13 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     // conv1 writes its image with a zero halo when the LDS-DMA conv2 kernel consumes it (captures want the plain image)
     const int halo = (!cap && conv2_dma_applies(m->prec, d, d)) ? 1 : 0;
     {
+        // the halo cells of the image buffer are zero already when the previous haloed image had this very shape (and nothing
+        // else wrote the buffer since): conv1 then writes the interior only (halo mode 2)
+        const bool same = halo && m->c1_halo_B == B && m->c1_halo_T1 == T1;
         ProfScope ps(m, "conv1", 2.0 * 9 * B * T1 * F1 * d, (double)B * T * F * 4 + (double)B * T1 * F1 * d * m->es, s);
-        CN_TRY(launch_conv1(m->prec, feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, halo, s));
+        CN_TRY(launch_conv1(m->prec, feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : halo, s));
+        m->c1_halo_B = halo ? B : -1;
+        m->c1_halo_T1 = halo ? T1 : -1;
     }
     if (cap) CN_TRY(capture(m, "conv1", m->c1, true, CN_DTYPE_F32, {B, T1, F1, d}, s));
     {

@@ -255,3 +255,34 @@ def test_lm_scoring_bf16_fast_path_against_the_fp32_engine():
     a, b = got["fp32"][mask], got["bf16"][mask]
     assert torch.isfinite(b).all()
     assert (a - b).abs().max().item() < 0.12 and (a - b).abs().mean().item() < 0.02
+
+
+def test_bf16_engine_is_stateless_across_calls_of_different_shapes():
+    """The bf16 engine reuses buffers between calls (the zero halo of the conv1 image is only rewritten when the batch shape
+    changes; K|V of the decoder side come from the encoder's last launch): a batch decoded again after a batch of another
+    shape, and again right after itself, gives bit-identical encoder outputs and hypotheses."""
+    args = synth.make_args("config2", N_enc=2)
+    args.hip_precision, args.hip_capture = "bf16", False
+    args.hip_max_batch, args.hip_max_frames = 4, 200
+    state = synth.make_state(args, seed=4, blank_bias=0.3)
+    model = make_model(args.input_size, args).cuda()
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.copy_(torch.from_numpy(state[k]))
+    a = synth.make_feats(2, 64, 80, lengths=[64, 41], seed=1)
+    b = synth.make_feats(4, 200, 80, lengths=[200, 150, 90, 33], seed=2)
+    c = synth.make_feats(3, 64, 80, lengths=[64, 64, 10], seed=3)  # same frame count as `a`, another batch size
+
+    def run(fs):
+        src = torch.from_numpy(fs[0])
+        with torch.no_grad():
+            out, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(fs[1]).cuda(), Vocab, args)
+        return [s[0]["hyp"] for s in out], [s[0]["score"] for s in out], model._engine.fetch("enc_h_live").copy()
+
+    first = run(a)
+    for other in (b, c, a):
+        got = run(other)
+        if other is a:
+            assert got[0] == first[0] and got[1] == first[1] and np.array_equal(got[2], first[2])
+    again = run(a)
+    assert again[0] == first[0] and again[1] == first[1] and np.array_equal(again[2], first[2])
