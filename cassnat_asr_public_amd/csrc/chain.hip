@@ -262,6 +262,8 @@ __device__ __forceinline__ void ch_add_channel(f32x16 (&acc)[8], unsigned tab_la
     X(4, ra1, 8, ra1, 16, 0xC000, 0xC000, sb_next)   X(5, ra1, 24, ra1, 32, 0x10000, 0x10000, sb_next)         \
     X(6, ra1, 40, ra1, 48, 0x14000, 0x14000, sb_next) X(7, ra1, 56, ra0, 0, 0x18000, 0x18000, sb_next)
 
+// SWISH: the feed-forward activation is x * sigmoid(x) (the conformer's macaron halves) instead of ReLU
+template <bool SWISH>
 __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -408,8 +410,13 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
             {                                                                                                 \
                 /* (ReLU as an integer max on the fp32 bits, before the pack: a packed int16 max after it measured slower) */ \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
-                    const int bits = __float_as_int(xh[r]);                                                   \
-                    pb[r >> 3][r & 7] = (bf16)__int_as_float(bits > 0 ? bits : 0);                            \
+                    if constexpr (SWISH) {                                                                    \
+                        const float v_ = xh[r];                                                               \
+                        pb[r >> 3][r & 7] = (bf16)(v_ * (1.f / (1.f + __expf(-v_))));                          \
+                    } else {                                                                                  \
+                        const int bits = __float_as_int(xh[r]);                                               \
+                        pb[r >> 3][r & 7] = (bf16)__int_as_float(bits > 0 ? bits : 0);                        \
+                    }                                                                                         \
                 }                                                                                             \
                 ch_tab4_nowait(tb + ((k) / 2 + 1 < 4 ? ((k) / 2 + 1) * 128 : 0), b1v[0], b1v[1], b1v[2], b1v[3]); \
             }
@@ -558,10 +565,14 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
     p.store_x = a.store_x && (a.ctx || a.dff);
     static bool attr_done = false;
     if (!attr_done) {
-        CN_HIP_CHECK(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
         attr_done = true;
     }
-    hipLaunchKernelGGL(chain_kernel, dim3(cn_ceil_div(p.M, 128)), dim3(256), CH_LDS, s, p);
+    if (a.swish)
+        hipLaunchKernelGGL(chain_kernel<true>, dim3(cn_ceil_div(p.M, 128)), dim3(256), CH_LDS, s, p);
+    else
+        hipLaunchKernelGGL(chain_kernel<false>, dim3(cn_ceil_div(p.M, 128)), dim3(256), CH_LDS, s, p);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -186,6 +186,7 @@ struct ChainArgs {
     // (row % 32) + 32 half holds channels 32 nt + 8 g + 4 half + (0..3) - each load/store instruction moves 1 KiB contiguous
     // (buffer must hold ceil(M / 32) * 32 rows).  store_x = 0: x is not written back (nothing reads it afterwards)
     int x_in_blocked = 0, x_out_blocked = 0, store_x = 1;
+    int swish = 0;  // feed-forward activation: x * sigmoid(x) instead of ReLU (conformer)
     float eps = 1e-6f;
 };
 int launch_chain(const ChainArgs& a, hipStream_t s);

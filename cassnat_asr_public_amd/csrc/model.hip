@@ -49,6 +49,12 @@ struct ConvMod {
     float *gn_w = nullptr, *gn_b = nullptr;  // GroupNorm(1, d) affine
     int k = 0;
 };
+struct ChainRef {
+    void* w = nullptr;
+    float* tab = nullptr;
+    int dff = 0, tail_n = 0;
+    bool has_wo = false, has_next = false, swish = false;
+};
 struct Layer {
     Norm n[5];
     // conformer blocks: w1/w2 are feed_forward1 (or the extractor's feed_forward), ff2_* feed_forward2; relative-position
@@ -58,6 +64,7 @@ struct Layer {
     float *pos_proj = nullptr, *pos_u = nullptr, *pos_v = nullptr;
     int rel_R = 0;
     bool conformer = false;
+    ChainRef cf_a, cf_b, cf_c;  // conformer encoder layer on the row-chain kernel (bf16 / d_model 256): see run_conformer_enc_chain
     int kv_slot = -1;  // >= 0: this layer's cross-attention K|V are columns kv_slot * 2d.. of m->kv_all (written by the last encoder chain)
     Linear qkv;       // self-attention: fused Q|K|V projection
     Linear self_o;
@@ -69,12 +76,6 @@ struct Layer {
 
 // One packed stream of the row-chain kernel (chain.hip): [attention output projection] + [FFN] + [the NEXT sublayer's
 // pre-norm and input projection: tail_n columns, 0 = the norm itself is the output]
-struct ChainRef {
-    void* w = nullptr;
-    float* tab = nullptr;
-    int dff = 0, tail_n = 0;
-    bool has_wo = false, has_next = false;
-};
 // decoder-side sublayers in execution order (extractor: src; SAD: self; MAD: self, src), each followed by its chain
 struct DecStep {
     int stack = 0;       // 0 extractor, 1 SAD, 2 MAD
@@ -518,6 +519,84 @@ struct Packer {
         r.has_next = !nln.empty();
         return r;
     }
+    // The same stream for a conformer sublayer group (fanat_conformer_blocks.py:26-38): explicit tensor names, the
+    // output projection / tail may be a pointwise convolution ([rows][d][1]), the feed-forward is a macaron half -
+    // Swish, and its 0.5 residual scale folded into w_2 and b_2 (a power of two: exact in bf16)
+    struct ConfChain {
+        std::string wo;          // "" or prefix of a [d][d] Linear / [d][d][1] pointwise conv (+ ".bias")
+        bool wo_conv = false;
+        std::string ln1, ffn;    // FFN pre-norm and prefix (".w_1" / ".w_2"), "" = none
+        int64_t dff = 0;
+        float ffn_scale = 1.f;
+        std::string nln;         // next norm ("" = none)
+        std::vector<std::string> tails;  // each a prefix of [rows][d](,1) weights
+        int64_t tail_rows = 0;   // rows per tail tensor
+        bool tail_conv = false;
+    };
+    ChainRef conf_chain(const ConfChain& c, int64_t d) {
+        ChainRef r;
+        const int tail_n = (int)(c.tails.size() * c.tail_rows);
+        const size_t units = chain_stream_units(!c.wo.empty(), (int)c.dff, tail_n);
+        const size_t aw = reserve((units + 7) * CHAIN_UNIT_BYTES), at = reserve((size_t)CHAIN_TAB_FLOATS * 4);
+        if (fill) {
+            ChainWeights w;
+            bool ok = true;
+            auto get = [&](const std::string& n, std::initializer_list<int64_t> shape) -> const float* {
+                const HostTensor* t = find(n, shape);
+                if (!t) ok = false;
+                return t ? t->data.data() : nullptr;
+            };
+            std::vector<float> w2s, b2s;
+            if (!c.wo.empty()) {
+                w.wo = c.wo_conv ? get(c.wo + ".weight", {d, d, 1}) : get(c.wo + ".weight", {d, d});
+                w.bo = get(c.wo + ".bias", {d});
+            }
+            if (c.dff) {
+                w.ln1_a = get(c.ln1 + ".a_2", {d});
+                w.ln1_b = get(c.ln1 + ".b_2", {d});
+                w.w1 = get(c.ffn + ".w_1.weight", {c.dff, d});
+                w.b1 = get(c.ffn + ".w_1.bias", {c.dff});
+                const float* w2 = get(c.ffn + ".w_2.weight", {d, c.dff});
+                const float* b2 = get(c.ffn + ".w_2.bias", {d});
+                if (w2 && b2) {
+                    w2s.assign(w2, w2 + (size_t)d * c.dff);
+                    b2s.assign(b2, b2 + d);
+                    for (auto& v : w2s) v *= c.ffn_scale;
+                    for (auto& v : b2s) v *= c.ffn_scale;
+                    w.w2 = w2s.data();
+                    w.b2 = b2s.data();
+                }
+            }
+            if (!c.nln.empty()) {
+                w.nln_a = get(c.nln + ".a_2", {d});
+                w.nln_b = get(c.nln + ".b_2", {d});
+            }
+            std::vector<float> tw((size_t)tail_n * d), tb((size_t)tail_n);
+            size_t k = 0;
+            for (auto& tp : c.tails) {
+                const float* a = c.tail_conv ? get(tp + ".weight", {c.tail_rows, d, 1}) : get(tp + ".weight", {c.tail_rows, d});
+                const float* b = get(tp + ".bias", {c.tail_rows});
+                if (a && b) {
+                    std::memcpy(&tw[k * c.tail_rows * d], a, (size_t)c.tail_rows * d * 4);
+                    std::memcpy(&tb[k * c.tail_rows], b, (size_t)c.tail_rows * 4);
+                }
+                ++k;
+            }
+            w.wt = tw.data();
+            w.bt = tb.data();
+            w.dff = (int)c.dff;
+            w.tail_n = tail_n;
+            if (ok) pack_chain(w, reinterpret_cast<uint16_t*>(&host[aw]), reinterpret_cast<float*>(&host[at]));
+        }
+        r.w = reinterpret_cast<void*>(aw);
+        r.tab = reinterpret_cast<float*>(at);
+        r.dff = (int)c.dff;
+        r.tail_n = tail_n;
+        r.has_wo = !c.wo.empty();
+        r.has_next = !c.nln.empty();
+        r.swish = c.dff > 0;
+        return r;
+    }
     // generator: the plain matrix (beam search / capture) plus the fused-argmax fragment stream when it applies
     Linear generator(const std::string& prefix, int64_t V, int64_t d) {
         Linear l = linear({prefix}, V, d);
@@ -642,6 +721,39 @@ int build_weights(cn_model* m) {
         }
     }
     m->enc_norm = pk.norm("encoder.norm", d);
+    if (c.conf_enc && pk.chain_ok(d, c.d_encff) && c.d_encff % 128 == 0) {
+        // conformer encoder layer = three row-chain launches around the attention and the depthwise-convolution kernels:
+        //   A: x += 0.5 FFN1(LN x);            next: attention pre-norm + Q|K|V
+        //   B: x += W_o ctx;                   next: convolution pre-norm + pointwise conv 1 (2d columns)
+        //   C: x += pointwise conv 2 (module); x += 0.5 FFN2(LN x);   last layer: encoder.norm -> enc_h
+        for (int n = 0; n < c.n_enc; ++n) {
+            const std::string p = "encoder.layers." + std::to_string(n);
+            Layer& L = m->enc[n];
+            Packer::ConfChain a, b, cc;
+            a.ln1 = p + ".sublayer.0.norm";
+            a.ffn = p + ".feed_forward1";
+            a.dff = c.d_encff;
+            a.ffn_scale = 0.5f;
+            a.nln = p + ".sublayer.2.norm";
+            a.tails = {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"};
+            a.tail_rows = d;
+            L.cf_a = pk.conf_chain(a, d);
+            b.wo = p + ".self_attn.linears.3";
+            b.nln = p + ".sublayer.1.norm";
+            b.tails = {p + ".conv_module.pointwise_conv1"};
+            b.tail_rows = 2 * d;
+            b.tail_conv = true;
+            L.cf_b = pk.conf_chain(b, d);
+            cc.wo = p + ".conv_module.pointwise_conv2";
+            cc.wo_conv = true;
+            cc.ln1 = p + ".sublayer.3.norm";
+            cc.ffn = p + ".feed_forward2";
+            cc.dff = c.d_encff;
+            cc.ffn_scale = 0.5f;
+            if (n + 1 == c.n_enc) cc.nln = "encoder.norm";
+            L.cf_c = pk.conf_chain(cc, d);
+        }
+    }
     m->enc_chain.clear();
     m->kv_cols = 0;
     if (!c.conf_enc && !m->fp8_enc && pk.chain_ok(d, c.d_encff))  // (the TransformerLM's layers are encoder layers: same chains)
@@ -791,6 +903,12 @@ int build_weights(cn_model* m) {
     auto rebase_layers = [&](std::vector<Layer>& v) {
         for (auto& L : v) {
             for (int i = 0; i < 5; ++i) rebase_norm(L.n[i], base);
+            rebase(L.cf_a.w, base);
+            rebase(L.cf_a.tab, base);
+            rebase(L.cf_b.w, base);
+            rebase(L.cf_b.tab, base);
+            rebase(L.cf_c.w, base);
+            rebase(L.cf_c.tab, base);
             rebase_linear(L.ff2_w1, base);
             rebase_linear(L.ff2_w2, base);
             rebase_linear(L.conv.pw1, base);
@@ -1028,6 +1146,7 @@ int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ld
     a.x_in_blocked = (x_mode & CHX_IN_BLK) != 0;
     a.x_out_blocked = (x_mode & CHX_OUT_BLK) != 0;
     a.store_x = (x_mode & CHX_NO_STORE) == 0;
+    a.swish = r.swish ? 1 : 0;
     return launch_chain(a, s);
 }
 
@@ -1113,11 +1232,20 @@ int run_ffn_swish(cn_model* m, const Linear& w1, const Linear& w2, const Norm& n
 }
 
 // x += O(RelAttn(LN(x))) with relative-position scores
+// ctx <- relative-position attention on the fused [M][3d] projection buffer m->qkv
+int run_rel_attn_core(cn_model* m, const Layer& L, int B, int Lseq, const unsigned char* keymask, const int* klen, hipStream_t s);
+
 int run_rel_self_attn(cn_model* m, const Layer& L, const Norm& n, float* x, int B, int Lseq, const unsigned char* keymask,
                       const int* klen, hipStream_t s) {
     const int d = m->cfg.d_model, M = B * Lseq;
     CN_TRY(run_ln(m, n, x, m->xn, M, s));
     CN_TRY(run_linear(m, "qkv_proj", L.qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
+    CN_TRY(run_rel_attn_core(m, L, B, Lseq, keymask, klen, s));
+    return run_linear(m, "out_proj_resid", L.self_o, m->ctx, d, x, d, 1, M, CN_EPI_RESID, x, d, s);
+}
+
+int run_rel_attn_core(cn_model* m, const Layer& L, int B, int Lseq, const unsigned char* keymask, const int* klen, hipStream_t s) {
+    const int d = m->cfg.d_model, M = B * Lseq;
     AttnArgs a;
     const size_t es = m->es;
     a.Q = m->qkv;
@@ -1137,11 +1265,8 @@ int run_rel_self_attn(cn_model* m, const Layer& L, const Norm& n, float* x, int 
     a.rel_v = L.pos_v;
     a.rel_R = L.rel_R;
     a.ld_pos = d;
-    {
-        ProfScope ps(m, "rel_self_attention", 4.0 * B * a.H * (double)Lseq * Lseq * 64, (double)M * 4 * d * m->es, s);
-        CN_TRY(launch_attention(m->prec, a, s));
-    }
-    return run_linear(m, "out_proj_resid", L.self_o, m->ctx, d, x, d, 1, M, CN_EPI_RESID, x, d, s);
+    ProfScope ps(m, "rel_self_attention", 4.0 * B * a.H * (double)Lseq * Lseq * 64, (double)M * 4 * d * m->es, s);
+    return launch_attention(m->prec, a, s);
 }
 
 // x += ConvModule(LN(x))
@@ -1355,6 +1480,31 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         CN_TRY(launch_gemm(m->prec, g, s));
     }
     if (cap) CN_TRY(capture(m, "x_embed", m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
+    static const bool no_chain_c = getenv("CASSNAT_NO_CHAIN") != nullptr;
+    if (c.conf_enc && !m->enc.empty() && m->enc[0].cf_a.w && !no_chain_c) {
+        // conformer encoder on the row-chain kernel: per layer A -> relative-position attention -> B -> GLU / depthwise
+        // conv / GroupNorm + Swish -> C (see build_weights); the residual stream stays in the blocked layout in between
+        for (size_t n = 0; n < m->enc.size(); ++n) {
+            const Layer& L = m->enc[n];
+            const bool last = n + 1 == m->enc.size();
+            const int in0 = (cap || n == 0) ? 0 : CHX_IN_BLK, blk = cap ? 0 : (CHX_IN_BLK | CHX_OUT_BLK);
+            CN_TRY(run_chain(m, L.cf_a, m->x, M, m->qkv, 3 * d, true, in0 | (cap ? 0 : CHX_OUT_BLK), s));
+            CN_TRY(run_rel_attn_core(m, L, B, Tp, m->keymask, nullptr, s));
+            CN_TRY(run_chain(m, L.cf_b, m->x, M, m->cv_a, 2 * d, true, blk, s));
+            {
+                ProfScope ps(m, "conv_glu_depthwise_norm", 2.0 * M * d * L.conv.k, (double)M * d * (4 * m->es + 12), s);
+                CN_TRY(launch_glu(m->prec, m->cv_a, m->xn, M, d, s));
+                CN_TRY(launch_dwconv(m->prec, m->xn, L.conv.dw_w, L.conv.dw_b, m->cv_f, B, Tp, d, L.conv.k, s));
+                CN_TRY(launch_groupnorm_swish(m->prec, m->cv_f, m->gn_stats, L.conv.gn_w, L.conv.gn_b, m->ctx, B, Tp, d, 1e-5f, s));
+            }
+            // (the module's output sits in m->ctx: chain C's output projection is pointwise conv 2)
+            const int xc = cap ? 0 : (CHX_IN_BLK | (last ? CHX_NO_STORE : CHX_OUT_BLK));
+            CN_TRY(run_chain(m, L.cf_c, m->x, M, last ? m->enc_h : nullptr, d, last, xc, s));
+            if (cap) CN_TRY(capture(m, ("enc_layer" + std::to_string(n)).c_str(), m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
+        }
+        if (cap) CN_TRY(capture(m, "enc_h", m->enc_h, true, CN_DTYPE_F32, {B, Tp, d}, s));
+        return 0;
+    }
     if (c.conf_enc) {  // conformer encoder (fanat_conformer_blocks.py:141-170)
         for (size_t n = 0; n < m->enc.size(); ++n) {
             CN_TRY(run_conformer_self_layer(m, m->enc[n], m->x, B, Tp, m->keymask, nullptr, s));
@@ -2366,6 +2516,7 @@ extern "C" int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, con
     a.x_in_blocked = (x_mode & 1) != 0;
     a.x_out_blocked = (x_mode & 2) != 0;
     a.store_x = (x_mode & 4) == 0;
+    a.swish = (x_mode & 8) != 0;
     int rc = launch_chain(a, (hipStream_t)stream);
     if (const char* rep = getenv("CASSNAT_CHAIN_REPEAT")) {  // timing runs only: x keeps being updated
         // CASSNAT_CHAIN_STREAMS = n: the repeats go round-robin onto n private streams (how do concurrent launches share

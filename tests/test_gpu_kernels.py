@@ -523,7 +523,7 @@ def _from_blocked(xb, M):
     return xb.view(nrb, 8, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(nrb * 32, 256)[:M].contiguous()
 
 
-@pytest.mark.parametrize("x_mode", [0, 3, 1, 2])
+@pytest.mark.parametrize("x_mode", [0, 3, 1, 2, 8, 11])  # (bit 8: Swish feed-forward)
 @pytest.mark.parametrize("M,dff,tail_n,with_ctx,with_next", [
     (8000, 2048, 768, True, True),    # encoder layer at config 2: out-proj + FFN + next layer's QKV
     (8000, 2048, 0, True, True),      # last encoder layer: the stack's final LayerNorm is the output
@@ -554,7 +554,8 @@ def test_chain_bf16(M, dff, tail_n, with_ctx, with_next, x_mode):
         ref = ref + F.linear(rounded(ctx, "bf16"), rounded(wo, "bf16"), bo)
     if dff:
         xn = rounded(layer_norm(ref, a1, b1n), "bf16")
-        h = rounded(F.relu(F.linear(xn, rounded(w1, "bf16"), b1)), "bf16")
+        act = F.silu if x_mode & 8 else F.relu
+        h = rounded(act(F.linear(xn, rounded(w1, "bf16"), b1)), "bf16")
         ref = ref + F.linear(h, rounded(w2, "bf16"), b2)
     xd = dev(_to_blocked(x) if x_mode & 1 else x)
     if x_mode & 2 and not x_mode & 1:  # row-major in, blocked out: the buffer must hold whole 32-row blocks
