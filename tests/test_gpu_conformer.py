@@ -74,3 +74,34 @@ def test_conformer_shipped_shape(prec, capsys):
         assert exact == len(out)
     else:
         assert flips <= 0.1 * clear.sum() and ctc_err < 0.2
+
+
+@pytest.mark.parametrize("conv_enc", [True, False])
+def test_conformer_bf16_fast_paths_against_the_fp32_engine(conv_enc):
+    """d_model 256 in bf16: the conformer encoder runs on the Swish row-chain launches; with a transformer encoder under a
+    conformer decoder (what the shipped decode YAML configures) the encoder is the plain row chain and the decoder side the
+    generic conformer kernels.  Both against the fp32 engine on the same weights: encoder output within bf16 error, and - when
+    both pick the same CTC path - the same token counts and a decoder output within the same error."""
+    args = synth.make_args("conf_small", N_enc=3, N_mix_dec=2, use_conv_enc=conv_enc)
+    state = synth.make_state(args, seed=8, blank_bias=0.35)
+    feats, sizes = synth.make_feats(3, 170, 80, lengths=[170, 133, 29], seed=41)
+    got = {}
+    for prec in ("fp32", "bf16"):
+        model = build(args, state, prec, capture=True)
+        decode(model, args, feats, sizes)
+        e = model._engine
+        got[prec] = dict(enc_h=e.fetch("enc_h"), best=e.fetch("best_paths"), ylen=e.fetch("ylen"), dec_h=e.fetch("dec_h"))
+        model2 = build(args, state, prec, capture=False)  # the production call (blocked stream between chain launches)
+        out2 = decode(model2, args, feats, sizes)
+        got[prec]["hyp"] = [s[0]["hyp"] for s in out2]
+        got[prec]["enc_live"] = model2._engine.fetch("enc_h_live")
+    a, b = got["fp32"], got["bf16"]
+    assert np.isfinite(b["enc_h"]).all() and np.isfinite(b["dec_h"]).all()
+    scale = np.abs(a["enc_h"]).max()
+    assert np.abs(a["enc_h"] - b["enc_h"]).max() < 0.06 * scale
+    assert np.abs(b["enc_live"] - b["enc_h"]).max() < 1e-6 * scale + 1e-6  # capture and production layouts: same numbers
+    if (a["best"] == b["best"]).all():
+        np.testing.assert_array_equal(a["ylen"], b["ylen"])
+        for i in range(3):
+            n = int(a["ylen"][i])
+            assert np.abs(a["dec_h"][i, :n] - b["dec_h"][i, :n]).max() < 0.08 * np.abs(a["dec_h"][i, :n]).max()
