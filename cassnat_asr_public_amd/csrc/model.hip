@@ -64,7 +64,7 @@ struct Layer {
     float *pos_proj = nullptr, *pos_u = nullptr, *pos_v = nullptr;
     int rel_R = 0;
     bool conformer = false;
-    ChainRef cf_a, cf_b, cf_c;  // conformer encoder layer on the row-chain kernel (bf16 / d_model 256): see run_conformer_enc_chain
+    ChainRef cf_a, cf_b, cf_c, cf_d;  // conformer layer on the row-chain kernel (bf16 / d_model 256): see conf_layer_chains
     int kv_slot = -1;  // >= 0: this layer's cross-attention K|V are columns kv_slot * 2d.. of m->kv_all (written by the last encoder chain)
     Linear qkv;       // self-attention: fused Q|K|V projection
     Linear self_o;
@@ -721,39 +721,54 @@ int build_weights(cn_model* m) {
         }
     }
     m->enc_norm = pk.norm("encoder.norm", d);
-    if (c.conf_enc && pk.chain_ok(d, c.d_encff) && c.d_encff % 128 == 0) {
-        // conformer encoder layer = three row-chain launches around the attention and the depthwise-convolution kernels:
-        //   A: x += 0.5 FFN1(LN x);            next: attention pre-norm + Q|K|V
-        //   B: x += W_o ctx;                   next: convolution pre-norm + pointwise conv 1 (2d columns)
-        //   C: x += pointwise conv 2 (module); x += 0.5 FFN2(LN x);   last layer: encoder.norm -> enc_h
-        for (int n = 0; n < c.n_enc; ++n) {
-            const std::string p = "encoder.layers." + std::to_string(n);
-            Layer& L = m->enc[n];
-            Packer::ConfChain a, b, cc;
-            a.ln1 = p + ".sublayer.0.norm";
-            a.ffn = p + ".feed_forward1";
-            a.dff = c.d_encff;
-            a.ffn_scale = 0.5f;
-            a.nln = p + ".sublayer.2.norm";
-            a.tails = {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"};
-            a.tail_rows = d;
-            L.cf_a = pk.conf_chain(a, d);
-            b.wo = p + ".self_attn.linears.3";
-            b.nln = p + ".sublayer.1.norm";
-            b.tails = {p + ".conv_module.pointwise_conv1"};
-            b.tail_rows = 2 * d;
-            b.tail_conv = true;
-            L.cf_b = pk.conf_chain(b, d);
-            cc.wo = p + ".conv_module.pointwise_conv2";
-            cc.wo_conv = true;
+    // conformer layer = row-chain launches around the attention and the depthwise-convolution kernels:
+    //   A: x += 0.5 FFN1(LN x);            next: self-attention pre-norm + Q|K|V
+    //   B: x += W_o ctx;                   next: convolution pre-norm + pointwise conv 1 (2d columns)
+    //   C: x += pointwise conv 2 (module); self layers: x += 0.5 FFN2(LN x) (+ `final_norm` -> output after the last one)
+    //      mixed-attention layers: next: source-attention pre-norm + its query projection, then
+    //   D: x += W_o' ctx;  x += 0.5 FFN2(LN x) (+ `final_norm`)
+    auto conf_layer_chains = [&](Layer& L, const std::string& p, int64_t dff, bool mixed, const std::string& final_norm) {
+        Packer::ConfChain a, b, cc, dd;
+        a.ln1 = p + ".sublayer.0.norm";
+        a.ffn = p + ".feed_forward1";
+        a.dff = dff;
+        a.ffn_scale = 0.5f;
+        a.nln = p + ".sublayer.2.norm";
+        a.tails = {p + ".self_attn.linears.0", p + ".self_attn.linears.1", p + ".self_attn.linears.2"};
+        a.tail_rows = d;
+        L.cf_a = pk.conf_chain(a, d);
+        b.wo = p + ".self_attn.linears.3";
+        b.nln = p + ".sublayer.1.norm";
+        b.tails = {p + ".conv_module.pointwise_conv1"};
+        b.tail_rows = 2 * d;
+        b.tail_conv = true;
+        L.cf_b = pk.conf_chain(b, d);
+        cc.wo = p + ".conv_module.pointwise_conv2";
+        cc.wo_conv = true;
+        if (!mixed) {
             cc.ln1 = p + ".sublayer.3.norm";
             cc.ffn = p + ".feed_forward2";
-            cc.dff = c.d_encff;
+            cc.dff = dff;
             cc.ffn_scale = 0.5f;
-            if (n + 1 == c.n_enc) cc.nln = "encoder.norm";
-            L.cf_c = pk.conf_chain(cc, d);
+            cc.nln = final_norm;
+        } else {
+            cc.nln = p + ".sublayer.3.norm";
+            cc.tails = {p + ".src_attn.linears.0"};
+            cc.tail_rows = d;
+            dd.wo = p + ".src_attn.linears.3";
+            dd.ln1 = p + ".sublayer.4.norm";
+            dd.ffn = p + ".feed_forward2";
+            dd.dff = dff;
+            dd.ffn_scale = 0.5f;
+            dd.nln = final_norm;
+            L.cf_d = pk.conf_chain(dd, d);
         }
-    }
+        L.cf_c = pk.conf_chain(cc, d);
+    };
+    if (c.conf_enc && pk.chain_ok(d, c.d_encff) && c.d_encff % 128 == 0)
+        for (int n = 0; n < c.n_enc; ++n)
+            conf_layer_chains(m->enc[n], "encoder.layers." + std::to_string(n), c.d_encff, false,
+                              n + 1 == c.n_enc ? "encoder.norm" : "");
     m->enc_chain.clear();
     m->kv_cols = 0;
     if (!c.conf_enc && !m->fp8_enc && pk.chain_ok(d, c.d_encff))  // (the TransformerLM's layers are encoder layers: same chains)
@@ -820,6 +835,14 @@ int build_weights(cn_model* m) {
             add_src(L, p);
             m->mad.push_back(L);
         }
+    }
+    if (c.conf_dec && pk.chain_ok(d, c.d_decff) && c.d_decff % 128 == 0) {
+        for (int n = 0; n < c.n_self_dec; ++n)
+            conf_layer_chains(m->sad[n], "embed_mapper.layers." + std::to_string(n), c.d_decff, false,
+                              (c.n_mix_dec == 0 && n + 1 == c.n_self_dec) ? "decoder.norm" : "");
+        for (int n = 0; n < c.n_mix_dec; ++n)
+            conf_layer_chains(m->mad[n], "decoder.layers." + std::to_string(n), c.d_decff, true,
+                              n + 1 == c.n_mix_dec ? "decoder.norm" : "");
     }
     if (m->kv_cols > 0) {
         for (size_t j = 0; j < m->extra.size(); ++j) m->extra[j].kv_slot = (int)j;
@@ -909,6 +932,8 @@ int build_weights(cn_model* m) {
             rebase(L.cf_b.tab, base);
             rebase(L.cf_c.w, base);
             rebase(L.cf_c.tab, base);
+            rebase(L.cf_d.w, base);
+            rebase(L.cf_d.tab, base);
             rebase_linear(L.ff2_w1, base);
             rebase_linear(L.ff2_w2, base);
             rebase_linear(L.conv.pw1, base);
@@ -1295,6 +1320,32 @@ int run_conformer_self_layer(cn_model* m, const Layer& L, float* x, int B, int L
 
 int run_src_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B, int U, int Tp, const int* intervals,
                  hipStream_t s);
+int run_src_attn_core(cn_model* m, const Layer& L, int B, int U, int Tp, const int* intervals, hipStream_t s);
+
+// A conformer layer on the row-chain kernel (chains packed by conf_layer_chains in build_weights): A -> relative-position
+// attention -> B -> GLU / depthwise conv / GroupNorm + Swish -> C [-> source attention -> D for a mixed-attention layer].
+// x_in / x_out: CHX_* layout bits of the residual stream at the layer's ends (blocked between its own launches unless
+// `rowmajor`); `final_out`: where the norm packed behind the last chain goes (null: none packed).
+int run_conformer_layer_chain(cn_model* m, const Layer& L, float* x, int B, int Lseq, const unsigned char* keymask, const int* klen,
+                              bool mixed, int Tp, const int* src_intervals, bool rowmajor, int x_in, int x_out, void* final_out,
+                              hipStream_t s) {
+    const int d = m->cfg.d_model, M = B * Lseq;
+    const int mid_in = rowmajor ? 0 : CHX_IN_BLK, mid_out = rowmajor ? 0 : CHX_OUT_BLK;
+    CN_TRY(run_chain(m, L.cf_a, x, M, m->qkv, 3 * d, true, x_in | mid_out, s));
+    CN_TRY(run_rel_attn_core(m, L, B, Lseq, keymask, klen, s));
+    CN_TRY(run_chain(m, L.cf_b, x, M, m->cv_a, 2 * d, true, mid_in | mid_out, s));
+    {
+        ProfScope ps(m, "conv_glu_depthwise_norm", 2.0 * M * d * L.conv.k, (double)M * d * (4 * m->es + 12), s);
+        CN_TRY(launch_glu(m->prec, m->cv_a, m->xn, M, d, s));
+        CN_TRY(launch_dwconv(m->prec, m->xn, L.conv.dw_w, L.conv.dw_b, m->cv_f, B, Lseq, d, L.conv.k, s));
+        // (the module's output goes to m->ctx: the next chain's output projection is pointwise conv 2)
+        CN_TRY(launch_groupnorm_swish(m->prec, m->cv_f, m->gn_stats, L.conv.gn_w, L.conv.gn_b, m->ctx, B, Lseq, d, 1e-5f, s));
+    }
+    if (!mixed) return run_chain(m, L.cf_c, x, M, final_out, d, final_out != nullptr, mid_in | x_out, s);
+    CN_TRY(run_chain(m, L.cf_c, x, M, m->qd, d, true, mid_in | mid_out, s));
+    CN_TRY(run_src_attn_core(m, L, B, Lseq, Tp, src_intervals, s));
+    return run_chain(m, L.cf_d, x, M, final_out, d, final_out != nullptr, mid_in | x_out, s);
+}
 
 // ctx <- Attn(m->qd, enc_h Wk, enc_h Wv) with the padding mask and (optionally) trigger intervals
 int run_src_attn_core(cn_model* m, const Layer& L, int B, int U, int Tp, const int* intervals, hipStream_t s) {
@@ -1485,21 +1536,10 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         // conformer encoder on the row-chain kernel: per layer A -> relative-position attention -> B -> GLU / depthwise
         // conv / GroupNorm + Swish -> C (see build_weights); the residual stream stays in the blocked layout in between
         for (size_t n = 0; n < m->enc.size(); ++n) {
-            const Layer& L = m->enc[n];
             const bool last = n + 1 == m->enc.size();
-            const int in0 = (cap || n == 0) ? 0 : CHX_IN_BLK, blk = cap ? 0 : (CHX_IN_BLK | CHX_OUT_BLK);
-            CN_TRY(run_chain(m, L.cf_a, m->x, M, m->qkv, 3 * d, true, in0 | (cap ? 0 : CHX_OUT_BLK), s));
-            CN_TRY(run_rel_attn_core(m, L, B, Tp, m->keymask, nullptr, s));
-            CN_TRY(run_chain(m, L.cf_b, m->x, M, m->cv_a, 2 * d, true, blk, s));
-            {
-                ProfScope ps(m, "conv_glu_depthwise_norm", 2.0 * M * d * L.conv.k, (double)M * d * (4 * m->es + 12), s);
-                CN_TRY(launch_glu(m->prec, m->cv_a, m->xn, M, d, s));
-                CN_TRY(launch_dwconv(m->prec, m->xn, L.conv.dw_w, L.conv.dw_b, m->cv_f, B, Tp, d, L.conv.k, s));
-                CN_TRY(launch_groupnorm_swish(m->prec, m->cv_f, m->gn_stats, L.conv.gn_w, L.conv.gn_b, m->ctx, B, Tp, d, 1e-5f, s));
-            }
-            // (the module's output sits in m->ctx: chain C's output projection is pointwise conv 2)
-            const int xc = cap ? 0 : (CHX_IN_BLK | (last ? CHX_NO_STORE : CHX_OUT_BLK));
-            CN_TRY(run_chain(m, L.cf_c, m->x, M, last ? m->enc_h : nullptr, d, last, xc, s));
+            const int xin = (cap || n == 0) ? 0 : CHX_IN_BLK, xout = cap ? 0 : (last ? CHX_NO_STORE : CHX_OUT_BLK);
+            CN_TRY(run_conformer_layer_chain(m, m->enc[n], m->x, B, Tp, m->keymask, nullptr, false, 0, nullptr, cap, xin, xout,
+                                             last ? m->enc_h : nullptr, s));
             if (cap) CN_TRY(capture(m, ("enc_layer" + std::to_string(n)).c_str(), m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
         }
         if (cap) CN_TRY(capture(m, "enc_h", m->enc_h, true, CN_DTYPE_F32, {B, Tp, d}, s));
@@ -1619,6 +1659,25 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
             CN_TRY(run_ffn_swish(m, L.w1, L.w2, L.n[0], x, MU, 1.0f, s));
         }
         if (cap) CN_TRY(capture(m, "ac_embed", x, false, CN_DTYPE_F32, {B, U, d}, s));
+        static const bool no_chain_d = getenv("CASSNAT_NO_CHAIN") != nullptr;
+        const bool dchain = !no_chain_d && ((!m->sad.empty() && m->sad[0].cf_a.w) || (!m->mad.empty() && m->mad[0].cf_a.w));
+        if (dchain) {
+            // the self- and mixed-attention conformer layers on the row-chain kernel (the extractor above stays generic);
+            // the stream is row-major where something else reads it (extractor output, the pred_embed capture), blocked otherwise
+            const size_t ns = m->sad.size(), nm = m->mad.size();
+            for (size_t i = 0; i < ns + nm; ++i) {
+                const bool mixed = i >= ns, last = i + 1 == ns + nm;
+                const Layer& L = mixed ? m->mad[i - ns] : m->sad[i];
+                const bool rm_in = cap || i == 0, rm_out = cap;
+                const int xin = rm_in ? 0 : CHX_IN_BLK, xout = last ? CHX_NO_STORE : (rm_out ? 0 : CHX_OUT_BLK);
+                CN_TRY(run_conformer_layer_chain(m, L, x, B, U, nullptr, m->ylen, mixed, Tp, o->src_trigger ? m->intervals : nullptr,
+                                                 cap, xin, xout, last ? m->dec_h : nullptr, s));
+                if (cap && !mixed && i + 1 == ns) CN_TRY(capture(m, "pred_embed", x, false, CN_DTYPE_F32, {B, U, d}, s));
+            }
+            if (cap && ns == 0) CN_TRY(capture(m, "pred_embed", x, false, CN_DTYPE_F32, {B, U, d}, s));
+            if (ns + nm == 0) CN_TRY(run_ln(m, m->dec_norm, x, m->dec_h, MU, s));
+            return stage_decode_tail(m, U, o, hyp, hyp_stride, hyp_len, score, s);
+        }
         for (size_t i = 0; i < m->sad.size(); ++i) CN_TRY(run_conformer_self_layer(m, m->sad[i], x, B, U, nullptr, m->ylen, s));
         if (cap) CN_TRY(capture(m, "pred_embed", x, false, CN_DTYPE_F32, {B, U, d}, s));
         for (size_t i = 0; i < m->mad.size(); ++i) {  // MixAttLayer, relative branch (:85-97)

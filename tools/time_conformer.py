@@ -21,9 +21,11 @@ def main():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--transformer-encoder", action="store_true",
+                    help="use_conv_enc False: transformer encoder under the conformer decoder (the shipped cassnat_decode.yaml)")
     ap.add_argument("--streams", type=int, default=1, help="also time N decode pipelines (pipeline.DecodePipelines) over 40 batches")
     a = ap.parse_args()
-    args = synth.make_args("conf_small")
+    args = synth.make_args("conf_small", use_conv_enc=not a.transformer_encoder)
     args.hip_precision = a.precision
     args.hip_max_batch, args.hip_max_frames = a.batch, a.frames
     state = synth.make_state(args, seed=0, blank_bias=synth.BENCH_BLANK_BIAS)
@@ -55,7 +57,7 @@ def main():
             el = time.perf_counter() - t0
         piped = round(40 * a.batch / el, 1)
         pipes.close()
-    print(json.dumps({"workload": "conformer CASS-NAT (conf_small: 12L conformer encoder, 1+1+6 conformer decoder, d 256, V 1028), greedy",
+    print(json.dumps({"workload": "conformer CASS-NAT (conf_small: 12L %s encoder, 1+1+6 conformer decoder, d 256, V 1028), greedy" % ("transformer" if a.transformer_encoder else "conformer"),
                       "batch": a.batch, "frames": a.frames, "precision": a.precision, "sec_per_batch": round(best, 5),
                       "utt_per_sec": round(a.batch / best, 1), "rtf": round(best / (a.batch * a.frames * 0.01), 7),
                       "tokens_max": int(hyp_len.max()), "pipelines": a.streams, "pipelined_utt_per_sec": piped,
