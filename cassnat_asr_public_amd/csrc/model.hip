@@ -1964,8 +1964,9 @@ extern "C" int cn_decode_nast(cn_model* m, const float* feats_dev, const float* 
 // draws, or select == NULL with n_samples == 1: the best path itself) - and runs the alignment + decoder side on all of
 // them in ONE pass of B * n_samples query sets over the B utterances' encoder outputs (n_samples <= cfg.esa_group, which
 // sizes the decoder-side workspace): tok_out / val_out [n_samples][B][out_stride] = argmax token and its log-probability per
-// decoder row, ylen_out [n_samples][B] (EOS row included), *ymax_host = rows of this pass.  The random draws are the
-// caller's (the reference takes them from torch.randint).
+// decoder row, ylen_out [n_samples][B] (EOS row included), *ymax_host = rows of this pass.  force_U: 0 = decode on this pass's
+// own row count, > 0 = on that many rows, -1 = only count (no decode).  The random draws are the caller's (the reference takes
+// them from torch.randint).
 extern "C" int cn_esa_begin(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts,
                             void* stream) {
     CN_TRY(check_call(m, B, T, F));
@@ -1986,8 +1987,9 @@ extern "C" int cn_esa_begin(cn_model* m, const float* feats_dev, int32_t B, int3
 
 extern "C" int cn_esa_sample(cn_model* m, const uint8_t* select_dev, int32_t n_samples, float threshold,
                              const float* size_ratio_dev, const cn_decode_opts* opts, int32_t* tok_out_dev, float* val_out_dev,
-                             int32_t out_stride, int32_t* ylen_out_dev, int32_t* ymax_host, void* stream) {
-    if (!m || !opts || !tok_out_dev || !val_out_dev || !ylen_out_dev || !ymax_host || m->B < 1 || opts->beam_width != 1) {
+                             int32_t out_stride, int32_t* ylen_out_dev, int32_t* ymax_host, int32_t force_U, void* stream) {
+    if (!m || !opts || !ymax_host || m->B < 1 || opts->beam_width != 1 ||
+        (force_U >= 0 && (!tok_out_dev || !val_out_dev || !ylen_out_dev))) {
         cn_set_error("cn_esa_sample: call cn_esa_begin first; beam_width must be 1");
         return -1;
     }
@@ -2017,7 +2019,21 @@ extern "C" int cn_esa_sample(cn_model* m, const uint8_t* select_dev, int32_t n_s
     CN_TRY(launch_ctc_align(al, s));
     CN_HIP_CHECK(hipMemcpyAsync(m->ymax_pinned, m->ymax, sizeof(int), hipMemcpyDeviceToHost, s));
     CN_HIP_CHECK(hipStreamSynchronize(s));
-    const int U = *m->ymax_pinned;
+    int U = *m->ymax_pinned;
+    if (force_U < 0) {  // count only: the caller wants the row count of these alignments (to take the maximum over all groups)
+        *ymax_host = U;
+        return 0;
+    }
+    if (force_U > 0) {
+        // decode on force_U rows per alignment (>= this pass's own count): the conformer's GroupNorm runs over an utterance's
+        // whole (channels x rows) image, padded rows included, so every group has to use the row count of ALL samples to give
+        // what the reference's one big batch gives
+        if (force_U < U) {
+            cn_set_error("cn_esa_sample: force_U is smaller than the row count of this pass");
+            return -3;
+        }
+        U = force_U;
+    }
     if (U < 1 || U > Tp + 1 || U > out_stride) {
         cn_set_error("cn_esa_sample: token count outside the output stride");
         return -3;

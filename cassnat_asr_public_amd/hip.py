@@ -118,7 +118,7 @@ def lib():
                            C.c_int32, C.c_float, C.c_void_p]
     L.cn_esa_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts), C.c_void_p]
     L.cn_esa_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.POINTER(CnDecodeOpts), C.c_void_p,
-                                C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
+                                C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p]
     L.cn_lm_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.cn_decode_ast.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts),
                                 C.POINTER(CnAstOpts), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -239,14 +239,18 @@ class Engine:
         B, T, F = feats.shape
         check(self.L.cn_esa_begin(self.handle, _ptr(feats), B, T, F, C.byref(opts), current_stream()), "cn_esa_begin")
 
-    def esa_sample(self, select, threshold, size_ratio, opts, tok, val, ylen):
+    def esa_sample(self, select, threshold, size_ratio, opts, tok, val, ylen, force_U=0):
         """One pass over n sampled alignments per utterance (n <= cfg.esa_group): select uint8 (n, B, T') cuda draws (all-zero
-        = the best path) -> rows (U) of this pass; tok / val (n, B, stride), ylen (n, B)."""
+        = the best path) -> rows (U) of this pass; tok / val (n, B, stride), ylen (n, B).  force_U > 0: decode on that many
+        rows; force_U = -1: only count the rows (tok / val / ylen may be None)."""
         ymax = C.c_int32()
-        n = tok.shape[0]
-        assert select.shape[0] == n and select.is_contiguous() and tok.is_contiguous() and val.is_contiguous() and ylen.is_contiguous()
+        n = select.shape[0]
+        assert select.is_contiguous()
+        if force_U >= 0:
+            assert tok.shape[0] == n and tok.is_contiguous() and val.is_contiguous() and ylen.is_contiguous()
         check(self.L.cn_esa_sample(self.handle, _ptr(select), n, float(threshold), _ptr(size_ratio), C.byref(opts), _ptr(tok),
-                                   _ptr(val), tok.shape[2], _ptr(ylen), C.byref(ymax), current_stream()), "cn_esa_sample")
+                                   _ptr(val), tok.shape[2] if tok is not None else 0, _ptr(ylen), C.byref(ymax), int(force_U),
+                                   current_stream()), "cn_esa_sample")
         return ymax.value
 
     def lm_score(self, tok, tgt, length, U, score):

@@ -314,8 +314,8 @@ class CassNAT(nn.Module):
         if getattr(args, "sample_num", 0) > 1:
             if getattr(args, "rank_model", "lm") != "lm" or lm_model is None or not hasattr(lm_model, "score_tokens"):
                 raise NotImplementedError("ESA ranking needs rank_model == 'lm' and a cassnat_asr_public_amd.models.lm.TransformerLM")
-            if args.beam_width != 1 or self._conf_dec or self._hyper.get("conf_enc"):
-                raise NotImplementedError("ESA is implemented for the transformer blocks with beam_width == 1")
+            if args.beam_width != 1:
+                raise NotImplementedError("ESA is implemented for beam_width == 1")
         if getattr(args, "test_hitrate", False):
             raise NotImplementedError("test_hitrate needs the training-time viterbi aligner")
         if self._conf_dec and getattr(args, "use_unimask", False):
@@ -394,10 +394,15 @@ class CassNAT(nn.Module):
         tok = torch.zeros(S, B, stride, dtype=torch.int32, device=dev)
         val = torch.zeros(S, B, stride, dtype=torch.float32, device=dev)
         ylen = torch.zeros(S, B, dtype=torch.int32, device=dev)
-        U = 0
+        U, force = 0, 0
+        if (self._conf_dec or self._hyper.get("conf_enc")) and S > group:
+            # conformer blocks: GroupNorm covers an utterance's padded rows too, so all groups decode on the row count of ALL
+            # samples (what the reference's single batch has); a first, alignment-only sweep finds it
+            force = max(eng.esa_sample(select[g0:min(S, g0 + group)], args.threshold, ratio, opts, None, None, None, force_U=-1)
+                        for g0 in range(0, S, group))
         for g0 in range(0, S, group):
             g1 = min(S, g0 + group)
-            U = max(U, eng.esa_sample(select[g0:g1], args.threshold, ratio, opts, tok[g0:g1], val[g0:g1], ylen[g0:g1]))
+            U = max(U, eng.esa_sample(select[g0:g1], args.threshold, ratio, opts, tok[g0:g1], val[g0:g1], ylen[g0:g1], force_U=force))
         # LM input = [sos] + predictions shifted right; score of every predicted token under the causal + length mask
         tokf, ylf = tok.reshape(S * B, stride), ylen.reshape(S * B)
         lm_in = torch.cat([torch.full((S * B, 1), sos, dtype=torch.int32, device=dev), tokf[:, : stride - 1]], 1).contiguous()

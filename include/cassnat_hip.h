@@ -136,12 +136,14 @@ int cn_decode_ast(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int
  * draws - or select_dev == NULL with n_samples == 1 - give the best path); then alignment -> extractor -> decoder ->
  * generator over B * n_samples query sets that share the B utterances' encoder outputs: tok_out / val_out
  * [n_samples][B][out_stride] = argmax token and its log-probability per decoder row, ylen_out [n_samples][B] (EOS row
- * included), *ymax_host = rows of this pass.  The caller owns the random draws (the reference takes them from
+ * included), *ymax_host = rows of this pass.  force_U: 0 = decode on this pass's own row count; > 0 = on that many rows
+ * (conformer blocks: GroupNorm sees an utterance's padded rows, so every group must use the row count of ALL samples, as the
+ * reference's single batch does); -1 = count only (outputs may be NULL).  The caller owns the random draws (the reference takes them from
  * torch.randint) and loops over groups of samples.  opts->beam_width must be 1. */
 int cn_esa_begin(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts, void* stream);
 int cn_esa_sample(cn_model* m, const uint8_t* select_dev, int32_t n_samples, float threshold, const float* size_ratio_dev,
                   const cn_decode_opts* opts, int32_t* tok_out_dev, float* val_out_dev, int32_t out_stride,
-                  int32_t* ylen_out_dev, int32_t* ymax_host, void* stream);
+                  int32_t* ylen_out_dev, int32_t* ymax_host, int32_t force_U, void* stream);
 /* TransformerLM (src/models/lm.py; model created with cfg.ast = 2: n_enc layers of width d_encff, parameters
  * text_embed.0.lut / encoder.* / out_generator.proj): score[b][u] = log p(tgt[b][u] | tok[b][0..u]) with key j allowed
  * iff j <= u and j < len[b].  tok / tgt / score are [B][ld] with ld >= U. */

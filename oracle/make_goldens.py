@@ -155,7 +155,8 @@ def top2_margin(ctc_out):
 def main():
     from cassnat_asr_public_amd import synth
 
-    only = sys.argv[1] if len(sys.argv) > 1 else None  # regenerate one fixture group only: 'conformer' or 'config5_shape'
+    only = sys.argv[1] if len(sys.argv) > 1 else None  # regenerate one fixture group only: 'conformer', 'esa' or 'config5_shape'
+    only_name = sys.argv[2] if len(sys.argv) > 2 else None  # ... and within 'esa' one fixture by name
 
     torch, make_model = import_reference()
     torch.manual_seed(0)
@@ -167,11 +168,15 @@ def main():
     if only in (None, "esa"):
         from models.lm import make_model as make_lm
 
+        # (esa_conf_tiny: the shipped decode YAML's combination in small - conformer decoder blocks under ESA)
         for name, preset, lmp, bshape, seed in (("esa_tiny", "tiny", "tiny_lm", (3, 61, [61, 50, 37]), 777),
-                                                ("esa_config2", "config2", "lm_small", (2, 300, [300, 231]), 4242)):
+                                                ("esa_config2", "config2", "lm_small", (2, 300, [300, 231]), 4242),
+                                                ("esa_conf_tiny", "tiny_conf", "tiny_lm", (3, 61, [61, 50, 37]), 31337)):
+            if only_name and name != only_name:
+                continue
             ae = synth.make_args(preset, sample_num=4, threshold=0.9, rank_model="lm")
             la = synth.make_args_lm(lmp, vocab_size=ae.vocab_size)
-            se = synth.make_state(ae, seed=0, gain=2.0) if preset == "tiny" else synth.make_state(ae, seed=0, blank_bias=0.35)
+            se = synth.make_state(ae, seed=0, gain=2.0) if preset.startswith("tiny") else synth.make_state(ae, seed=0, blank_bias=0.35)
             sl = synth.make_state(la, seed=9, gain=2.0)
             fe, ze = synth.make_feats(bshape[0], bshape[1], 80, lengths=bshape[2], seed=11)
             model = make_model(ae.input_size, ae).eval()

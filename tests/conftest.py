@@ -90,10 +90,11 @@ def esa_case(which):
     from cassnat_asr_public_amd import synth
 
     preset, lmp, (B, T, lens) = {"esa_tiny": ("tiny", "tiny_lm", (3, 61, [61, 50, 37])),
-                                 "esa_config2": ("config2", "lm_small", (2, 300, [300, 231]))}[which]
+                                 "esa_config2": ("config2", "lm_small", (2, 300, [300, 231])),
+                                 "esa_conf_tiny": ("tiny_conf", "tiny_lm", (3, 61, [61, 50, 37]))}[which]
     args = synth.make_args(preset, sample_num=4, threshold=0.9, rank_model="lm")
     lm_args = synth.make_args_lm(lmp, vocab_size=args.vocab_size)
-    state = synth.make_state(args, seed=0, gain=2.0) if preset == "tiny" else synth.make_state(args, seed=0, blank_bias=0.35)
+    state = synth.make_state(args, seed=0, gain=2.0) if preset.startswith("tiny") else synth.make_state(args, seed=0, blank_bias=0.35)
     lm_state = synth.make_state(lm_args, seed=9, gain=2.0)
     feats, sizes = synth.make_feats(B, T, 80, lengths=lens, seed=11)
     return args, lm_args, state, lm_state, feats, sizes

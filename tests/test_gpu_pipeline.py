@@ -284,7 +284,8 @@ def test_bf16_production_path_against_golden(capsys):
 
 
 # ------------------------------------------------------------------------------------------- ESA + LM ranking (8f rank 3)
-@pytest.mark.parametrize("which,prec", [("esa_tiny", "fp32"), ("esa_config2", "fp32"), ("esa_config2", "bf16")])
+@pytest.mark.parametrize("which,prec", [("esa_tiny", "fp32"), ("esa_config2", "fp32"), ("esa_config2", "bf16"),
+                                        ("esa_conf_tiny", "fp32")])  # (conformer blocks under ESA: the shipped YAML's combination)
 def test_esa_sampling_with_lm_ranking(which, prec, capsys):
     """sample_num = 4 alignments per utterance (random draws = the fixture's, i.e. the reference's torch.randint stream),
     TransformerLM ranking on the device.  fp32: hypotheses (up to the position the reference reads from a masked row, see
@@ -314,7 +315,7 @@ def test_esa_sampling_with_lm_ranking(which, prec, capsys):
     if prec == "fp32":
         assert same == len(out)
         np.testing.assert_allclose([s[0]["score"] for s in out], g["score"], rtol=1e-5, atol=2e-3)
-    if which == "esa_tiny":  # the samples go through the decoder side in groups: any group size gives the same answer
+    if which in ("esa_tiny", "esa_conf_tiny"):  # the samples go through the decoder side in groups: any group size gives the same answer
         for group in (1, 3):
             args.hip_esa_group = group
             with torch.no_grad():
