@@ -174,3 +174,38 @@ def decode_nast_conformer(state, feats, size_ratio, args, stages=False):
         out.update(enc_layers=layers, enc_h=enc_h, ctc_out=ctc_out, trigger=trig, ac_embed=ac, pred_embed=pred, dec_h=dec_h,
                    att_out=att_out, src_mask=src_mask)
     return out
+
+
+def decode_nast_esa_conformer(state, lm_state, feats, size_ratio, args, lm_args, select, sos=1):
+    """ESA decoding (cassnat_oracle.decode_nast_esa: src/models/cassnat.py:370-376, 441-445, 499-561) with the conformer blocks
+    of this file in place of the transformer ones - the shipped cassnat_decode.yaml's combination (use_conv_dec + sample_num)."""
+    from .cassnat_oracle import decode_nast_esa
+
+    H = args.n_head
+
+    def encode(st, feats_t, x_mask):
+        if args.use_conv_enc:
+            x, src_mask, pos = conv_embed_rel(st, feats_t, x_mask, args.enc_max_relative_len)
+            for n in range(args.N_enc):
+                x = conformer_self_layer(st, f"encoder.layers.{n}", x, src_mask, pos, H)
+            return layer_norm(x, st["encoder.norm.a_2"], st["encoder.norm.b_2"]), src_mask
+        from .cassnat_oracle import conv_embed, encoder
+        x, src_mask, _, _ = conv_embed(st, feats_t, x_mask)
+        return encoder(st, x, src_mask, args.N_enc, H), src_mask
+
+    def decode(st, queries, memory, src_mask, trigger_t, tmask_t):
+        assert args.use_conv_dec and args.N_extra == 1
+        d, ymax = memory.size(-1), queries.size(1)
+        cross_mask = trigger_t if args.src_trigger else src_mask
+        p = "acembed_extractor.layers.0"
+        ac = multi_head_attention(st, p + ".src_attn", queries, memory, memory, trigger_t, H) * math.sqrt(d)
+        dpos = rel_pos_embed(d, ymax, args.dec_max_relative_len)
+        ac = ac + feed_forward_swish(st, p + ".feed_forward", layer_norm(ac, st[p + ".sublayer.norm.a_2"], st[p + ".sublayer.norm.b_2"]))
+        x = ac
+        for n in range(args.N_self_dec):
+            x = conformer_self_layer(st, f"embed_mapper.layers.{n}", x, tmask_t, dpos, H)
+        for n in range(args.N_mix_dec):
+            x = conformer_mix_layer(st, f"decoder.layers.{n}", x, memory, cross_mask, tmask_t, dpos, H)
+        return layer_norm(x, st["decoder.norm.a_2"], st["decoder.norm.b_2"])
+
+    return decode_nast_esa(state, lm_state, feats, size_ratio, args, lm_args, select, sos=sos, encode_fn=encode, decode_fn=decode)

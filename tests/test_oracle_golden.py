@@ -182,14 +182,18 @@ def test_conformer_shipped_shape():
 
 
 # ------------------------------------------------------------------------------------------- ESA + LM ranking (8f rank 3)
-@pytest.mark.parametrize("which", ["esa_tiny", "esa_config2"])
+@pytest.mark.parametrize("which", ["esa_tiny", "esa_config2", "esa_conf_tiny"])
 def test_esa_sampling_and_lm_ranking(which):
     """The random 0/1 draws of cassnat.py:372 are an input (stored in the fixture).  A hypothesis shorter than the longest
     selected one ends with one token read from an all-zero (masked) row: the reference takes torch.topk of equal values
     there, which is implementation-defined - compared up to that position, scores (unaffected: + 0.0) in full."""
     g = load_golden(which)
     args, lm_args, state, lm_state, feats, sizes = esa_case(which)
-    out = orc.decode_nast_esa(state, lm_state, feats, sizes, args, lm_args, torch.from_numpy(g["select"].astype(np.int64)))
+    if getattr(args, "use_conv_dec", False):  # conformer blocks under ESA: the shipped decode YAML's combination
+        from oracle.conformer_oracle import decode_nast_esa_conformer as esa_fn
+    else:
+        esa_fn = orc.decode_nast_esa
+    out = esa_fn(state, lm_state, feats, sizes, args, lm_args, torch.from_numpy(g["select"].astype(np.int64)))
     for b, h in enumerate(out["hyps"]):
         n = int(out["ylen"][b]) + 1  # sos + ylen tokens are well defined
         assert len(h) == g["hyp_len"][b]
