@@ -105,3 +105,39 @@ def test_conformer_bf16_fast_paths_against_the_fp32_engine(conv_enc):
         for i in range(3):
             n = int(a["ylen"][i])
             assert np.abs(a["dec_h"][i, :n] - b["dec_h"][i, :n]).max() < 0.08 * np.abs(a["dec_h"][i, :n]).max()
+
+
+def test_esa_on_the_conformer_decoder_bf16_runs_the_chain_path_in_groups(capsys):
+    """The shipped decode YAML's combination at d_model 256 in bf16: transformer encoder (row chain), conformer decoder (Swish
+    row chain, GroupNorm over padded rows), ESA with 6 samples in groups of 4 + 2 and TransformerLM ranking.  Against the fp32
+    engine with the same draws: reported; gated on finite scores of the fp32 order and mostly identical token counts."""
+    from cassnat_asr_public_amd.models.lm import make_model as make_lm
+
+    args = synth.make_args("conf_small", N_enc=2, N_mix_dec=2, use_conv_enc=False, sample_num=6, threshold=0.9, rank_model="lm")
+    args.hip_esa_group = 4
+    lm_args = synth.make_args_lm("lm_small", vocab_size=args.vocab_size)
+    state = synth.make_state(args, seed=8, blank_bias=0.35)
+    lm_state = synth.make_state(lm_args, seed=9, gain=2.0)
+    feats, sizes = synth.make_feats(3, 170, 80, lengths=[170, 133, 29], seed=41)
+    Tp = ((170 - 1) // 2 + 1 - 1) // 2 + 1
+    args.esa_select = torch.randint(0, 2, (3 * 6, Tp, 1), generator=torch.Generator().manual_seed(5))
+    res = {}
+    for prec in ("fp32", "bf16"):
+        lm_args.hip_precision = prec
+        model = build(args, state, prec)
+        lm = make_lm(lm_args).cuda()
+        with torch.no_grad():
+            for k, p in lm.named_parameters():
+                p.copy_(torch.from_numpy(lm_state[k]))
+            src = torch.from_numpy(feats)
+            out, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, args, lm)
+        res[prec] = out
+    with capsys.disabled():
+        print("\n[ESA conformer decoder] lengths fp32 / bf16:", [len(s[0]["hyp"]) for s in res["fp32"]], [len(s[0]["hyp"]) for s in res["bf16"]],
+              "scores", [round(s[0]["score"], 2) for s in res["fp32"]], [round(s[0]["score"], 2) for s in res["bf16"]])
+    # (random weights: the LM ranks the six samples almost level, so bf16 may pick another sample than fp32 - the gate is on the
+    # order of magnitude, per token)
+    for a, b in zip(res["fp32"], res["bf16"]):
+        assert np.isfinite(b[0]["score"]) and abs(len(a[0]["hyp"]) - len(b[0]["hyp"])) <= 8
+        pa, pb = a[0]["score"] / len(a[0]["hyp"]), b[0]["score"] / len(b[0]["hyp"])
+        assert abs(pa - pb) < 0.3 * abs(pa) + 0.2
