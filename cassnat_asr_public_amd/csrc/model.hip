@@ -100,6 +100,7 @@ struct Capture {
     size_t bytes = 0;
     int dtype = CN_DTYPE_F32;
     std::vector<int64_t> shape;
+    long long call = -1;  // the engine call (cn_model::call_id) that produced it
 };
 
 inline uint16_t f32_to_bf16_host(float f) {
@@ -154,6 +155,7 @@ struct cn_model {
     void* kv_all = nullptr;   // [M][kv_cols] bf16: cross-attention K|V of every decoder-side layer, projected by the last encoder
     int kv_cols = 0;          // chain launch's tail (0: each layer projects its own into kvm)
     bool kv_ready = false;    // ... and that launch ran for the current batch
+    long long call_id = 0;  // counts encoder passes: a captured tensor is only served for the call that wrote it
     int c1_halo_B = -1, c1_halo_T1 = -1;  // shape of the haloed conv1 image the buffer currently holds (-1: none)
     bool ctc_maxlp_valid = false;  // the fused arg-max-only CTC generator does not produce it
 
@@ -1039,6 +1041,7 @@ int capture(cn_model* m, const char* name, const void* src, bool model_prec, int
     }
     cp.dtype = dtype;
     cp.shape = shape;
+    cp.call = m->call_id;
     if (model_prec)
         CN_TRY(launch_convert_back(m->prec, src, (float*)cp.p, n, s));
     else
@@ -1467,6 +1470,7 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     const int M = B * Tp;
     const bool cap = o->capture != 0;
     m->B = B;
+    ++m->call_id;
     m->dec_group = 1;
     m->kv_ready = false;
     m->T = T;
@@ -2184,7 +2188,8 @@ extern "C" int cn_fetch(cn_model* m, const char* name, void* host_dst, int64_t m
     bool model_prec = false;
     const int64_t B = m->B, Tp = m->Tp, U = m->U, d = m->cfg.d_model;
     auto it = m->captures.find(n);
-    if (it != m->captures.end()) {
+    const bool stale = it != m->captures.end() && it->second.call != m->call_id;  // captured by an earlier call: not served
+    if (it != m->captures.end() && !stale) {
         src = it->second.p;
         dtype = it->second.dtype;
         shape = it->second.shape;
@@ -2206,6 +2211,9 @@ extern "C" int cn_fetch(cn_model* m, const char* name, void* host_dst, int64_t m
     } else if (n == "topk_idx") { src = m->topk_idx; dtype = CN_DTYPE_I32; shape = {B, U, m->last_k};
     } else if (n == "topk_val") { src = m->topk_val; shape = {B, U, m->last_k};
     } else if (n == "enc_h_live") { src = m->enc_h; model_prec = true; shape = {B, Tp, d};
+    } else if (stale) {
+        cn_set_error("cn_fetch: '" + n + "' was captured by an earlier call, not by the last one (capture is a per-call option)");
+        return -1;
     } else {
         cn_set_error("cn_fetch: unknown tensor '" + n + "' (captures need opts.capture=1)");
         return -1;

@@ -286,3 +286,48 @@ def test_bf16_engine_is_stateless_across_calls_of_different_shapes():
             assert got[0] == first[0] and got[1] == first[1] and np.array_equal(got[2], first[2])
     again = run(a)
     assert again[0] == first[0] and again[1] == first[1] and np.array_equal(again[2], first[2])
+
+
+def test_randomised_shapes_and_options_against_the_oracle():
+    """30 random cases on the tiny model, fp32 engine vs the oracle: batch 1-5, 1-140 frames, ragged lengths (down to one
+    frame), trigger dilation, src_trigger, use_unimask, blank bias from 'every frame a token' to 'almost none', one engine
+    reused throughout.  Integer results identical whenever no near-tie frame flipped; log-posteriors within 1e-3 always."""
+    rng = np.random.default_rng(20260930)
+    base = synth.make_args("tiny")
+    base.hip_max_batch, base.hip_max_frames = 5, 140
+    models = {}
+    flipped = 0
+    for case in range(30):
+        B, T = int(rng.integers(1, 6)), int(rng.integers(1, 141))
+        lens = sorted((int(v) for v in rng.integers(1, T + 1, size=B)), reverse=True)
+        lens[0] = T
+        ov = dict(left_trigger=int(rng.integers(0, 2)), right_trigger=int(rng.integers(0, 2)), src_trigger=bool(rng.integers(0, 2)),
+                  use_unimask=bool(rng.integers(0, 2)))
+        bias = float(rng.choice([0.0, 1.0, 3.0, 8.0]))
+        args = synth.make_args("tiny", **ov)
+        args.hip_max_batch, args.hip_max_frames = 5, 140
+        args.hip_precision, args.hip_capture = "fp32", True  # (the capture switch is read per call)
+        state = synth.make_state(args, seed=0, gain=2.0, blank_bias=bias)
+        if bias not in models:  # one engine per weight set, reused across shapes and options
+            models[bias] = build(args, state)
+        model = models[bias]
+        feats, sizes = synth.make_feats(B, T, 80, lengths=lens, seed=1000 + case)
+        out, ref = run_both(model, state, args, feats, sizes)
+        flipped += not assert_same(model, out, ref)
+    assert flipped <= 3  # near-tie frames are rare
+
+
+def test_fetch_refuses_captures_of_an_earlier_call():
+    from cassnat_asr_public_amd import hip as _hip
+
+    args = synth.make_args("tiny")
+    state = synth.make_state(args, seed=0, gain=2.0)
+    model = build(args, state, capture=True)
+    feats, sizes = synth.make_feats(2, 40, 80, lengths=[40, 31], seed=2)
+    run_both(model, state, args, feats, sizes)
+    assert model._engine.fetch("ctc_out").shape[0] == 2
+    args.hip_capture = False
+    run_both(model, state, args, feats[:1], sizes[:1])
+    with pytest.raises(_hip.HipError, match="earlier call"):
+        model._engine.fetch("ctc_out")
+    assert model._engine.fetch("best_paths").shape[0] == 1  # live buffers are always served
