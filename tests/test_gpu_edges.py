@@ -331,3 +331,47 @@ def test_fetch_refuses_captures_of_an_earlier_call():
     with pytest.raises(_hip.HipError, match="earlier call"):
         model._engine.fetch("ctc_out")
     assert model._engine.fetch("best_paths").shape[0] == 1  # live buffers are always served
+
+
+def test_randomised_shapes_bf16_fast_path_against_the_fp32_engine():
+    """16 random batch shapes (1-6 utterances, 1-330 frames, ragged) through ONE bf16 engine (fused kernels: tiles of 128 / 256
+    rows, so M = B * T' lands on and around tile boundaries) and ONE fp32 engine on the same weights: encoder output within bf16
+    error for every shape, decoder output too whenever both pick the same CTC path."""
+    args = synth.make_args("config2", N_enc=2)
+    args.hip_max_batch, args.hip_max_frames = 6, 330
+    state = synth.make_state(args, seed=4, blank_bias=0.3)
+    eng = {}
+    for prec in ("fp32", "bf16"):
+        a = synth.make_args("config2", N_enc=2)
+        a.hip_max_batch, a.hip_max_frames, a.hip_precision, a.hip_capture = 6, 330, prec, True
+        m = make_model(a.input_size, a).cuda()
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                p.copy_(torch.from_numpy(state[k]))
+        eng[prec] = (m, a)
+    rng = np.random.default_rng(77)
+    same_path = 0
+    for case in range(16):
+        B = int(rng.integers(1, 7))
+        T = int(rng.choice([int(rng.integers(1, 331)), 4 * int(rng.choice([32, 64, 128 // B + 1])) - int(rng.integers(0, 4))]))
+        T = max(1, min(T, 330))
+        lens = sorted((int(v) for v in rng.integers(1, T + 1, size=B)), reverse=True)
+        lens[0] = T
+        feats, sizes = synth.make_feats(B, T, 80, lengths=lens, seed=500 + case)
+        got = {}
+        for prec, (m, a) in eng.items():
+            src = torch.from_numpy(feats)
+            with torch.no_grad():
+                m.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, a)
+            e = m._engine
+            got[prec] = dict(enc_h=e.fetch("enc_h"), best=e.fetch("best_paths"), ylen=e.fetch("ylen"), dec_h=e.fetch("dec_h"))
+        x, y = got["fp32"], got["bf16"]
+        assert np.isfinite(y["enc_h"]).all() and np.isfinite(y["dec_h"]).all(), (case, B, T)
+        assert np.abs(x["enc_h"] - y["enc_h"]).max() < 0.06 * np.abs(x["enc_h"]).max(), (case, B, T)
+        if (x["best"] == y["best"]).all():
+            same_path += 1
+            np.testing.assert_array_equal(x["ylen"], y["ylen"])
+            for i in range(B):
+                n = int(x["ylen"][i])
+                assert np.abs(x["dec_h"][i, :n] - y["dec_h"][i, :n]).max() < 0.08 * np.abs(x["dec_h"][i, :n]).max(), (case, B, T, i)
+    assert same_path >= 4
