@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--streams", type=int, default=4,
                     help="decode pipelines per GPU (own engine handle, HIP stream and host thread each): keeps the GPU fed "
                          "across the two host syncs every batch needs (token count readback, hypotheses to host)")
+    ap.add_argument("--no-coalesced", action="store_true",
+                    help="skip the extra measurement with pairs of batches coalesced into one engine pass (reported separately, "
+                         "never as `value`)")
     a = ap.parse_args()
 
     import numpy as np
@@ -233,6 +236,32 @@ def main():
     if roofline is None:
         roofline = roofline_conv2
 
+    # ---- extra (never `value`): the same steps with the pipelines coalescing pairs of batches into one engine pass - wider
+    # launches, per-batch hypotheses unchanged (cn_decode_opts.sub_batch); what CassNATTask.decode does for test sets
+    coalesced = None
+    if not a.no_coalesced and a.precision != "fp32":
+        pipes2 = DecodePipelines(model, NS, B, T, with_weights=(rank == 0), after_engine=receive_weights, coalesce=2)
+
+        def run2(n_steps):
+            for _ in pipes2.decode(((feats, sizes, k) for k in range(n_steps)), args, sos=1, gather=world > 1, as_lists=False):
+                pass
+
+        run2(max(a.warmup, 2 * NS))
+        fence()
+        c0 = time.perf_counter()
+        run2(a.steps)
+        fence()
+        el2 = time.perf_counter() - c0
+        if world > 1:
+            tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el2 = float(tt.item())
+        coalesced = {"value": round(a.steps * B * world / el2, 2), "unit": "utt/s", "ms_per_step": round(el2 / a.steps * 1e3, 4),
+                     "note": "same workload and step count; each decode pipeline takes two batches of 32 through one engine pass "
+                             "(hypotheses and scores per batch identical to separate passes: tests/test_gpu_edges.py); reported "
+                             "beside, not as, `value`"}
+        pipes2.close()
+
     cpu = None
     if not a.no_cpu_baseline and world == 1:
         from oracle import cassnat_oracle as orc
@@ -283,7 +312,8 @@ def main():
         "rtf": round(elapsed / audio_s, 8), "rtfx": round(audio_s / elapsed, 1),
         "gflop_per_utt": round(flops / B / 1e9, 3),
         "mfma_frac_end_to_end": round(flops / B * value / (PEAK_BF16_DENSE_TFLOPS * 1e12), 5),
-        "roofline": roofline, "roofline_conv2": roofline_conv2, "cpu_baseline": cpu, "stage_ms": stage_ms,
+        "roofline": roofline, "roofline_conv2": roofline_conv2, "cpu_baseline": cpu, "coalesced_pairs": coalesced,
+        "stage_ms": stage_ms,
         "weight_blob_mb": round(blob_bytes / 1e6, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
     }
     print(json.dumps(out), flush=True)

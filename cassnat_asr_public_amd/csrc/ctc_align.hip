@@ -119,13 +119,22 @@ int launch_ctc_align(const AlignArgs& a, hipStream_t s) {
 
 // beam_width == 1 case of src/models/cassnat.py:574-637: position i is consumed while i <= ylen[b]
 // (ylen already includes the EOS row), the score is a sequential double sum of the float32 maxima.
+// sub > 0: the batch is `B / sub` coalesced reference batches of `sub` utterances each; the row limit of an utterance is then
+// the largest ylen of ITS batch (what U would have been had that batch been decoded alone), so its hypothesis is the same.
 __global__ void greedy_pack_kernel(const int* __restrict__ tok, const float* __restrict__ val,
                                    const int* __restrict__ ylen, int B, int U, int sos, int hyp_stride,
-                                   int* __restrict__ hyp, int* __restrict__ hyp_len, double* __restrict__ score) {
+                                   int* __restrict__ hyp, int* __restrict__ hyp_len, double* __restrict__ score, int sub) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    int ulim = U;
+    if (sub > 0 && sub < B) {
+        const int b0 = (b / sub) * sub, b1 = b0 + sub < B ? b0 + sub : B;
+        ulim = 0;
+        for (int j = b0; j < b1; ++j) ulim = ylen[j] > ulim ? ylen[j] : ulim;
+        if (ulim > U) ulim = U;
+    }
     int n = ylen[b] + 1;
-    if (n > U) n = U;
+    if (n > ulim) n = ulim;
     if (n > hyp_stride - 1) n = hyp_stride - 1;
     int* h = hyp + (long long)b * hyp_stride;
     h[0] = sos;
@@ -140,10 +149,10 @@ __global__ void greedy_pack_kernel(const int* __restrict__ tok, const float* __r
 }
 
 int launch_greedy_pack(const int* tok, const float* val, const int* ylen, int B, int U, int sos, int hyp_stride,
-                       int* hyp, int* hyp_len, double* score, hipStream_t s) {
+                       int* hyp, int* hyp_len, double* score, hipStream_t s, int sub) {
     if (B <= 0) return 0;
     hipLaunchKernelGGL(greedy_pack_kernel, dim3(cn_ceil_div(B, 64)), dim3(64), 0, s, tok, val, ylen, B, U, sos,
-                       hyp_stride, hyp, hyp_len, score);
+                       hyp_stride, hyp, hyp_len, score, sub);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

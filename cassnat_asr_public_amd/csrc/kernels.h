@@ -118,7 +118,7 @@ struct AlignArgs {
 int launch_ctc_align(const AlignArgs& a, hipStream_t s);
 // hyp[b] = [sos] + tok[b][0 .. min(ylen[b]+1, U)) ; score = sequential double sum of val
 int launch_greedy_pack(const int* tok, const float* val, const int* ylen, int B, int U, int sos, int hyp_stride,
-                       int* hyp, int* hyp_len, double* score, hipStream_t s);
+                       int* hyp, int* hyp_len, double* score, hipStream_t s, int sub = 0);
 // per row top-k (k <= 16) of log-probs [M][V] -> idx/val [M][k], sorted descending (ties: lower index first)
 int launch_topk(const float* logp, int M, int V, int ldl, int k, int* idx, float* val, hipStream_t s);
 // log_softmax(logits / T) and its per-row top-k in one pass (the (M, V) log-probabilities are not written)

@@ -1797,7 +1797,7 @@ int stage_decode_tail(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp,
         CN_TRY(launch_topk(m->logits, MU, c.vocab_size, c.vocab_size, k, m->topk_idx, m->topk_val, s));
         m->last_k = k;
     }
-    if (hyp) CN_TRY(launch_greedy_pack(m->tok, m->val, m->ylen, B, U, o->sos, hyp_stride, hyp, hyp_len, score, s));
+    if (hyp) CN_TRY(launch_greedy_pack(m->tok, m->val, m->ylen, B, U, o->sos, hyp_stride, hyp, hyp_len, score, s, o->sub_batch));
     return 0;
 }
 

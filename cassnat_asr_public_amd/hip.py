@@ -26,7 +26,7 @@ class CnConfig(C.Structure):
 class CnDecodeOpts(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "padding_idx", "sos", "left_trigger", "right_trigger", "src_trigger", "use_unimask", "beam_width",
-        "capture")] + [("reserved", C.c_int32 * 8)]
+        "capture", "sub_batch")] + [("reserved", C.c_int32 * 7)]
 
 
 class CnAstOpts(C.Structure):

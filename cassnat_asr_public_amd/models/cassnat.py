@@ -322,7 +322,7 @@ class CassNAT(nn.Module):
             raise NotImplementedError("use_unimask with the conformer decoder: the reference itself cannot run it "
                                       "(cassnat.py:486-488 indexes the (x, pos_embed) tuple)")
 
-    def decode_device(self, src, src_size, args, sos=1, engine=None):
+    def decode_device(self, src, src_size, args, sos=1, engine=None, sub_batch=0):
         """The device half of beam_decode: returns cuda tensors (hyp (B,S) int32, hyp_len (B,) int32, score (B,) f64).
         ``engine``: run on this handle (a decode pipeline's) instead of the model's own."""
         dev = torch.device("cuda", getattr(self, "_device", torch.cuda.current_device()))
@@ -332,6 +332,7 @@ class CassNAT(nn.Module):
         eng = engine if engine is not None else self.engine(B, T)
         opts = hip.Engine.make_opts(args, capture=getattr(args, "hip_capture", False))
         opts.sos = sos
+        opts.sub_batch = int(sub_batch)  # coalesced batches of that size each (pipeline.DecodePipelines): per-batch hypotheses
         stride = ((T - 1) // 2 + 1 - 1) // 2 + 1 + 2
         hyp = torch.empty(B, stride, dtype=torch.int32, device=dev)
         hyp_len = torch.empty(B, dtype=torch.int32, device=dev)

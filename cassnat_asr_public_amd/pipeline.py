@@ -20,15 +20,21 @@ from . import dist as cdist
 
 
 class DecodePipelines:
-    def __init__(self, model, n_pipelines, batch, frames, with_weights=True, after_engine=None):
+    def __init__(self, model, n_pipelines, batch, frames, with_weights=True, after_engine=None, coalesce=1):
         """``model``: a CassNAT holding the parameters; ``batch`` / ``frames``: workspace size of every pipeline.
         ``with_weights=False`` + ``after_engine(engine)``: multi-GPU start-up, where the packed weights arrive by RCCL
-        broadcast (``dist.broadcast_weights``) instead of from the local parameters."""
+        broadcast (``dist.broadcast_weights``) instead of from the local parameters.
+        ``coalesce`` = 2: a worker takes two consecutive batches of the same shape through ONE engine pass (wider launches: the
+        command processor keeps only about three kernels in flight, so width is what fills the chip) with the greedy finish
+        limited per original batch (``cn_decode_opts.sub_batch``) - every batch's hypotheses and scores are exactly those of
+        a pass of its own.  Transformer blocks only (a conformer's GroupNorm sees the padded rows of the merged batch)."""
         self.model = model
         self.n = max(1, int(n_pipelines))
+        self.coalesce = 2 if (int(coalesce) >= 2 and not getattr(model, "_conf_dec", False)
+                              and not getattr(model, "_hyper", {}).get("conf_enc")) else 1
         self.engines = []
         for _ in range(self.n):
-            eng = model.new_engine(batch, frames, with_weights=with_weights)
+            eng = model.new_engine(batch * self.coalesce, frames, with_weights=with_weights)
             if after_engine is not None:
                 after_engine(eng)
             self.engines.append(eng)
@@ -47,7 +53,7 @@ class DecodePipelines:
         lock = threading.Lock()
         slots = {}            # index -> queue of one (tag, records, event) / exception
         cv = threading.Condition()
-        state = {"next": 0, "done": False, "err": None}
+        state = {"next": 0, "done": False, "err": None, "held": None}
         ahead = threading.Semaphore(2 * self.n + 2)  # batches decoded but not yet consumed (bounds device memory held by records)
         device = getattr(self.model, "_device", None)
         if device is None and torch.cuda.is_available():
@@ -84,21 +90,45 @@ class DecodePipelines:
                         with lock:
                             if state["done"] or state["err"] is not None:
                                 break
-                            try:
-                                item = next(it)
-                            except StopIteration:
-                                state["done"] = True
-                                break
+                            items = []
+                            if state["held"] is not None:
+                                items.append(state["held"])
+                                state["held"] = None
+                            else:
+                                try:
+                                    items.append(next(it))
+                                except StopIteration:
+                                    state["done"] = True
+                                    break
+                            if self.coalesce == 2:  # a second batch of the same shape rides along; another shape waits
+                                try:
+                                    nxt = next(it)
+                                    if tuple(nxt[0].shape) == tuple(items[0][0].shape) and ahead.acquire(blocking=False):
+                                        items.append(nxt)
+                                    else:
+                                        state["held"] = nxt
+                                except StopIteration:
+                                    pass  # (the next worker to look finds the iterator exhausted)
                             i = state["next"]
-                            state["next"] += 1
-                        feats, ratio, tag = item
-                        hyp, hyp_len, score = self.model.decode_device(feats, ratio, args, sos, engine=self.engines[k])
-                        rec = cdist.pack_records(hyp, hyp_len, score)
+                            state["next"] += len(items)
+                        if len(items) == 1:
+                            feats, ratio, tag = items[0]
+                            hyp, hyp_len, score = self.model.decode_device(feats, ratio, args, sos, engine=self.engines[k])
+                            recs = [cdist.pack_records(hyp, hyp_len, score)]
+                        else:
+                            nb = items[0][0].shape[0]
+                            dev_ = torch.device("cuda", device) if on_gpu else None
+                            feats = torch.cat([x[0].to(dev_) if on_gpu else x[0] for x in items], 0)
+                            ratio = torch.cat([x[1].to(dev_) if on_gpu else x[1] for x in items], 0)
+                            hyp, hyp_len, score = self.model.decode_device(feats, ratio, args, sos, engine=self.engines[k], sub_batch=nb)
+                            rec = cdist.pack_records(hyp, hyp_len, score)
+                            recs = [rec[j * nb : (j + 1) * nb] for j in range(len(items))]
                         ev = None
                         if on_gpu:
                             ev = torch.cuda.Event()
                             ev.record(st)
-                        slot(i).put((tag, rec, ev))
+                        for j, item in enumerate(items):
+                            slot(i + j).put((item[2], recs[j], ev))
                     st.synchronize()
             except BaseException as e:  # surfaces in the consumer
                 with lock:

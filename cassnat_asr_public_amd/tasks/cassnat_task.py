@@ -134,7 +134,8 @@ class CassNATTask(BaseTask):
         first = next(iter(self.test_loader))
         max_frames = max(getattr(args, "hip_max_frames", 4096), first[1].shape[1])
         pipes = DecodePipelines(self.model, n_pipes, args.batch_size, max_frames, with_weights=(self.rank == 0),
-                                after_engine=(lambda e: cdist.broadcast_weights(e, src=0)) if self.world > 1 else None)
+                                after_engine=(lambda e: cdist.broadcast_weights(e, src=0)) if self.world > 1 else None,
+                                coalesce=int(getattr(args, "hip_coalesce", 2)))  # (equal-shaped neighbours share a pass)
         meta, frames, i, end = {}, 0, -1, time.time()
 
         def batches():

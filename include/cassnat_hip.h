@@ -59,7 +59,11 @@ typedef struct cn_decode_opts {
     int32_t use_unimask;
     int32_t beam_width; /* 1: greedy finish on device; 2..16: per-position top-k kept for the host beam */
     int32_t capture;    /* debug: keep an fp32 copy of every stage tensor for cn_fetch */
-    int32_t reserved[8];
+    int32_t sub_batch;  /* > 0: the call carries B / sub_batch coalesced batches of that many utterances; the greedy finish limits
+                           every hypothesis by the row count of its own batch (src/models/cassnat.py:580-637 reads
+                           min(ylen + 1, U of the batch) rows), so each batch's hypotheses are what a call of its own gives.
+                           Transformer blocks only (a conformer's GroupNorm sees the padded rows) */
+    int32_t reserved[7];
 } cn_decode_opts;
 
 const char* cn_last_error(void);

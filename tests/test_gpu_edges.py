@@ -226,6 +226,27 @@ def test_decode_pipelines_equal_the_plain_loop():
     for (tag, hyps, scores), (wh, ws) in zip(got, want):
         assert hyps == wh, tag
         assert list(scores) == ws, tag
+    # coalescing: equal-shaped neighbours share an engine pass; each batch keeps the hypotheses (incl. the batch-dependent
+    # trailing token of the reference's greedy finish) and scores of a pass of its own
+    same = []
+    for k in range(9):  # runs of equal shapes: 3 x (3, 61), 1 x (2, 40), 4 x (4, 77), 1 x (1, 9)
+        B, T = ([(3, 61)] * 3 + [(2, 40)] + [(4, 77)] * 4 + [(1, 9)])[k]
+        lens = sorted((int(x) for x in rng.integers(1, T + 1, size=B)), reverse=True)
+        lens[0] = T
+        same.append(synth.make_feats(B, T, 80, lengths=lens, seed=300 + k))
+    want2 = []
+    for feats, sizes in same:
+        src = torch.from_numpy(feats)
+        with torch.no_grad():
+            out, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, args)
+        want2.append(([s[0]["hyp"] for s in out], [s[0]["score"] for s in out]))
+    pipes2 = DecodePipelines(model, 2, 4, 90, coalesce=2)
+    got2 = list(pipes2.decode(((torch.from_numpy(f), torch.from_numpy(s), k) for k, (f, s) in enumerate(same)), args, sos=1))
+    pipes2.close()
+    assert [t for t, _, _ in got2] == list(range(9))
+    for (tag, hyps, scores), (wh, ws) in zip(got2, want2):
+        assert hyps == wh, tag
+        assert list(scores) == ws, tag
 
 
 def test_lm_scoring_bf16_fast_path_against_the_fp32_engine():

@@ -242,12 +242,16 @@ def test_decode_pipelines_keep_submission_order_and_surface_errors():
 
     class StubModel:
         def __init__(self, fail_at=None):
-            self.seen, self.fail_at = [], fail_at
+            self.seen, self.fail_at, self.pairs = [], fail_at, 0
 
         def new_engine(self, batch, frames, with_weights=True):
             return StubEngine()
 
-        def decode_device(self, feats, ratio, args, sos, engine=None):
+        def decode_device(self, feats, ratio, args, sos, engine=None, sub_batch=0):
+            if feats.shape[0] > 1:  # a coalesced pair: one pass, records of both in order
+                parts = [self.decode_device(feats[j : j + 1], ratio[j : j + 1], args, sos) for j in range(feats.shape[0])]
+                self.pairs += 1
+                return tuple(_torch.cat([p_[i] for p_ in parts], 0) for i in range(3))
             k = int(feats[0, 0, 0])
             if self.fail_at is not None and k == self.fail_at:
                 raise RuntimeError("boom")
@@ -267,6 +271,17 @@ def test_decode_pipelines_keep_submission_order_and_surface_errors():
     assert [h for _, h, _ in out] == [[[1, 10 + k]] for k in range(25)]
     assert [float(s[0]) for _, _, s in out] == [float(k) for k in range(25)]
     assert sorted(m.seen) == list(range(25))
+    # coalescing: pairs of equal-shaped consecutive batches ride one pass; order, tags and contents unchanged
+    def mixed(n):
+        for k in range(n):
+            t = 4 if k % 7 else 6  # every seventh batch has another shape: it must not be merged with its neighbours
+            yield _torch.full((1, t, 2), float(k)), _torch.ones(1), ("tag", k)
+
+    m4 = StubModel()
+    out4 = list(DecodePipelines(m4, 3, 1, 6, coalesce=2).decode(mixed(31), args=None, sos=1))
+    assert [t for t, _, _ in out4] == [("tag", k) for k in range(31)]
+    assert [h for _, h, _ in out4] == [[[1, 10 + k]] for k in range(31)]
+    assert sorted(m4.seen) == list(range(31)) and m4.pairs >= 3  # (how many pairs form depends on how far the consumer is behind)
     # a failing batch surfaces in the consumer
     m2 = StubModel(fail_at=6)
     with pytest.raises(RuntimeError, match="boom"):
