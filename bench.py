@@ -183,6 +183,33 @@ def main():
             gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0
             print(f"{k:20s} n={v['count'] // 3:3d} {v['ms'] / 3:8.3f} ms  {tf:8.1f} TFLOP/s  {gb:8.1f} GB/s(alg)", file=sys.stderr)
 
+    # ---- extra (never `value`; EVERY rank takes part: it broadcasts and all-gathers): the same steps with the pipelines
+    # coalescing pairs of batches into one engine pass - wider launches, per-batch hypotheses unchanged
+    # (cn_decode_opts.sub_batch); what CassNATTask.decode does for test sets
+    coalesced = None
+    if not a.no_coalesced and a.precision != "fp32":
+        pipes2 = DecodePipelines(model, NS, B, T, with_weights=(rank == 0), after_engine=receive_weights, coalesce=2)
+
+        def run2(n_steps):
+            for _ in pipes2.decode(((feats, sizes, k) for k in range(n_steps)), args, sos=1, gather=world > 1, as_lists=False):
+                pass
+
+        run2(max(a.warmup, 2 * NS))
+        fence()
+        c0 = time.perf_counter()
+        run2(a.steps)
+        fence()
+        el2 = time.perf_counter() - c0
+        if world > 1:
+            tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el2 = float(tt.item())
+        coalesced = {"value": round(a.steps * B * world / el2, 2), "unit": "utt/s", "ms_per_step": round(el2 / a.steps * 1e3, 4),
+                     "note": "same workload and step count; each decode pipeline takes two batches of 32 through one engine pass "
+                             "(hypotheses and scores per batch identical to separate passes: tests/test_gpu_edges.py); reported "
+                             "beside, not as, `value`"}
+        pipes2.close()
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -235,32 +262,6 @@ def main():
                           if a.precision in ("bf16", "fp8") else "gemm_kernel<implicit-conv> (conv2)", {})
     if roofline is None:
         roofline = roofline_conv2
-
-    # ---- extra (never `value`): the same steps with the pipelines coalescing pairs of batches into one engine pass - wider
-    # launches, per-batch hypotheses unchanged (cn_decode_opts.sub_batch); what CassNATTask.decode does for test sets
-    coalesced = None
-    if not a.no_coalesced and a.precision != "fp32":
-        pipes2 = DecodePipelines(model, NS, B, T, with_weights=(rank == 0), after_engine=receive_weights, coalesce=2)
-
-        def run2(n_steps):
-            for _ in pipes2.decode(((feats, sizes, k) for k in range(n_steps)), args, sos=1, gather=world > 1, as_lists=False):
-                pass
-
-        run2(max(a.warmup, 2 * NS))
-        fence()
-        c0 = time.perf_counter()
-        run2(a.steps)
-        fence()
-        el2 = time.perf_counter() - c0
-        if world > 1:
-            tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el2 = float(tt.item())
-        coalesced = {"value": round(a.steps * B * world / el2, 2), "unit": "utt/s", "ms_per_step": round(el2 / a.steps * 1e3, 4),
-                     "note": "same workload and step count; each decode pipeline takes two batches of 32 through one engine pass "
-                             "(hypotheses and scores per batch identical to separate passes: tests/test_gpu_edges.py); reported "
-                             "beside, not as, `value`"}
-        pipes2.close()
 
     cpu = None
     if not a.no_cpu_baseline and world == 1:
