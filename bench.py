@@ -183,11 +183,11 @@ def main():
             gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0
             print(f"{k:20s} n={v['count'] // 3:3d} {v['ms'] / 3:8.3f} ms  {tf:8.1f} TFLOP/s  {gb:8.1f} GB/s(alg)", file=sys.stderr)
 
-    # ---- extra (never `value`; EVERY rank takes part: it broadcasts and all-gathers): the same steps with the pipelines
+    # ---- extra (never `value`; N = 1 only): the same steps with the pipelines
     # coalescing pairs of batches into one engine pass - wider launches, per-batch hypotheses unchanged
     # (cn_decode_opts.sub_batch); what CassNATTask.decode does for test sets
     coalesced = None
-    if not a.no_coalesced and a.precision != "fp32":
+    if not a.no_coalesced and a.precision != "fp32" and world == 1:  # (like cpu_baseline: at N = 1 only)
         pipes2 = DecodePipelines(model, NS, B, T, with_weights=(rank == 0), after_engine=receive_weights, coalesce=2)
 
         def run2(n_steps):
