@@ -40,8 +40,14 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local)
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.hip_dist_backend == "gloo":  # rehearsal: the ranks may share a GPU
+            local = min(local, torch.cuda.device_count() - 1)
+            os.environ["LOCAL_RANK"] = str(local)
+            torch.cuda.set_device(local)
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     task_dict = {"cassnat": CassNATTask, "art": ArtTask}  # (the reference's ctc / lmnat* / hubert tasks are out of scope)
     if args.task not in task_dict:
         raise NotImplementedError("task '%s' is not on the accelerated path (only %s)" % (args.task, sorted(task_dict)))

@@ -557,17 +557,17 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
     p.tail_tiles = a.tail_n / 32;
     p.has_next = a.has_next;
     p.eps = a.eps;
-    static int stamps = -1;
-    if (stamps < 0) stamps = getenv("CASSNAT_CHAIN_STAMPS") ? atoi(getenv("CASSNAT_CHAIN_STAMPS")) : 0;
+    static const int stamps = getenv("CASSNAT_CHAIN_STAMPS") ? atoi(getenv("CASSNAT_CHAIN_STAMPS")) : 0;  // (thread-safe init)
     p.stamps = stamps;
     p.x_in_blk = a.x_in_blocked;
     p.x_out_blk = a.x_out_blocked;
     p.store_x = a.store_x && (a.ctx || a.dff);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CnAttrOnce attr_once;
+    int attr_dev;
+    if (attr_once.need(&attr_dev)) {
         CN_HIP_CHECK(hipFuncSetAttribute((const void*)chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
         CN_HIP_CHECK(hipFuncSetAttribute((const void*)chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS));
-        attr_done = true;
+        attr_once.mark(attr_dev);
     }
     if (a.swish)
         hipLaunchKernelGGL(chain_kernel<true>, dim3(cn_ceil_div(p.M, 128)), dim3(256), CH_LDS, s, p);

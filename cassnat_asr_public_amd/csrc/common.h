@@ -118,3 +118,18 @@ void cn_set_error(const std::string& msg);
 #endif
 
 static inline int cn_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and the launchers run on several host threads (one decode
+// pipeline each): a per-kernel atomic bit mask of the devices already done.  Setting the attribute twice is harmless, so two
+// threads racing on the first launch both set it and both publish the bit.
+#include <atomic>
+struct CnAttrOnce {
+    std::atomic<unsigned long long> done{0};
+    bool need(int* dev_out) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+        *dev_out = dev;
+        return ((done.load(std::memory_order_acquire) >> dev) & 1ull) == 0;
+    }
+    void mark(int dev) { done.fetch_or(1ull << dev, std::memory_order_release); }
+};

@@ -291,10 +291,11 @@ bool conv2_dma_applies(int prec, int C, int N) { return prec == CN_PREC_BF16 && 
 // `in`: conv1 output WITH the zero halo, [B][T1 + 2][F1 + 2][256] bf16
 int launch_conv2_dma(const void* in, const void* w, const float* bias, void* out, int B, int T1, int F1, int T2, int F2,
                      hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CnAttrOnce attr_once;
+    int attr_dev;
+    if (attr_once.need(&attr_dev)) {
         CN_HIP_CHECK(hipFuncSetAttribute((const void*)conv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS));
-        attr_done = true;
+        attr_once.mark(attr_dev);
     }
     Conv2Params p;
     p.A = (const unsigned char*)in;
@@ -320,10 +321,11 @@ bool linear256_dma_applies(int prec, int N, int K) { return prec == CN_PREC_BF16
 
 int launch_linear256_dma(const void* A, int lda, const void* W, const float* bias, float* out, int M, int K, float scale,
                          const float* pe, int pe_period, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CnAttrOnce attr_once;
+    int attr_dev;
+    if (attr_once.need(&attr_dev)) {
         CN_HIP_CHECK(hipFuncSetAttribute((const void*)conv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS));
-        attr_done = true;
+        attr_once.mark(attr_dev);
     }
     if (M <= 0) return 0;
     if ((long long)M * lda * 2 >= (1ll << 32)) {

@@ -106,11 +106,12 @@ int launch_ctc_align(const AlignArgs& a, hipStream_t s) {
         cn_set_error("ctc_align: T' too large for one workgroup's LDS");
         return -1;
     }
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CnAttrOnce attr_once;
+    int attr_dev;
+    if (attr_once.need(&attr_dev)) {
         CN_HIP_CHECK(hipFuncSetAttribute((const void*)ctc_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024));
-        attr_done = true;
+        attr_once.mark(attr_dev);
     }
     hipLaunchKernelGGL(ctc_align_kernel, dim3(a.B), dim3(256), lds, s, a);
     CN_HIP_CHECK(hipGetLastError());

@@ -362,10 +362,11 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
 
 template <int MT, int DBG> static int launch_ffn_variant(const FfnParams& p, hipStream_t s) {
     constexpr int lds = ff_lds_bytes<MT>();
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CnAttrOnce attr_once;
+    int attr_dev;
+    if (attr_once.need(&attr_dev)) {
         CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_fused_kernel<MT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
+        attr_once.mark(attr_dev);
     }
     hipLaunchKernelGGL((ffn_fused_kernel<MT, DBG>), dim3(cn_ceil_div(p.M, 32 * MT), p.nslice), dim3(256), lds, s, p);
     CN_HIP_CHECK(hipGetLastError());
@@ -398,9 +399,8 @@ int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s) {
         cn_set_error("ffn_fused: a d_ff split needs d_ff % (128 * slices) == 0 and a partial-sum buffer");
         return -1;
     }
-    static int dbg = -1, force_mt = -1;
-    if (dbg < 0) dbg = getenv("CASSNAT_FFN_DEBUG") ? atoi(getenv("CASSNAT_FFN_DEBUG")) : 0;
-    if (force_mt < 0) force_mt = getenv("CASSNAT_FFN_MT") ? atoi(getenv("CASSNAT_FFN_MT")) : 0;
+    static const int dbg = getenv("CASSNAT_FFN_DEBUG") ? atoi(getenv("CASSNAT_FFN_DEBUG")) : 0;  // (magic statics: thread-safe)
+    static const int force_mt = getenv("CASSNAT_FFN_MT") ? atoi(getenv("CASSNAT_FFN_MT")) : 0;
     const int mt = force_mt ? force_mt : (a.M > 32 ? 2 : 1);
     if (mt == 2) {
         if (dbg == 3) return launch_ffn_variant<2, 3>(p, s);

@@ -257,10 +257,11 @@ static int run_gemm(const GemmArgs& a, hipStream_t s) {
     const int ntm = cn_ceil_div(a.M, BM);
     const size_t lds = (FULLK ? 4 : 2) * (size_t)(BM + BN) * 128;
     auto kern = gemm_kernel<T, TC, BM, BN, CONV, FULLK>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CnAttrOnce attr_once;
+    int attr_dev;
+    if (attr_once.need(&attr_dev)) {
         CN_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_once.mark(attr_dev);
     }
     (void)BK;
     hipLaunchKernelGGL(kern, dim3(ntm * p.ntn), dim3(256), lds, s, p);

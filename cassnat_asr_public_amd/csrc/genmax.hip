@@ -238,10 +238,11 @@ __global__ __launch_bounds__(256) void genmax_kernel(GenmaxParams p) {
 
 template <int MT, bool GATHER, bool LSE> static int launch_genmax_variant(const GenmaxParams& p, hipStream_t s) {
     constexpr int lds = 4 * GM_RING_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CnAttrOnce attr_once;
+    int attr_dev;
+    if (attr_once.need(&attr_dev)) {
         CN_HIP_CHECK(hipFuncSetAttribute((const void*)genmax_kernel<MT, GATHER, LSE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
+        attr_once.mark(attr_dev);
     }
     hipLaunchKernelGGL((genmax_kernel<MT, GATHER, LSE>), dim3(cn_ceil_div(p.M, 32 * MT)), dim3(256), lds, s, p);
     CN_HIP_CHECK(hipGetLastError());

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -123,6 +124,16 @@ struct cn_model {
     int pe_rows = 0;
     bool finalized = false;
 
+    // packed weights: owned through a reference count, so that several handles (the decode pipelines of one GPU, or a
+    // handle rebuilt for a larger workspace) use ONE device copy (cn_model_create_shared)
+    struct BlobOwner {
+        unsigned char* p = nullptr;
+        ~BlobOwner() {
+            if (p) (void)hipFree(p);
+        }
+    };
+    std::shared_ptr<BlobOwner> blob_owner;
+    bool blob_borrowed = false;  // the blob belongs to a donor handle: never re-packed or re-allocated here
     unsigned char* blob = nullptr;
     size_t blob_bytes = 0;
 
@@ -646,7 +657,7 @@ int build_weights(cn_model* m) {
     const int64_t d = c.d_model, V = c.vocab_size, C = c.d_model;
     Packer pk;
     pk.m = m;
-    pk.fill = !m->host.empty();
+    pk.fill = !m->host.empty() && !m->blob_borrowed;
     const int64_t F2 = m->F2;
     // cfg.ast == 2: the TransformerLM that ranks ESA samples (src/models/lm.py): token embedding, encoder stack, generator
     const bool lm = c.ast == 2;
@@ -912,13 +923,26 @@ int build_weights(cn_model* m) {
         cn_set_error("cn_model_finalize: missing or mis-shaped parameters: " + pk.missing);
         return -1;
     }
-    if (m->blob && m->blob_bytes != pk.off) {
-        (void)hipFree(m->blob);
-        m->blob = nullptr;
+    if (m->blob_borrowed) {
+        if (m->blob_bytes != pk.off) {
+            cn_set_error("cn_model_create_shared: the donor's weight blob has another layout (" + std::to_string(m->blob_bytes) +
+                         " vs " + std::to_string(pk.off) + " bytes): the model hyper-parameters must agree");
+            return -1;
+        }
+    } else {
+        if (m->blob && (m->blob_bytes != pk.off || m->blob_owner.use_count() > 1)) {  // (a blob others still use is left to them)
+            m->blob_owner.reset();
+            m->blob = nullptr;
+        }
+        if (!m->blob) {
+            auto owner = std::make_shared<cn_model::BlobOwner>();
+            CN_HIP_CHECK(hipMalloc((void**)&owner->p, pk.off));
+            m->blob_owner = owner;
+            m->blob = owner->p;
+        }
+        m->blob_bytes = pk.off;
+        if (pk.fill) CN_HIP_CHECK(hipMemcpy(m->blob, pk.host.data(), pk.off, hipMemcpyHostToDevice));
     }
-    if (!m->blob) CN_HIP_CHECK(hipMalloc((void**)&m->blob, pk.off));
-    m->blob_bytes = pk.off;
-    if (pk.fill) CN_HIP_CHECK(hipMemcpy(m->blob, pk.host.data(), pk.off, hipMemcpyHostToDevice));
 
     unsigned char* base = m->blob;
     rebase(m->conv1_w, base);
@@ -1850,6 +1874,31 @@ extern "C" int cn_model_create(const cn_config* cfg, cn_model** out) {
     return 0;
 }
 
+extern "C" int cn_model_create_shared(const cn_config* cfg, cn_model* donor, cn_model** out) {
+    if (!donor || !donor->finalized || !donor->blob) {
+        cn_set_error("cn_model_create_shared: the donor must be a finalized model");
+        return -1;
+    }
+    if (cfg->device != donor->cfg.device || cfg->precision != donor->cfg.precision) {
+        cn_set_error("cn_model_create_shared: device and precision must be the donor's");
+        return -1;
+    }
+    cn_model* m = nullptr;
+    CN_TRY(cn_model_create(cfg, &m));
+    m->blob_owner = donor->blob_owner;
+    m->blob = donor->blob;
+    m->blob_bytes = donor->blob_bytes;
+    m->blob_borrowed = true;
+    m->pe_rows = donor->pe_rows;
+    const int rc = cn_model_finalize(m);  // layout pass over the donor's blob + this handle's own workspace
+    if (rc != 0) {
+        cn_model_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return 0;
+}
+
 extern "C" void cn_model_destroy(cn_model* m) {
     if (!m) return;
     for (void* p : m->allocs) (void)hipFree(p);
@@ -1858,7 +1907,7 @@ extern "C" void cn_model_destroy(cn_model* m) {
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->ymax_pinned) (void)hipHostFree(m->ymax_pinned);
     for (void* q : m->ast_allocs) (void)hipFree(q);
-    if (m->blob) (void)hipFree(m->blob);
+    m->blob_owner.reset();  // the last handle that uses the blob frees it
     delete m;
 }
 

@@ -89,6 +89,7 @@ def lib():
     L.cn_op_quantize_fp8.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     L.cn_op_logsoftmax_topk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_model_create.argtypes = [C.POINTER(CnConfig), C.POINTER(C.c_void_p)]
+    L.cn_model_create_shared.argtypes = [C.POINTER(CnConfig), C.c_void_p, C.POINTER(C.c_void_p)]
     L.cn_model_destroy.argtypes = [C.c_void_p]
     L.cn_model_load_weights.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
     L.cn_model_load_pe.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
@@ -150,7 +151,9 @@ def current_stream():
 class Engine:
     """Owns one ``cn_model`` handle: weights, workspace and the decode pipeline on one GPU."""
 
-    def __init__(self, args, precision="bf16", max_batch=32, max_frames=2048, device=0, esa_group=1):
+    def __init__(self, args, precision="bf16", max_batch=32, max_frames=2048, device=0, esa_group=1, share_with=None):
+        """``share_with``: a finalized Engine of the same model - the new handle uses ITS device copy of the packed weights
+        (reference counted in the library) and only allocates a workspace of its own; it is ready to decode."""
         self.L = lib()
         ast = int(getattr(args, "ast", 0))
         self.cfg = CnConfig(
@@ -164,8 +167,14 @@ class Engine:
             d_ff=int(getattr(args, "d_ff", 0)), esa_group=int(esa_group))
         self.precision = precision
         self.handle = C.c_void_p()
-        check(self.L.cn_model_create(C.byref(self.cfg), C.byref(self.handle)), "cn_model_create")
-        self.finalized = False
+        if share_with is not None:
+            if not share_with.finalized or not share_with.handle:
+                raise HipError("share_with needs a finalized engine")
+            check(self.L.cn_model_create_shared(C.byref(self.cfg), share_with.handle, C.byref(self.handle)), "cn_model_create_shared")
+            self.finalized = True
+        else:
+            check(self.L.cn_model_create(C.byref(self.cfg), C.byref(self.handle)), "cn_model_create")
+            self.finalized = False
 
     def close(self):
         if getattr(self, "handle", None):

@@ -256,32 +256,52 @@ class CassNAT(nn.Module):
     def _weights_version(self):
         return tuple(p._version for p in self.parameters())
 
-    def build_engine(self, batch, frames, with_weights=True, esa_group=1):
-        """Create the HIP engine.  ``with_weights=False`` allocates the (layout-identical) weight blob only: the
-        contents then arrive by RCCL broadcast from the rank that read the checkpoint (cassnat_asr_public_amd.dist)."""
+    def _new_handle(self, batch, frames, esa_group=1, share_with=None):
         from types import SimpleNamespace
 
-        if self._engine is not None:
-            self._engine.close()
-        eng = hip.Engine(SimpleNamespace(**self._hyper), precision=self.hip_precision,
-                         max_batch=max(batch, self.hip_max_batch), max_frames=max(frames, self.hip_max_frames),
-                         device=getattr(self, "_device", torch.cuda.current_device()), esa_group=esa_group)
-        if with_weights:
-            eng.load_state({k: v.detach() for k, v in self.named_parameters()}, self.pe)
+        return hip.Engine(SimpleNamespace(**self._hyper), precision=self.hip_precision,
+                          max_batch=max(batch, self.hip_max_batch), max_frames=max(frames, self.hip_max_frames),
+                          device=getattr(self, "_device", torch.cuda.current_device()), esa_group=esa_group, share_with=share_with)
+
+    def build_engine(self, batch, frames, with_weights=True, esa_group=1):
+        """Create the model's HIP engine.  ``with_weights=False`` allocates the (layout-identical) weight blob only: the
+        contents then arrive by RCCL broadcast from the rank that read the checkpoint (cassnat_asr_public_amd.dist).
+
+        An engine whose weights are still current (same parameter versions, same precision) is never re-packed: the new
+        handle shares its device blob (``cn_model_create_shared``) and only gets the larger workspace.  That also makes a
+        rebuild rank-safe - on a rank that received its weights by broadcast the local ``nn.Parameter``s were never loaded,
+        so packing from them would silently decode with random weights."""
+        key = (self._weights_version(), self.hip_precision)
+        old = self._engine
+        if old is not None and self._engine_key == key and old.finalized:
+            eng = self._new_handle(batch, frames, esa_group, share_with=old)
+            old.close()  # (the blob stays: reference counted in the library)
         else:
-            eng.finalize()
-        self._engine, self._engine_key = eng, (self._weights_version(), self.hip_precision)
+            if old is not None:
+                old.close()
+            if with_weights and self._params_unloaded():
+                raise hip.HipError("this rank's parameters were never loaded (its weights arrived by broadcast): the engine cannot "
+                                   "be re-packed from them - load the checkpoint here, or broadcast again into a new engine")
+            eng = self._new_handle(batch, frames, esa_group)
+            if with_weights:
+                eng.load_state({k: v.detach() for k, v in self.named_parameters()}, self.pe)
+            else:
+                eng.finalize()
+                self._remote_version = key[0]  # the parameters as they are now are NOT what the engine will hold
+        self._engine, self._engine_key = eng, key
         return eng
 
-    def new_engine(self, batch, frames, with_weights=True):
-        """An additional, independent engine handle (own weight blob and workspace) for the same parameters: what a decode
-        pipeline owns (cassnat_asr_public_amd.pipeline).  The model's own engine (``engine()``) is not touched."""
-        from types import SimpleNamespace
-
-        eng = hip.Engine(SimpleNamespace(**self._hyper), precision=self.hip_precision,
-                         max_batch=max(batch, self.hip_max_batch), max_frames=max(frames, self.hip_max_frames),
-                         device=getattr(self, "_device", torch.cuda.current_device()))
+    def new_engine(self, batch, frames, with_weights=True, share=None):
+        """An additional engine handle for the same parameters: what a decode pipeline owns (cassnat_asr_public_amd.pipeline).
+        ``share``: an engine whose device copy of the packed weights the new handle uses (own workspace only) - the pipelines of
+        one GPU share ONE blob.  Without it the handle packs (``with_weights``) or allocates (broadcast receiver) its own.
+        The model's own engine (``engine()``) is not touched."""
+        if share is not None:
+            return self._new_handle(batch, frames, share_with=share)
+        eng = self._new_handle(batch, frames)
         if with_weights:
+            if self._params_unloaded():
+                raise hip.HipError("this rank's parameters were never loaded: share an engine that received the broadcast instead")
             eng.load_state({k: v.detach() for k, v in self.named_parameters()}, self.pe)
         else:
             eng.finalize()
@@ -291,8 +311,14 @@ class CassNAT(nn.Module):
         """Call after changing parameters through ``.data`` (which does not bump tensor versions)."""
         self._engine_key = None
 
+    def _params_unloaded(self):
+        """True while the local nn.Parameters are still the untouched initial values of a rank whose engine weights came by
+        broadcast (``build_engine(with_weights=False)``); any later in-place load changes the tensor versions."""
+        return getattr(self, "_remote_version", None) is not None and self._remote_version == self._weights_version()
+
     def load_state_dict(self, *a, **k):
         self.invalidate_engine()
+        self._remote_version = None
         return super().load_state_dict(*a, **k)
 
     def engine(self, batch, frames, esa_group=1):

@@ -53,21 +53,47 @@ class Transformer(nn.Module):
     def forward(self, *a, **k):
         raise NotImplementedError("training forward is out of scope; use beam_decode")
 
+    def _new_handle(self, batch, frames, share_with=None):
+        return hip.Engine(SimpleNamespace(**self._hyper), precision=self.hip_precision,
+                          max_batch=max(batch, self.hip_max_batch), max_frames=max(frames, self.hip_max_frames),
+                          device=getattr(self, "_device", torch.cuda.current_device()), share_with=share_with)
+
+    def build_engine(self, batch, frames, with_weights=True):
+        """The model's engine.  Current weights are never re-packed: a rebuild for a larger workspace shares the old handle's
+        device blob.  ``with_weights=False``: layout only, the blob arrives by RCCL broadcast (dist.broadcast_weights)."""
+        key = (tuple(p._version for p in self.parameters()), self.hip_precision)
+        old = self._engine
+        if old is not None and self._engine_key == key and old.finalized:
+            eng = self._new_handle(batch, frames, share_with=old)
+            old.close()
+        else:
+            if old is not None:
+                old.close()
+            if with_weights and getattr(self, "_remote_version", None) == key[0]:
+                raise hip.HipError("this rank's parameters were never loaded (its weights arrived by broadcast)")
+            eng = self._new_handle(batch, frames)
+            if with_weights:
+                eng.load_state({k: v.detach() for k, v in self.named_parameters()}, self.pe)
+            else:
+                eng.finalize()
+                self._remote_version = key[0]
+        self._engine, self._engine_key = eng, key
+        return eng
+
+    def new_engine(self, batch, frames, share):
+        """A further handle (own workspace and KV cache) on the device blob of ``share``: what a decode pipeline owns."""
+        return self._new_handle(batch, frames, share_with=share)
+
     def engine(self, batch, frames):
         key = (tuple(p._version for p in self.parameters()), self.hip_precision)
         if (self._engine is None or self._engine_key != key or batch > self._engine.cfg.max_batch
                 or frames > self._engine.cfg.max_frames):
-            if self._engine is not None:
-                self._engine.close()
-            eng = hip.Engine(SimpleNamespace(**self._hyper), precision=self.hip_precision,
-                             max_batch=max(batch, self.hip_max_batch), max_frames=max(frames, self.hip_max_frames),
-                             device=getattr(self, "_device", torch.cuda.current_device()))
-            eng.load_state({k: v.detach() for k, v in self.named_parameters()}, self.pe)
-            self._engine, self._engine_key = eng, key
+            self.build_engine(batch, frames)
         return self._engine
 
-    def beam_decode(self, src, src_mask, vocab, args, lm_model=None):
-        """Same contract as the reference's Transformer.beam_decode (src/models/transformer.py:122-241), lm_weight == 0."""
+    def beam_decode(self, src, src_mask, vocab, args, lm_model=None, engine=None):
+        """Same contract as the reference's Transformer.beam_decode (src/models/transformer.py:122-241), lm_weight == 0.
+        ``engine``: run on this handle (a decode pipeline's, see ``new_engine``) instead of the model's own."""
         if getattr(args, "lm_weight", 0) > 0:
             raise NotImplementedError("LM fusion is outside the accelerated path")
         sos, eos = vocab.word2index["sos"], vocab.word2index["eos"]
@@ -76,7 +102,7 @@ class Transformer(nn.Module):
         feats = src.to(dev, torch.float32).contiguous()
         B, T, _ = feats.shape
         Tp = ((T - 1) // 2 + 1 - 1) // 2 + 1
-        eng = self.engine(B, T)
+        eng = engine if engine is not None else self.engine(B, T)
         use_ctc = args.ctc_weight > 0
         bw = int(args.beam_width)
         K = int(args.ctc_beam) if use_ctc else bw

@@ -3,8 +3,8 @@
 One ``beam_decode`` call needs the host twice - the token count U of the batch is data dependent (the decoder side is
 launched after it is read back) and the hypotheses themselves have to reach the host - and most of its kernels occupy a
 fraction of the chip (a row-chain launch of a 32-utterance batch sits on 63 of 256 CUs).  So the throughput form of the path
-is N independent pipelines per GPU: each owns an engine handle (its copy of the packed weights and a workspace), a HIP
-stream and a host thread (ctypes releases the GIL inside the C call), pulls the next batch from a shared iterator - so
+is N independent pipelines per GPU: each owns an engine handle (a workspace; the packed weights are ONE device copy shared
+by all of them), a HIP stream and a persistent host thread (ctypes releases the GIL inside the C call), pulls the next batch from a shared iterator - so
 feature loading and collation run in the workers too - and hands back device-resident hypothesis records in submission
 order.  ``bench.py`` measures exactly this object; ``tasks.cassnat_task.CassNATTask.decode`` uses it for test sets.
 
@@ -19,152 +19,211 @@ import torch
 from . import dist as cdist
 
 
+class _NoStream:
+    """Stand-in for a HIP stream in the host-logic tests (no GPU)."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def synchronize(self):
+        pass
+
+
+class _Job:
+    """One ``records()`` call: the shared iterator and the bookkeeping its workers and its consumer meet on."""
+
+    def __init__(self, it, args, sos, n):
+        self.it, self.args, self.sos = it, args, sos
+        self.lock = threading.Lock()
+        self.cv = threading.Condition()
+        self.slots = {}          # index -> queue of one (tag, records, event)
+        self.state = {"next": 0, "done": False, "err": None, "held": None}
+        self.ahead = threading.Semaphore(2 * n + 2)  # batches decoded but not yet consumed (bounds device memory held by records)
+        self.finished = threading.Semaphore(0)       # released once by every worker when it has left the job
+
+    def slot(self, i):
+        with self.cv:
+            if i not in self.slots:
+                self.slots[i] = queue.Queue(1)
+            return self.slots[i]
+
+
 class DecodePipelines:
-    def __init__(self, model, n_pipelines, batch, frames, with_weights=True, after_engine=None, coalesce=1):
+    def __init__(self, model, n_pipelines, batch, frames, with_weights=True, after_engine=None, coalesce=1, share_from=None):
         """``model``: a CassNAT holding the parameters; ``batch`` / ``frames``: workspace size of every pipeline.
-        ``with_weights=False`` + ``after_engine(engine)``: multi-GPU start-up, where the packed weights arrive by RCCL
-        broadcast (``dist.broadcast_weights``) instead of from the local parameters.
+        The pipelines of one GPU share ONE device copy of the packed weights (``cn_model_create_shared``): the first engine
+        packs them - or, with ``with_weights=False`` + ``after_engine(engine)`` (multi-GPU start-up), receives them by RCCL
+        broadcast (``dist.broadcast_weights``), once per rank - and the others only get a workspace of their own.
+        The worker threads and their HIP streams are created once (at the first call) and live until ``close()``: a short
+        run is not thread start-up.
         ``coalesce`` = 2: a worker takes two consecutive batches of the same shape through ONE engine pass (wider launches: the
         command processor keeps only about three kernels in flight, so width is what fills the chip) with the greedy finish
         limited per original batch (``cn_decode_opts.sub_batch``) - every batch's hypotheses and scores are exactly those of
-        a pass of its own.  Transformer blocks only (a conformer's GroupNorm sees the padded rows of the merged batch)."""
+        a pass of its own.  Transformer blocks only (a conformer's GroupNorm sees the padded rows of the merged batch).
+        ``share_from``: an engine of the same model whose device copy of the weights ALL pipelines of this object use."""
         self.model = model
         self.n = max(1, int(n_pipelines))
         self.coalesce = 2 if (int(coalesce) >= 2 and not getattr(model, "_conf_dec", False)
                               and not getattr(model, "_hyper", {}).get("conf_enc")) else 1
-        self.engines = []
-        for _ in range(self.n):
-            eng = model.new_engine(batch * self.coalesce, frames, with_weights=with_weights)
+        if share_from is not None:
+            first = model.new_engine(batch * self.coalesce, frames, share=share_from)
+        else:
+            first = model.new_engine(batch * self.coalesce, frames, with_weights=with_weights)
             if after_engine is not None:
-                after_engine(eng)
-            self.engines.append(eng)
+                after_engine(first)
+        self.engines = [first]
+        for _ in range(self.n - 1):
+            self.engines.append(model.new_engine(batch * self.coalesce, frames, share=first))
+        self._threads = []
+        self._inbox = []
+        self._busy = threading.Lock()  # one records() call at a time
+
+    # ------------------------------------------------------------------------------------------ workers
+    def _start(self):
+        if self._threads:
+            return
+        self._on_gpu = torch.cuda.is_available()  # (False only in the host-logic tests, which drive this class with a stub model)
+        device = getattr(self.model, "_device", None)
+        if device is None and self._on_gpu:
+            device = torch.cuda.current_device()
+        self._device = device
+        self._inbox = [queue.Queue() for _ in range(self.n)]
+        ready = threading.Semaphore(0)
+
+        def loop(k):
+            if self._on_gpu:
+                torch.cuda.set_device(device)
+            st = torch.cuda.Stream() if self._on_gpu else _NoStream()
+            ready.release()
+            with (torch.cuda.stream(st) if self._on_gpu else st), torch.no_grad():
+                while True:
+                    job = self._inbox[k].get()
+                    if job is None:
+                        return
+                    try:
+                        self._work(k, st, job)
+                    except BaseException as e:  # surfaces in the consumer
+                        with job.lock:
+                            job.state["err"] = e
+                        with job.cv:
+                            job.cv.notify_all()
+                    finally:
+                        job.finished.release()
+
+        self._threads = [threading.Thread(target=loop, args=(k,), daemon=True) for k in range(self.n)]
+        for t in self._threads:
+            t.start()
+        for _ in self._threads:
+            ready.acquire()
+
+    def _work(self, k, st, job):
+        state, lock, ahead, it = job.state, job.lock, job.ahead, job.it
+        on_gpu, device = self._on_gpu, self._device
+        while True:
+            while not ahead.acquire(timeout=0.05):  # the consumer is behind: wait, but notice a shutdown
+                if state["done"] or state["err"] is not None:
+                    break
+            with lock:
+                if state["done"] or state["err"] is not None:
+                    break
+                items = []
+                if state["held"] is not None:
+                    items.append(state["held"])
+                    state["held"] = None
+                else:
+                    try:
+                        items.append(next(it))
+                    except StopIteration:
+                        state["done"] = True
+                        break
+                if self.coalesce == 2:  # a second batch of the same shape rides along; another shape waits
+                    try:
+                        nxt = next(it)
+                        if tuple(nxt[0].shape) == tuple(items[0][0].shape) and ahead.acquire(blocking=False):
+                            items.append(nxt)
+                        else:
+                            state["held"] = nxt
+                    except StopIteration:
+                        pass  # (the next worker to look finds the iterator exhausted)
+                i = state["next"]
+                state["next"] += len(items)
+            if len(items) == 1:
+                feats, ratio, tag = items[0]
+                hyp, hyp_len, score = self.model.decode_device(feats, ratio, job.args, job.sos, engine=self.engines[k])
+                recs = [cdist.pack_records(hyp, hyp_len, score)]
+            else:
+                nb = items[0][0].shape[0]
+                dev_ = torch.device("cuda", device) if on_gpu else None
+                feats = torch.cat([x[0].to(dev_) if on_gpu else x[0] for x in items], 0)
+                ratio = torch.cat([x[1].to(dev_) if on_gpu else x[1] for x in items], 0)
+                hyp, hyp_len, score = self.model.decode_device(feats, ratio, job.args, job.sos, engine=self.engines[k], sub_batch=nb)
+                rec = cdist.pack_records(hyp, hyp_len, score)
+                recs = [rec[j * nb : (j + 1) * nb] for j in range(len(items))]
+            ev = None
+            if on_gpu:
+                ev = torch.cuda.Event()
+                ev.record(st)
+            for j, item in enumerate(items):
+                job.slot(i + j).put((item[2], recs[j], ev))
+        st.synchronize()
 
     def close(self):
+        for q in self._inbox:
+            q.put(None)
+        for t in self._threads:
+            t.join()
+        self._threads, self._inbox = [], []
         for e in self.engines:
             e.close()
         self.engines = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def records(self, batches, args, sos=1):
         """``batches``: iterable of ``(feats (B,T,F), size_ratio (B,), tag)`` (host or device tensors).  Yields
         ``(tag, records)`` in the order of the iterable: ``records`` is the device tensor of ``dist.pack_records`` (per
         utterance: length, float64 score, [sos] + tokens), ready for ``dist.all_gather_records`` / ``unpack_records``.  The
         consumer's current stream is made to wait for the producing pipeline's work."""
-        it = iter(batches)
-        lock = threading.Lock()
-        slots = {}            # index -> queue of one (tag, records, event) / exception
-        cv = threading.Condition()
-        state = {"next": 0, "done": False, "err": None, "held": None}
-        ahead = threading.Semaphore(2 * self.n + 2)  # batches decoded but not yet consumed (bounds device memory held by records)
-        device = getattr(self.model, "_device", None)
-        if device is None and torch.cuda.is_available():
-            device = torch.cuda.current_device()
-
-        def slot(i):
-            with cv:
-                if i not in slots:
-                    slots[i] = queue.Queue(1)
-                return slots[i]
-
-        on_gpu = torch.cuda.is_available()  # (False only in the host-logic tests, which drive this class with a stub model)
-
-        class _NoStream:
-            def __enter__(self):
-                return self
-
-            def __exit__(self, *exc):
-                return False
-
-            def synchronize(self):
-                pass
-
-        def worker(k):
-            if on_gpu:
-                torch.cuda.set_device(device)
-            st = torch.cuda.Stream() if on_gpu else _NoStream()
+        self._start()
+        job = _Job(iter(batches), args, sos, self.n)
+        state, lock = job.state, job.lock
+        with self._busy:
+            for q in self._inbox:
+                q.put(job)
+            i = 0
             try:
-                with (torch.cuda.stream(st) if on_gpu else st), torch.no_grad():
-                    while True:
-                        while not ahead.acquire(timeout=0.05):  # the consumer is behind: wait, but notice a shutdown
-                            if state["done"] or state["err"] is not None:
-                                break
-                        with lock:
-                            if state["done"] or state["err"] is not None:
-                                break
-                            items = []
-                            if state["held"] is not None:
-                                items.append(state["held"])
-                                state["held"] = None
-                            else:
-                                try:
-                                    items.append(next(it))
-                                except StopIteration:
-                                    state["done"] = True
-                                    break
-                            if self.coalesce == 2:  # a second batch of the same shape rides along; another shape waits
-                                try:
-                                    nxt = next(it)
-                                    if tuple(nxt[0].shape) == tuple(items[0][0].shape) and ahead.acquire(blocking=False):
-                                        items.append(nxt)
-                                    else:
-                                        state["held"] = nxt
-                                except StopIteration:
-                                    pass  # (the next worker to look finds the iterator exhausted)
-                            i = state["next"]
-                            state["next"] += len(items)
-                        if len(items) == 1:
-                            feats, ratio, tag = items[0]
-                            hyp, hyp_len, score = self.model.decode_device(feats, ratio, args, sos, engine=self.engines[k])
-                            recs = [cdist.pack_records(hyp, hyp_len, score)]
-                        else:
-                            nb = items[0][0].shape[0]
-                            dev_ = torch.device("cuda", device) if on_gpu else None
-                            feats = torch.cat([x[0].to(dev_) if on_gpu else x[0] for x in items], 0)
-                            ratio = torch.cat([x[1].to(dev_) if on_gpu else x[1] for x in items], 0)
-                            hyp, hyp_len, score = self.model.decode_device(feats, ratio, args, sos, engine=self.engines[k], sub_batch=nb)
-                            rec = cdist.pack_records(hyp, hyp_len, score)
-                            recs = [rec[j * nb : (j + 1) * nb] for j in range(len(items))]
-                        ev = None
-                        if on_gpu:
-                            ev = torch.cuda.Event()
-                            ev.record(st)
-                        for j, item in enumerate(items):
-                            slot(i + j).put((item[2], recs[j], ev))
-                    st.synchronize()
-            except BaseException as e:  # surfaces in the consumer
+                while True:
+                    with lock:
+                        finished = state["done"] and i >= state["next"]
+                        err = state["err"]
+                    if err is not None:
+                        raise err
+                    if finished:
+                        break
+                    try:
+                        tag, rec, ev = job.slot(i).get(timeout=0.05)
+                    except queue.Empty:
+                        continue
+                    with job.cv:
+                        job.slots.pop(i, None)
+                    if ev is not None:
+                        ev.wait(torch.cuda.current_stream())
+                    job.ahead.release()
+                    yield tag, rec
+                    i += 1
+            finally:
                 with lock:
-                    state["err"] = e
-                with cv:
-                    cv.notify_all()
-
-        threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(self.n)]
-        for t in threads:
-            t.start()
-        i = 0
-        try:
-            while True:
-                with lock:
-                    finished = state["done"] and i >= state["next"]
-                    err = state["err"]
-                if err is not None:
-                    raise err
-                if finished:
-                    break
-                try:
-                    tag, rec, ev = slot(i).get(timeout=0.05)
-                except queue.Empty:
-                    continue
-                with cv:
-                    slots.pop(i, None)
-                if ev is not None:
-                    ev.wait(torch.cuda.current_stream())
-                ahead.release()
-                yield tag, rec
-                i += 1
-        finally:
-            with lock:
-                state["done"] = True
-            for t in threads:
-                t.join()
+                    state["done"] = True
+                for _ in range(self.n):  # every worker has left the job (its stream is drained) before the next one starts
+                    job.finished.acquire()
 
     def decode(self, batches, args, sos=1, gather=False, as_lists=True):
         """Hypotheses on the host, in order: yields ``(tag, hyps, scores)`` with ``hyps`` a list of token lists starting

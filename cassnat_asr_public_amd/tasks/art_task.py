@@ -4,15 +4,22 @@
 Same constructor / decode surface and result-file lines ("<utt> tok tok ...").  ``decode_type == 'ctc_att'`` (joint
 CTC/attention beam search, src/models/transformer.py:122-241) is the accelerated path; ``ctc_only`` / ``ctc_correct``, LM
 fusion and the conformer AST raise.  A decode step keeps a handful of CUs busy, so a test set goes through
-``args.hip_pipelines`` (default 4) independent model replicas on their own HIP streams and host threads - batches pulled from
-the loader by the workers, result lines written in input order.
+``args.hip_pipelines`` (default 4) engine handles (own workspace + KV cache, ONE shared device copy of the weights) on their
+own HIP streams and host threads - batches pulled from the loader by the workers, result lines written in input order.
+With torch.distributed initialised (one process per GPU) the utterances are dealt over the ranks by length exactly as
+``CassNATTask`` does, rank 0 reads the checkpoint and broadcasts the packed weights over RCCL, and rank 0 writes the one
+input-ordered result file - the reference fans out with split_scp.pl and one process + checkpoint read per GPU
+(egs/librispeech/run_art.sh:115-135).
 """
+import os
 import threading
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
+from .. import dist as cdist
 from ..data.vocab import Vocab
 from ..models import make_transformer
 from ..utils import util
@@ -32,18 +39,31 @@ class ArtTask(BaseTask):
         super(ArtTask, self).__init__(args)
         if mode != "test":
             raise NotImplementedError("training is out of scope of the accelerated path")
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            raise NotImplementedError("--task art decodes on one GPU per process (split the scp file as the reference's recipe does)")
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
         self.vocab = Vocab(args.vocab_file, args.rank)
         args.vocab_size = self.vocab.n_words
         args.rank = 0
         for k in ("ctc_alpha", "interctc_alpha", "interctc_layer", "label_smooth"):
             setattr(args, k, 0)
         self.set_model(args)
-        self.set_test_dataloader(args)
-        self.load_test_model(args.resume_model)
-        self.model_stats(0, False, False)
+        self.set_test_dataloader(args, indices=self._shard(args))
+        if self.rank == 0:
+            self.load_test_model(args.resume_model)
+        local = int(os.environ.get("LOCAL_RANK", "0")) if self.world > 1 else 0
+        self.model_stats(local, False, False)
         self.lm_model = None
+
+    def _shard(self, args):
+        """Indices of this rank's utterances (None = all): the length-sorted snake deal of CassNATTask."""
+        if self.world == 1:
+            return None
+        n = sum(1 for _ in open(args.test_paths[0]["scp_path"]))
+        lengths = np.zeros(n)
+        u2n = args.test_paths[0].get("utt2num_frames")
+        if u2n:
+            lengths = np.array([int(line.split()[1]) for line in open(u2n)])
+        return cdist.shard_indices(lengths, self.world, self.rank)
 
     def set_model(self, args):
         assert args.input_size == (args.left_ctx + args.right_ctx + 1) // args.skip_frame * args.n_features
@@ -56,17 +76,14 @@ class ArtTask(BaseTask):
             raise NotImplementedError("LM shallow fusion (lm_weight > 0) is outside the accelerated path")
         self.lm_model = None
 
-    def _replicas(self, n):
-        """n models on the same parameters (each builds its own engine handle on first use)."""
-        models = [self.model]
-        state = {k: v.detach() for k, v in self.model.named_parameters()}
-        for _ in range(n - 1):
-            m = make_transformer(self._args.input_size, self._args).cuda(getattr(self.model, "_device", 0))
-            with torch.no_grad():
-                for k, p in m.named_parameters():
-                    p.copy_(state[k])
-            models.append(m)
-        return models
+    def _engines(self, n, args):
+        """n engine handles on ONE device copy of the weights; with several ranks that copy is rank 0's, broadcast once."""
+        first = next(iter(self.test_loader))[1] if len(self.test_loader) else None
+        frames = max(getattr(args, "hip_max_frames", 4096), first.shape[1] if first is not None else 16)
+        eng0 = self.model.build_engine(args.batch_size, frames, with_weights=(self.rank == 0))
+        if self.world > 1:
+            cdist.broadcast_weights(eng0, src=0)
+        return [eng0] + [self.model.new_engine(args.batch_size, frames, share=eng0) for _ in range(n - 1)]
 
     def decode(self, args):
         if args.decode_type != "ctc_att":
@@ -74,8 +91,8 @@ class ArtTask(BaseTask):
         self._args = args
         batch_time = util.AverageMeter("Time", ":6.3f")
         progress = util.ProgressMeter(len(self.test_loader), batch_time)
-        n = max(1, min(int(getattr(args, "hip_pipelines", 4)), len(self.test_loader)))
-        models = self._replicas(n)
+        n = max(1, min(int(getattr(args, "hip_pipelines", 4)), max(1, len(self.test_loader))))
+        engines = self._engines(n, args)
         it = iter(enumerate(self.test_loader))
         lock = threading.Lock()
         done = {}
@@ -94,7 +111,7 @@ class ArtTask(BaseTask):
                             except StopIteration:
                                 break
                         src_mask = (feats[:, :, 0] != args.padding_idx).unsqueeze(1)
-                        recog = models[k].beam_decode(feats, src_mask, self.vocab, args, self.lm_model)
+                        recog = self.model.beam_decode(feats, src_mask, self.vocab, args, self.lm_model, engine=engines[k])
                         lines = [utt + " " + " ".join(hyp_to_words(seqs[0]["hyp"], self.vocab, args.padding_idx))
                                  for utt, seqs in zip(utt_list, recog)]
                         with cv:
@@ -110,22 +127,33 @@ class ArtTask(BaseTask):
         for t in threads:
             t.start()
         i = -1
-        with open(args.result_file, "w") as out_file:
-            for i in range(len(self.test_loader)):
-                with cv:
-                    while i not in done and not err:
-                        cv.wait(0.05)
-                    if err:
-                        raise err[0]
-                    lines = done.pop(i)
-                for line in lines:
-                    print(line, flush=True, file=out_file)
-                batch_time.update(time.time() - end)
-                end = time.time()
-                if i % args.print_freq == 0:
-                    progress.print(i)
+        results = {}
+        for i in range(len(self.test_loader)):
+            with cv:
+                while i not in done and not err:
+                    cv.wait(0.05)
+                if err:
+                    raise err[0]
+                lines = done.pop(i)
+            for line in lines:
+                results[line.split(" ", 1)[0]] = line
+            batch_time.update(time.time() - end)
+            end = time.time()
+            if i % args.print_freq == 0 and self.rank == 0:
+                progress.print(i)
         for t in threads:
             t.join()
-        if i >= 0:
+        for e in engines[1:]:
+            e.close()
+        if i >= 0 and self.rank == 0:
             progress.print(i)
+        if self.world > 1:
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, results)
+            results = {k: v for part in gathered for k, v in part.items()}
+        if self.rank == 0:
+            order = [line.split()[0] for line in open(args.test_paths[0]["scp_path"]) if line.strip()]
+            with open(args.result_file, "w") as out_file:
+                for utt in order:
+                    print(results[utt], flush=True, file=out_file)
         return 0

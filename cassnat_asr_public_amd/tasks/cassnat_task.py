@@ -115,8 +115,8 @@ class CassNATTask(BaseTask):
                 recog, args = self.model.beam_decode(feats, src_mask, feat_sizes, self.vocab, args, self.lm_model,
                                                      labels=labels, label_sizes=label_sizes)
                 for utt, seqs, lab in zip(utt_list, recog, labels):
-                    results[utt] = (hyp_to_words(seqs[0]["hyp"], self.vocab, args.padding_idx),
-                                    len(seqs[0]["hyp"]) - int((lab != args.padding_idx).sum()))
+                    # utt2diff as the reference computes it (cassnat_task.py:358-360): against the PADDED label row's width
+                    results[utt] = (hyp_to_words(seqs[0]["hyp"], self.vocab, args.padding_idx), len(seqs[0]["hyp"]) - len(lab))
                 batch_time.update(time.time() - end)
                 end = time.time()
                 if i % args.print_freq == 0 and self.rank == 0:
@@ -147,7 +147,7 @@ class CassNATTask(BaseTask):
             utt_list, labels, nfr = meta.pop(i)
             frames += nfr
             for utt, hyp, lab in zip(utt_list, hyps, labels):
-                results[utt] = (hyp_to_words(hyp, self.vocab, args.padding_idx), len(hyp) - int((lab != args.padding_idx).sum()))
+                results[utt] = (hyp_to_words(hyp, self.vocab, args.padding_idx), len(hyp) - len(lab))
             batch_time.update(time.time() - end)
             end = time.time()
             if i % args.print_freq == 0 and self.rank == 0:
@@ -162,13 +162,23 @@ class CassNATTask(BaseTask):
         # args.hip_pipelines (default 4; 1 = the plain loop): beam search, ESA and capture runs keep the plain loop
         n_pipes = int(getattr(args, "hip_pipelines", 4))
         plain_greedy = (args.beam_width == 1 and getattr(args, "sample_num", 0) <= 1 and not getattr(args, "hip_capture", False))
-        if n_pipes > 1 and plain_greedy and len(self.test_loader) > 1:
+        # Both branches issue the same collectives (one weight broadcast; the result gather below), and the choice is made from
+        # rank-invariant data: the snake deal can leave ranks with batch counts that differ by one.
+        n_batches = len(self.test_loader)
+        if self.world > 1:
+            counts = [None] * self.world
+            dist.all_gather_object(counts, n_batches)
+            n_batches = min(counts)
+        if n_pipes > 1 and plain_greedy and n_batches > 1:
             frames, i = self._decode_pipelined(args, n_pipes, results, batch_time, progress)
         else:
             if self.world > 1:  # weights travel once over RCCL instead of N checkpoint reads
                 lens = [b[1].shape[1] for b in [next(iter(self.test_loader))]] if len(self.test_loader) else [16]
+                group = 1
+                if getattr(args, "sample_num", 0) > 1:  # ESA: size the decoder-side workspace now (a later rebuild would only
+                    group = max(1, min(int(args.sample_num), int(getattr(args, "hip_esa_group", 16))))  # share this blob anyway)
                 eng = self.model.build_engine(args.batch_size, max(getattr(args, "hip_max_frames", 4096), max(lens)),
-                                              with_weights=(self.rank == 0))
+                                              with_weights=(self.rank == 0), esa_group=group)
                 cdist.broadcast_weights(eng, src=0)
             frames, i = self._decode_plain(args, results, batch_time, progress)
         if self.rank == 0 and i >= 0:

@@ -26,6 +26,9 @@ class DecodeParser(object):
         p.add_argument("--hip_max_frames", default=4096, type=int, help="workspace size in input frames")
         p.add_argument("--hip_pipelines", default=4, type=int,
                        help="decode pipelines per GPU for greedy decoding of a test set (1 = batch after batch)")
+        p.add_argument("--hip_dist_backend", default="nccl", choices=["nccl", "gloo"],
+                       help="torch.distributed backend under torch.distributed.run (nccl = RCCL over xGMI; gloo: rehearsal of the "
+                            "N-rank path, also with several ranks on one GPU)")
         self.parser = p
 
     def get_args(self, argv=None):

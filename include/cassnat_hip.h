@@ -71,6 +71,12 @@ const char* cn_version(void);
 
 /* replaces models.cassnat.make_model (src/models/cassnat.py:21) */
 int cn_model_create(const cn_config* cfg, cn_model** out);
+/* A further handle on the SAME device copy of the packed weights as the finalized `donor` (reference counted: the last
+ * handle to go frees them): own workspace sized by cfg->max_batch / max_frames / esa_group, ready to decode (no load /
+ * finalize).  The model hyper-parameters, device and precision must be the donor's.  What the decode pipelines of one GPU
+ * use (one engine per pipeline, one 118 MB blob per GPU - and one RCCL broadcast per rank), and what a handle rebuilt for
+ * a larger workspace uses.  No reference counterpart: nn.Module parameters are shared by reference in Python. */
+int cn_model_create_shared(const cn_config* cfg, cn_model* donor, cn_model** out);
 void cn_model_destroy(cn_model* m);
 
 /* replaces the per-parameter copy of BaseTask.load_test_model (src/tasks/base_task.py:50-54): called once per

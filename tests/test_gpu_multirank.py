@@ -1,0 +1,208 @@
+"""The N-rank path of the recogniser on real GPUs, and the one-blob-per-GPU engine sharing it rests on.
+
+  * engine handles of one model share ONE device copy of the packed weights (cn_model_create_shared): decode pipelines,
+    and a handle rebuilt for a larger workspace (ESA group, more frames) - which is what keeps a rank whose weights came by
+    broadcast from ever re-packing its never-loaded nn.Parameters;
+  * `decode_asr` under two ranks (`gloo` with both ranks on GPU 0 - always runnable on the one-GPU box; `nccl` = RCCL when
+    the box has two GPUs, skipped otherwise): rank 0 reads the checkpoint, the blob is broadcast once, utterances are dealt by
+    length, rank 0 writes one input-ordered result file - equal to the one-process run's.  Greedy (pipelined and plain), ESA
+    with LM ranking (sample_num > 1: the engine grows its decoder-side workspace after the broadcast) and `--task art`.
+Reference fan-out: egs/librispeech/run_hubert.sh:94-116, run_art.sh:115-135 (split_scp.pl + one process per GPU).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import REPO, ast_tiny_case, config1_case, esa_case, tiny_case
+from cassnat_asr_public_amd import hip, synth
+from cassnat_asr_public_amd.models.cassnat import make_model
+
+pytestmark = pytest.mark.gpu
+
+
+class Vocab:
+    word2index = {"blank": 0, "sos": 1, "eos": 2, "unk": 3}
+
+
+def _hyps(model, args, feats, sizes, lm=None):
+    src = torch.from_numpy(feats)
+    with torch.no_grad():
+        out, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, args, lm)
+    return [s[0]["hyp"] for s in out], [s[0]["score"] for s in out]
+
+
+def test_engine_handles_share_one_weight_blob():
+    from cassnat_asr_public_amd.pipeline import DecodePipelines
+
+    args, state, feats, sizes = tiny_case()
+    args.hip_precision = "bf16"
+    model = make_model(80, args).cuda()
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.copy_(torch.from_numpy(state[k]))
+    ref = _hyps(model, args, feats, sizes)
+    blob0 = model._engine.weight_blob()
+    with DecodePipelines(model, 3, 3, 64) as pipes:
+        ptrs = {e.weight_blob() for e in pipes.engines}
+        assert len(ptrs) == 1  # one device copy for the three pipelines
+        got = list(pipes.decode(((torch.from_numpy(feats), torch.from_numpy(sizes), k) for k in range(7)), args, sos=1))
+        assert all(h == ref[0] for _, h, _ in got)
+        # a second call reuses the same worker threads and streams
+        names = [t.name for t in pipes._threads]
+        got2 = list(pipes.decode(((torch.from_numpy(feats), torch.from_numpy(sizes), k) for k in range(3)), args, sos=1))
+        assert [t.name for t in pipes._threads] == names and all(h == ref[0] for _, h, _ in got2)
+    # a rebuild for a larger workspace keeps the device copy (no re-pack) ...
+    model.engine(8, 200)
+    assert model._engine.weight_blob() == blob0
+    assert _hyps(model, args, feats, sizes) == ref
+    # ... and another model's blob is refused when the layouts differ
+    other = synth.make_args("tiny", d_encff=128)
+    other.hip_precision = "bf16"
+    eng_other = hip.Engine(synth_hyper(other), precision="bf16", max_batch=2, max_frames=64)
+    eng_other.finalize()
+    with pytest.raises(hip.HipError, match="another layout"):
+        hip.Engine(synth_hyper(args), precision="bf16", max_batch=2, max_frames=64, share_with=eng_other)
+
+
+def synth_hyper(args):
+    from types import SimpleNamespace
+
+    return SimpleNamespace(input_size=80, d_model=args.d_model, n_head=args.n_head, d_encff=args.d_encff, d_decff=args.d_decff,
+                           N_enc=args.N_enc, N_extra=args.N_extra, N_self_dec=args.N_self_dec, N_mix_dec=args.N_mix_dec,
+                           vocab_size=args.vocab_size)
+
+
+def test_broadcast_receiver_never_repacks_its_unloaded_parameters():
+    """A rank != 0 holds xavier-initialised parameters and an engine whose blob came from rank 0.  Growing that engine (ESA's
+    decoder-side workspace, a longer batch) must keep rank 0's weights; packing from the local parameters must raise."""
+    from cassnat_asr_public_amd import dist as cdist
+    from cassnat_asr_public_amd.models.lm import make_model as make_lm
+
+    args, lm_args, state, lm_state, feats, sizes = esa_case("esa_tiny")
+    args.hip_precision = lm_args.hip_precision = "fp32"
+    args.esa_select = np.random.default_rng(5).integers(0, 2, (3 * 4, 16, 1))
+    lm = make_lm(lm_args).cuda()
+    with torch.no_grad():
+        for k, p in lm.named_parameters():
+            p.copy_(torch.from_numpy(lm_state[k]))
+    src = make_model(80, args).cuda()
+    with torch.no_grad():
+        for k, p in src.named_parameters():
+            p.copy_(torch.from_numpy(state[k]))
+    want = _hyps(src, args, feats, sizes, lm)
+    dst = make_model(80, args).cuda()  # never loaded
+    eng = dst.build_engine(3, 64, with_weights=False)  # esa_group 1: the ESA call below has to grow it
+    (pa, na), (pb, nb) = src._engine.weight_blob(), eng.weight_blob()
+    assert na == nb
+    torch.as_tensor(cdist._CudaBlob(pb, nb), device="cuda").copy_(torch.as_tensor(cdist._CudaBlob(pa, na), device="cuda"))
+    torch.cuda.synchronize()
+    got = _hyps(dst, args, feats, sizes, lm)
+    assert dst._engine is not eng and dst._engine.cfg.esa_group >= 4 and dst._engine.weight_blob() == (pb, nb)
+    assert got == want
+    with pytest.raises(hip.HipError, match="never loaded"):
+        dst.new_engine(3, 64, with_weights=True)
+    dst._engine.close()
+    dst._engine = None
+    with pytest.raises(hip.HipError, match="never loaded"):
+        dst.build_engine(3, 64)
+
+
+# ------------------------------------------------------------------------------------------- two ranks through the CLI
+def _write_case(tmp, args, state, feats, lengths, extra_conf=None, ast=False):
+    from cassnat_asr_public_amd.data import kaldi_io
+
+    mats = [(f"spk-utt{b:02d}", feats[b, :n]) for b, n in enumerate(lengths)]
+    scp = str(tmp / "feats.scp")
+    kaldi_io.write_ark_scp(str(tmp / "feats.ark"), scp, mats)
+    vocab_file = tmp / "vocab.txt"
+    vocab_file.write_text("".join(f"w{i}\n" for i in range(args.vocab_size - 4)))
+    ckpt = str(tmp / "model.mdl")
+    torch.save({"model_state": {"module." + k: torch.from_numpy(v) for k, v in state.items()}}, ckpt)
+    keys = ("input_size", "d_model", "n_head", "d_ff", "N_enc", "model_type", "n_features", "left_ctx", "right_ctx", "skip_frame",
+            "padding_idx", "beam_width", "length_penalty")
+    keys += ("N_dec", "ctc_beam", "ctc_weight", "max_decode_ratio", "T") if ast else ("d_encff", "d_decff", "N_extra", "N_self_dec",
+                                                                                  "N_mix_dec", "use_trigger")
+    conf = {k: getattr(args, k) for k in keys}
+    conf.update(vocab_file=str(vocab_file), use_gpu=True)
+    conf.update(extra_conf or {})
+    cfg = tmp / "decode.yaml"
+    cfg.write_text(yaml.safe_dump(conf))
+    return scp, ckpt, str(cfg)
+
+
+def _run_cli(tmp, cli, world, backend, tag):
+    result = str(tmp / f"result_{tag}.txt")
+    cmd = [sys.executable, "-m", "cassnat_asr_public_amd.bin.decode_asr"] + cli + ["--result_file", result, "--hip_dist_backend", backend]
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if world == 1:
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        out = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    else:
+        port = str(29600 + os.getpid() % 2000)
+        procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                                                MASTER_PORT=port), cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                 for r in range(world)]
+        for pr in procs:
+            text, _ = pr.communicate(timeout=600)
+            assert pr.returncode == 0, text[-4000:]
+    return open(result).read().splitlines()
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_equal_one_process_greedy_and_esa(tmp_path, backend):
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL); the gloo variant rehearses the same path on one")
+    args, lm_args, state, lm_state, _, _ = esa_case("esa_tiny")
+    lengths = [61, 58, 55, 50, 47, 44, 41, 37, 33]
+    feats, _ = synth.make_feats(len(lengths), 61, 80, lengths=lengths, seed=11)
+    scp, ckpt, cfg = _write_case(tmp_path, args, state, feats, lengths)
+    base = ["--task", "cassnat", "--test_config", cfg, "--data_path", scp, "--resume_model", ckpt, "--batch_size", "2",
+            "--hip_precision", "fp32", "--load_data_workers", "0"]
+    # greedy through the decode pipelines, batch_size 1 (an utterance decoded with batch mates sees their padding in its last
+    # conv frames and their row count in its greedy finish, as in the reference - and the mates differ between one and two ranks)
+    b1 = base[:-6] + ["--batch_size", "1"] + base[-4:]
+    one1 = _run_cli(tmp_path, b1, 1, backend, "g1b")
+    two1 = _run_cli(tmp_path, b1, 2, backend, "g2b")
+    assert [l.split()[0] for l in one1] == [f"spk-utt{b:02d}" for b in range(len(lengths))]
+    assert one1 == two1
+    # batch_size 2 (5 batches on one rank; 3 and 2 on two: the ranks' batch counts differ, both must take the same branch):
+    # complete, input-ordered files whose lines agree except near an utterance's end
+    one = _run_cli(tmp_path, base, 1, backend, "g1")
+    two = _run_cli(tmp_path, base, 2, backend, "g2")
+    assert [l.split()[0] for l in one] == [l.split()[0] for l in two] == [l.split()[0] for l in one1]
+    assert np.mean([a.split()[:4] == b.split()[:4] for a, b in zip(one, two)]) > 0.6
+    # ESA + TransformerLM ranking (sample_num 4): rank 1's engine grows its decoder-side workspace AFTER the broadcast - it must
+    # keep rank 0's weights (a re-pack from its never-loaded parameters gives unrelated text).  threshold 0: no frame is
+    # re-drawn, so the result does not depend on each rank's torch.randint stream
+    lm_cfg = tmp_path / "lm.yaml"
+    lm_cfg.write_text(yaml.safe_dump({k: v for k, v in vars(lm_args).items() if isinstance(v, (int, float, str, bool))}))
+    lm_ckpt = str(tmp_path / "lm.mdl")
+    torch.save({"model_state": {k: torch.from_numpy(v) for k, v in lm_state.items()}}, lm_ckpt)
+    scp2, ckpt2, cfg2 = _write_case(tmp_path, args, state, feats, lengths,
+                                    extra_conf=dict(sample_num=4, threshold=0.0, ctc_lm_weight=1.0, rank_model="lm"))
+    esa = ["--task", "cassnat", "--test_config", cfg2, "--data_path", scp2, "--resume_model", ckpt2, "--batch_size", "1",
+           "--hip_precision", "fp32", "--load_data_workers", "0", "--lm_config", str(lm_cfg), "--rnnlm", lm_ckpt, "--seed", "7"]
+    e1 = _run_cli(tmp_path, esa, 1, backend, "e1")
+    e2 = _run_cli(tmp_path, esa, 2, backend, "e2")
+    assert len(e1) == len(lengths) and e1 == e2
+    # the ESA picks of identical samples are the greedy best path (up to the greedy finish's extra row)
+    assert np.mean([a.split()[:3] == b.split()[:3] for a, b in zip(e1, one1)]) > 0.8
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_art_task(tmp_path, backend):
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL)")
+    args, state, feats = ast_tiny_case()
+    lengths = [61, 57, 51]
+    scp, ckpt, cfg = _write_case(tmp_path, args, state, feats, lengths, ast=True)
+    base = ["--task", "art", "--test_config", cfg, "--data_path", scp, "--resume_model", ckpt, "--batch_size", "1",
+            "--hip_precision", "fp32", "--load_data_workers", "0"]
+    assert _run_cli(tmp_path, base, 1, backend, "a1") == _run_cli(tmp_path, base, 2, backend, "a2")

@@ -244,7 +244,7 @@ def test_decode_pipelines_keep_submission_order_and_surface_errors():
         def __init__(self, fail_at=None):
             self.seen, self.fail_at, self.pairs = [], fail_at, 0
 
-        def new_engine(self, batch, frames, with_weights=True):
+        def new_engine(self, batch, frames, with_weights=True, share=None):
             return StubEngine()
 
         def decode_device(self, feats, ratio, args, sos, engine=None, sub_batch=0):
