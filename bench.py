@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--frames", type=int, default=1000)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8", "bf16x3"],
                     help="fp8: BASELINE config 5's mode - the bf16 engine with the encoder layers' products on the e4m3fn MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-engine", action="store_true",
@@ -58,12 +58,14 @@ def main():
     ap.add_argument("--cpu-batches", type=int, default=3)
     ap.add_argument("--stage-profile", action="store_true", help="also print a per-kernel-tag table to stderr")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 path on one GPU")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=3,
                     help="decode pipelines per GPU (own engine handle, HIP stream and host thread each): keeps the GPU fed "
                          "across the two host syncs every batch needs (token count readback, hypotheses to host)")
-    ap.add_argument("--no-coalesced", action="store_true",
-                    help="skip the extra measurement with pairs of batches coalesced into one engine pass (reported separately, "
-                         "never as `value`)")
+    ap.add_argument("--coalesce", type=int, default=3,
+                    help="batches of 32 a decode pipeline may take through ONE engine pass (wider launches; every batch's "
+                         "hypotheses and scores stay exactly those of a pass of its own: cn_decode_opts.sub_batch)")
+    ap.add_argument("--no-uncoalesced", action="store_true",
+                    help="skip the extra measurement with one batch per engine pass (reported beside `value`)")
     a = ap.parse_args()
 
     import numpy as np
@@ -119,7 +121,8 @@ def main():
             cdist.broadcast_weights(eng, src=0)
             bcast["ms"] = (time.perf_counter() - t0) * 1e3
 
-    pipes = DecodePipelines(model, NS, B, T, with_weights=(rank == 0), after_engine=receive_weights)
+    CO = max(1, a.coalesce) if a.precision != "fp32" else 1
+    pipes = DecodePipelines(model, NS, B, T, with_weights=(rank == 0), after_engine=receive_weights, coalesce=CO)
     engines = pipes.engines
     bcast_ms = bcast["ms"]
     blob_bytes = engines[0].weight_blob()[1]
@@ -142,11 +145,11 @@ def main():
         host happen here, in THIS thread only and in step order, so every rank issues the same sequence of collectives."""
         # (hypotheses reach the host as arrays - tokens, lengths, scores of all ranks' utterances - without per-utterance Python
         # work: at 8 ranks a step carries 256 of them)
-        for _, hyps_, scores_ in pipes.decode(((feats, sizes, k) for k in range(n_steps)), args, sos=1, gather=world > 1,
+        for _, hyps_, scores_ in pipes.decode([(feats, sizes, k) for k in range(n_steps)], args, sos=1, gather=world > 1,
                                               as_lists=False):
             last[0] = (hyps_, scores_)
 
-    run_steps(max(a.warmup, NS))
+    run_steps(max(a.warmup, NS * CO))
     U = int(engines[0].fetch("ymax")[0])
     eng = engines[0]
     fence()
@@ -185,31 +188,23 @@ def main():
             gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0
             print(f"{k:20s} n={v['count'] // 3:3d} {v['ms'] / 3:8.3f} ms  {tf:8.1f} TFLOP/s  {gb:8.1f} GB/s(alg)", file=sys.stderr)
 
-    # ---- extra (never `value`; N = 1 only): the same steps with the pipelines
-    # coalescing pairs of batches into one engine pass - wider launches, per-batch hypotheses unchanged
-    # (cn_decode_opts.sub_batch); what CassNATTask.decode does for test sets
-    coalesced = None
-    if not a.no_coalesced and a.precision != "fp32" and world == 1:  # (like cpu_baseline: at N = 1 only)
-        pipes2 = DecodePipelines(model, NS, B, T, coalesce=2, share_from=engines[0])  # (the same device copy of the weights)
+    # ---- extra (never `value`; N = 1 only): the same steps with one batch per engine pass
+    uncoalesced = None
+    if not a.no_uncoalesced and CO > 1 and world == 1:  # (like cpu_baseline: at N = 1 only)
+        pipes2 = DecodePipelines(model, NS, B, T, coalesce=1, share_from=engines[0])  # (the same device copy of the weights)
 
         def run2(n_steps):
-            for _ in pipes2.decode(((feats, sizes, k) for k in range(n_steps)), args, sos=1, gather=world > 1, as_lists=False):
+            for _ in pipes2.decode([(feats, sizes, k) for k in range(n_steps)], args, sos=1, as_lists=False):
                 pass
 
-        run2(max(a.warmup, 2 * NS))
+        run2(max(a.warmup, NS))
         fence()
         c0 = time.perf_counter()
         run2(a.steps)
         fence()
         el2 = time.perf_counter() - c0
-        if world > 1:
-            tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el2 = float(tt.item())
-        coalesced = {"value": round(a.steps * B * world / el2, 2), "unit": "utt/s", "ms_per_step": round(el2 / a.steps * 1e3, 4),
-                     "note": "same workload and step count; each decode pipeline takes two batches of 32 through one engine pass "
-                             "(hypotheses and scores per batch identical to separate passes: tests/test_gpu_edges.py); reported "
-                             "beside, not as, `value`"}
+        uncoalesced = {"value": round(a.steps * B * world / el2, 2), "unit": "utt/s", "ms_per_step": round(el2 / a.steps * 1e3, 4),
+                       "note": "same workload and step count with one batch of 32 per engine pass"}
         pipes2.close()
 
     if rank != 0:
@@ -256,7 +251,7 @@ def main():
         roofline = roof("row_chain",
                         "chain_kernel (per layer: attention out-projection + residual + LayerNorm + FFN + residual + next "
                         "LayerNorm + next Q|K|V projection; 21 launches per step: 12 encoder, 9 decoder-side)",
-                        {"workgroups_encoder_launch": enc_wgs,
+                        {"workgroups_encoder_launch": enc_wgs * CO,
                          "design_note": "a launch deliberately occupies ceil(rows / 128) CUs (63 of 256 for the encoder): its weight "
                                         "stream is bound per CU, so the remaining CUs are left to the other decode pipelines; "
                                         "'frac' is against the whole chip's peak all the same"})
@@ -301,11 +296,11 @@ def main():
         with torch.no_grad():
             for k, p in mx.named_parameters():
                 p.copy_(torch.from_numpy(state[k]))
-        px = DecodePipelines(mx, NS, B, T)
+        px = DecodePipelines(mx, NS, B, T, coalesce=1 if prec == "fp32" else CO)
         got = {}
 
         def runx(n_steps):
-            for _, h_, s_ in px.decode(((feats, sizes, k) for k in range(n_steps)), ax, sos=1, as_lists=False):
+            for _, h_, s_ in px.decode([(feats, sizes, k) for k in range(n_steps)], ax, sos=1, as_lists=False):
                 got[0] = h_
 
         runx(max(2, NS))
@@ -337,12 +332,13 @@ def main():
                                "V 5000, greedy NAST; 32 utterances x 1000 frames x 80 fbank per GPU per step",
                    "batch_per_gpu": B, "frames": T, "feat_dim": F, "global_batch": B * world, "tokens_U_max": U,
                    "parallelism": f"utterance-sharded x{world}", "decode_pipelines_per_gpu": NS,
+                   "batches_per_engine_pass": CO,
                    "blank_bias": synth.BENCH_BLANK_BIAS},
         "rtf": round(elapsed / audio_s, 8), "rtfx": round(audio_s / elapsed, 1),
         "gflop_per_utt": round(flops / B / 1e9, 3),
         "mfma_frac_end_to_end": round(flops / B * value / (world * PEAK_BF16_DENSE_TFLOPS * 1e12), 5),
         "roofline": roofline, "roofline_conv2": roofline_conv2, "cpu_baseline": cpu, "parity_engine": parity_engine,
-        "fp32_engine": fp32_engine, "coalesced_pairs": coalesced,
+        "fp32_engine": fp32_engine, "one_batch_per_pass": uncoalesced,
         "stage_ms": stage_ms,
         "weight_blob_mb": round(blob_bytes / 1e6, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
     }

@@ -60,6 +60,13 @@ template <> struct AttnCfg<float> {
     __device__ static int swz(int row) { return row & 15; }
 };
 
+template <> struct AttnCfg<split_t> {   // split-bf16 rows: per head [32 hi][32 lo][32 hi][32 lo] = 256 B, 16 chunks
+    static constexpr int KROW = 256;
+    static constexpr int VROW = 192;  // per PLANE (hi / lo): 64 bf16 of data + 64 B pad, as the bf16 tile
+    static constexpr int CPR = 16;
+    __device__ static int swz(int row) { return row & 15; }
+};
+
 // NW waves per workgroup (32 query rows each): 4 -> 128-row tiles, 2 -> 64-row tiles (more, smaller workgroups when
 // the grid would otherwise be ~1 workgroup per CU with nothing to overlap its barriers and load latency)
 // RES (bf16, Lk <= 256): ALL keys/values of the (batch, head) are brought into LDS at once by LDS-DMA (the XOR swizzles
@@ -74,10 +81,12 @@ template <typename T, int NW, bool RES, bool REL = false>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
     typedef AttnCfg<T> Cfg;
     typedef typename Frag<T>::type frag_t;
+    constexpr bool SPLIT = __is_same(T, split_t);
+    static_assert(!SPLIT || (!RES && !REL), "split-bf16 attention: plain staged form only");
     constexpr int KROW = Cfg::KROW, CPR = Cfg::CPR;
     constexpr int VROW = RES ? 128 : Cfg::VROW;  // RES: unpadded rows, 64-byte halves swapped on rows with (row>>1)&1
-    constexpr int KT_BYTES = 64 * KROW, VT_BYTES = 64 * VROW, NRES = RES ? 4 : 1;
-    constexpr int NF = KROW / 32;           // 16-byte fragments of one 64-wide head row per lane half
+    constexpr int KT_BYTES = 64 * KROW, VT_BYTES = (SPLIT ? 2 : 1) * 64 * VROW, NRES = RES ? 4 : 1;
+    constexpr int NF = SPLIT ? 4 : KROW / 32;  // fragments of one 64-wide head row per lane half (split: k-steps of 16, hi + lo each)
     constexpr int NT = 64 * NW;
     constexpr int ST_IT = 64 * CPR / NT;    // 16-byte chunks per thread per 64-key tile
 
@@ -98,13 +107,22 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
     frag_t qf[NF];
     {
         const unsigned char* qp = p.Q + ((long long)b * p.Lq + qc) * p.ldq_b + (long long)h * KROW;
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int s = 0; s < NF; ++s) qf[s] = as_frag<T>(ld16(qp + (2 * s + half) * 16));
+            for (int s = 0; s < NF; ++s) {  // k-step s: group s >> 1, chunk 2 (s & 1) + half of its hi quarter; lo 64 B further
+                const unsigned char* c = qp + (s >> 1) * 128 + (2 * (s & 1) + half) * 16;
+                qf[s].hi = as_frag<bf16>(ld16(c));
+                qf[s].lo = as_frag<bf16>(ld16(c + 64));
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NF; ++s) qf[s] = as_frag<T>(ld16(qp + (2 * s + half) * 16));
+        }
     }
     constexpr int REL_N = REL ? 64 : 1;
     __shared__ float rel_tab[REL ? 64 * 64 : 1];        // P rows of this head: [2R+1][64]
     __shared__ float rel_bias[REL ? NW : 1][32][REL_N];  // bd[i][r] per wave
-    if constexpr (REL) {
+    if constexpr (REL && !SPLIT) {
         constexpr int E = Frag<T>::ELEMS;
         const int nr = 2 * p.rel_R + 1;
         for (int i = tid; i < nr * 64; i += NT) rel_tab[i] = p.rel_pos[(long long)(i >> 6) * p.ld_pos + h * 64 + (i & 63)];
@@ -171,7 +189,10 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
             const int cidx = tid + NT * i;
             const int row = cidx / CPR, ch = cidx % CPR;
             st16(Ks + row * KROW + ((ch ^ Cfg::swz(row)) << 4), k_reg[i]);
-            st16(Vs + row * VROW + (ch << 4), v_reg[i]);
+            if constexpr (SPLIT)  // chunk ch = 8 g + c: c < 4 hi, else lo, of head dims 32 g + 8 (c & 3) ..; one LDS plane each
+                st16(Vs + ((ch >> 2) & 1) * 64 * VROW + row * VROW + ((((ch >> 3) << 2) | (ch & 3)) << 4), v_reg[i]);
+            else
+                st16(Vs + row * VROW + (ch << 4), v_reg[i]);
         }
         if (tid < 64) {
             const int key = kt * 64 + tid;
@@ -250,9 +271,17 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
             const int row = sub * 32 + l31;
 #pragma unroll
             for (int s = 0; s < NF; ++s) {
-                const int chunk = 2 * s + half;
-                const frag_t kf = as_frag<T>(ld16(Ks + row * KROW + ((chunk ^ Cfg::swz(row)) << 4)));
-                sc[sub] = mfma_frag(kf, qf[s], sc[sub]);
+                if constexpr (SPLIT) {
+                    const int chunk = (s >> 1) * 8 + 2 * (s & 1) + half;
+                    split_frag kf;
+                    kf.hi = as_frag<bf16>(ld16(Ks + row * KROW + ((chunk ^ Cfg::swz(row)) << 4)));
+                    kf.lo = as_frag<bf16>(ld16(Ks + row * KROW + (((chunk + 4) ^ Cfg::swz(row)) << 4)));
+                    sc[sub] = mfma_frag(kf, qf[s], sc[sub]);
+                } else {
+                    const int chunk = 2 * s + half;
+                    const frag_t kf = as_frag<T>(ld16(Ks + row * KROW + ((chunk ^ Cfg::swz(row)) << 4)));
+                    sc[sub] = mfma_frag(kf, qf[s], sc[sub]);
+                }
             }
         }
         // ---- scale + mask + online softmax.  Fast path (wave-uniform): no key of this tile is masked and there are no
@@ -329,7 +358,41 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
         }
 
         // ---- O^T[dk][q] += V^T[dk][key] . P^T[key][q]
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (SPLIT) {
+            // as the bf16 form below, on the hi and lo planes of V and the hi / lo halves of P: three MFMAs per product
+            const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 ph, pl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        ph[j] = (bf16)sc[sub][8 * s + j];
+                        pl[j] = (bf16)(sc[sub][8 * s + j] - (float)ph[j]);
+                    }
+                    const int key0 = sub * 32 + 16 * s + 4 * half + (i16 >> 2);
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        bf16x8 vf[2];
+#pragma unroll
+                        for (int pl_ = 0; pl_ < 2; ++pl_) {
+                            const unsigned char* a1 = Vs + pl_ * 64 * VROW + key0 * VROW + (32 * d + 16 * g1 + 4 * (i16 & 3)) * 2;
+                            const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
+                            const s16x4 r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1 + 8 * VROW));
+                            s16x8 cat;
+                            cat[0] = r1[0]; cat[1] = r1[1]; cat[2] = r1[2]; cat[3] = r1[3];
+                            cat[4] = r2[0]; cat[5] = r2[1]; cat[6] = r2[2]; cat[7] = r2[3];
+                            vf[pl_] = __builtin_bit_cast(bf16x8, cat);
+                        }
+                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], ph, o_acc[d], 0, 0, 0);
+                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pl, o_acc[d], 0, 0, 0);
+                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], ph, o_acc[d], 0, 0, 0);
+                    }
+                }
+            }
+        } else if constexpr (sizeof(T) == 2) {
             const int i16 = lane & 15, g1 = (lane >> 4) & 1;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
@@ -383,7 +446,16 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int dk0 = 32 * d + 8 * g + 4 * half;
-                if constexpr (sizeof(T) == 2) {
+                if constexpr (SPLIT) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = o_acc[d][4 * g + e] * inv;
+                    bf16x4 hi, lo;
+                    cn_split4(o, hi, lo);
+                    unsigned char* ob = reinterpret_cast<unsigned char*>(orow) + cn_split_off((size_t)dk0);
+                    *reinterpret_cast<bf16x4*>(ob) = hi;
+                    *reinterpret_cast<bf16x4*>(ob + 64) = lo;
+                } else if constexpr (sizeof(T) == 2) {
                     bf16x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (bf16)(o_acc[d][4 * g + e] * inv);
@@ -437,14 +509,16 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     p.rel_v = a.rel_v;
     p.rel_R = a.rel_R;
     p.ld_pos = a.ld_pos;
-    if (a.rel_pos) {
-        if (a.rel_R < 0 || a.rel_R > 31 || !a.rel_u || !a.rel_v || a.Lq != a.Lk) {
-            cn_set_error("attention: relative positions need self attention and max_relative_len <= 31");
-            return -1;
+    if constexpr (!__is_same(T, split_t)) {
+        if (a.rel_pos) {
+            if (a.rel_R < 0 || a.rel_R > 31 || !a.rel_u || !a.rel_v || a.Lq != a.Lk) {
+                cn_set_error("attention: relative positions need self attention and max_relative_len <= 31");
+                return -1;
+            }
+            hipLaunchKernelGGL((attention_kernel<T, 2, false, true>), dim3(cn_ceil_div(a.Lq, 64), a.H, a.B), dim3(128), 0, s, p);
+            CN_HIP_CHECK(hipGetLastError());
+            return 0;
         }
-        hipLaunchKernelGGL((attention_kernel<T, 2, false, true>), dim3(cn_ceil_div(a.Lq, 64), a.H, a.B), dim3(128), 0, s, p);
-        CN_HIP_CHECK(hipGetLastError());
-        return 0;
     }
     const long long big_grid = (long long)cn_ceil_div(a.Lq, 128) * a.H * a.B;
     if constexpr (sizeof(T) == 2) {
@@ -478,6 +552,13 @@ int launch_attention(int prec, const AttnArgs& a, hipStream_t s) {
     if ((a.ldq * es) % 16 || (a.ldk * es) % 16 || (a.ldv * es) % 16 || (a.ldo * es) % 16) {
         cn_set_error("attention: row strides must keep rows 16-byte aligned");
         return -1;
+    }
+    if (prec == CN_PREC_X3) {
+        if (a.rel_pos || a.ldq % 32 || a.ldk % 32 || a.ldv % 32 || a.ldo % 32) {
+            cn_set_error("attention: split-bf16 rows need strides that are multiples of 32 elements; no relative-position form");
+            return -1;
+        }
+        return run_attention<split_t>(a, s);
     }
     return prec == CN_PREC_F32 ? run_attention<float>(a, s) : run_attention<bf16>(a, s);
 }

@@ -15,6 +15,16 @@ struct fp8_t {
     unsigned char bits;
 };
 #define CN_FP8_MAX 448.0f
+// Split-bf16 element ("bf16x3" precision): a value v is kept as hi = bf16(v) and lo = bf16(v - hi); hi + lo carries ~17
+// significant bits, and a product is three bf16 MFMAs (hi.hi + hi.lo + lo.hi, fp32 accumulation; the dropped lo.lo term is
+// 2^-18 relative).  Storage of a row of K elements (K % 32 == 0): groups of 32 elements = 128 bytes, [32 x bf16 hi][32 x bf16 lo].
+// sizeof == 4 on purpose: row strides, column offsets that are multiples of 32 elements (heads, Q|K|V thirds) and buffer
+// sizes are those of the fp32 engine, and a 128-byte LDS slab row holds exactly one group.
+struct split_t {
+    unsigned int bits;
+};
+// byte offset of element c's hi half inside its row (the lo half sits 64 bytes further)
+__host__ __device__ static inline size_t cn_split_off(size_t c) { return (c >> 5) * 128 + (c & 31) * 2; }
 
 #define CN_WAVE 64
 #define CN_NEG_FILL (-3.4028234663852886e38f) /* float32 min: the reference's masked_fill value */
@@ -41,6 +51,27 @@ template <> struct Frag<fp8_t> {
     typedef i64x2 type;
     static constexpr int ELEMS = 16;
 };
+struct split_frag {
+    bf16x8 hi, lo;
+};
+template <> struct Frag<split_t> {
+    typedef split_frag type;
+    static constexpr int ELEMS = 8;
+};
+__device__ __forceinline__ f32x16 mfma_frag(const split_frag& a, const split_frag& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);  // (small terms first)
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+    return c;
+}
+// v -> (hi, lo); four consecutive elements -> 8 bytes of hi and 8 bytes of lo
+__device__ __forceinline__ void cn_split4(const float (&v)[4], bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = (bf16)v[j];
+        lo[j] = (bf16)(v[j] - (float)hi[j]);
+    }
+}
 
 __device__ __forceinline__ f32x16 mfma_frag(i64x2 a, i64x2 b, f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a[0], b[0], c, 0, 0, 0);

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
     const int rows = B * T1p;
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
         const int b = row / T1p, t1 = row - b * T1p - halo;
-        T* orow = out + (long long)row * F1p * C + c0;
+        T* orow = out + (long long)row * F1p * C + (__is_same(T, split_t) ? 0 : c0);
         const bool row_in = t1 >= 0 && t1 < T1;
         // the three input rows of this output row (null = outside the padded input)
         const float* xr[3];
@@ -45,6 +45,35 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
         for (int fp = p0; fp < F1p; fp += pstep) {
             const int f1 = fp - halo;
             T* dst = orow + (long long)fp * C;
+            if constexpr (__is_same(T, split_t)) {  // (no bordered image in this precision: halo == 0)
+                float o[8];
+                float acc[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = bz[j];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int f = 2 * f1 - 1 + kw;
+                        float v = 0.f;
+                        if (xr[kh] && f >= 0 && f < F) v = xr[kh][f];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, w[kh * 3 + kw][j], acc[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = fmaxf(acc[j], 0.f);
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    hi[j] = (bf16)o[j];
+                    lo[j] = (bf16)(o[j] - (float)hi[j]);
+                }
+                unsigned char* db = reinterpret_cast<unsigned char*>(dst) + cn_split_off((size_t)c0);
+                *reinterpret_cast<bf16x8*>(db) = hi;
+                *reinterpret_cast<bf16x8*>(db + 64) = lo;
+                continue;
+            }
             if (!row_in || f1 < 0 || f1 >= F1) {  // border cell
                 if (skip_border) continue;
                 if constexpr (sizeof(T) == 2) {
@@ -98,8 +127,15 @@ int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, 
     if (blocks > 256 * 8) blocks = 256 * 8;             // 8 workgroups per CU, grid-stride the rest
     if (blocks < 1) blocks = 1;
     const size_t lds = 0;
+    if (prec == CN_PREC_X3 && (halo || C % 32 != 0)) {
+        cn_set_error("conv1: the split-bf16 image has no halo form and needs C % 32 == 0");
+        return -1;
+    }
     if (prec == CN_PREC_F32)
         hipLaunchKernelGGL(conv1_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (float*)out, B, T,
+                           F, T1, F1, C, halo);
+    else if (prec == CN_PREC_X3)
+        hipLaunchKernelGGL(conv1_kernel<split_t>, dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (split_t*)out, B, T,
                            F, T1, F1, C, halo);
     else
         hipLaunchKernelGGL(conv1_kernel<bf16>, dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (bf16*)out, B, T,

@@ -137,24 +137,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     auto compute_slab = [&](int buf) {
         const unsigned char* a_base = smem + buf * BUF;
         const unsigned char* w_base = a_base + BM * ROWB;
+        if constexpr (__is_same(T, split_t)) {
+            // a 128-byte slab row = one 32-element group: chunks 0-3 the hi halves of k = 8 c .. 8 c + 7, chunks 4-7 the lo halves
 #pragma unroll
-        for (int cs = 0; cs < 4; ++cs) {
-            const int chunk = 2 * cs + half;
-            frag_t af[MI], wf[NI];
+            for (int ks = 0; ks < 2; ++ks) {
+                const int ch = 2 * ks + half;
+                split_frag af[MI], wf[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int r = a_row0 + 32 * i;
-                af[i] = as_frag<T>(ld16(a_base + r * ROWB + ((chunk ^ ((r >> 1) & 7)) << 4)));
+                for (int i = 0; i < MI; ++i) {
+                    const int r = a_row0 + 32 * i, sw = (r >> 1) & 7;
+                    af[i].hi = as_frag<bf16>(ld16(a_base + r * ROWB + ((ch ^ sw) << 4)));
+                    af[i].lo = as_frag<bf16>(ld16(a_base + r * ROWB + (((ch + 4) ^ sw) << 4)));
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int r = w_row0 + 32 * j, sw = (r >> 1) & 7;
+                    wf[j].hi = as_frag<bf16>(ld16(w_base + r * ROWB + ((ch ^ sw) << 4)));
+                    wf[j].lo = as_frag<bf16>(ld16(w_base + r * ROWB + (((ch + 4) ^ sw) << 4)));
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma_frag(af[i], wf[j], acc[i][j]);
             }
+        } else {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int r = w_row0 + 32 * j;
-                wf[j] = as_frag<T>(ld16(w_base + r * ROWB + ((chunk ^ ((r >> 1) & 7)) << 4)));
+            for (int cs = 0; cs < 4; ++cs) {
+                const int chunk = 2 * cs + half;
+                frag_t af[MI], wf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int r = a_row0 + 32 * i;
+                    af[i] = as_frag<T>(ld16(a_base + r * ROWB + ((chunk ^ ((r >> 1) & 7)) << 4)));
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int r = w_row0 + 32 * j;
+                    wf[j] = as_frag<T>(ld16(w_base + r * ROWB + ((chunk ^ ((r >> 1) & 7)) << 4)));
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma_frag(af[i], wf[j], acc[i][j]);
             }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = mfma_frag(af[i], wf[j], acc[i][j]);
         }
     };
 
@@ -219,7 +244,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                 if (p.epi & CN_EPI_EMBED) v = v * p.scale + (p.pe ? p.pe[(long long)(m % p.pe_period) * p.N + n] : 0.f);
                 if (p.epi & CN_EPI_RESID) v = p.resid[(long long)m * p.ldr + n] + p.resid_scale * v;
                 if constexpr (sizeof(TC) == 1) v *= p.c_scale;
-                C[(long long)m * p.ldc + n] = from_f32<TC>(v);
+                if constexpr (__is_same(TC, split_t)) {
+                    unsigned char* cb = reinterpret_cast<unsigned char*>(p.C) + (long long)m * p.ldc * 4 + cn_split_off((size_t)n);
+                    const bf16 hi = (bf16)v;
+                    *reinterpret_cast<bf16*>(cb) = hi;
+                    *reinterpret_cast<bf16*>(cb + 64) = (bf16)(v - (float)hi);
+                } else {
+                    C[(long long)m * p.ldc + n] = from_f32<TC>(v);
+                }
             }
         }
     }
@@ -324,5 +356,12 @@ int launch_gemm(int prec, const GemmArgs& a, hipStream_t s) {
     // K-deep products onto all 256 output columns with the embedding epilogue (linear_out): the LDS-DMA tile kernel
     if (!a.conv && a.epi == CN_EPI_EMBED && a.c_f32 && a.ldc == a.N && a.K >= 1024 && linear256_dma_applies(prec, a.N, a.K))
         return launch_linear256_dma(a.A, a.lda, a.W, a.bias, (float*)a.C, a.M, a.K, a.scale, a.pe, a.pe_period, s);
+    if (prec == CN_PREC_X3) {
+        if (a.lda % 32 != 0 || (!a.c_f32 && a.ldc % 32 != 0)) {
+            cn_set_error("gemm: split-bf16 operands need row strides that are multiples of 32 elements");
+            return -1;
+        }
+        return dispatch_gemm<split_t>(a, s);
+    }
     return prec == CN_PREC_F32 ? dispatch_gemm<float>(a, s) : dispatch_gemm<bf16>(a, s);
 }

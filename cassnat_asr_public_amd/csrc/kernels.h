@@ -3,8 +3,9 @@
 #pragma once
 #include "common.h"
 
-enum { CN_PREC_F32 = 0, CN_PREC_BF16 = 1 };
-static inline size_t cn_elem_size(int prec) { return prec == CN_PREC_F32 ? 4 : 2; }
+// model precisions of the kernels (the public CN_PRECISION_FP8 = 2 is a CN_PREC_BF16 engine with fp8 encoder products)
+enum { CN_PREC_F32 = 0, CN_PREC_BF16 = 1, CN_PREC_X3 = 3 };  // X3: split-bf16 elements (common.h split_t), 3 bf16 MFMAs per product
+static inline size_t cn_elem_size(int prec) { return prec == CN_PREC_BF16 ? 2 : 4; }
 
 // ---- GEMM:  C[M][N] = epi( A[M][K] . W[N][K]^T + bias[N] )            (gemm.hip)
 enum { CN_EPI_RELU = 1, CN_EPI_RESID = 2, CN_EPI_EMBED = 4, CN_EPI_SWISH = 8 };

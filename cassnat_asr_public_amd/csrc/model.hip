@@ -270,7 +270,16 @@ struct Packer {
     void put_elem(size_t at, size_t idx, float v) {
         if (m->prec == CN_PREC_F32)
             std::memcpy(&host[at + idx * 4], &v, 4);
-        else {
+        else if (m->prec == CN_PREC_X3) {  // split-bf16: hi / lo halves of the element's 32-group (every packed row is a
+            const uint16_t hi = f32_to_bf16_host(v);  // multiple of 32 long, so flat groups never straddle rows)
+            uint32_t hb = (uint32_t)hi << 16;
+            float hf;
+            std::memcpy(&hf, &hb, 4);
+            const uint16_t lo = f32_to_bf16_host(v - hf);
+            const size_t o = at + cn_split_off(idx);
+            std::memcpy(&host[o], &hi, 2);
+            std::memcpy(&host[o + 64], &lo, 2);
+        } else {
             const uint16_t h = f32_to_bf16_host(v);
             std::memcpy(&host[at + idx * 2], &h, 2);
         }
@@ -1844,8 +1853,13 @@ extern "C" int cn_model_create(const cn_config* cfg, cn_model** out) {
         cn_set_error("cn_model_create: feed-forward widths must be multiples of 64 and d_model <= 1024");
         return -1;
     }
-    if (c.precision != CN_PRECISION_F32 && c.precision != CN_PRECISION_BF16 && c.precision != CN_PRECISION_FP8) {
+    if (c.precision != CN_PRECISION_F32 && c.precision != CN_PRECISION_BF16 && c.precision != CN_PRECISION_FP8 &&
+        c.precision != CN_PRECISION_BF16X3) {
         cn_set_error("cn_model_create: unknown precision");
+        return -1;
+    }
+    if (c.precision == CN_PRECISION_BF16X3 && (c.ast == 1 || c.conf_enc || c.conf_dec || c.d_encff % 32 || c.d_decff % 32)) {
+        cn_set_error("cn_model_create: the split-bf16 (bf16x3) engine covers the transformer-block NAT model and the TransformerLM");
         return -1;
     }
     if (c.precision == CN_PRECISION_FP8 && (c.ast || c.conf_enc || c.d_model % 128 != 0 || c.d_encff % 128 != 0)) {
@@ -1862,7 +1876,7 @@ extern "C" int cn_model_create(const cn_config* cfg, cn_model** out) {
     m->cfg = c;
     // fp8: a bf16 engine (storage, decoder side, conv front-end) whose encoder-layer products take e4m3fn operands
     m->fp8_enc = c.precision == CN_PRECISION_FP8;
-    m->prec = m->fp8_enc ? CN_PREC_BF16 : c.precision;
+    m->prec = m->fp8_enc ? CN_PREC_BF16 : (c.precision == CN_PRECISION_BF16X3 ? CN_PREC_X3 : c.precision);
     m->es = cn_elem_size(m->prec);
     m->maxB = c.max_batch;
     m->maxT = c.max_frames;
@@ -2368,6 +2382,15 @@ extern "C" int cn_op_gemm(int32_t precision, const void* A, int32_t lda, const v
     g.pe_period = pe_period;
     g.scale = scale;
     return launch_gemm(precision, g, (hipStream_t)stream);
+}
+
+extern "C" int cn_op_convert(int32_t precision, const void* src, void* dst, int64_t n, int32_t to_f32, void* stream) {
+    if (n < 0 || !src || !dst) {
+        cn_set_error("cn_op_convert: bad argument");
+        return -1;
+    }
+    return to_f32 ? launch_convert_back(precision, src, (float*)dst, (size_t)n, (hipStream_t)stream)
+                  : launch_convert(precision, (const float*)src, dst, (size_t)n, (hipStream_t)stream);
 }
 
 extern "C" int cn_op_conv1(int32_t precision, const float* x, const float* w9c, const float* bias, void* out, int32_t B,

@@ -58,6 +58,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ob[j] = (bf16)o[j];
                 *reinterpret_cast<bf16x4*>(yr + idx) = ob;
+            } else if constexpr (__is_same(TY, split_t)) {  // hi / lo halves of the element's 32-group (common.h)
+                bf16x4 hi, lo;
+                cn_split4(o, hi, lo);
+                unsigned char* yb = reinterpret_cast<unsigned char*>(yr) + cn_split_off((size_t)idx);
+                *reinterpret_cast<bf16x4*>(yb) = hi;
+                *reinterpret_cast<bf16x4*>(yb + 64) = lo;
             } else {
                 f32x4 of;
 #pragma unroll
@@ -76,8 +82,14 @@ int launch_layernorm(int prec, const float* x, const float* a2, const float* b2,
     }
     if (M <= 0) return 0;
     const dim3 grid(cn_ceil_div(M, 4));
+    if (prec == CN_PREC_X3 && !y_f32 && d % 32 != 0) {
+        cn_set_error("layernorm: split-bf16 rows need d % 32 == 0");
+        return -1;
+    }
     if (y_f32 || prec == CN_PREC_F32)
         hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, a2, b2, (float*)y, M, d, eps, 1.f);
+    else if (prec == CN_PREC_X3)
+        hipLaunchKernelGGL(layernorm_kernel<split_t>, grid, dim3(256), 0, s, x, a2, b2, (split_t*)y, M, d, eps, 1.f);
     else
         hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, dim3(256), 0, s, x, a2, b2, (bf16*)y, M, d, eps, 1.f);
     CN_HIP_CHECK(hipGetLastError());
@@ -428,6 +440,29 @@ __global__ void convert_kernel(const TS* __restrict__ src, TD* __restrict__ dst,
         dst[i] = from_f32<TD>(to_f32(src[i]));
 }
 
+// flat fp32 <-> split-bf16 (n % 32 == 0: contiguous rows whose length is a multiple of 32)
+__global__ void convert_to_split_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+        const float a[4] = {v[0], v[1], v[2], v[3]};
+        bf16x4 hi, lo;
+        cn_split4(a, hi, lo);
+        unsigned char* d = dst + cn_split_off(4 * i);
+        *reinterpret_cast<bf16x4*>(d) = hi;
+        *reinterpret_cast<bf16x4*>(d + 64) = lo;
+    }
+}
+__global__ void convert_from_split_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned char* p = src + cn_split_off(4 * i);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(p), lo = *reinterpret_cast<const bf16x4*>(p + 64);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (float)hi[j] + (float)lo[j];
+        *reinterpret_cast<f32x4*>(dst + 4 * i) = o;
+    }
+}
+
 static unsigned convert_grid(size_t n) {
     size_t g = (n + 255) / 256;
     return (unsigned)(g > 65536 ? 65536 : (g < 1 ? 1 : g));
@@ -435,8 +470,14 @@ static unsigned convert_grid(size_t n) {
 
 int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t s) {
     if (n == 0) return 0;
+    if (prec == CN_PREC_X3 && n % 32 != 0) {
+        cn_set_error("convert: split-bf16 tensors hold a multiple of 32 elements");
+        return -1;
+    }
     if (prec == CN_PREC_F32)
         CN_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    else if (prec == CN_PREC_X3)
+        hipLaunchKernelGGL(convert_to_split_kernel, dim3(convert_grid(n / 4)), dim3(256), 0, s, src, (unsigned char*)dst, n / 4);
     else
         hipLaunchKernelGGL((convert_kernel<bf16, float>), dim3(convert_grid(n)), dim3(256), 0, s, src, (bf16*)dst, n);
     CN_HIP_CHECK(hipGetLastError());
@@ -445,8 +486,15 @@ int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t 
 
 int launch_convert_back(int prec, const void* src, float* dst, size_t n, hipStream_t s) {
     if (n == 0) return 0;
+    if (prec == CN_PREC_X3 && n % 32 != 0) {
+        cn_set_error("convert: split-bf16 tensors hold a multiple of 32 elements");
+        return -1;
+    }
     if (prec == CN_PREC_F32)
         CN_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    else if (prec == CN_PREC_X3)
+        hipLaunchKernelGGL(convert_from_split_kernel, dim3(convert_grid(n / 4)), dim3(256), 0, s, (const unsigned char*)src, dst,
+                           n / 4);
     else
         hipLaunchKernelGGL((convert_kernel<float, bf16>), dim3(convert_grid(n)), dim3(256), 0, s, (const bf16*)src, dst,
                            n);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcassnat_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cassnat_hip.h")
 
-PRECISION = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp8": 2}
+PRECISION = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp8": 2, "bf16x3": 3}
 DTYPES = {0: np.float32, 1: np.int32, 2: np.uint8, 3: np.float64}
 
 
@@ -74,6 +74,7 @@ def lib():
     L.cn_op_gemm.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                              C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                              C.c_float, C.c_void_p]
+    L.cn_op_convert.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     L.cn_op_conv1.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]
     L.cn_op_conv2.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]
     L.cn_op_layernorm.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p]

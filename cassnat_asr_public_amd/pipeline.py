@@ -35,13 +35,14 @@ class _NoStream:
 class _Job:
     """One ``records()`` call: the shared iterator and the bookkeeping its workers and its consumer meet on."""
 
-    def __init__(self, it, args, sos, n):
+    def __init__(self, it, args, sos, n, total=None, coalesce=1):
         self.it, self.args, self.sos = it, args, sos
+        self.left = total  # batches not yet handed to a worker (None: unknown)
         self.lock = threading.Lock()
         self.cv = threading.Condition()
         self.slots = {}          # index -> queue of one (tag, records, event)
         self.state = {"next": 0, "done": False, "err": None, "held": None}
-        self.ahead = threading.Semaphore(2 * n + 2)  # batches decoded but not yet consumed (bounds device memory held by records)
+        self.ahead = threading.Semaphore(2 * n * max(1, coalesce) + 2)  # batches decoded but not yet consumed (bounds device memory held by records)
         self.finished = threading.Semaphore(0)       # released once by every worker when it has left the job
 
     def slot(self, i):
@@ -59,15 +60,17 @@ class DecodePipelines:
         broadcast (``dist.broadcast_weights``), once per rank - and the others only get a workspace of their own.
         The worker threads and their HIP streams are created once (at the first call) and live until ``close()``: a short
         run is not thread start-up.
-        ``coalesce`` = 2: a worker takes two consecutive batches of the same shape through ONE engine pass (wider launches: the
-        command processor keeps only about three kernels in flight, so width is what fills the chip) with the greedy finish
-        limited per original batch (``cn_decode_opts.sub_batch``) - every batch's hypotheses and scores are exactly those of
-        a pass of its own.  Transformer blocks only (a conformer's GroupNorm sees the padded rows of the merged batch).
+        ``coalesce`` = c > 1: a worker takes up to c consecutive batches of the same shape through ONE engine pass (wider
+        launches: the command processor keeps only about three kernels in flight, so width is what fills the chip) with the
+        greedy finish limited per original batch (``cn_decode_opts.sub_batch``) - every batch's hypotheses and scores are
+        exactly those of a pass of its own.  When the number of batches is known (``len(batches)``) the last passes are
+        cut so that every pipeline gets a similar share of the tail.  Transformer blocks only (a conformer's GroupNorm sees
+        the padded rows of the merged batch).
         ``share_from``: an engine of the same model whose device copy of the weights ALL pipelines of this object use."""
         self.model = model
         self.n = max(1, int(n_pipelines))
-        self.coalesce = 2 if (int(coalesce) >= 2 and not getattr(model, "_conf_dec", False)
-                              and not getattr(model, "_hyper", {}).get("conf_enc")) else 1
+        self.coalesce = max(1, int(coalesce)) if (not getattr(model, "_conf_dec", False)
+                                                  and not getattr(model, "_hyper", {}).get("conf_enc")) else 1
         if share_from is not None:
             first = model.new_engine(batch * self.coalesce, frames, share=share_from)
         else:
@@ -139,15 +142,23 @@ class DecodePipelines:
                     except StopIteration:
                         state["done"] = True
                         break
-                if self.coalesce == 2:  # a second batch of the same shape rides along; another shape waits
+                # further batches of the same shape ride along; another shape waits for the next pass.  Near the end of a
+                # list of known length the passes shrink so that the pipelines finish together
+                want = self.coalesce
+                if job.left is not None:
+                    want = min(want, max(1, -(-job.left // self.n)))
+                while len(items) < want:
                     try:
                         nxt = next(it)
-                        if tuple(nxt[0].shape) == tuple(items[0][0].shape) and ahead.acquire(blocking=False):
-                            items.append(nxt)
-                        else:
-                            state["held"] = nxt
                     except StopIteration:
-                        pass  # (the next worker to look finds the iterator exhausted)
+                        break  # (the next worker to look finds the iterator exhausted)
+                    if tuple(nxt[0].shape) == tuple(items[0][0].shape) and ahead.acquire(blocking=False):
+                        items.append(nxt)
+                    else:
+                        state["held"] = nxt
+                        break
+                if job.left is not None:
+                    job.left = max(0, job.left - len(items))
                 i = state["next"]
                 state["next"] += len(items)
             if len(items) == 1:
@@ -193,7 +204,8 @@ class DecodePipelines:
         utterance: length, float64 score, [sos] + tokens), ready for ``dist.all_gather_records`` / ``unpack_records``.  The
         consumer's current stream is made to wait for the producing pipeline's work."""
         self._start()
-        job = _Job(iter(batches), args, sos, self.n)
+        job = _Job(iter(batches), args, sos, self.n, total=len(batches) if hasattr(batches, "__len__") else None,
+                   coalesce=self.coalesce)
         state, lock = job.state, job.lock
         with self._busy:
             for q in self._inbox:

@@ -135,7 +135,7 @@ class CassNATTask(BaseTask):
         max_frames = max(getattr(args, "hip_max_frames", 4096), first[1].shape[1])
         pipes = DecodePipelines(self.model, n_pipes, args.batch_size, max_frames, with_weights=(self.rank == 0),
                                 after_engine=(lambda e: cdist.broadcast_weights(e, src=0)) if self.world > 1 else None,
-                                coalesce=int(getattr(args, "hip_coalesce", 2)))  # (equal-shaped neighbours share a pass)
+                                coalesce=int(getattr(args, "hip_coalesce", 3)))  # (equal-shaped neighbours share a pass)
         meta, frames, i, end = {}, 0, -1, time.time()
 
         def batches():
@@ -159,8 +159,8 @@ class CassNATTask(BaseTask):
         batch_time = util.AverageMeter("Time", ":6.3f")
         progress = util.ProgressMeter(len(self.test_loader), batch_time)
         results = {}
-        # args.hip_pipelines (default 4; 1 = the plain loop): beam search, ESA and capture runs keep the plain loop
-        n_pipes = int(getattr(args, "hip_pipelines", 4))
+        # args.hip_pipelines (default 3, each taking up to args.hip_coalesce = 3 equal-shaped batches per engine pass; 1 = the plain loop): beam search, ESA and capture runs keep the plain loop
+        n_pipes = int(getattr(args, "hip_pipelines", 3))
         plain_greedy = (args.beam_width == 1 and getattr(args, "sample_num", 0) <= 1 and not getattr(args, "hip_capture", False))
         # Both branches issue the same collectives (one weight broadcast; the result gather below), and the choice is made from
         # rank-invariant data: the snake deal can leave ranks with batch counts that differ by one.

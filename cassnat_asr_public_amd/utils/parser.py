@@ -21,11 +21,13 @@ class DecodeParser(object):
         p.add_argument("--lm_weight", type=float, default=0.0)
         p.add_argument("--seed", default=1, type=int)
         # engine switches (not in the reference)
-        p.add_argument("--hip_precision", default="bf16", choices=["bf16", "fp32", "fp8"],
+        p.add_argument("--hip_precision", default="bf16", choices=["bf16", "fp32", "fp8", "bf16x3"],
                        help="bf16 MFMA (throughput) or exact-f32 MFMA (parity with the reference CPU path)")
         p.add_argument("--hip_max_frames", default=4096, type=int, help="workspace size in input frames")
-        p.add_argument("--hip_pipelines", default=4, type=int,
+        p.add_argument("--hip_pipelines", default=3, type=int,
                        help="decode pipelines per GPU for greedy decoding of a test set (1 = batch after batch)")
+        p.add_argument("--hip_coalesce", default=3, type=int,
+                       help="equal-shaped batches a decode pipeline may take through one engine pass (hypotheses per batch unchanged)")
         p.add_argument("--hip_dist_backend", default="nccl", choices=["nccl", "gloo"],
                        help="torch.distributed backend under torch.distributed.run (nccl = RCCL over xGMI; gloo: rehearsal of the "
                             "N-rank path, also with several ranks on one GPU)")

@@ -23,7 +23,7 @@ extern "C" {
 
 typedef struct cn_model cn_model;
 
-enum { CN_PRECISION_F32 = 0, CN_PRECISION_BF16 = 1, CN_PRECISION_FP8 = 2 };
+enum { CN_PRECISION_F32 = 0, CN_PRECISION_BF16 = 1, CN_PRECISION_FP8 = 2, CN_PRECISION_BF16X3 = 3 };
 enum { CN_DTYPE_F32 = 0, CN_DTYPE_I32 = 1, CN_DTYPE_U8 = 2, CN_DTYPE_F64 = 3 };
 
 /* Model hyper-parameters: the subset of the flat `args` bag that make_model reads for the transformer
@@ -34,7 +34,10 @@ typedef struct cn_config {
     int32_t n_enc, n_extra, n_self_dec, n_mix_dec;
     int32_t vocab_size;
     int32_t precision;  /* CN_PRECISION_F32: exact-f32 MFMA (parity gate); CN_PRECISION_BF16: throughput; CN_PRECISION_FP8:
-                           the bf16 engine with the encoder layers' products on the e4m3fn MFMA (BASELINE config 5) */
+                           the bf16 engine with the encoder layers' products on the e4m3fn MFMA (BASELINE config 5);
+                           CN_PRECISION_BF16X3: split-bf16 - every value kept as a bf16 hi + bf16 lo pair (~17 significant
+                           bits), every product three bf16 MFMAs (hi.hi + hi.lo + lo.hi, fp32 accumulation): meets the same
+                           parity gate as F32 at several times its MFMA rate */
     int32_t max_batch;  /* workspace is sized for max_batch x max_frames */
     int32_t max_frames;
     int32_t device; /* HIP device ordinal */
@@ -207,7 +210,11 @@ int cn_fbank(const cn_fbank_opts* o, const float* wave_dev, const int32_t* num_s
              void* stream);
 
 /* ---- single-kernel entry points (parity tests drive each hand-written kernel through the ABI) ---------- */
-/* all pointers device; `precision` selects the element type of activations/weights (fp32 or bf16) */
+/* all pointers device; `precision` selects the element type of activations/weights: CN_PRECISION_F32, CN_PRECISION_BF16 or
+ * CN_PRECISION_BF16X3 (split-bf16 elements: each group of 32 consecutive elements of a row is 128 bytes, 32 bf16 hi halves
+ * then 32 bf16 lo halves; rows and row strides are multiples of 32 elements) */
+/* fp32 <-> a flat tensor of n elements in the given precision's element type (to_f32 = 0: src fp32 -> dst; 1: back) */
+int cn_op_convert(int32_t precision, const void* src, void* dst, int64_t n, int32_t to_f32, void* stream);
 int cn_op_gemm(int32_t precision, const void* A, int32_t lda, const void* W, const float* bias, void* C, int32_t ldc,
                int32_t c_is_f32, int32_t M, int32_t N, int32_t K, int32_t relu, const float* resid, int32_t ldr,
                const float* pe, int32_t pe_period, float scale, void* stream);

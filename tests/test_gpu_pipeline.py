@@ -133,13 +133,16 @@ def check_against_golden(model, args, feats, sizes, g, st, sv, dt, fp32):
     (config2_b32_case, "config2_b32", (25, 100, 8)),
     (config5_shape_case, "config5_shape", (10, 50, 4)),
 ])
-def test_fp32_parity_gate(case, name, strides, capsys):
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_fp32_parity_gate(case, name, strides, prec, capsys):
+    """north_star's gate - token-for-token alignment / indexing, 1e-3 on the log-posteriors - for BOTH engines that claim it:
+    the exact-f32 MFMA engine and the split-bf16 engine (three bf16 MFMAs per product; what bench.py times as `parity_engine`)."""
     g = load_golden(name)
     args, state, feats, sizes = case()
-    model = build(args, state, "fp32", capture=True)
+    model = build(args, state, prec, capture=True)
     rep = check_against_golden(model, args, feats, sizes, g, *strides, fp32=True)
     with capsys.disabled():
-        print(f"\n[parity fp32] {name}: {rep}")
+        print(f"\n[parity {prec}] {name}: {rep}")
 
 
 @pytest.mark.parametrize("case,name,strides", [
