@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void ctc_align_kernel(AlignArgs a) {
         const int t = base + tid;
         int sh = 0;
         if (t < Tp && t >= 1) {
-            const int p1 = km[t - 1] ? best[t - 1] : 0;
-            const int p2 = (t >= 2) ? (km[t - 2] ? best[t - 2] : 0) : 0;
+            const int p1 = (a.raw_path || km[t - 1]) ? best[t - 1] : 0;
+            const int p2 = (t >= 2) ? ((a.raw_path || km[t - 2]) ? best[t - 2] : 0) : 0;
             sh = (p1 == p2) ? 0 : p1;
         }
         if (t < Tp) shift[t] = sh;
@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void ctc_align_kernel(AlignArgs a) {
         if (tid == 255) s_carry[0] = c;
         __syncthreads();
     }
-    const int ylen0 = s_carry[0];  // number of non-blank entries of shift
+    // number of non-blank entries of shift - or the given label count (forced alignment: viterbi_align returns its input ylens)
+    const int ylen0 = a.ylen_in ? a.ylen_in[b] : s_carry[0];
     // src_size = (ratio * T').long()  (src/models/cassnat.py:436): fp32 product, truncation toward zero
     const int ssz = (int)(long long)(a.size_ratio[bs] * (float)Tp);
     if (tid == 0) {

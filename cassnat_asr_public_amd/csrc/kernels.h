@@ -68,6 +68,7 @@ int launch_esa_paths(const int* top2_idx, const float* top2_val, const unsigned 
 int launch_lm_embed(const int* tok, int ld, const float* lut, const float* pe, float* x, int B, int U, int d, float scale,
                     hipStream_t s);
 int launch_gather_logp(const float* logp, int V, const int* tgt, int ld, float* out, int B, int U, hipStream_t s);
+int launch_fill_int(int* p, size_t n, int v, hipStream_t s);
 int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t s);       // fp32 -> model precision
 int launch_convert_back(int prec, const void* src, float* dst, size_t n, hipStream_t s);  // model precision -> fp32
 
@@ -115,8 +116,41 @@ struct AlignArgs {
     int* ylen = nullptr;       // [B]   (token count + 1)
     int* ymax = nullptr;       // [1]   max ylen
     int* intervals = nullptr;  // [B][Tp+1][4]
+    // forced alignment (decode_type ctc_att, src/models/cassnat.py:391-414): `best` holds the per-frame labels of the Viterbi
+    // path, which are NOT zeroed on masked frames, and the label counts are the given ones (align_to_mask forces row ylens[b])
+    int raw_path = 0;
+    const int* ylen_in = nullptr;  // [B] or null
 };
 int launch_ctc_align(const AlignArgs& a, hipStream_t s);
+
+// ---- CTC prefix beam search + forced alignment (decode_type ctc_only / ctc_att)              (ctc_beam.hip)
+struct CtcBeamArgs {
+    const float* logp = nullptr;        // [B][Tp][V] CTC log-posteriors of ALL frames
+    const int* top_idx = nullptr;       // [B][Tp][P] the P best labels per frame, best first
+    const float* size_ratio = nullptr;  // [B]
+    int B = 0, Tp = 0, V = 0, P = 0, W = 0, blank = 0, Lmax = 0;
+    double lp = 0.0;                    // args.ctc_lp
+    unsigned char* hist_parent = nullptr;  // [B][Tp][W] scratch
+    int* hist_tok = nullptr;               // [B][Tp][W] scratch
+    int* hyp = nullptr;       // [B][W][Lmax]
+    int* hyp_len = nullptr;   // [B][W]
+    double* score = nullptr;  // [B][W] score_ctc
+    double* p_blk = nullptr;  // [B][W]
+    double* p_nblk = nullptr;
+    int* n_out = nullptr;     // [B] hypotheses kept
+};
+int launch_ctc_prefix_beam(const CtcBeamArgs& a, hipStream_t s);
+struct ViterbiArgs {
+    const float* logp = nullptr;             // [B][Tp][V]
+    const unsigned char* keymask = nullptr;  // [B][Tp]
+    const float* size_ratio = nullptr;       // [B]
+    const int* labels = nullptr;             // [B][ld]
+    const int* label_len = nullptr;          // [B]
+    int B = 0, Tp = 0, V = 0, ld = 0, ymax = 0, blank = 0;
+    unsigned char* bp = nullptr;  // [B][Tp][2 ymax + 1] scratch
+    int* out_path = nullptr;      // [B][Tp] label of the aligned state per frame (blank past src_size)
+};
+int launch_ctc_viterbi(const ViterbiArgs& a, hipStream_t s);
 // hyp[b] = [sos] + tok[b][0 .. min(ylen[b]+1, U)) ; score = sequential double sum of val
 int launch_greedy_pack(const int* tok, const float* val, const int* ylen, int B, int U, int sos, int hyp_stride,
                        int* hyp, int* hyp_len, double* score, hipStream_t s, int sub = 0);

@@ -174,6 +174,8 @@ struct cn_model {
     float* cv_f = nullptr;
     double* gn_stats = nullptr;
     int* ymax_pinned = nullptr;  // page-locked host word for the one data-dependent readback per batch
+    // CTC prefix beam / forced alignment scratch (cn_ctc_beam, cn_decode_nast_forced): grown on demand
+    std::map<std::string, std::pair<void*, size_t>> scratch;
 
     // autoregressive (AST) decoder state (cn_ast_*): token embedding, per-layer cross K|V, KV cache, CTC prefix states
     float* tgt_lut = nullptr;  // [V][d] fp32 (view into the blob)
@@ -1921,6 +1923,8 @@ extern "C" void cn_model_destroy(cn_model* m) {
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->ymax_pinned) (void)hipHostFree(m->ymax_pinned);
     for (void* q : m->ast_allocs) (void)hipFree(q);
+    for (auto& kv : m->scratch)
+        if (kv.second.first) (void)hipFree(kv.second.first);
     m->blob_owner.reset();  // the last handle that uses the blob frees it
     delete m;
 }
@@ -2023,6 +2027,154 @@ extern "C" int cn_decode_nast(cn_model* m, const float* feats_dev, const float* 
     return 0;
 }
 
+
+// ---- decode_type ctc_only / ctc_att: CTC prefix beam search, and the NAT decode on the forced alignment of given labels ----
+namespace {
+int scratch_buf(cn_model* m, const char* name, size_t bytes, void** out) {
+    auto& e = m->scratch[name];
+    if (e.second < bytes) {
+        if (e.first) (void)hipFree(e.first);
+        e.first = nullptr;
+        e.second = 0;
+        CN_HIP_CHECK(hipMalloc(&e.first, bytes));
+        e.second = bytes;
+    }
+    *out = e.first;
+    return 0;
+}
+// encoder + CTC generator with the log-posteriors of ALL rows kept in m->logits (ctc_out of the reference)
+int stage_encode_ctc_rows(cn_model* m, const float* feats, int B, int T, int F, const cn_decode_opts* o, hipStream_t s) {
+    CN_TRY(stage_encode(m, feats, B, T, F, o, s));
+    m->ctc_maxlp_valid = true;
+    return run_generator(m, m->ctc_gen, m->enc_h, B * m->Tp, m->best, m->ctc_maxlp, true, s);
+}
+}  // namespace
+
+// ctc_beam_decode (src/utils/beam_decode.py:8-93) without a language model: hyp_out_dev [B][beam][hyp_cap] labels (no sos),
+// hyp_len_dev / score_dev (score_ctc, float64) / p_blk_dev / p_nblk_dev [B][beam], nbeam_dev [B] hypotheses kept (best first).
+extern "C" int cn_ctc_beam(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,
+                           const cn_decode_opts* opts, int32_t beam, int32_t pruning, double length_penalty, int32_t* hyp_out_dev,
+                           int32_t hyp_cap, int32_t* hyp_len_dev, double* score_dev, double* p_blk_dev, double* p_nblk_dev,
+                           int32_t* nbeam_dev, void* stream) {
+    CN_TRY(check_call(m, B, T, F));
+    if (!opts || m->cfg.ast || beam < 1 || beam > 32 || pruning < 0 || pruning > 32 || !hyp_out_dev || !hyp_len_dev || !score_dev ||
+        !p_blk_dev || !p_nblk_dev || !nbeam_dev) {
+        cn_set_error("cn_ctc_beam: needs a NAT model, 1 <= ctc_beam <= 32, 0 <= ctc_pruning <= 32 and all output buffers");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+    CN_TRY(stage_encode_ctc_rows(m, feats_dev, B, T, F, opts, s));
+    const int Tp = m->Tp, M = B * Tp, V = m->cfg.vocab_size;
+    if (hyp_cap < Tp + 1) {
+        cn_set_error("cn_ctc_beam: hyp_cap must be at least T' + 1");
+        return -1;
+    }
+    void *top_idx = nullptr, *top_val = nullptr, *hpar = nullptr, *htok = nullptr;
+    const int P = pruning > 0 ? pruning : 1;  // (a zero-width pruning still needs a buffer; the kernel then sees P = 0)
+    CN_TRY(scratch_buf(m, "cb_top_idx", (size_t)M * P * 4, &top_idx));
+    CN_TRY(scratch_buf(m, "cb_top_val", (size_t)M * P * 4, &top_val));
+    CN_TRY(scratch_buf(m, "cb_hist_par", (size_t)M * beam, &hpar));
+    CN_TRY(scratch_buf(m, "cb_hist_tok", (size_t)M * beam * 4, &htok));
+    if (pruning > 0) {
+        ProfScope ps(m, "ctc_topk", 0, (double)M * V * 4, s);
+        CN_TRY(launch_topk(m->logits, M, V, V, pruning, (int*)top_idx, (float*)top_val, s));
+    }
+    CtcBeamArgs a;
+    a.logp = m->logits;
+    a.top_idx = (const int*)top_idx;
+    a.size_ratio = size_ratio_dev;
+    a.B = B;
+    a.Tp = Tp;
+    a.V = V;
+    a.P = pruning;
+    a.W = beam;
+    a.blank = opts->padding_idx;
+    a.Lmax = hyp_cap;
+    a.lp = length_penalty;
+    a.hist_parent = (unsigned char*)hpar;
+    a.hist_tok = (int*)htok;
+    a.hyp = hyp_out_dev;
+    a.hyp_len = hyp_len_dev;
+    a.score = score_dev;
+    a.p_blk = p_blk_dev;
+    a.p_nblk = p_nblk_dev;
+    a.n_out = nbeam_dev;
+    ProfScope ps(m, "ctc_prefix_beam", 0, (double)M * (pruning + 1) * 4, s);
+    return launch_ctc_prefix_beam(a, s);
+}
+
+// CassNAT.beam_decode with decode_type 'ctc_att' and sample_num 1 (src/models/cassnat.py:446-448, 391-414): the trigger mask
+// comes from the forced (Viterbi) alignment of the given label sequences - the best CTC beam hypotheses - instead of the greedy
+// path; everything after align_to_mask is cn_decode_nast's.  labels_dev [B][ld] (no sos), label_len_dev [B].
+extern "C" int cn_decode_nast_forced(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,
+                                     const cn_decode_opts* opts, const int32_t* labels_dev, const int32_t* label_len_dev, int32_t ld,
+                                     int32_t max_label_len, int32_t* hyp_out_dev, int32_t hyp_stride, int32_t* hyp_len_dev,
+                                     double* score_dev, void* stream) {
+    CN_TRY(check_call(m, B, T, F));
+    if (!opts || m->cfg.ast || opts->beam_width < 1 || opts->beam_width > 16 || !labels_dev || !label_len_dev || max_label_len < 0 ||
+        max_label_len > ld) {
+        cn_set_error("cn_decode_nast_forced: bad argument");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+    CN_TRY(stage_encode_ctc_rows(m, feats_dev, B, T, F, opts, s));
+    const int Tp = m->Tp, V = m->cfg.vocab_size;
+    if (max_label_len > Tp) {
+        cn_set_error("cn_decode_nast_forced: more labels than frames");
+        return -1;
+    }
+    const bool cap = opts->capture != 0;
+    if (cap) CN_TRY(capture(m, "ctc_out", m->logits, false, CN_DTYPE_F32, {B, Tp, V}, s));
+    if (max_label_len == 0) {  // every hypothesis empty: aligned_seq_shift is all blank (cassnat.py:410-411)
+        CN_TRY(launch_fill_int(m->best, (size_t)B * Tp, opts->padding_idx, s));
+    } else {
+        void* bp = nullptr;
+        CN_TRY(scratch_buf(m, "vit_bp", (size_t)B * Tp * (2 * (size_t)max_label_len + 1), &bp));
+        ViterbiArgs v;
+        v.logp = m->logits;
+        v.keymask = m->keymask;
+        v.size_ratio = size_ratio_dev;
+        v.labels = labels_dev;
+        v.label_len = label_len_dev;
+        v.B = B;
+        v.Tp = Tp;
+        v.V = V;
+        v.ld = ld;
+        v.ymax = max_label_len;
+        v.blank = opts->padding_idx;
+        v.bp = (unsigned char*)bp;
+        v.out_path = m->best;
+        ProfScope ps(m, "ctc_viterbi", 0, (double)B * Tp * (2 * max_label_len + 1) * 5, s);
+        CN_TRY(launch_ctc_viterbi(v, s));
+    }
+    AlignArgs al;
+    al.best = m->best;
+    al.keymask = m->keymask;
+    al.size_ratio = size_ratio_dev;
+    al.B = B;
+    al.Tp = Tp;
+    al.blank = opts->padding_idx;
+    al.left = opts->left_trigger;
+    al.right = opts->right_trigger;
+    al.shift = m->shift;
+    al.src_size = m->src_size;
+    al.ylen = m->ylen;
+    al.ymax = m->ymax;
+    al.intervals = m->intervals;
+    al.raw_path = 1;
+    al.ylen_in = label_len_dev;
+    CN_TRY(launch_ctc_align(al, s));
+    CN_HIP_CHECK(hipMemcpyAsync(m->ymax_pinned, m->ymax, sizeof(int), hipMemcpyDeviceToHost, s));
+    CN_HIP_CHECK(hipStreamSynchronize(s));
+    const int ymax = *m->ymax_pinned;
+    if (ymax < 1 || ymax > Tp + 1 || (hyp_out_dev && hyp_stride < ymax + 1)) {
+        cn_set_error("cn_decode_nast_forced: token count outside the output buffers");
+        return -1;
+    }
+    return stage_decode(m, ymax, opts, hyp_out_dev, hyp_stride, hyp_len_dev, score_dev, s);
+}
 
 // ---- ESA: error-based sampling of alignments (src/models/cassnat.py:370-376, 441-445) ------------------------------
 // cn_esa_begin runs the encoder and the CTC generator once and keeps the two best labels of every frame.  Every
@@ -2178,6 +2330,53 @@ extern "C" int cn_lm_score(cn_model* m, const int32_t* tok_dev, const int32_t* t
     CN_TRY(launch_logsoftmax_argmax(m->logits, M, V, V, m->best, m->ctc_maxlp, 1, s));
     m->ctc_maxlp_valid = true;
     return launch_gather_logp(m->logits, V, tgt_dev, ld, score_dev, B, U, s);
+}
+
+// ESA ranking with rank_model == 'at_baseline' (src/models/cassnat.py:514-520; Transformer.forward_decoder,
+// src/models/transformer.py:113-116): the autoregressive model (cfg.ast = 1) scores the NAT predictions teacher-forced.
+// Its own encoder runs on the B utterances; the decoder then takes N = B * n_per_utt token rows (row e belongs to utterance
+// e % B: the sample-major order of cn_esa_sample) under the causal + length mask, with cross attention to its utterance's
+// encoder output under the padding mask: score[e][u] = log softmax(att_generator(dec_h))[e][u][tgt[e][u]] (the reference
+// takes the probability itself: exp on the caller's side).  tok / tgt / score are [N][ld], ld >= U; cfg.esa_group >= n_per_utt.
+extern "C" int cn_ast_teacher_score(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts,
+                                    const int32_t* tok_dev, const int32_t* tgt_dev, const int32_t* len_dev, int32_t n_per_utt,
+                                    int32_t U, int32_t ld, float* score_dev, void* stream) {
+    CN_TRY(check_call(m, B, T, F));
+    if (!opts || m->cfg.ast != 1 || !m->tgt_lut || n_per_utt < 1 || n_per_utt > std::max(1, m->cfg.esa_group) || U < 1 || ld < U ||
+        U > m->pe_rows) {
+        cn_set_error("cn_ast_teacher_score: needs an autoregressive model (cfg.ast = 1) whose cfg.esa_group covers the samples per utterance");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+    CN_TRY(stage_encode(m, feats_dev, B, T, F, opts, s));
+    const int d = m->cfg.d_model, V = m->cfg.vocab_size, Tp = m->Tp, N = B * n_per_utt, M = N * U;
+    if ((size_t)M > (size_t)m->maxB * (m->maxTp + 1) * std::max(1, m->cfg.esa_group)) {
+        cn_set_error("cn_ast_teacher_score: token rows exceed the workspace");
+        return -1;
+    }
+    m->dec_group = n_per_utt;  // N query sets over the B utterances' encoder outputs
+    float* x = m->xd;
+    CN_TRY(launch_lm_embed(tok_dev, ld, m->tgt_lut, m->pe, x, N, U, d, sqrtf((float)d), s));
+    for (size_t i = 0; i < m->mad.size(); ++i) {  // DecoderLayer: self attention, source attention, feed-forward
+        const Layer& L = m->mad[i];
+        CN_TRY(run_self_attn(m, L, &L.n[0], x, N, U, nullptr, len_dev, 1, s));
+        CN_TRY(run_src_attn(m, L, &L.n[1], x, N, U, Tp, nullptr, s));
+        CN_TRY(run_ffn(m, L, L.n[2], x, M, nullptr, nullptr, s));
+    }
+    CN_TRY(run_ln(m, m->dec_norm, x, m->dec_h, M, s));
+    // generator in chunks of whole token rows that fit the logits buffer (B * (T' + 1) rows)
+    const int cap_rows = m->maxB * (m->maxTp + 1);
+    const int seq_per = std::max(1, cap_rows / U);
+    for (int e0 = 0; e0 < N; e0 += seq_per) {
+        const int ne = std::min(seq_per, N - e0), rows = ne * U;
+        const void* h = (const unsigned char*)m->dec_h + (size_t)e0 * U * d * m->es;
+        CN_TRY(run_linear(m, "generator_proj", m->att_gen, h, d, m->logits, V, 1, rows, 0, nullptr, 0, s));
+        CN_TRY(launch_logsoftmax_argmax(m->logits, rows, V, V, m->tok, m->val, 1, s));
+        CN_TRY(launch_gather_logp(m->logits, V, tgt_dev + (size_t)e0 * ld, ld, score_dev + (size_t)e0 * ld, ne, U, s));
+    }
+    m->dec_group = 1;
+    return 0;
 }
 
 extern "C" int cn_profile_begin(cn_model* m, const char* tags) {
@@ -2500,6 +2699,79 @@ extern "C" int cn_op_ctc_align(const int32_t* best, const uint8_t* keymask, cons
     a.ymax = ymax;
     a.intervals = intervals;
     return launch_ctc_align(a, (hipStream_t)stream);
+}
+
+// the two kernels of decode_type ctc_only / ctc_att on given log-posteriors (test entries; all pointers device)
+extern "C" int cn_op_ctc_prefix_beam(const float* logp, const float* size_ratio, int32_t B, int32_t Tp, int32_t V, int32_t beam,
+                                     int32_t pruning, double length_penalty, int32_t blank, int32_t* hyp, int32_t hyp_cap,
+                                     int32_t* hyp_len, double* score, double* p_blk, double* p_nblk, int32_t* nbeam, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const size_t M = (size_t)B * Tp;
+    const int P = pruning > 0 ? pruning : 1;
+    int* top_idx = nullptr;
+    float* top_val = nullptr;
+    unsigned char* hpar = nullptr;
+    int* htok = nullptr;
+    CN_HIP_CHECK(hipMalloc((void**)&top_idx, M * P * 4));
+    CN_HIP_CHECK(hipMalloc((void**)&top_val, M * P * 4));
+    CN_HIP_CHECK(hipMalloc((void**)&hpar, M * (size_t)std::max(beam, 1)));
+    CN_HIP_CHECK(hipMalloc((void**)&htok, M * (size_t)std::max(beam, 1) * 4));
+    int rc = pruning > 0 ? launch_topk(logp, (int)M, V, V, pruning, top_idx, top_val, s) : 0;
+    if (rc == 0) {
+        CtcBeamArgs a;
+        a.logp = logp;
+        a.top_idx = top_idx;
+        a.size_ratio = size_ratio;
+        a.B = B;
+        a.Tp = Tp;
+        a.V = V;
+        a.P = pruning;
+        a.W = beam;
+        a.blank = blank;
+        a.Lmax = hyp_cap;
+        a.lp = length_penalty;
+        a.hist_parent = hpar;
+        a.hist_tok = htok;
+        a.hyp = hyp;
+        a.hyp_len = hyp_len;
+        a.score = score;
+        a.p_blk = p_blk;
+        a.p_nblk = p_nblk;
+        a.n_out = nbeam;
+        rc = launch_ctc_prefix_beam(a, s);
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(top_idx);
+    (void)hipFree(top_val);
+    (void)hipFree(hpar);
+    (void)hipFree(htok);
+    return rc;
+}
+
+extern "C" int cn_op_ctc_viterbi(const float* logp, const uint8_t* keymask, const float* size_ratio, const int32_t* labels,
+                                 const int32_t* label_len, int32_t B, int32_t Tp, int32_t V, int32_t ld, int32_t ymax, int32_t blank,
+                                 int32_t* out_path, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char* bp = nullptr;
+    CN_HIP_CHECK(hipMalloc((void**)&bp, (size_t)B * Tp * (2 * (size_t)ymax + 1)));
+    ViterbiArgs v;
+    v.logp = logp;
+    v.keymask = keymask;
+    v.size_ratio = size_ratio;
+    v.labels = labels;
+    v.label_len = label_len;
+    v.B = B;
+    v.Tp = Tp;
+    v.V = V;
+    v.ld = ld;
+    v.ymax = ymax;
+    v.blank = blank;
+    v.bp = bp;
+    v.out_path = out_path;
+    const int rc = launch_ctc_viterbi(v, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(bp);
+    return rc;
 }
 
 extern "C" int cn_op_greedy_pack(const int32_t* tok, const float* val, const int32_t* ylen, int32_t B, int32_t U,

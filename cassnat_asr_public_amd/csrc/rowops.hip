@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ log
 }
 
 int launch_topk(const float* logp, int M, int V, int ldl, int k, int* idx, float* val, hipStream_t s) {
-    if (k < 1 || k > 16 || V > 16384) {
-        cn_set_error("topk: need 1 <= k <= 16 and V <= 16384");
+    if (k < 1 || k > 64 || V > 16384) {
+        cn_set_error("topk: need 1 <= k <= 64 and V <= 16384");
         return -1;
     }
     if (M <= 0) return 0;
@@ -498,6 +498,16 @@ int launch_convert_back(int prec, const void* src, float* dst, size_t n, hipStre
     else
         hipLaunchKernelGGL((convert_kernel<float, bf16>), dim3(convert_grid(n)), dim3(256), 0, s, (const bf16*)src, dst,
                            n);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ void fill_int_kernel(int* p, size_t n, int v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+int launch_fill_int(int* p, size_t n, int v, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_int_kernel, dim3(convert_grid(n)), dim3(256), 0, s, p, n, v);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -84,6 +84,10 @@ def lib():
     L.cn_op_logsoftmax_argmax.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.cn_op_ctc_align.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 5 + [C.c_void_p] * 6
     L.cn_op_greedy_pack.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p] * 4
+    L.cn_op_ctc_prefix_beam.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                        C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
+    L.cn_op_ctc_viterbi.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]
     L.cn_op_topk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_op_gemm_fp8.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                  C.c_int32, C.POINTER(C.c_float), C.c_void_p]
@@ -126,6 +130,14 @@ def lib():
                                 C.POINTER(CnAstOpts), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_ast_ctc_score.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.cn_ctc_beam.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts), C.c_int32,
+                              C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_void_p]
+    L.cn_decode_nast_forced.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts),
+                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
+    L.cn_ast_teacher_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts), C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.cn_profile_begin.argtypes = [C.c_void_p, C.c_char_p]
     L.cn_profile_end.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     _lib = L
@@ -273,6 +285,35 @@ class Engine:
         B, T, F = feats.shape
         check(self.L.cn_decode_ast(self.handle, _ptr(feats), B, T, F, C.byref(opts), C.byref(ast_opts), _ptr(hyp),
                                    hyp.shape[2], _ptr(hyp_len), _ptr(score), current_stream()), "cn_decode_ast")
+
+    # ---- decode_type ctc_only / ctc_att, rank_model at_baseline
+    def ctc_beam(self, feats, size_ratio, opts, beam, pruning, length_penalty):
+        """CTC prefix beam search on the device -> (hyp (B, beam, T'+1) int32, hyp_len (B, beam) int32, score_ctc / p_blk /
+        p_nblk (B, beam) float64, nbeam (B,) int32) as cuda tensors; hypotheses carry no sos, best first."""
+        import torch
+
+        B, T, F = feats.shape
+        cap = ((T - 1) // 2 + 1 - 1) // 2 + 1 + 1
+        dev = feats.device
+        hyp = torch.empty(B, beam, cap, dtype=torch.int32, device=dev)
+        hlen = torch.empty(B, beam, dtype=torch.int32, device=dev)
+        sc, pb, pnb = (torch.empty(B, beam, dtype=torch.float64, device=dev) for _ in range(3))
+        nb = torch.empty(B, dtype=torch.int32, device=dev)
+        check(self.L.cn_ctc_beam(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts), int(beam), int(pruning),
+                                 float(length_penalty), _ptr(hyp), cap, _ptr(hlen), _ptr(sc), _ptr(pb), _ptr(pnb), _ptr(nb),
+                                 current_stream()), "cn_ctc_beam")
+        return hyp, hlen, sc, pb, pnb, nb
+
+    def decode_forced(self, feats, size_ratio, opts, labels, label_len, max_label_len, hyp, hyp_len, score):
+        B, T, F = feats.shape
+        check(self.L.cn_decode_nast_forced(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts), _ptr(labels),
+                                           _ptr(label_len), labels.shape[1], int(max_label_len), _ptr(hyp), hyp.shape[1],
+                                           _ptr(hyp_len), _ptr(score), current_stream()), "cn_decode_nast_forced")
+
+    def ast_teacher_score(self, feats, opts, tok, tgt, length, n_per_utt, U, score):
+        B, T, F = feats.shape
+        check(self.L.cn_ast_teacher_score(self.handle, _ptr(feats), B, T, F, C.byref(opts), _ptr(tok), _ptr(tgt), _ptr(length),
+                                          int(n_per_utt), int(U), tok.shape[1], _ptr(score), current_stream()), "cn_ast_teacher_score")
 
     def profile_begin(self, tags=None):
         """Start HIP-event timing of the tagged kernels (None = all) on the launch stream."""

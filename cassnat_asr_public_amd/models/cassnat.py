@@ -333,13 +333,23 @@ class CassNAT(nn.Module):
     def _check_args(self, args, lm_model):
         if not getattr(args, "use_trigger", True):
             raise NotImplementedError("use_trigger=False is not on the accelerated path")
-        if getattr(args, "decode_type", "att_only") not in ("att_only",):
-            raise NotImplementedError("ctc_att / oracle_att decoding are outside the accelerated path")
+        dtype = getattr(args, "decode_type", "att_only")
+        if dtype not in ("att_only", "ctc_att"):
+            raise NotImplementedError("decode_type '%s' is outside the accelerated path (att_only, ctc_att; ctc_only goes through "
+                                      "utils.beam_decode.ctc_beam_decode)" % dtype)
+        if dtype == "ctc_att" and getattr(args, "sample_num", 0) > 1:
+            raise NotImplementedError("ctc_att with sample_num > 1 (the n best CTC hypotheses ranked by a language model) needs the "
+                                      "in-loop LM fusion of ctc_beam_decode, which is outside the accelerated path")
         if getattr(args, "lm_weight", 0) > 0 and lm_model is not None:
             raise NotImplementedError("LM shallow fusion in the finish loop is outside the accelerated path")
         if getattr(args, "sample_num", 0) > 1:
-            if getattr(args, "rank_model", "lm") != "lm" or lm_model is None or not hasattr(lm_model, "score_tokens"):
-                raise NotImplementedError("ESA ranking needs rank_model == 'lm' and a cassnat_asr_public_amd.models.lm.TransformerLM")
+            rank = getattr(args, "rank_model", "lm")
+            ok = (lm_model is not None and ((rank == "lm" and hasattr(lm_model, "score_tokens")) or
+                                            (rank == "at_baseline" and hasattr(lm_model, "teacher_score")) or
+                                            (rank == "n-gram" and hasattr(lm_model, "score"))))
+            if not ok:
+                raise NotImplementedError("ESA ranking needs rank_model 'lm' (models.lm.TransformerLM), 'at_baseline' "
+                                          "(models.transformer.Transformer) or 'n-gram' (an object with kenlm's score(str))")
             if args.beam_width != 1:
                 raise NotImplementedError("ESA is implemented for beam_width == 1")
         if getattr(args, "test_hitrate", False):
@@ -379,8 +389,11 @@ class CassNAT(nn.Module):
         sos = vocab.word2index["sos"]
         assert vocab.word2index["blank"] == args.padding_idx, "CTC blank id and padding_idx must agree"
         if getattr(args, "sample_num", 0) > 1:
-            return self._esa_decode(src, src_size, args, lm_model, sos), args
-        hyp, hyp_len, score = self.decode_device(src, src_size, args, sos)
+            return self._esa_decode(src, src_size, args, lm_model, sos, vocab), args
+        if getattr(args, "decode_type", "att_only") == "ctc_att":
+            hyp, hyp_len, score = self._decode_forced(src, src_size, args, sos, ctc_top_seqs)
+        else:
+            hyp, hyp_len, score = self.decode_device(src, src_size, args, sos)
         if args.beam_width > 1:
             return self._host_beam(self._engine, args, sos), args
         hyp_h, len_h, score_h = hyp.cpu().numpy(), hyp_len.cpu().numpy(), score.cpu().numpy()
@@ -390,7 +403,33 @@ class CassNAT(nn.Module):
             out.append([{"ys": ys, "score": float(score_h[b]), "hyp": hyp_h[b, : len_h[b]].tolist()}])
         return out, args
 
-    def _esa_decode(self, src, src_size, args, lm_model, sos):
+    def _decode_forced(self, src, src_size, args, sos, ctc_top_seqs):
+        """decode_type 'ctc_att' (src/models/cassnat.py:446-448): the decoder side is triggered by the forced (Viterbi)
+        alignment of the best CTC beam hypothesis of every utterance - ``ctc_top_seqs[b][0]['hyp']``, what
+        ``utils.beam_decode.ctc_beam_decode`` returned for this batch - instead of the greedy CTC path."""
+        if ctc_top_seqs is None:
+            raise ValueError("decode_type 'ctc_att' needs ctc_top_seqs (utils.beam_decode.ctc_beam_decode of the same batch)")
+        dev = torch.device("cuda", getattr(self, "_device", torch.cuda.current_device()))
+        feats = src.to(dev, torch.float32).contiguous()
+        ratio = src_size.to(dev, torch.float32).contiguous()
+        B, T, _ = feats.shape
+        Tp = ((T - 1) // 2 + 1 - 1) // 2 + 1
+        lab = [list(ctc_top_seqs[b][0]["hyp"]) for b in range(B)]
+        ymax = max(len(x) for x in lab)
+        labels = np.zeros((B, max(ymax, 1)), np.int32)
+        for b, x in enumerate(lab):
+            labels[b, : len(x)] = x
+        eng = self.engine(B, T)
+        opts = hip.Engine.make_opts(args, capture=getattr(args, "hip_capture", False))
+        opts.sos = sos
+        hyp = torch.empty(B, Tp + 2, dtype=torch.int32, device=dev)
+        hyp_len = torch.empty(B, dtype=torch.int32, device=dev)
+        score = torch.empty(B, dtype=torch.float64, device=dev)
+        eng.decode_forced(feats, ratio, opts, torch.from_numpy(labels).to(dev), torch.tensor([len(x) for x in lab], dtype=torch.int32, device=dev),
+                          ymax, hyp, hyp_len, score)
+        return hyp, hyp_len, score
+
+    def _esa_decode(self, src, src_size, args, lm_model, sos, vocab=None):
         """Error-based sampling of alignments + LM ranking (src/models/cassnat.py:370-376, 441-445, 499-561; sample_num > 1,
         rank_model 'lm', lm_weight 0, beam_width 1).  The encoder and the CTC generator run once; the samples (one alignment
         per utterance each, sample 0 = the best path) go through the decoder side ``args.hip_esa_group`` (default 16) at a time -
@@ -432,13 +471,27 @@ class CassNAT(nn.Module):
             U = max(U, eng.esa_sample(select[g0:g1], args.threshold, ratio, opts, tok[g0:g1], val[g0:g1], ylen[g0:g1], force_U=force))
         # LM input = [sos] + predictions shifted right; score of every predicted token under the causal + length mask
         tokf, ylf = tok.reshape(S * B, stride), ylen.reshape(S * B)
-        lm_in = torch.cat([torch.full((S * B, 1), sos, dtype=torch.int32, device=dev), tokf[:, : stride - 1]], 1).contiguous()
-        lm_score = lm_model.score_tokens(lm_in, tokf.contiguous(), ylf.contiguous(), U, max_frames=max(T, 64))
-        lm_score = lm_score.reshape(S, B, stride)[:, :, :U].transpose(0, 1).cpu()                  # (B, S, U)
         ylen_h = ylen.transpose(0, 1).cpu().long()                                                # (B, S)
-        tmask = torch.arange(U).view(1, 1, U) < ylen_h.unsqueeze(-1)
-        lm_score = lm_score.masked_fill(tmask == 0, 0)
-        prob_sum = lm_score.sum(-1) / (lm_score != 0).sum(-1).float()                             # cassnat.py:521-522
+        rank = getattr(args, "rank_model", "lm")
+        if rank == "n-gram":
+            # cassnat.py:523-535: the n-gram model (kenlm) scores the predicted word pieces as text, per sample: score / tgt_len
+            tok_c = tok.cpu().numpy()
+            prob_sum = torch.zeros(B, S)
+            for b in range(B):
+                for s_i in range(S):
+                    n = int(ylen_h[b, s_i])
+                    pieces = [vocab.index2word[int(t)] for t in tok_c[s_i, b, :n] if int(t) != 2]
+                    prob_sum[b, s_i] = lm_model.score("".join(pieces).replace("\u2581", " ").strip()) / n
+        else:
+            lm_in = torch.cat([torch.full((S * B, 1), sos, dtype=torch.int32, device=dev), tokf[:, : stride - 1]], 1).contiguous()
+            if rank == "at_baseline":  # the autoregressive model scores the predictions teacher-forced; PROBABILITIES, not logs
+                lm_score = lm_model.teacher_score(feats, lm_in, tokf.contiguous(), ylf.contiguous(), S, U, args).exp()
+            else:
+                lm_score = lm_model.score_tokens(lm_in, tokf.contiguous(), ylf.contiguous(), U, max_frames=max(T, 64))
+            lm_score = lm_score.reshape(S, B, stride)[:, :, :U].transpose(0, 1).cpu()              # (B, S, U)
+            tmask = torch.arange(U).view(1, 1, U) < ylen_h.unsqueeze(-1)
+            lm_score = lm_score.masked_fill(tmask == 0, 0)
+            prob_sum = lm_score.sum(-1) / (lm_score != 0).sum(-1).float()                         # cassnat.py:521-522
         pick = prob_sum.max(-1, keepdim=True)[1]
         tok_h, val_h = tok.cpu().numpy(), val.cpu().numpy()
         ylen_sel = ylen_h.gather(1, pick).squeeze(1).numpy()

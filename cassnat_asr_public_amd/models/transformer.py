@@ -53,10 +53,34 @@ class Transformer(nn.Module):
     def forward(self, *a, **k):
         raise NotImplementedError("training forward is out of scope; use beam_decode")
 
-    def _new_handle(self, batch, frames, share_with=None):
+    def _new_handle(self, batch, frames, share_with=None, esa_group=1):
         return hip.Engine(SimpleNamespace(**self._hyper), precision=self.hip_precision,
                           max_batch=max(batch, self.hip_max_batch), max_frames=max(frames, self.hip_max_frames),
-                          device=getattr(self, "_device", torch.cuda.current_device()), share_with=share_with)
+                          device=getattr(self, "_device", torch.cuda.current_device()), share_with=share_with, esa_group=esa_group)
+
+    def teacher_score(self, feats, lm_input, target, length, n_per_utt, U, args):
+        """ESA ranking with ``rank_model == 'at_baseline'`` (src/models/cassnat.py:514-520): this model's encoder on the B
+        utterances, then its decoder teacher-forced on ``lm_input`` (N = B * n_per_utt rows, row e of utterance e % B) ->
+        log-probabilities of ``target`` (float32 (N, ld) cuda; the reference takes softmax probabilities: ``.exp()``)."""
+        B, T, _ = feats.shape
+        eng = self._engine
+        key = (tuple(p._version for p in self.parameters()), self.hip_precision)
+        if (eng is None or self._engine_key != key or B > eng.cfg.max_batch or T > eng.cfg.max_frames
+                or n_per_utt > max(1, eng.cfg.esa_group)):
+            if eng is not None and self._engine_key == key:
+                new = self._new_handle(B, T, share_with=eng, esa_group=n_per_utt)
+                eng.close()
+            else:
+                if eng is not None:
+                    eng.close()
+                new = self._new_handle(B, T, esa_group=n_per_utt)
+                new.load_state({k: v.detach() for k, v in self.named_parameters()}, self.pe)
+            self._engine, self._engine_key = new, key
+            eng = new
+        opts = hip.CnDecodeOpts(padding_idx=int(args.padding_idx), sos=1, beam_width=1)
+        score = torch.zeros(lm_input.shape, dtype=torch.float32, device=lm_input.device)
+        eng.ast_teacher_score(feats, opts, lm_input, target, length, n_per_utt, U, score)
+        return score
 
     def build_engine(self, batch, frames, with_weights=True):
         """The model's engine.  Current weights are never re-packed: a rebuild for a larger workspace shares the old handle's

@@ -17,6 +17,7 @@ from .. import dist as cdist
 from ..data.vocab import Vocab
 from ..models import make_cassnat_model
 from ..utils import util
+from ..utils.beam_decode import ctc_beam_decode
 from .base_task import BaseTask
 
 # YAML-only keys the reference reads without defaults: explicit defaults here
@@ -24,7 +25,7 @@ _DEFAULTS = dict(use_gpu=True, decode_type="att_only", use_cmvn=False, dataset_t
                  print_utt2diff=False, save_embedding=False, use_conv_enc=False, use_conv_dec=False,
                  use_trigger=True, src_trigger=False, use_unimask=False, left_trigger=0, right_trigger=0,
                  sample_num=0, threshold=0.9, test_hitrate=False, beam_width=1, length_penalty=0, lm_weight=0,
-                 ctc_lm_weight=0, rank_model="lm", left_ctx=0, right_ctx=0, skip_frame=1, padding_idx=0,
+                 ctc_lm_weight=0, ctc_beam=1, ctc_pruning=0, ctc_lp=0, rank_model="lm", left_ctx=0, right_ctx=0, skip_frame=1, padding_idx=0,
                  model_type="transformer", dropout=0.0, rank=0)
 
 
@@ -80,24 +81,40 @@ class CassNATTask(BaseTask):
         return cdist.shard_indices(lengths, self.world, self.rank)
 
     def load_lm_model(self, args):
-        """src/tasks/cassnat_task.py:85-125: the TransformerLM that ranks ESA samples (rank_model 'lm'); the n-gram and
-        at_baseline rankers and LM shallow fusion (lm_weight > 0) are outside the accelerated path."""
+        """src/tasks/cassnat_task.py:85-125: the model that ranks ESA samples - a TransformerLM (rank_model 'lm'), the
+        autoregressive baseline (rank_model 'at_baseline': models.transformer, scoring teacher-forced) or a kenlm n-gram model
+        (rank_model 'n-gram', scored on the host as the reference does).  LM shallow fusion (lm_weight > 0) is outside the
+        accelerated path."""
         self.lm_model = None
         if args.lm_weight > 0:
             raise NotImplementedError("LM shallow fusion (lm_weight > 0) is outside the accelerated path")
         if getattr(args, "ctc_lm_weight", 0) > 0:
-            if getattr(args, "rank_model", "lm") != "lm":
-                raise NotImplementedError("only rank_model == 'lm' is on the accelerated path")
+            rank = getattr(args, "rank_model", "lm")
+            if rank == "n-gram":
+                import kenlm  # (not a dependency of this package: needed for this ranker only, as in the reference)
+
+                self.lm_model = kenlm.Model(args.rnnlm)
+                return
+            if rank not in ("lm", "at_baseline"):
+                raise NotImplementedError("rank_model '%s' is not on the accelerated path" % rank)
             import yaml
             from types import SimpleNamespace
-
-            from ..models.lm import make_model as make_lm_model
 
             with open(args.lm_config) as f:
                 lm_args = SimpleNamespace(**yaml.safe_load(f))
             lm_args.vocab_size = self.vocab.n_words
             lm_args.hip_precision = getattr(args, "hip_precision", "bf16")
-            lm_model = make_lm_model(lm_args)
+            if rank == "lm":
+                from ..models.lm import make_model as make_lm_model
+
+                lm_model = make_lm_model(lm_args)
+            else:
+                if getattr(lm_args, "model_type", "transformer") != "transformer":
+                    raise NotImplementedError("the conformer AST baseline is outside the accelerated path")
+                from ..models.transformer import make_model as make_ast_model
+
+                lm_args.interctc_alpha = 0
+                lm_model = make_ast_model(args.input_size, lm_args)
             state = torch.load(args.rnnlm, map_location="cpu")["model_state"]
             with torch.no_grad():
                 for name, param in lm_model.named_parameters():
@@ -112,8 +129,15 @@ class CassNATTask(BaseTask):
             for i, (utt_list, feats, labels, feat_sizes, label_sizes) in enumerate(self.test_loader):
                 frames += int(feats.shape[0] * feats.shape[1])
                 src_mask = (feats[:, :, 0] != args.padding_idx).unsqueeze(1)
-                recog, args = self.model.beam_decode(feats, src_mask, feat_sizes, self.vocab, args, self.lm_model,
-                                                     labels=labels, label_sizes=label_sizes)
+                if args.decode_type == "ctc_only":  # src/tasks/cassnat_task.py:335-336
+                    recog = ctc_beam_decode(self.model, feats, src_mask, feat_sizes, self.vocab, args, self.lm_model)
+                elif args.decode_type == "ctc_att":  # :338-340
+                    top = ctc_beam_decode(self.model, feats, src_mask, feat_sizes, self.vocab, args, self.lm_model)
+                    recog, args = self.model.beam_decode(feats, src_mask, feat_sizes, self.vocab, args, self.lm_model, top,
+                                                         labels=labels, label_sizes=label_sizes)
+                else:
+                    recog, args = self.model.beam_decode(feats, src_mask, feat_sizes, self.vocab, args, self.lm_model,
+                                                         labels=labels, label_sizes=label_sizes)
                 for utt, seqs, lab in zip(utt_list, recog, labels):
                     # utt2diff as the reference computes it (cassnat_task.py:358-360): against the PADDED label row's width
                     results[utt] = (hyp_to_words(seqs[0]["hyp"], self.vocab, args.padding_idx), len(seqs[0]["hyp"]) - len(lab))
@@ -161,7 +185,8 @@ class CassNATTask(BaseTask):
         results = {}
         # args.hip_pipelines (default 3, each taking up to args.hip_coalesce = 3 equal-shaped batches per engine pass; 1 = the plain loop): beam search, ESA and capture runs keep the plain loop
         n_pipes = int(getattr(args, "hip_pipelines", 3))
-        plain_greedy = (args.beam_width == 1 and getattr(args, "sample_num", 0) <= 1 and not getattr(args, "hip_capture", False))
+        plain_greedy = (args.beam_width == 1 and getattr(args, "sample_num", 0) <= 1 and not getattr(args, "hip_capture", False)
+                        and args.decode_type == "att_only")
         # Both branches issue the same collectives (one weight broadcast; the result gather below), and the choice is made from
         # rank-invariant data: the snake deal can leave ranks with batch counts that differ by one.
         n_batches = len(self.test_loader)

@@ -163,6 +163,32 @@ int cn_esa_sample(cn_model* m, const uint8_t* select_dev, int32_t n_samples, flo
 int cn_lm_score(cn_model* m, const int32_t* tok_dev, const int32_t* tgt_dev, const int32_t* len_dev, int32_t B, int32_t U,
                 int32_t ld, float* score_dev, void* stream);
 
+/* ---- decode_type ctc_only / ctc_att (src/tasks/cassnat_task.py:335-341) ------------------------------------------------
+ * cn_ctc_beam replaces utils.beam_decode.ctc_beam_decode (src/utils/beam_decode.py:8-93) without a language model: encoder,
+ * CTC generator, the `pruning` best labels per frame, then the prefix beam search over the frames (frames past src_size and
+ * frames with blank probability > 0.95 skipped, candidates not merged by prefix, stable sort by score_ctc + length_penalty *
+ * len(hyp), float64 scores) on the device.  hyp_out_dev [B][beam][hyp_cap] labels (no sos; hyp_cap >= T' + 1), hyp_len_dev /
+ * score_dev (score_ctc) / p_blk_dev / p_nblk_dev [B][beam], nbeam_dev [B] hypotheses kept, best first. */
+int cn_ctc_beam(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,
+                const cn_decode_opts* opts, int32_t beam, int32_t pruning, double length_penalty, int32_t* hyp_out_dev,
+                int32_t hyp_cap, int32_t* hyp_len_dev, double* score_dev, double* p_blk_dev, double* p_nblk_dev, int32_t* nbeam_dev,
+                void* stream);
+/* CassNAT.beam_decode for decode_type 'ctc_att' with sample_num 1 (src/models/cassnat.py:446-448): the trigger mask comes from
+ * the forced (Viterbi) alignment of labels_dev [B][ld] / label_len_dev [B] (beam_path_align -> viterbi_align, :391-414,
+ * 272-353) instead of the greedy path; max_label_len = the largest label_len (the width of the reference's label tensor).
+ * Outputs as cn_decode_nast. */
+int cn_decode_nast_forced(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,
+                          const cn_decode_opts* opts, const int32_t* labels_dev, const int32_t* label_len_dev, int32_t ld,
+                          int32_t max_label_len, int32_t* hyp_out_dev, int32_t hyp_stride, int32_t* hyp_len_dev, double* score_dev,
+                          void* stream);
+/* ESA ranking with rank_model 'at_baseline' (src/models/cassnat.py:514-520, Transformer.forward_decoder): the autoregressive
+ * model (cfg.ast = 1, cfg.esa_group >= n_per_utt) scores token rows teacher-forced: its encoder on the B utterances, then the
+ * decoder on N = B * n_per_utt rows (row e belongs to utterance e % B) under the causal + length mask:
+ * score[e][u] = log softmax(att_generator(dec_h[e][u]))[tgt[e][u]].  tok / tgt / score [N][ld], ld >= U. */
+int cn_ast_teacher_score(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts,
+                         const int32_t* tok_dev, const int32_t* tgt_dev, const int32_t* len_dev, int32_t n_per_utt, int32_t U,
+                         int32_t ld, float* score_dev, void* stream);
+
 /* Copy a named internal / captured tensor to the host (synchronous; test + host-beam use).  Activations are
  * returned as fp32 whatever the model precision.  shape_out has room for 4 dims. */
 int cn_fetch(cn_model* m, const char* name, void* host_dst, int64_t max_bytes, int64_t* shape_out, int32_t* ndim_out,
@@ -233,6 +259,15 @@ int cn_op_logsoftmax_argmax(float* logits, int32_t M, int32_t V, int32_t* arg, f
 int cn_op_ctc_align(const int32_t* best, const uint8_t* keymask, const float* size_ratio, int32_t B, int32_t Tp,
                     int32_t blank, int32_t left, int32_t right, int32_t* shift, int32_t* src_size, int32_t* ylen,
                     int32_t* ymax, int32_t* intervals, void* stream);
+/* CTC prefix beam search (src/utils/beam_decode.py:8-93, no LM) and forced alignment (src/models/cassnat.py:272-345: the label of
+ * the aligned state per frame, before the collapse / shift that cn_op_ctc_align's kernel applies) on given log-posteriors
+ * logp [B][Tp][V]; buffers as cn_ctc_beam / cn_decode_nast_forced */
+int cn_op_ctc_prefix_beam(const float* logp, const float* size_ratio, int32_t B, int32_t Tp, int32_t V, int32_t beam, int32_t pruning,
+                          double length_penalty, int32_t blank, int32_t* hyp, int32_t hyp_cap, int32_t* hyp_len, double* score,
+                          double* p_blk, double* p_nblk, int32_t* nbeam, void* stream);
+int cn_op_ctc_viterbi(const float* logp, const uint8_t* keymask, const float* size_ratio, const int32_t* labels,
+                      const int32_t* label_len, int32_t B, int32_t Tp, int32_t V, int32_t ld, int32_t ymax, int32_t blank,
+                      int32_t* out_path, void* stream);
 int cn_op_greedy_pack(const int32_t* tok, const float* val, const int32_t* ylen, int32_t B, int32_t U, int32_t sos,
                       int32_t hyp_stride, int32_t* hyp, int32_t* hyp_len, double* score, void* stream);
 /* fused LN -> W1 -> ReLU -> W2 -> residual (-> next LN) sublayer, bf16 / d_model 256.  x_dev fp32 [M][256] is updated

@@ -100,6 +100,18 @@ def esa_case(which):
     return args, lm_args, state, lm_state, feats, sizes
 
 
+def ctcbeam_case(which):
+    """decode_type ctc_only / ctc_att cases of oracle/make_goldens.py ('ctcbeam' group)."""
+    from cassnat_asr_public_amd import synth
+
+    preset, (B, T, lens), cfg = {"ctcbeam_tiny": ("tiny", (3, 61, [61, 50, 37]), dict(ctc_beam=5, ctc_pruning=8, ctc_lp=0.2)),
+                                 "ctcbeam_config2": ("config2", (2, 300, [300, 231]), dict(ctc_beam=10, ctc_pruning=15, ctc_lp=0.0))}[which]
+    args = synth.make_args(preset, decode_type="ctc_att", sample_num=1, ctc_lm_weight=0, **cfg)
+    state = synth.make_state(args, seed=0, gain=2.0) if preset == "tiny" else synth.make_state(args, seed=0, blank_bias=0.35)
+    feats, sizes = synth.make_feats(B, T, 80, lengths=lens, seed=11)
+    return args, state, feats, sizes
+
+
 def config2_b32_case():
     """The benchmark workload (bench.py): B=32 x 1000 frames, blank bias 0.9."""
     from cassnat_asr_public_amd import synth

@@ -224,3 +224,38 @@ def test_ast_config4_beam10(name, ov):
 
     args, state, feats = ast_config4_case(**ov)
     _check_beams(ast_oracle.decode_ast(state, feats, args), load_golden(name))
+
+
+# ---------------------------------------------------------------------------- decode_type ctc_only / ctc_att, at_baseline ranker
+def _beams_equal(beams, g, prefix=""):
+    for b, seqs in enumerate(beams):
+        assert len(seqs) == int(g[prefix + "beam_n"][b])
+        for j, s in enumerate(seqs):
+            assert s["hyp"] == g[prefix + "beam_hyp"][b, j, : g[prefix + "beam_len"][b, j]].tolist(), (b, j)
+        for key, name in (("score_ctc", "beam_score"), ("p_blk", "beam_p_blk"), ("p_nblk", "beam_p_nblk")):
+            np.testing.assert_allclose([s[key] for s in seqs], g[prefix + name][b, : len(seqs)], rtol=0, atol=1e-9)
+
+
+def test_ctc_prefix_beam_and_viterbi_known_answer_vectors():
+    """The reference's own ctc_beam_decode (src/utils/beam_decode.py) and viterbi_align (src/models/cassnat.py:272) on random
+    log-posteriors with a mask hole, a shortened utterance and an empty label sequence."""
+    g = load_golden("ctc_kat")
+    src_size = orc.src_size_frames(g["ratio"], g["ctc"].shape[1])
+    for tag in "abc":
+        W, P, lp = g[tag + "_cfg"]
+        _beams_equal(orc.ctc_prefix_beam(g["ctc"], src_size, int(W), int(P), float(lp)), g, tag + "_")
+    shift = orc.viterbi_align(g["ctc"], g["mask"], src_size, g["ys"], g["ylens"])
+    np.testing.assert_array_equal(shift, g["viterbi_shift"])
+
+
+@pytest.mark.parametrize("name,preset,cfg", [("ctcbeam_tiny", "tiny", dict(ctc_beam=5, ctc_pruning=8, ctc_lp=0.2))])
+def test_ctc_only_and_ctc_att_end_to_end(name, preset, cfg):
+    from conftest import ctcbeam_case
+
+    g = load_golden(name)
+    args, state, feats, sizes = ctcbeam_case(name)
+    out = orc.decode_nast_ctc(state, feats, sizes, args)
+    _close(out["ctc_out"], g["ctc_out"])
+    _beams_equal(out["beams"], g)
+    np.testing.assert_array_equal(out["aligned_seq_shift"], g["aligned_seq_shift"])
+    _hyps_equal(out, g)
