@@ -185,6 +185,22 @@ int launch_ffn_reduce(float* x, const float* partial, int nslice, const float* b
 void pack_ffn_w1(const float* w1, int dff, uint16_t* out);  // [dff][256] fp32 -> fragment stream (dff*256 bf16)
 void pack_ffn_w2(const float* w2, int dff, uint16_t* out);  // [256][dff] fp32 -> fragment stream (dff*256 bf16)
 
+// ---- the same sublayer in the split-bf16 (bf16x3) precision: hi + lo operands, three MFMAs per product   (fused_x3.hip)
+struct FfnX3Args {
+    float* x = nullptr;
+    const float *ln_a = nullptr, *ln_b = nullptr;
+    const void* wst = nullptr;  // pack_ffn_x3 stream
+    const float *b1 = nullptr, *b2 = nullptr;
+    const float *nln_a = nullptr, *nln_b = nullptr;
+    void* xn_out = nullptr;  // [M][256] split-bf16 (when nln_a)
+    int M = 0, d = 0, dff = 0;
+    float eps = 1e-6f;
+};
+bool ffn_x3_applies(int d, int dff);
+int launch_ffn_x3(const FfnX3Args& a, hipStream_t s);
+size_t ffn_x3_stream_bytes(int dff);
+void pack_ffn_x3(const float* w1, const float* w2, int dff, uint16_t* out);
+
 // ---- waveform -> log-mel filterbank (+ CMVN), Kaldi compute-fbank-feats semantics with dither 0 (fbank.hip)
 struct FbankOpts {
     float sample_rate = 16000.f, frame_length_ms = 25.f, frame_shift_ms = 10.f, preemph = 0.97f, low_freq = 20.f, high_freq = 0.f;

@@ -72,6 +72,7 @@ struct Layer {
     Linear src_q, src_kv, src_o;  // source attention: Q from the stream, K|V from the encoder memory
     Linear w1, w2;
     void *w1p = nullptr, *w2p = nullptr;  // fused-FFN fragment streams (bf16, d_model == 256); then w1/w2 hold biases only
+    void* wx3 = nullptr;  // split-bf16 engine: the fused-FFN stream of fused_x3.hip (hi and lo fragments); w1/w2 hold biases only
     bool has_self = false, has_src = false;
 };
 
@@ -461,6 +462,22 @@ struct Packer {
     // feed-forward weights: fragment streams for the fused kernel when it applies, plain matrices otherwise
     void ffn(Layer& L, const std::string& p, int64_t dff, int64_t d) {
         const bool fused = m->prec == CN_PREC_BF16 && d == 256 && dff % 128 == 0 && dff <= 2048;
+        if (m->prec == CN_PREC_X3 && ffn_x3_applies((int)d, (int)dff)) {
+            const size_t ax = reserve(ffn_x3_stream_bytes((int)dff));
+            if (fill) {
+                const HostTensor* t1 = find(p + ".feed_forward.w_1.weight", {dff, d});
+                const HostTensor* t2 = find(p + ".feed_forward.w_2.weight", {d, dff});
+                if (t1 && t2) pack_ffn_x3(t1->data.data(), t2->data.data(), (int)dff, reinterpret_cast<uint16_t*>(&host[ax]));
+            }
+            L.wx3 = reinterpret_cast<void*>(ax);
+            L.w1.N = (int)dff;
+            L.w1.K = (int)d;
+            L.w1.b = vec({p + ".feed_forward.w_1.bias"}, dff);
+            L.w2.N = (int)d;
+            L.w2.K = (int)dff;
+            L.w2.b = vec({p + ".feed_forward.w_2.bias"}, d);
+            return;
+        }
         if (!fused) {
             L.w1 = linear({p + ".feed_forward.w_1"}, dff, d);
             L.w2 = linear({p + ".feed_forward.w_2"}, d, dff);
@@ -991,6 +1008,7 @@ int build_weights(cn_model* m) {
             rebase_linear(L.w2, base);
             rebase(L.w1p, base);
             rebase(L.w2p, base);
+            rebase(L.wx3, base);
         }
     };
     auto rebase_chain = [&](ChainRef& r) {
@@ -1118,6 +1136,26 @@ int run_ln(cn_model* m, const Norm& n, const float* x, void* y, int M, hipStream
 int run_ffn(cn_model* m, const Layer& L, const Norm& n, float* x, int M, const Norm* next, void* next_out,
             hipStream_t s) {
     const int d = m->cfg.d_model;
+    if (L.wx3) {  // split-bf16 engine: LN + w_1 + ReLU + w_2 + residual (+ next LN) in one launch, 3 MFMAs per product
+        ProfScope ps(m, "ffn_fused_x3", 4.0 * M * (double)L.w1.N * d,
+                     (double)M * d * 8 + 2.0 * L.w1.N * d * 4 + (next ? (double)M * d * 4 : 0.0), s);
+        FfnX3Args a;
+        a.x = x;
+        a.ln_a = n.a;
+        a.ln_b = n.b;
+        a.wst = L.wx3;
+        a.b1 = L.w1.b;
+        a.b2 = L.w2.b;
+        if (next) {
+            a.nln_a = next->a;
+            a.nln_b = next->b;
+            a.xn_out = next_out;
+        }
+        a.M = M;
+        a.d = d;
+        a.dff = L.w1.N;
+        return launch_ffn_x3(a, s);
+    }
     if (L.w1p) {
         ProfScope ps(m, "ffn_fused", 4.0 * M * (double)L.w1.N * d,
                      (double)M * d * 8 + 2.0 * L.w1.N * d * 2 + (next ? (double)M * d * 2 : 0.0), s);
@@ -2888,6 +2926,44 @@ extern "C" int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float*
     if (part) (void)hipFree(part);
     if (rc == 0 && e != hipSuccess) {
         cn_set_error(std::string("cn_op_ffn_fused: ") + hipGetErrorString(e));
+        rc = -2;
+    }
+    return rc;
+}
+
+// the same sublayer in the split-bf16 precision (fused_x3.hip); xn_out_dev: split-bf16 [M][256] or NULL
+extern "C" int cn_op_ffn_x3(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, const float* w1_host, const float* b1_dev,
+                            const float* w2_host, const float* b2_dev, const float* nln_a_dev, const float* nln_b_dev,
+                            void* xn_out_dev, int32_t M, int32_t dff, float eps, void* stream) {
+    if (!ffn_x3_applies(256, dff)) {
+        cn_set_error("cn_op_ffn_x3: d_ff must be a positive multiple of 128, at most 2048");
+        return -1;
+    }
+    const size_t bytes = ffn_x3_stream_bytes(dff);
+    std::vector<uint16_t> h(bytes / 2);
+    pack_ffn_x3(w1_host, w2_host, dff, h.data());
+    void* dw = nullptr;
+    CN_HIP_CHECK(hipMalloc(&dw, bytes));
+    CN_HIP_CHECK(hipMemcpy(dw, h.data(), bytes, hipMemcpyHostToDevice));
+    FfnX3Args a;
+    a.x = x_dev;
+    a.ln_a = ln_a_dev;
+    a.ln_b = ln_b_dev;
+    a.wst = dw;
+    a.b1 = b1_dev;
+    a.b2 = b2_dev;
+    a.nln_a = nln_a_dev;
+    a.nln_b = nln_b_dev;
+    a.xn_out = xn_out_dev;
+    a.M = M;
+    a.d = 256;
+    a.dff = dff;
+    a.eps = eps;
+    int rc = launch_ffn_x3(a, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(dw);
+    if (rc == 0 && e != hipSuccess) {
+        cn_set_error(std::string("cn_op_ffn_x3: ") + hipGetErrorString(e));
         rc = -2;
     }
     return rc;

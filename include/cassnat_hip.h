@@ -279,6 +279,11 @@ int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, 
                     const float* b1_dev, const float* w2_host, const float* b2_dev, const float* nln_a_dev,
                     const float* nln_b_dev, void* xn_out_dev, int32_t M, int32_t dff, float eps, int32_t nslice,
                     void* stream);
+/* the same sublayer in the split-bf16 precision (CN_PRECISION_BF16X3; fused_x3.hip): three MFMAs per product on hi + lo
+ * operands; xn_out_dev is split-bf16 [M][256] (or NULL) */
+int cn_op_ffn_x3(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, const float* w1_host, const float* b1_dev,
+                 const float* w2_host, const float* b2_dev, const float* nln_a_dev, const float* nln_b_dev, void* xn_out_dev,
+                 int32_t M, int32_t dff, float eps, void* stream);
 /* fused generator tail, bf16 / d_model 256: arg[m] = argmax_v, maxlp[m] = max_v of log_softmax(W h[m] + b); h_dev bf16 [M][256],
  * W/b HOST fp32 nn.Linear parameters (packed and uploaded by the call; the model packs once at cn_model_finalize). */
 int cn_op_genmax(const void* h_dev, const float* w_host, const float* b_host, int32_t M, int32_t V, int32_t* arg_dev,

@@ -216,3 +216,30 @@ def test_attention_rescale_branch():
     q, k, v = (torch.randn(B, L, H, 64, generator=g) for L in (Lq, Lk, Lk))
     k[0, 170, 0] = q[0, 3, 0] * 10.0
     assert relerr(run_attention(q, k, v), attention_reference(q, k, v, torch.ones(B, 1, Lk, dtype=torch.bool))) < ATT_TOL
+
+
+@pytest.mark.parametrize("M,dff,with_next", [(8000, 2048, True), (45, 256, False), (2304, 2048, True), (64, 128, True), (1, 1024, True)])
+def test_ffn_fused_x3(M, dff, with_next):
+    """fused_x3.hip: x += W2 relu(W1 LN(x) + b1) + b2 and the next LayerNorm, against fp64 on the unrounded operands."""
+    from oracle.cassnat_oracle import layer_norm
+
+    g = torch.Generator().manual_seed(M + dff)
+    x = torch.randn(M, 256, generator=g) * 2
+    a1, b1n = torch.randn(256, generator=g) * 0.5 + 1, torch.randn(256, generator=g) * 0.2
+    a2, b2n = torch.randn(256, generator=g) * 0.5 + 1, torch.randn(256, generator=g) * 0.2
+    w1, bb1 = torch.randn(dff, 256, generator=g) / 16, torch.randn(dff, generator=g) * 0.1
+    w2, bb2 = torch.randn(256, dff, generator=g) / math.sqrt(dff), torch.randn(256, generator=g) * 0.1
+    xd = x.cuda()
+    devs = [t.cuda() for t in (a1, b1n, bb1, bb2, a2, b2n)]
+    xn = torch.zeros(M, 256, dtype=torch.int32, device="cuda")
+    w1c, w2c = w1.contiguous(), w2.contiguous()
+    hip.check(hip.lib().cn_op_ffn_x3(p(xd), p(devs[0]), p(devs[1]), C.c_void_p(w1c.data_ptr()), p(devs[2]), C.c_void_p(w2c.data_ptr()),
+                                     p(devs[3]), p(devs[4]) if with_next else None, p(devs[5]) if with_next else None,
+                                     p(xn) if with_next else None, M, dff, 1e-6, stream()))
+    torch.cuda.synchronize()
+    xr = x.double()
+    h = F.relu(F.linear(layer_norm(xr, a1.double(), b1n.double()), w1.double(), bb1.double()))
+    ref = xr + F.linear(h, w2.double(), bb2.double())
+    assert relerr(xd, ref) < 2e-5
+    if with_next:
+        assert relerr(from_split(xn), layer_norm(ref, a2.double(), b2n.double())) < 3e-5

@@ -1,7 +1,11 @@
 """Summarise rocprofv3 --pmc passes (separate runs for FETCH_SIZE and WRITE_SIZE, CSV output) into the per-launch HBM
 traffic figures bench.py's roofline objects quote.
 
-    python tools/pmc_summary.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <out dir (profiles/)>
+    python tools/pmc_summary.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <out dir (profiles/)> [<dir with the SQ pass>]
+
+The optional SQ pass (--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE)
+becomes pmc_mfma.json: per kernel, matrix-pipe busy cycles against the cycles its waves were resident and against the
+launch's duration x SIMDs (MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts cycles, SQ_WAVE_CYCLES quad-cycles).
 
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read,
 so it is doubled; WRITE_SIZE is exact.  Both are reported by rocprofv3 in units of 1024 B.
@@ -23,8 +27,37 @@ def per_kernel(path, counter):
     return acc
 
 
+def mfma_summary(sdir, out):
+    names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "GRBM_GUI_ACTIVE"]
+    acc = {n: per_kernel(sdir, n) for n in names}
+    kernels = {"chain_kernel": "chain_kernel", "conv2_kernel<false>": "conv2_kernel (conv2)", "conv2_kernel<true>": "conv2_kernel<LINEAR> (linear_out)",
+               "attention_kernel": "attention_kernel", "genmax_kernel": "genmax_kernel", "conv1_kernel": "conv1_kernel"}
+    rec = {"source": "rocprofv3 --pmc " + " ".join(names) + " (its own pass, --kernel-trace only), bench.py --steps 3 --warmup 1 --streams 1 "
+                     "--coalesce 1 (one pipeline, one batch of 32 per pass: the kernels have the GPU to themselves)",
+           "units": "SQ_VALU_MFMA_BUSY_CYCLES: cycles, summed over SIMDs; SQ_WAVE_CYCLES / SQ_BUSY_CYCLES: quad-cycles (x4); "
+                    "GRBM_GUI_ACTIVE: cycles summed over the 8 XCDs (/8); MOPS_BF16 x 512 = bf16 MFMA FLOPs",
+           "kernels": {}}
+    for needle, label in kernels.items():
+        def tot(n):
+            return [v for k, vs in acc[n].items() if needle in k for v in vs]
+        busy, wave, gui, mops = tot("SQ_VALU_MFMA_BUSY_CYCLES"), tot("SQ_WAVE_CYCLES"), tot("GRBM_GUI_ACTIVE"), tot("SQ_INSTS_VALU_MFMA_MOPS_BF16")
+        if not busy:
+            continue
+        n = len(busy)
+        b, w, g, m = sum(busy) / n, 4 * sum(wave) / n, sum(gui) / n / 8, sum(mops) / n
+        rec["kernels"][label] = {
+            "launches_sampled": n, "mfma_busy_cycles_per_launch": round(b), "wave_cycles_per_launch": round(w),
+            "gui_active_cycles_per_launch": round(g), "bf16_mfma_flops_per_launch": round(m * 512),
+            "mfma_busy_over_wave_cycles": round(b / w, 4) if w else None,  # share of the resident waves' time with the matrix pipe busy
+            "mfma_busy_over_chip_simd_cycles": round(b / (g * 1024), 4) if g else None}  # 256 CUs x 4 SIMDs for the launch's duration
+    json.dump(rec, open(os.path.join(out, "pmc_mfma.json"), "w"), indent=2)
+    print("mfma", json.dumps(rec["kernels"]))
+
+
 def main():
     fdir, wdir, out = sys.argv[1:4]
+    if len(sys.argv) > 4:
+        mfma_summary(sys.argv[4], out)
     fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
     targets = {"row_chain": ("chain_kernel", "chain_kernel (all 21 launches of a step: 12 encoder at 8000 rows, 9 decoder-side)"),
                "conv2": ("conv2_kernel<false>", "conv2_kernel<false> (LDS-DMA implicit GEMM, B=32 x 1000 frames)"),
