@@ -32,6 +32,7 @@ struct FfnX3Params {
     unsigned char* xn_out;  // [M][256] split-bf16, written when nln_a != null
     int M, dff;
     float eps;
+    int rotate;
 };
 
 constexpr int FX_D = 256;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
     const int ft0 = wave_u * tiles_per_wave;
     // every workgroup / wave walks its hidden tiles in a rotation of its own (the sum over tiles is order-free; the
     // workgroups then do not pull the same L2 lines at the same moment)
-    const int rot = (blockIdx.x * 7 + wave_u * 3) % tiles_per_wave;
+    const int rot = p.rotate ? (blockIdx.x * 7 + wave_u * 3) % tiles_per_wave : 0;
 #define FX_TT(t) (((t) + rot) % tiles_per_wave)
     const uint4* wst = p.wst + (long long)ft0 * 64 * 64 + lane;
 #define FX_DMA(src, slot)                                                                              \
@@ -136,73 +137,83 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // Block g of a tile: [counted vmcnt: this group has landed] -> its LDS reads -> lgkmcnt(0) -> twelve MFMAs with the four
-    // DMAs that re-request THIS group's slots (for group g + 4: the fragments are in registers now) in their gaps, one per
-    // three MFMAs - an LDS-DMA issued in a burst costs the wave as much as three MFMAs, in a gap it is nearly free.  The DMAs
-    // younger than group g's are then always three groups = 12 (8, 4, 0 for the last three blocks of the last tile).
-    // phase A block a: k-steps 2a, 2a+1; slots (a & 3) * 4 + {0: W1 hi(2a), 1: W1 lo(2a), 2: W1 hi(2a+1), 3: W1 lo(2a+1)}
-#define FX_PHASE_A(a, WAITN, REFILL)                                                                          \
-    {                                                                                                         \
-        bf16x8 wh0, wl0, wh1, wl1, xh0, xl0, xh1, xl1, yh0, yl0, yh1, yl1;                                    \
-        asm volatile("s_waitcnt vmcnt(" FX_STR(WAITN) ")\n\t"                                                 \
-                     "ds_read_b128 %0, %12 offset:" FX_STR((4 * ((a) & 3) + 0) * 1024) "\n\t"                 \
-                     "ds_read_b128 %1, %12 offset:" FX_STR((4 * ((a) & 3) + 1) * 1024) "\n\t"                 \
-                     "ds_read_b128 %2, %12 offset:" FX_STR((4 * ((a) & 3) + 2) * 1024) "\n\t"                 \
-                     "ds_read_b128 %3, %12 offset:" FX_STR((4 * ((a) & 3) + 3) * 1024) "\n\t"                 \
-                     "ds_read_b128 %4, %13 offset:" FX_STR((2 * (a) + 0) * 1024) "\n\t"                       \
-                     "ds_read_b128 %5, %13 offset:" FX_STR(FX_PLANE_B + (2 * (a) + 0) * 1024) "\n\t"            \
-                     "ds_read_b128 %6, %13 offset:" FX_STR((2 * (a) + 1) * 1024) "\n\t"                       \
-                     "ds_read_b128 %7, %13 offset:" FX_STR(FX_PLANE_B + (2 * (a) + 1) * 1024) "\n\t"            \
-                     "ds_read_b128 %8, %13 offset:" FX_STR(16384 + (2 * (a) + 0) * 1024) "\n\t"               \
-                     "ds_read_b128 %9, %13 offset:" FX_STR(FX_PLANE_B + 16384 + (2 * (a) + 0) * 1024) "\n\t"    \
-                     "ds_read_b128 %10, %13 offset:" FX_STR(16384 + (2 * (a) + 1) * 1024) "\n\t"              \
-                     "ds_read_b128 %11, %13 offset:" FX_STR(FX_PLANE_B + 16384 + (2 * (a) + 1) * 1024)          \
-                     : "=&v"(wh0), "=&v"(wl0), "=&v"(wh1), "=&v"(wl1), "=&v"(xh0), "=&v"(xl0), "=&v"(xh1),    \
-                       "=&v"(xl1), "=&v"(yh0), "=&v"(yl0), "=&v"(yh1), "=&v"(yl1)                             \
-                     : "v"(slot_a), "v"(xfrag_a)                                                              \
-                     : "memory");                                                                             \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh0), "+v"(wl0), "+v"(wh1), "+v"(wl1), "+v"(xh0), "+v"(xl0), \
-                     "+v"(xh1), "+v"(xl1), "+v"(yh0), "+v"(yl0), "+v"(yh1), "+v"(yl1) :: "memory");           \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-        FX_MFMA(wl0, xh0, xh[0]); FX_MFMA(wh0, xl0, xh[0]); FX_MFMA(wh0, xh0, xh[0]); REFILL(0)               \
-        FX_MFMA(wl0, yh0, xh[1]); FX_MFMA(wh0, yl0, xh[1]); FX_MFMA(wh0, yh0, xh[1]); REFILL(1)               \
-        FX_MFMA(wl1, xh1, xh[0]); FX_MFMA(wh1, xl1, xh[0]); FX_MFMA(wh1, xh1, xh[0]); REFILL(2)               \
-        FX_MFMA(wl1, yh1, xh[1]); FX_MFMA(wh1, yl1, xh[1]); FX_MFMA(wh1, yh1, xh[1]); REFILL(3)               \
-        FX_PIN_3M1V() FX_PIN_3M1V() FX_PIN_3M1V() FX_PIN_3M1V()                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-    }
-    // phase B block b: s = b >> 2, output tiles nt0 = 2 (b & 3), nt0 + 1; slots (b & 3) * 4 + {W2 hi(nt0), lo(nt0), hi(nt0+1), lo(nt0+1)}
-#define FX_PHASE_B(b, WAITN, REFILL)                                                                          \
-    {                                                                                                         \
-        bf16x8 wh0, wl0, wh1, wl1;                                                                            \
-        asm volatile("s_waitcnt vmcnt(" FX_STR(WAITN) ")\n\t"                                                 \
-                     "ds_read_b128 %0, %4 offset:" FX_STR((4 * ((b) & 3) + 0) * 1024) "\n\t"                  \
-                     "ds_read_b128 %1, %4 offset:" FX_STR((4 * ((b) & 3) + 1) * 1024) "\n\t"                  \
-                     "ds_read_b128 %2, %4 offset:" FX_STR((4 * ((b) & 3) + 2) * 1024) "\n\t"                  \
-                     "ds_read_b128 %3, %4 offset:" FX_STR((4 * ((b) & 3) + 3) * 1024)                          \
-                     : "=&v"(wh0), "=&v"(wl0), "=&v"(wh1), "=&v"(wl1)                                         \
-                     : "v"(slot_a)                                                                            \
-                     : "memory");                                                                             \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh0), "+v"(wl0), "+v"(wh1), "+v"(wl1) :: "memory");        \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-        FX_MFMA(wl0, pbh[0][(b) >> 2], acc[0][2 * ((b) & 3)]);                                                \
-        FX_MFMA(wh0, pbl[0][(b) >> 2], acc[0][2 * ((b) & 3)]);                                                \
-        FX_MFMA(wh0, pbh[0][(b) >> 2], acc[0][2 * ((b) & 3)]); REFILL(0)                                      \
-        FX_MFMA(wl1, pbh[0][(b) >> 2], acc[0][2 * ((b) & 3) + 1]);                                            \
-        FX_MFMA(wh1, pbl[0][(b) >> 2], acc[0][2 * ((b) & 3) + 1]);                                            \
-        FX_MFMA(wh1, pbh[0][(b) >> 2], acc[0][2 * ((b) & 3) + 1]); REFILL(1)                                  \
-        FX_MFMA(wl0, pbh[1][(b) >> 2], acc[1][2 * ((b) & 3)]);                                                \
-        FX_MFMA(wh0, pbl[1][(b) >> 2], acc[1][2 * ((b) & 3)]);                                                \
-        FX_MFMA(wh0, pbh[1][(b) >> 2], acc[1][2 * ((b) & 3)]); REFILL(2)                                      \
-        FX_MFMA(wl1, pbh[1][(b) >> 2], acc[1][2 * ((b) & 3) + 1]);                                            \
-        FX_MFMA(wh1, pbl[1][(b) >> 2], acc[1][2 * ((b) & 3) + 1]);                                            \
-        FX_MFMA(wh1, pbh[1][(b) >> 2], acc[1][2 * ((b) & 3) + 1]); REFILL(3)                                  \
-        FX_PIN_3M1V() FX_PIN_3M1V() FX_PIN_3M1V() FX_PIN_3M1V()                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-    }
-    // bias + ReLU on hidden unit f = 32 tile + acc_row(r, lane), split into the hi / lo B operands of phase B
+    // Software pipeline, one block = one group of four weight fragments (g = 0..15 per hidden tile: 8 of W1, 8 of W2):
+    //   block g:  [counted vmcnt: group g + 1 has landed] -> issue the LDS reads of block g + 1 into the OTHER register set
+    //             -> the twelve MFMAs of block g, with the four DMAs that re-request group g's slots (for group g + 4) in
+    //                their gaps, one per three MFMAs -> lgkmcnt(0) for block g + 1's operands.
+    // The LDS read burst of a block (12 KiB per wave for a W1 block) and its latency thus run under the previous block's
+    // MFMAs instead of in front of its own (one wave per SIMD: nothing else would cover them).  DMAs younger than group
+    // g + 1's at the wait: groups g + 2, g + 3 = 8 (4, 0 at the end of the last tile).
+    // Register sets: weights W0 / W1 (four fragments each), activations X0 / X1 (eight each: hi / lo x two k-steps x two
+    // M-tiles); block g uses set g & 1.
+    bf16x8 w0a, w0b, w0c, w0d, w1a, w1b, w1c, w1d;
+    bf16x8 x0a, x0b, x0c, x0d, x0e, x0f, x0g, x0h, x1a, x1b, x1c, x1d, x1e, x1f, x1g, x1h;
+    // reads of W1 block a (k-steps 2a, 2a + 1): weights from ring section a & 3, activations hi/lo for both M-tiles
+#define FX_READ_A(AI_, WAITN, W_, X_)                                                                           \
+    asm volatile("s_waitcnt vmcnt(" FX_STR(WAITN) ")\n\t"                                                     \
+                 "ds_read_b128 %0, %12 offset:" FX_STR((4 * ((AI_) & 3) + 0) * 1024) "\n\t"                     \
+                 "ds_read_b128 %1, %12 offset:" FX_STR((4 * ((AI_) & 3) + 1) * 1024) "\n\t"                     \
+                 "ds_read_b128 %2, %12 offset:" FX_STR((4 * ((AI_) & 3) + 2) * 1024) "\n\t"                     \
+                 "ds_read_b128 %3, %12 offset:" FX_STR((4 * ((AI_) & 3) + 3) * 1024) "\n\t"                     \
+                 "ds_read_b128 %4, %13 offset:" FX_STR((2 * (AI_) + 0) * 1024) "\n\t"                           \
+                 "ds_read_b128 %5, %13 offset:" FX_STR(FX_PLANE_B + (2 * (AI_) + 0) * 1024) "\n\t"              \
+                 "ds_read_b128 %6, %13 offset:" FX_STR((2 * (AI_) + 1) * 1024) "\n\t"                           \
+                 "ds_read_b128 %7, %13 offset:" FX_STR(FX_PLANE_B + (2 * (AI_) + 1) * 1024) "\n\t"              \
+                 "ds_read_b128 %8, %13 offset:" FX_STR(16384 + (2 * (AI_) + 0) * 1024) "\n\t"                   \
+                 "ds_read_b128 %9, %13 offset:" FX_STR(FX_PLANE_B + 16384 + (2 * (AI_) + 0) * 1024) "\n\t"      \
+                 "ds_read_b128 %10, %13 offset:" FX_STR(16384 + (2 * (AI_) + 1) * 1024) "\n\t"                  \
+                 "ds_read_b128 %11, %13 offset:" FX_STR(FX_PLANE_B + 16384 + (2 * (AI_) + 1) * 1024)              \
+                 : "=&v"(W_##a), "=&v"(W_##b), "=&v"(W_##c), "=&v"(W_##d), "=&v"(X_##a), "=&v"(X_##b), "=&v"(X_##c), \
+                   "=&v"(X_##d), "=&v"(X_##e), "=&v"(X_##f), "=&v"(X_##g), "=&v"(X_##h)                       \
+                 : "v"(slot_a), "v"(xfrag_a)                                                                  \
+                 : "memory");                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+    // reads of W2 block b: four weight fragments from ring section b & 3
+#define FX_READ_B(BI_, WAITN, W_)                                                                               \
+    asm volatile("s_waitcnt vmcnt(" FX_STR(WAITN) ")\n\t"                                                     \
+                 "ds_read_b128 %0, %4 offset:" FX_STR((4 * ((BI_) & 3) + 0) * 1024) "\n\t"                      \
+                 "ds_read_b128 %1, %4 offset:" FX_STR((4 * ((BI_) & 3) + 1) * 1024) "\n\t"                      \
+                 "ds_read_b128 %2, %4 offset:" FX_STR((4 * ((BI_) & 3) + 2) * 1024) "\n\t"                      \
+                 "ds_read_b128 %3, %4 offset:" FX_STR((4 * ((BI_) & 3) + 3) * 1024)                               \
+                 : "=&v"(W_##a), "=&v"(W_##b), "=&v"(W_##c), "=&v"(W_##d)                                     \
+                 : "v"(slot_a)                                                                                \
+                 : "memory");                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+#define FX_NOREAD()
+#define FX_WAIT_A(W_, X_)                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W_##a), "+v"(W_##b), "+v"(W_##c), "+v"(W_##d), "+v"(X_##a), "+v"(X_##b), \
+                 "+v"(X_##c), "+v"(X_##d), "+v"(X_##e), "+v"(X_##f), "+v"(X_##g), "+v"(X_##h) :: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);
+#define FX_WAIT_B(W_)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W_##a), "+v"(W_##b), "+v"(W_##c), "+v"(W_##d) :: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);
+    // MFMAs of a W1 block on register set (W_, X_): fragments a..d = W1 hi(k0), lo(k0), hi(k1), lo(k1); X a..h = M-tile 0
+    // hi(k0), lo(k0), hi(k1), lo(k1), M-tile 1 hi(k0), lo(k0), hi(k1), lo(k1)
+#define FX_MFMA_A(W_, X_, REFILL)                                                                             \
+    FX_MFMA(W_##b, X_##a, xh[0]); FX_MFMA(W_##a, X_##b, xh[0]); FX_MFMA(W_##a, X_##a, xh[0]); REFILL(0)       \
+    FX_MFMA(W_##b, X_##e, xh[1]); FX_MFMA(W_##a, X_##f, xh[1]); FX_MFMA(W_##a, X_##e, xh[1]); REFILL(1)       \
+    FX_MFMA(W_##d, X_##c, xh[0]); FX_MFMA(W_##c, X_##d, xh[0]); FX_MFMA(W_##c, X_##c, xh[0]); REFILL(2)       \
+    FX_MFMA(W_##d, X_##g, xh[1]); FX_MFMA(W_##c, X_##h, xh[1]); FX_MFMA(W_##c, X_##g, xh[1]); REFILL(3)       \
+    FX_PIN_3M1V() FX_PIN_3M1V() FX_PIN_3M1V() FX_PIN_3M1V()                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+    // MFMAs of W2 block b: s = b >> 2, output tiles nt0 = 2 (b & 3), nt0 + 1; fragments a..d = W2 hi(nt0), lo(nt0), hi(nt0+1), lo(nt0+1)
+#define FX_MFMA_B(BI_, W_, REFILL)                                                                              \
+    FX_MFMA(W_##b, pbh[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3)]);                                                  \
+    FX_MFMA(W_##a, pbl[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3)]);                                                  \
+    FX_MFMA(W_##a, pbh[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3)]); REFILL(0)                                        \
+    FX_MFMA(W_##d, pbh[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3) + 1]);                                              \
+    FX_MFMA(W_##c, pbl[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3) + 1]);                                              \
+    FX_MFMA(W_##c, pbh[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3) + 1]); REFILL(1)                                    \
+    FX_MFMA(W_##b, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3)]);                                                  \
+    FX_MFMA(W_##a, pbl[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3)]);                                                  \
+    FX_MFMA(W_##a, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3)]); REFILL(2)                                        \
+    FX_MFMA(W_##d, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3) + 1]);                                              \
+    FX_MFMA(W_##c, pbl[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3) + 1]);                                              \
+    FX_MFMA(W_##c, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3) + 1]); REFILL(3)                                    \
+    FX_PIN_3M1V() FX_PIN_3M1V() FX_PIN_3M1V() FX_PIN_3M1V()                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+    // bias + ReLU on hidden unit f = 32 tile + acc_row(r, lane), split into the hi / lo B operands of the W2 blocks
 #define FX_RELU_PACK(pos)                                                                                     \
-    bf16x8 pbh[FX_MT][2], pbl[FX_MT][2];                                                                      \
     {                                                                                                         \
         const int src0 = 32 * ((pos) & 1) + 4 * half;                                                         \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) _Pragma("unroll") for (int e = 0; e < 4; ++e) {         \
@@ -217,110 +228,66 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
         if ((pos) & 1) { _Pragma("unroll") for (int j = 0; j < 7; ++j) bq[j] = bq[j + 1]; }                   \
     }
 #define FX_ZERO_XH()                                                                                          \
-    f32x16 xh[FX_MT];                                                                                         \
     _Pragma("unroll") for (int mt = 0; mt < FX_MT; ++mt) _Pragma("unroll") for (int r = 0; r < 16; ++r) xh[mt][r] = 0.f;
-
-    // REFILL(j): re-request slot j of this block's ring section for the group four blocks ahead
+    // the sixteen blocks of a tile; RF(g): refill macro of block g (group g + 4 of this tile, or g - 12 of the next);
+    // NEXT_A0: the reads of the next tile's block 0 (nothing after the last tile); VA / VB / VC: vmcnt of the reads issued in
+    // blocks 12 / 13 / 14 (8 8 8 in a middle tile; 8 4 0 in the last one, where nothing is re-requested any more)
+#define FX_TILE(RF12, RF13, RF14, RF15, VB, VC, NEXT_A0, NEXT_WAIT)                                           \
+    FX_ZERO_XH()                                                                                              \
+    FX_READ_A(1, 8, w1, x1) FX_MFMA_A(w0, x0, R4_) FX_WAIT_A(w1, x1)                                          \
+    FX_READ_A(2, 8, w0, x0) FX_MFMA_A(w1, x1, R5_) FX_WAIT_A(w0, x0)                                          \
+    FX_READ_A(3, 8, w1, x1) FX_MFMA_A(w0, x0, R6_) FX_WAIT_A(w1, x1)                                          \
+    FX_READ_A(4, 8, w0, x0) FX_MFMA_A(w1, x1, R7_) FX_WAIT_A(w0, x0)                                          \
+    FX_READ_A(5, 8, w1, x1) FX_MFMA_A(w0, x0, R8_) FX_WAIT_A(w1, x1)                                          \
+    FX_READ_A(6, 8, w0, x0) FX_MFMA_A(w1, x1, R9_) FX_WAIT_A(w0, x0)                                          \
+    FX_READ_A(7, 8, w1, x1) FX_MFMA_A(w0, x0, R10_) FX_WAIT_A(w1, x1)                                         \
+    FX_READ_B(0, 8, w0) FX_MFMA_A(w1, x1, R11_) FX_WAIT_B(w0)                                                 \
+    FX_RELU_PACK(t)                                                                                           \
+    FX_READ_B(1, 8, w1) FX_MFMA_B(0, w0, R12_) FX_WAIT_B(w1)                                                  \
+    FX_READ_B(2, 8, w0) FX_MFMA_B(1, w1, R13_) FX_WAIT_B(w0)                                                  \
+    FX_READ_B(3, 8, w1) FX_MFMA_B(2, w0, R14_) FX_WAIT_B(w1)                                                  \
+    FX_READ_B(4, 8, w0) FX_MFMA_B(3, w1, R15_) FX_WAIT_B(w0)                                                  \
+    FX_READ_B(5, 8, w1) FX_MFMA_B(4, w0, RF12) FX_WAIT_B(w1)                                                  \
+    FX_READ_B(6, VB, w0) FX_MFMA_B(5, w1, RF13) FX_WAIT_B(w0)                                                 \
+    FX_READ_B(7, VC, w1) FX_MFMA_B(6, w0, RF14) FX_WAIT_B(w1)                                                 \
+    NEXT_A0 FX_MFMA_B(7, w1, RF15) NEXT_WAIT
+#define R4_(j) FX_FILL1(cur, 4, j)
+#define R5_(j) FX_FILL1(cur, 5, j)
+#define R6_(j) FX_FILL1(cur, 6, j)
+#define R7_(j) FX_FILL1(cur, 7, j)
+#define R8_(j) FX_FILL1(cur, 8, j)
+#define R9_(j) FX_FILL1(cur, 9, j)
+#define R10_(j) FX_FILL1(cur, 10, j)
+#define R11_(j) FX_FILL1(cur, 11, j)
+#define R12_(j) FX_FILL1(cur, 12, j)
+#define R13_(j) FX_FILL1(cur, 13, j)
+#define R14_(j) FX_FILL1(cur, 14, j)
+#define R15_(j) FX_FILL1(cur, 15, j)
+#define RN0_(j) FX_FILL1(nxt, 0, j)
+#define RN1_(j) FX_FILL1(nxt, 1, j)
+#define RN2_(j) FX_FILL1(nxt, 2, j)
+#define RN3_(j) FX_FILL1(nxt, 3, j)
+#define RNONE_(j)
+    f32x16 xh[FX_MT];
+    bf16x8 pbh[FX_MT][2], pbl[FX_MT][2];
+    // the first block's operands: groups 1..3 of the prologue are younger
+    FX_READ_A(0, 12, w0, x0) FX_WAIT_A(w0, x0)
     int t = 0;
     for (; t + 1 < tiles_per_wave; ++t) {
         const int cur = FX_TT(t), nxt = FX_TT(t + 1);
-        FX_ZERO_XH()
-#define R_(j) FX_FILL1(cur, 4, j)
-        FX_PHASE_A(0, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 5, j)
-        FX_PHASE_A(1, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 6, j)
-        FX_PHASE_A(2, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 7, j)
-        FX_PHASE_A(3, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 8, j)
-        FX_PHASE_A(4, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 9, j)
-        FX_PHASE_A(5, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 10, j)
-        FX_PHASE_A(6, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 11, j)
-        FX_PHASE_A(7, 12, R_)
-#undef R_
-        FX_RELU_PACK(t)
-#define R_(j) FX_FILL1(cur, 12, j)
-        FX_PHASE_B(0, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 13, j)
-        FX_PHASE_B(1, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 14, j)
-        FX_PHASE_B(2, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 15, j)
-        FX_PHASE_B(3, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(nxt, 0, j)
-        FX_PHASE_B(4, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(nxt, 1, j)
-        FX_PHASE_B(5, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(nxt, 2, j)
-        FX_PHASE_B(6, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(nxt, 3, j)
-        FX_PHASE_B(7, 12, R_)
-#undef R_
+        FX_TILE(RN0_, RN1_, RN2_, RN3_, 8, 8, FX_READ_A(0, 8, w0, x0), FX_WAIT_A(w0, x0))
     }
     {
         const int cur = FX_TT(t);
-        FX_ZERO_XH()
-#define R_(j) FX_FILL1(cur, 4, j)
-        FX_PHASE_A(0, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 5, j)
-        FX_PHASE_A(1, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 6, j)
-        FX_PHASE_A(2, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 7, j)
-        FX_PHASE_A(3, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 8, j)
-        FX_PHASE_A(4, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 9, j)
-        FX_PHASE_A(5, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 10, j)
-        FX_PHASE_A(6, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 11, j)
-        FX_PHASE_A(7, 12, R_)
-#undef R_
-        FX_RELU_PACK(t)
-#define R_(j) FX_FILL1(cur, 12, j)
-        FX_PHASE_B(0, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 13, j)
-        FX_PHASE_B(1, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 14, j)
-        FX_PHASE_B(2, 12, R_)
-#undef R_
-#define R_(j) FX_FILL1(cur, 15, j)
-        FX_PHASE_B(3, 12, R_)
-#undef R_
-#define R_(j)
-        FX_PHASE_B(4, 12, R_) FX_PHASE_B(5, 8, R_) FX_PHASE_B(6, 4, R_) FX_PHASE_B(7, 0, R_)
-#undef R_
+        FX_TILE(RNONE_, RNONE_, RNONE_, RNONE_, 4, 0, FX_NOREAD(), FX_NOREAD())
     }
-#undef FX_PHASE_A
-#undef FX_PHASE_B
+#undef FX_TILE
+#undef FX_READ_A
+#undef FX_READ_B
+#undef FX_WAIT_A
+#undef FX_WAIT_B
+#undef FX_MFMA_A
+#undef FX_MFMA_B
 #undef FX_RELU_PACK
 #undef FX_ZERO_XH
 #undef FX_FILL
@@ -404,6 +371,8 @@ int launch_ffn_x3(const FfnX3Args& a, hipStream_t s) {
     p.M = a.M;
     p.dff = a.dff;
     p.eps = a.eps;
+    static const int rotate = getenv("CASSNAT_FFN_X3_ROTATE") ? atoi(getenv("CASSNAT_FFN_X3_ROTATE")) : 1;
+    p.rotate = rotate;
     static CnAttrOnce attr_once;
     int attr_dev;
     if (attr_once.need(&attr_dev)) {

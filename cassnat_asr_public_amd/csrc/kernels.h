@@ -69,6 +69,7 @@ int launch_lm_embed(const int* tok, int ld, const float* lut, const float* pe, f
                     hipStream_t s);
 int launch_gather_logp(const float* logp, int V, const int* tgt, int ld, float* out, int B, int U, hipStream_t s);
 int launch_fill_int(int* p, size_t n, int v, hipStream_t s);
+int launch_copy_rows(void* dst, int dst_ld, const void* src, int src_ld, int width, int rows, hipStream_t s);  // 4-byte words
 int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t s);       // fp32 -> model precision
 int launch_convert_back(int prec, const void* src, float* dst, size_t n, hipStream_t s);  // model precision -> fp32
 

@@ -2299,9 +2299,9 @@ extern "C" int cn_esa_sample(cn_model* m, const uint8_t* select_dev, int32_t n_s
     const int rc = stage_decode(m, U, opts, nullptr, 0, nullptr, nullptr, s);
     m->dec_group = 1;
     if (rc) return rc;
-    CN_HIP_CHECK(hipMemcpy2DAsync(tok_out_dev, (size_t)out_stride * 4, m->tok, (size_t)U * 4, (size_t)U * 4, BG, hipMemcpyDeviceToDevice, s));
-    CN_HIP_CHECK(hipMemcpy2DAsync(val_out_dev, (size_t)out_stride * 4, m->val, (size_t)U * 4, (size_t)U * 4, BG, hipMemcpyDeviceToDevice, s));
-    CN_HIP_CHECK(hipMemcpyAsync(ylen_out_dev, m->ylen, (size_t)BG * 4, hipMemcpyDeviceToDevice, s));
+    CN_TRY(launch_copy_rows(tok_out_dev, out_stride, m->tok, U, U, BG, s));
+    CN_TRY(launch_copy_rows(val_out_dev, out_stride, m->val, U, U, BG, s));
+    CN_TRY(launch_copy_rows(ylen_out_dev, BG, m->ylen, BG, BG, 1, s));
     *ymax_host = U;
     return 0;
 }

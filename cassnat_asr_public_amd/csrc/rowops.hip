@@ -502,6 +502,25 @@ int launch_convert_back(int prec, const void* src, float* dst, size_t n, hipStre
     return 0;
 }
 
+// rows of `width` 4-byte words from a [rows][src_ld] buffer into a [rows][dst_ld] one (a kernel, not hipMemcpy2DAsync: the
+// runtime's pitched device-to-device copy takes a staging path of its own with occasional tens-of-milliseconds stalls)
+__global__ void copy_rows_kernel(unsigned* __restrict__ dst, int dst_ld, const unsigned* __restrict__ src, int src_ld, int width,
+                                 long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / width;
+        const int c = (int)(i - r * width);
+        dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+}
+int launch_copy_rows(void* dst, int dst_ld, const void* src, int src_ld, int width, int rows, hipStream_t s) {
+    const long long total = (long long)width * rows;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(convert_grid((size_t)total)), dim3(256), 0, s, (unsigned*)dst, dst_ld, (const unsigned*)src,
+                       src_ld, width, total);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 __global__ void fill_int_kernel(int* p, size_t n, int v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
