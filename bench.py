@@ -76,6 +76,10 @@ def main():
     from cassnat_asr_public_amd import hip, synth
     from cassnat_asr_public_amd.models.cassnat import make_model
 
+    # host-side torch ops of the GPU legs run single-threaded: an OpenMP team spun up by a CPU tensor op keeps spinning and, under
+    # the box's per-process CPU quota, gets the whole process throttled for tens of milliseconds (tools/esa_stall_probe.py); the
+    # cpu_baseline leg sets its own thread count
+    torch.set_num_threads(1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -289,6 +293,7 @@ def main():
                          f"{med:.2f} s after 1 warm-up; RTF {med / (B * T * 0.01):.5f}",
                "hyp_agreement_with_gpu": round(float(np.mean([h == r for h, r in zip(hyps[:B], ref["hyps"])])), 3),
                "note": "hyp_agreement_with_gpu: whole hypotheses of the timed engine (`dtype`) equal to this fp32 CPU run's"}
+        torch.set_num_threads(1)  # (back to single-threaded host ops for the GPU legs below)
 
     # ---- the engines that meet north_star's tolerance (1e-3 on the CTC log-posteriors, token-exact alignment: tests/
     # test_gpu_pipeline.py::test_fp32_parity_gate), timed through the SAME decode pipelines for the SAME number of steps on

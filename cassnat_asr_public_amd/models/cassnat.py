@@ -17,6 +17,25 @@ import torch.nn as nn
 from .. import hip
 
 
+class _OneHostThread:
+    """The host-side tensor arithmetic of a decode call (masks, means and picks over a few hundred thousand numbers) runs
+    single-threaded.  Measured: left to torch's intra-op pool, those few CPU ops start an OpenMP team whose idle workers keep
+    spinning; on a GPU box whose process has a CPU quota (16 cores for one GPU) the spinning exhausts the cgroup's CFS quota
+    and the whole process - the thread that launches kernels included - is throttled for the rest of the 100 ms period:
+    sporadic 60-90 ms stalls on every other ESA decode (18 ms each otherwise; tools/esa_stall_probe.py)."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        if self.n != 1:
+            torch.set_num_threads(1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.n != 1:
+            torch.set_num_threads(self.n)
+        return False
+
+
 def create_pe(d_model, max_len=5000):
     """Sinusoid table, same closed form as src/models/cassnat.py:91-99 (a buffer, not a parameter)."""
     position = torch.arange(0.0, max_len).unsqueeze(1)
@@ -389,7 +408,8 @@ class CassNAT(nn.Module):
         sos = vocab.word2index["sos"]
         assert vocab.word2index["blank"] == args.padding_idx, "CTC blank id and padding_idx must agree"
         if getattr(args, "sample_num", 0) > 1:
-            return self._esa_decode(src, src_size, args, lm_model, sos, vocab), args
+            with _OneHostThread():
+                return self._esa_decode(src, src_size, args, lm_model, sos, vocab), args
         if getattr(args, "decode_type", "att_only") == "ctc_att":
             hyp, hyp_len, score = self._decode_forced(src, src_size, args, sos, ctc_top_seqs)
         else:

@@ -210,5 +210,6 @@ def test_decode_asr_cli_with_ctc_decode_types(tmp_path, decode_type):
     ref = orc.decode_nast_ctc(state, feats, sizes, args)
     hyps = [b[0]["hyp"] for b in ref["beams"]] if decode_type == "ctc_only" else ref["hyps"]
     index2word = {i + 4: f"w{i}" for i in range(args.vocab_size - 4)}
+    index2word[3] = "unk"  # (a CTC hypothesis may carry the unk id: data.vocab.Vocab maps ids 0..3 to blank/sos/eos/unk)
     expect = [f"spk-utt{b:02d} " + " ".join(orc.hyp_to_text(h, index2word)) for b, h in enumerate(hyps)]
     assert open(result).read().splitlines() == expect
