@@ -354,7 +354,8 @@ def main():
                    "blank_bias": synth.BENCH_BLANK_BIAS},
         "rtf": round(elapsed / audio_s, 8), "rtfx": round(audio_s / elapsed, 1),
         "gflop_per_utt": round(flops / B / 1e9, 3),
-        "mfma_frac_end_to_end": round(flops / B * value / (world * PEAK_BF16_DENSE_TFLOPS * 1e12), 5),
+        # algorithmic FLOP/s of the whole path against the chip's peak for this precision's products (bf16x3: three MFMAs each)
+        "mfma_frac_end_to_end": round(flops / B * value / (world * peak * 1e12 / (3.0 if a.precision == "bf16x3" else 1.0)), 5),
         "roofline": roofline, "roofline_conv2": roofline_conv2, "cpu_baseline": cpu, "parity_engine": parity_engine,
         "fp32_engine": fp32_engine, "one_batch_per_pass": uncoalesced,
         "stage_ms": stage_ms,
