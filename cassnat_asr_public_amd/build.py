@@ -22,17 +22,18 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir=None):
+    """extra_flags / lib / objdir: measurement variants (e.g. -DFX_STAMPS into a library of their own); the product is the default."""
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(CSRC), "..", "include", "cassnat_hip.h"))
-    objdir = os.path.join(CSRC, "build")
+    objdir = objdir or os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         path = os.path.join(CSRC, src)
         if force or _stale(obj, [path] + headers):
-            cmd = [_hipcc()] + FLAGS + ["-c", path, "-o", obj]
+            cmd = [_hipcc()] + FLAGS + list(extra_flags) + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -42,12 +43,12 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    if force or _stale(LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

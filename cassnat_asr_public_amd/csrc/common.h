@@ -114,15 +114,32 @@ template <> __device__ __forceinline__ bf16x8 as_frag<bf16>(uint4 v) { return __
 template <> __device__ __forceinline__ f32x4 as_frag<float>(uint4 v) { return __builtin_bit_cast(f32x4, v); }
 template <> __device__ __forceinline__ i64x2 as_frag<fp8_t>(uint4 v) { return __builtin_bit_cast(i64x2, v); }
 
+// Wave-wide reductions on the DPP cross-lane paths (no LDS round trip per step as with ds_bpermute: a LayerNorm row costs
+// two of these back to back).  Steps: lane ^ 1 and lane ^ 2 (quad permutes), the other quad of the 8 (row_half_mirror: the
+// quads are uniform by then), the other 8 of the row of 16 (row_mirror), lane 15 of the previous row into rows 1 and 3
+// (row_bcast15), lane 31 into rows 2 and 3 (row_bcast31): lane 63 holds the result, read back as a wave-uniform value.
+// All 64 lanes must be active.
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float cn_dpp(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += cn_dpp<0xB1, 0xf, true>(0.f, v);
+    v += cn_dpp<0x4E, 0xf, true>(0.f, v);
+    v += cn_dpp<0x141, 0xf, true>(0.f, v);
+    v += cn_dpp<0x140, 0xf, true>(0.f, v);
+    v += cn_dpp<0x142, 0xa, false>(0.f, v);
+    v += cn_dpp<0x143, 0xc, false>(0.f, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, cn_dpp<0xB1, 0xf, true>(v, v));
+    v = fmaxf(v, cn_dpp<0x4E, 0xf, true>(v, v));
+    v = fmaxf(v, cn_dpp<0x141, 0xf, true>(v, v));
+    v = fmaxf(v, cn_dpp<0x140, 0xf, true>(v, v));
+    v = fmaxf(v, cn_dpp<0x142, 0xa, false>(v, v));
+    v = fmaxf(v, cn_dpp<0x143, 0xc, false>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -7,9 +7,9 @@
 // they never leave registers:
 //   * LN(x) of the workgroup's 64 rows is written once to LDS as B-operand fragments, a hi plane and a lo plane;
 //   * every wave owns d_ff / 4 hidden units and streams ITS weight fragments (hi and lo, pre-tiled at pack time in
-//     consumption order: 64 KiB per 32 hidden units) by LDS-DMA into a private 16-slot ring - four groups of four 1-KiB
-//     fragments; a group's slots are re-requested as soon as its fragments are in registers, every wait is a counted
-//     vmcnt on the wave's own queue, no barrier in the main loop;
+//     consumption order: 64 KiB per 32 hidden units) straight from global memory (L2) into four rotating register sets,
+//     three groups of four 1-KiB fragments in flight under the MFMAs of the current one; the stream is read once and by
+//     one wave, so there is no LDS hop and no barrier in the main loop;
 //   * X^T[f][m] = W1 . xn^T is computed swapped, so its accumulator (after bias + ReLU and the hi / lo split) is directly the
 //     B operand of out^T[n][m] += W2[n][f] X[f][m];
 //   * the four waves' out^T partials are summed through LDS, fused with b2, the residual and the next LayerNorm.
@@ -33,34 +33,51 @@ struct FfnX3Params {
     int M, dff;
     float eps;
     int rotate;
+#ifdef FX_STAMPS
+    unsigned long long* stamps;  // [workgroup][wave][8]: kernel entry, main loop entry, main loop exit, kernel exit (s_memtime);
+                                 // then the main loop's cycles by phase: W1 blocks, bias / ReLU (first half), W2 blocks
+#endif
 };
+#ifdef FX_STAMPS  // measurement build only (tools/ffn_x3_stamps.py): where a workgroup's time goes
+#define FX_STAMP(i) if (lane == 0) p.stamps[(blockIdx.x * 4 + wave) * 8 + (i)] = __builtin_readcyclecounter();
+#define FX_PHASE(i) { const unsigned long long now_ = __builtin_readcyclecounter(); phase_[i] += now_ - last_; last_ = now_; }
+#else
+#define FX_STAMP(i)
+#define FX_PHASE(i)
+#endif
 
 constexpr int FX_D = 256;
 constexpr int FX_MT = 2;                          // 32-row M-tiles per workgroup
-#define FX_PLANE_B 32768                          /* literal for the asm offsets: FX_MT * 16384 */
-constexpr int FX_PLANE = FX_PLANE_B;              // bytes of one plane (hi or lo) of the xn fragments
-static_assert(FX_PLANE == FX_MT * 16384, "plane size");
-constexpr int FX_RING = 16 * 1024;                // per wave: 4 groups x 4 fragments x 1 KiB
+constexpr int FX_PLANE = FX_MT * 16384;           // bytes of one plane (hi or lo) of the xn fragments
+constexpr int FX_MAX_DFF = 2048;
 constexpr int FX_P_STRIDE = FX_D + 4;             // floats per partial row in LDS
-constexpr int FX_LDS_MAIN = 2 * FX_PLANE + 4 * FX_RING;
+constexpr int FX_LDS_MAIN = 2 * FX_PLANE + FX_MAX_DFF * 4;
 constexpr int FX_LDS_PART = 4 * 32 * FX_P_STRIDE * 4;
 constexpr int FX_LDS = FX_LDS_MAIN > FX_LDS_PART ? FX_LDS_MAIN : FX_LDS_PART;
 static_assert(FX_LDS <= 160 * 1024, "LDS budget");
 
-#define FX_STR2(x) #x
-#define FX_STR(x) FX_STR2(x)
 #define FX_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+// The kernel holds 18 accumulator tiles (16 of out^T, 2 of the hidden tile) = 288 registers.  The compiler selects every MFMA
+// builtin with an AGPR destination (there are 256) and, left alone, parks the hidden tile there too and shuttles output tiles
+// between the register files every iteration (96-160 v_accvgpr moves per hidden tile, plus the reads the VALU needs to see
+// the hidden tile at all).  The W1 MFMAs are therefore written out with the hidden tile in ordinary VGPRs; the 16 output
+// tiles then fill the AGPRs exactly and never move.  Written-out instructions are opaque to the hazard recogniser and to
+// sched_group_barrier: the W1 blocks are ordered by sched_barrier fences instead, and the one read-after-MFMA the
+// compiler cannot see (bias / ReLU on the finished tile) gets its own s_nop.
+#define FX_MFMA_V(a, b, c) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+#define FX_MFMA_V0(a, b, c) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b))
 
 __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xn_s = smem;                    // [plane][mt][16 k-steps][64 lanes][16 B]
-    float* part = reinterpret_cast<float*>(smem);  // [4][32][260] fp32, epilogue only (aliases everything)
+    unsigned char* xn_s = smem;                                          // [plane][mt][16 k-steps][64 lanes][16 B]
+    float* b1_s = reinterpret_cast<float*>(smem + 2 * FX_PLANE);         // [dff]
+    float* part = reinterpret_cast<float*>(smem);                        // [4][32][260] fp32, epilogue only (aliases everything)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.x * 32 * FX_MT;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    unsigned char* ring = smem + 2 * FX_PLANE + wave_u * FX_RING;
+    FX_STAMP(0)
 
     const int tiles_per_wave = p.dff / 32 / 4;
     const int ft0 = wave_u * tiles_per_wave;
@@ -68,32 +85,25 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
     // workgroups then do not pull the same L2 lines at the same moment)
     const int rot = p.rotate ? (blockIdx.x * 7 + wave_u * 3) % tiles_per_wave : 0;
 #define FX_TT(t) (((t) + rot) % tiles_per_wave)
-    const uint4* wst = p.wst + (long long)ft0 * 64 * 64 + lane;
-#define FX_DMA(src, slot)                                                                              \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
-                                     (__attribute__((address_space(3))) void*)(ring + (slot) * 1024), 16, 0, 0)
-    // group g (0..15) of tile `tile` into ring section g & 3
-#define FX_FILL(tile, g) { _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                             \
-        FX_DMA(wst + ((long long)(tile) * 64 + 4 * (g) + j_) * 64, 4 * ((g) & 3) + j_); }
-    // one fragment of it (the refills ride in the MFMA gaps of a block, one per three MFMAs)
-#define FX_FILL1(tile, g, j_) FX_DMA(wst + ((long long)(tile) * 64 + 4 * (g) + (j_)) * 64, 4 * ((g) & 3) + (j_));
-#define FX_NOFILL1(tile, g, j_)
-#define FX_PIN_3M1V()                                                                                  \
-    __builtin_amdgcn_sched_group_barrier(0x8, 3, 0); __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+    const bf16x8* wst = reinterpret_cast<const bf16x8*>(p.wst) + (long long)ft0 * 64 * 64 + lane;
 
-    // biases of the wave's hidden tiles in PROCESSING order (as fused.hip): register j, lane 32 p + i holds b1 of hidden
-    // unit i of the tile processed at position 2 j + p
-    float bq[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int pos = 2 * j + half;
-        bq[j] = pos < tiles_per_wave ? p.b1[32 * (ft0 + FX_TT(pos)) + l31] : 0.f;
+    // Weight register sets: group g (0..15 of a hidden tile: 8 of W1, 8 of W2; four 1-KiB fragments = hi, lo, hi, lo) lives
+    // in set g & 3.  The stream is private to the wave and read once, so it goes global -> VGPR with no LDS hop (an LDS-DMA
+    // ring was tried first: its requests cost 60-190 issue cycles apiece beside MFMAs, 4 per 12 MFMAs, and the kernel ran at
+    // 0.37 us per block whatever the ring depth, 4 or 6 groups).  Block g computes on set g & 3 and, in its MFMA gaps,
+    // requests group g + 3 into the set block g - 1 has just released.
+    bf16x8 w0a, w0b, w0c, w0d, w1a, w1b, w1c, w1d, w2a, w2b, w2c, w2d, w3a, w3b, w3c, w3d;
+#define FX_LDW(S_, tile, g)                                                                            \
+    {                                                                                                  \
+        const bf16x8* s_ = wst + ((long long)(tile) * 64 + 4 * (g)) * 64;                              \
+        w##S_##a = s_[0]; w##S_##b = s_[64]; w##S_##c = s_[128]; w##S_##d = s_[192];                    \
     }
-    // prologue: the first four groups go in flight before the LayerNorm below
+    // prologue: the first three groups go in flight before the LayerNorm below
     {
         const int t0 = FX_TT(0);
-        FX_FILL(t0, 0) FX_FILL(t0, 1) FX_FILL(t0, 2) FX_FILL(t0, 3)
+        FX_LDW(0, t0, 0) FX_LDW(1, t0, 1) FX_LDW(2, t0, 2)
     }
+    for (int i = tid; i < p.dff; i += 256) b1_s[i] = p.b1[i];
 
     // ---- LayerNorm of the workgroup's rows -> hi / lo bf16 fragments in LDS (wave w: rows w, w+4, ...)
     {
@@ -111,10 +121,10 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
             float ss = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) ss = fmaf(v[j] - mean, v[j] - mean, ss);
-            const float denom = sqrtf(wave_sum(ss) / (float)(FX_D - 1)) + p.eps;
+            const float inv = 1.f / (sqrtf(wave_sum(ss) / (float)(FX_D - 1)) + p.eps);  // one division per row, not per element
             float o[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[j] - mean) / denom + bb[j];
+            for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[j] - mean) * inv + bb[j];
             bf16x4 hi, lo;
             cn_split4(o, hi, lo);
             unsigned char* dst = xn_s + (((r >> 5) * 16 + ks) * 64 + kh * 32 + (r & 31)) * 16 + kb;
@@ -124,11 +134,6 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
     }
     __syncthreads();
 
-    // LDS byte addresses for the inline-asm reads (hipcc drains vmcnt in front of every LDS access it can see while an
-    // LDS-DMA is outstanding: all main-loop reads are asm with their own counted waits)
-    const unsigned xfrag_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(xn_s + lane * 16);
-    const unsigned slot_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(ring + lane * 16);
-
     f32x16 acc[FX_MT][8];
 #pragma unroll
     for (int mt = 0; mt < FX_MT; ++mt)
@@ -137,161 +142,136 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // Software pipeline, one block = one group of four weight fragments (g = 0..15 per hidden tile: 8 of W1, 8 of W2):
-    //   block g:  [counted vmcnt: group g + 1 has landed] -> issue the LDS reads of block g + 1 into the OTHER register set
-    //             -> the twelve MFMAs of block g, with the four DMAs that re-request group g's slots (for group g + 4) in
-    //                their gaps, one per three MFMAs -> lgkmcnt(0) for block g + 1's operands.
-    // The LDS read burst of a block (12 KiB per wave for a W1 block) and its latency thus run under the previous block's
-    // MFMAs instead of in front of its own (one wave per SIMD: nothing else would cover them).  DMAs younger than group
-    // g + 1's at the wait: groups g + 2, g + 3 = 8 (4, 0 at the end of the last tile).
-    // Register sets: weights W0 / W1 (four fragments each), activations X0 / X1 (eight each: hi / lo x two k-steps x two
-    // M-tiles); block g uses set g & 1.
-    bf16x8 w0a, w0b, w0c, w0d, w1a, w1b, w1c, w1d;
+    // Activation register sets x0 / x1 (eight fragments each: hi / lo x two k-steps x two M-tiles): W1 block a uses set a & 1;
+    // the LDS reads of block a + 1 ride between block a's MFMAs.
     bf16x8 x0a, x0b, x0c, x0d, x0e, x0f, x0g, x0h, x1a, x1b, x1c, x1d, x1e, x1f, x1g, x1h;
-    // reads of W1 block a (k-steps 2a, 2a + 1): weights from ring section a & 3, activations hi/lo for both M-tiles
-#define FX_READ_A(AI_, WAITN, W_, X_)                                                                           \
-    asm volatile("s_waitcnt vmcnt(" FX_STR(WAITN) ")\n\t"                                                     \
-                 "ds_read_b128 %0, %12 offset:" FX_STR((4 * ((AI_) & 3) + 0) * 1024) "\n\t"                     \
-                 "ds_read_b128 %1, %12 offset:" FX_STR((4 * ((AI_) & 3) + 1) * 1024) "\n\t"                     \
-                 "ds_read_b128 %2, %12 offset:" FX_STR((4 * ((AI_) & 3) + 2) * 1024) "\n\t"                     \
-                 "ds_read_b128 %3, %12 offset:" FX_STR((4 * ((AI_) & 3) + 3) * 1024) "\n\t"                     \
-                 "ds_read_b128 %4, %13 offset:" FX_STR((2 * (AI_) + 0) * 1024) "\n\t"                           \
-                 "ds_read_b128 %5, %13 offset:" FX_STR(FX_PLANE_B + (2 * (AI_) + 0) * 1024) "\n\t"              \
-                 "ds_read_b128 %6, %13 offset:" FX_STR((2 * (AI_) + 1) * 1024) "\n\t"                           \
-                 "ds_read_b128 %7, %13 offset:" FX_STR(FX_PLANE_B + (2 * (AI_) + 1) * 1024) "\n\t"              \
-                 "ds_read_b128 %8, %13 offset:" FX_STR(16384 + (2 * (AI_) + 0) * 1024) "\n\t"                   \
-                 "ds_read_b128 %9, %13 offset:" FX_STR(FX_PLANE_B + 16384 + (2 * (AI_) + 0) * 1024) "\n\t"      \
-                 "ds_read_b128 %10, %13 offset:" FX_STR(16384 + (2 * (AI_) + 1) * 1024) "\n\t"                  \
-                 "ds_read_b128 %11, %13 offset:" FX_STR(FX_PLANE_B + 16384 + (2 * (AI_) + 1) * 1024)              \
-                 : "=&v"(W_##a), "=&v"(W_##b), "=&v"(W_##c), "=&v"(W_##d), "=&v"(X_##a), "=&v"(X_##b), "=&v"(X_##c), \
-                   "=&v"(X_##d), "=&v"(X_##e), "=&v"(X_##f), "=&v"(X_##g), "=&v"(X_##h)                       \
-                 : "v"(slot_a), "v"(xfrag_a)                                                                  \
-                 : "memory");                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);
-    // reads of W2 block b: four weight fragments from ring section b & 3
-#define FX_READ_B(BI_, WAITN, W_)                                                                               \
-    asm volatile("s_waitcnt vmcnt(" FX_STR(WAITN) ")\n\t"                                                     \
-                 "ds_read_b128 %0, %4 offset:" FX_STR((4 * ((BI_) & 3) + 0) * 1024) "\n\t"                      \
-                 "ds_read_b128 %1, %4 offset:" FX_STR((4 * ((BI_) & 3) + 1) * 1024) "\n\t"                      \
-                 "ds_read_b128 %2, %4 offset:" FX_STR((4 * ((BI_) & 3) + 2) * 1024) "\n\t"                      \
-                 "ds_read_b128 %3, %4 offset:" FX_STR((4 * ((BI_) & 3) + 3) * 1024)                               \
-                 : "=&v"(W_##a), "=&v"(W_##b), "=&v"(W_##c), "=&v"(W_##d)                                     \
-                 : "v"(slot_a)                                                                                \
-                 : "memory");                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);
-#define FX_NOREAD()
-#define FX_WAIT_A(W_, X_)                                                                                     \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W_##a), "+v"(W_##b), "+v"(W_##c), "+v"(W_##d), "+v"(X_##a), "+v"(X_##b), \
-                 "+v"(X_##c), "+v"(X_##d), "+v"(X_##e), "+v"(X_##f), "+v"(X_##g), "+v"(X_##h) :: "memory");   \
-    __builtin_amdgcn_sched_barrier(0);
-#define FX_WAIT_B(W_)                                                                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W_##a), "+v"(W_##b), "+v"(W_##c), "+v"(W_##d) :: "memory");    \
-    __builtin_amdgcn_sched_barrier(0);
-    // MFMAs of a W1 block on register set (W_, X_): fragments a..d = W1 hi(k0), lo(k0), hi(k1), lo(k1); X a..h = M-tile 0
-    // hi(k0), lo(k0), hi(k1), lo(k1), M-tile 1 hi(k0), lo(k0), hi(k1), lo(k1)
-#define FX_MFMA_A(W_, X_, REFILL)                                                                             \
-    FX_MFMA(W_##b, X_##a, xh[0]); FX_MFMA(W_##a, X_##b, xh[0]); FX_MFMA(W_##a, X_##a, xh[0]); REFILL(0)       \
-    FX_MFMA(W_##b, X_##e, xh[1]); FX_MFMA(W_##a, X_##f, xh[1]); FX_MFMA(W_##a, X_##e, xh[1]); REFILL(1)       \
-    FX_MFMA(W_##d, X_##c, xh[0]); FX_MFMA(W_##c, X_##d, xh[0]); FX_MFMA(W_##c, X_##c, xh[0]); REFILL(2)       \
-    FX_MFMA(W_##d, X_##g, xh[1]); FX_MFMA(W_##c, X_##h, xh[1]); FX_MFMA(W_##c, X_##g, xh[1]); REFILL(3)       \
-    FX_PIN_3M1V() FX_PIN_3M1V() FX_PIN_3M1V() FX_PIN_3M1V()                                                   \
-    __builtin_amdgcn_sched_barrier(0);
-    // MFMAs of W2 block b: s = b >> 2, output tiles nt0 = 2 (b & 3), nt0 + 1; fragments a..d = W2 hi(nt0), lo(nt0), hi(nt0+1), lo(nt0+1)
-#define FX_MFMA_B(BI_, W_, REFILL)                                                                              \
-    FX_MFMA(W_##b, pbh[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3)]);                                                  \
-    FX_MFMA(W_##a, pbl[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3)]);                                                  \
-    FX_MFMA(W_##a, pbh[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3)]); REFILL(0)                                        \
-    FX_MFMA(W_##d, pbh[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3) + 1]);                                              \
-    FX_MFMA(W_##c, pbl[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3) + 1]);                                              \
-    FX_MFMA(W_##c, pbh[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3) + 1]); REFILL(1)                                    \
-    FX_MFMA(W_##b, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3)]);                                                  \
-    FX_MFMA(W_##a, pbl[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3)]);                                                  \
-    FX_MFMA(W_##a, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3)]); REFILL(2)                                        \
-    FX_MFMA(W_##d, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3) + 1]);                                              \
-    FX_MFMA(W_##c, pbl[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3) + 1]);                                              \
-    FX_MFMA(W_##c, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3) + 1]); REFILL(3)                                    \
-    FX_PIN_3M1V() FX_PIN_3M1V() FX_PIN_3M1V() FX_PIN_3M1V()                                                   \
-    __builtin_amdgcn_sched_barrier(0);
-    // bias + ReLU on hidden unit f = 32 tile + acc_row(r, lane), split into the hi / lo B operands of the W2 blocks
-#define FX_RELU_PACK(pos)                                                                                     \
-    {                                                                                                         \
-        const int src0 = 32 * ((pos) & 1) + 4 * half;                                                         \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) _Pragma("unroll") for (int e = 0; e < 4; ++e) {         \
-            const float bv = __shfl(bq[0], src0 + 8 * g + e);                                                 \
-            _Pragma("unroll") for (int mt = 0; mt < FX_MT; ++mt) {                                            \
-                const float h_ = fmaxf(xh[mt][4 * g + e] + bv, 0.f);                                          \
-                const bf16 hh_ = (bf16)h_;                                                                    \
-                pbh[mt][g >> 1][4 * (g & 1) + e] = hh_;                                                       \
-                pbl[mt][g >> 1][4 * (g & 1) + e] = (bf16)(h_ - (float)hh_);                                   \
-            }                                                                                                 \
-        }                                                                                                     \
-        if ((pos) & 1) { _Pragma("unroll") for (int j = 0; j < 7; ++j) bq[j] = bq[j + 1]; }                   \
+    const unsigned char* xfrag = xn_s + lane * 16;
+#define FX_XFRAG(off) (*reinterpret_cast<const bf16x8*>(xfrag + (off)))
+#define FX_LDX(S_, AI_)                                                                                  \
+    x##S_##a = FX_XFRAG((2 * (AI_) + 0) * 1024);             x##S_##b = FX_XFRAG(FX_PLANE + (2 * (AI_) + 0) * 1024);          \
+    x##S_##c = FX_XFRAG((2 * (AI_) + 1) * 1024);             x##S_##d = FX_XFRAG(FX_PLANE + (2 * (AI_) + 1) * 1024);          \
+    x##S_##e = FX_XFRAG(16384 + (2 * (AI_) + 0) * 1024);     x##S_##f = FX_XFRAG(FX_PLANE + 16384 + (2 * (AI_) + 0) * 1024);  \
+    x##S_##g = FX_XFRAG(16384 + (2 * (AI_) + 1) * 1024);     x##S_##h = FX_XFRAG(FX_PLANE + 16384 + (2 * (AI_) + 1) * 1024);
+    // the hi and lo fragment of k-step 2 a + q, M-tile at byte offset mo
+#define FX_LDX2(S_, F0_, F1_, AI_, q, mo)                                                              \
+    x##S_##F0_ = FX_XFRAG((mo) + (2 * (AI_) + (q)) * 1024); x##S_##F1_ = FX_XFRAG(FX_PLANE + (mo) + (2 * (AI_) + (q)) * 1024);
+    // issue order inside a W2 block: three MFMAs, one weight request
+#define FX_PIN_B()                                                                                     \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x8, 3, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);    \
     }
-#define FX_ZERO_XH()                                                                                          \
-    _Pragma("unroll") for (int mt = 0; mt < FX_MT; ++mt) _Pragma("unroll") for (int r = 0; r < 16; ++r) xh[mt][r] = 0.f;
-    // the sixteen blocks of a tile; RF(g): refill macro of block g (group g + 4 of this tile, or g - 12 of the next);
-    // NEXT_A0: the reads of the next tile's block 0 (nothing after the last tile); VA / VB / VC: vmcnt of the reads issued in
-    // blocks 12 / 13 / 14 (8 8 8 in a middle tile; 8 4 0 in the last one, where nothing is re-requested any more)
-#define FX_TILE(RF12, RF13, RF14, RF15, VB, VC, NEXT_A0, NEXT_WAIT)                                           \
-    FX_ZERO_XH()                                                                                              \
-    FX_READ_A(1, 8, w1, x1) FX_MFMA_A(w0, x0, R4_) FX_WAIT_A(w1, x1)                                          \
-    FX_READ_A(2, 8, w0, x0) FX_MFMA_A(w1, x1, R5_) FX_WAIT_A(w0, x0)                                          \
-    FX_READ_A(3, 8, w1, x1) FX_MFMA_A(w0, x0, R6_) FX_WAIT_A(w1, x1)                                          \
-    FX_READ_A(4, 8, w0, x0) FX_MFMA_A(w1, x1, R7_) FX_WAIT_A(w0, x0)                                          \
-    FX_READ_A(5, 8, w1, x1) FX_MFMA_A(w0, x0, R8_) FX_WAIT_A(w1, x1)                                          \
-    FX_READ_A(6, 8, w0, x0) FX_MFMA_A(w1, x1, R9_) FX_WAIT_A(w0, x0)                                          \
-    FX_READ_A(7, 8, w1, x1) FX_MFMA_A(w0, x0, R10_) FX_WAIT_A(w1, x1)                                         \
-    FX_READ_B(0, 8, w0) FX_MFMA_A(w1, x1, R11_) FX_WAIT_B(w0)                                                 \
-    FX_RELU_PACK(t)                                                                                           \
-    FX_READ_B(1, 8, w1) FX_MFMA_B(0, w0, R12_) FX_WAIT_B(w1)                                                  \
-    FX_READ_B(2, 8, w0) FX_MFMA_B(1, w1, R13_) FX_WAIT_B(w0)                                                  \
-    FX_READ_B(3, 8, w1) FX_MFMA_B(2, w0, R14_) FX_WAIT_B(w1)                                                  \
-    FX_READ_B(4, 8, w0) FX_MFMA_B(3, w1, R15_) FX_WAIT_B(w0)                                                  \
-    FX_READ_B(5, 8, w1) FX_MFMA_B(4, w0, RF12) FX_WAIT_B(w1)                                                  \
-    FX_READ_B(6, VB, w0) FX_MFMA_B(5, w1, RF13) FX_WAIT_B(w0)                                                 \
-    FX_READ_B(7, VC, w1) FX_MFMA_B(6, w0, RF14) FX_WAIT_B(w1)                                                 \
-    NEXT_A0 FX_MFMA_B(7, w1, RF15) NEXT_WAIT
-#define R4_(j) FX_FILL1(cur, 4, j)
-#define R5_(j) FX_FILL1(cur, 5, j)
-#define R6_(j) FX_FILL1(cur, 6, j)
-#define R7_(j) FX_FILL1(cur, 7, j)
-#define R8_(j) FX_FILL1(cur, 8, j)
-#define R9_(j) FX_FILL1(cur, 9, j)
-#define R10_(j) FX_FILL1(cur, 10, j)
-#define R11_(j) FX_FILL1(cur, 11, j)
-#define R12_(j) FX_FILL1(cur, 12, j)
-#define R13_(j) FX_FILL1(cur, 13, j)
-#define R14_(j) FX_FILL1(cur, 14, j)
-#define R15_(j) FX_FILL1(cur, 15, j)
-#define RN0_(j) FX_FILL1(nxt, 0, j)
-#define RN1_(j) FX_FILL1(nxt, 1, j)
-#define RN2_(j) FX_FILL1(nxt, 2, j)
-#define RN3_(j) FX_FILL1(nxt, 3, j)
-#define RNONE_(j)
+    // A W1 block on register sets (W_, X_): fragments a..d = W1 hi(k0), lo(k0), hi(k1), lo(k1); X a..h = M-tile 0 hi(k0),
+    // lo(k0), hi(k1), lo(k1), M-tile 1 hi(k0), lo(k0), hi(k1), lo(k1).  Per accumulator the order is lo.hi, hi.lo, hi.hi (k0),
+    // then the same for k1; the two accumulators alternate so that no MFMA waits for the one just issued.  Four fenced
+    // quarters of three MFMAs, each with one weight request (Q0..Q3: group a + 3, fragment by fragment) and two of the
+    // next block's activation reads (R0..R3).  M0, M1: the first two MFMAs (FX_MFMA_V0 in block 0: they start the tile).
+#define FX_FENCE() __builtin_amdgcn_sched_barrier(0);
+#define FX_MFMA_A(W_, X_, M0, M1, Q0, Q1, Q2, Q3, R0, R1, R2, R3)                                      \
+    M0(W_##b, X_##a, xh[0]); M1(W_##b, X_##e, xh[1]); FX_MFMA_V(W_##a, X_##b, xh[0]); Q0 R0 FX_FENCE()  \
+    FX_MFMA_V(W_##a, X_##f, xh[1]); FX_MFMA_V(W_##a, X_##a, xh[0]); FX_MFMA_V(W_##a, X_##e, xh[1]); Q1 R1 FX_FENCE() \
+    FX_MFMA_V(W_##d, X_##c, xh[0]); FX_MFMA_V(W_##d, X_##g, xh[1]); FX_MFMA_V(W_##c, X_##d, xh[0]); Q2 R2 FX_FENCE() \
+    FX_MFMA_V(W_##c, X_##h, xh[1]); FX_MFMA_V(W_##c, X_##c, xh[0]); FX_MFMA_V(W_##c, X_##g, xh[1]); Q3 R3 FX_FENCE()
+    // MFMAs of W2 block b: s = b >> 2, output tiles nt0 = 2 (b & 3), nt0 + 1; fragments a..d = W2 hi(nt0), lo(nt0), hi(nt0+1),
+    // lo(nt0+1); four accumulators in rotation, each in the order lo.hi, hi.lo, hi.hi
+#define FX_MFMA_B(BI_, W_)                                                                             \
+    FX_MFMA(W_##b, pbh[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3)]);                                       \
+    FX_MFMA(W_##d, pbh[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3) + 1]);                                   \
+    FX_MFMA(W_##b, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3)]);                                       \
+    FX_MFMA(W_##d, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3) + 1]);                                   \
+    FX_MFMA(W_##a, pbl[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3)]);                                       \
+    FX_MFMA(W_##c, pbl[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3) + 1]);                                   \
+    FX_MFMA(W_##a, pbl[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3)]);                                       \
+    FX_MFMA(W_##c, pbl[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3) + 1]);                                   \
+    FX_MFMA(W_##a, pbh[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3)]);                                       \
+    FX_MFMA(W_##c, pbh[0][(BI_) >> 2], acc[0][2 * ((BI_) & 3) + 1]);                                   \
+    FX_MFMA(W_##a, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3)]);                                       \
+    FX_MFMA(W_##c, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3) + 1]);
+    // W1 block a (weights in set WS, activations in XS): request group a + 3 into set WN, read block a + 1's activations into XN
+#define FX_LDW1(S_, F_, tile, g, j_) w##S_##F_ = wst[((long long)(tile) * 64 + 4 * (g) + (j_)) * 64];
+#define FX_BLOCK_A(AI_, WS, XS, WN, XN, M0, M1)                                                          \
+    FX_MFMA_A(w##WS, x##XS, M0, M1,                                                                    \
+              FX_LDW1(WN, a, cur, (AI_) + 3, 0), FX_LDW1(WN, b, cur, (AI_) + 3, 1), FX_LDW1(WN, c, cur, (AI_) + 3, 2), FX_LDW1(WN, d, cur, (AI_) + 3, 3), \
+              FX_LDX2(XN, a, b, (AI_) + 1, 0, 0), FX_LDX2(XN, c, d, (AI_) + 1, 1, 0), FX_LDX2(XN, e, f, (AI_) + 1, 0, 16384), FX_LDX2(XN, g, h, (AI_) + 1, 1, 16384))
+#define FX_BLOCK_A7(WS, XS, WN)                                                                        \
+    FX_MFMA_A(w##WS, x##XS, FX_MFMA_V, FX_MFMA_V,                                                      \
+              FX_LDW1(WN, a, cur, 10, 0), FX_LDW1(WN, b, cur, 10, 1), FX_LDW1(WN, c, cur, 10, 2), FX_LDW1(WN, d, cur, 10, 3), , , , )
+    // W2 block b: request group 8 + b + 3 (of this tile, or 0..2 of the next) into set WN
+#define FX_BLOCK_B(b, WS, WN, TILE, G)                                                                 \
+    FX_LDW(WN, TILE, G) FX_MFMA_B(b, w##WS) FX_PIN_B()                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+    // bias + ReLU on hidden units f = 32 tile + 8 g + 4 half + e, e = 0..3 (accumulator registers 4 g + e), split into the
+    // hi / lo B operands of the W2 blocks: g = 0, 1 feed blocks 0..3 (s = 0), g = 2, 3 blocks 4..7
+#define FX_RELU_PACK(tile, g)                                                                          \
+    {                                                                                                  \
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b1_s + 32 * (ft0 + (tile)) + 4 * half + 8 * (g)); \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) _Pragma("unroll") for (int mt = 0; mt < FX_MT; ++mt) { \
+            const float h_ = fmaxf(xh[mt][4 * (g) + e] + bv[e], 0.f);                                  \
+            const bf16 hh_ = (bf16)h_;                                                                 \
+            pbh[mt][(g) >> 1][4 * ((g) & 1) + e] = hh_;                                                \
+            pbl[mt][(g) >> 1][4 * ((g) & 1) + e] = (bf16)(h_ - (float)hh_);                            \
+        }                                                                                              \
+    }
+    // a W2 block that also carries one quarter of the bias / ReLU / split work (needed from block 4 on) between its MFMAs
+#define FX_PIN_BV()                                                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                                              \
+    }
+#define FX_BLOCK_BV(b, WS, WN, TILE, G, RG)                                                            \
+    FX_LDW(WN, TILE, G) FX_RELU_PACK(cur, RG) FX_MFMA_B(b, w##WS) FX_PIN_BV()                          \
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 xh[FX_MT];
     bf16x8 pbh[FX_MT][2], pbl[FX_MT][2];
-    // the first block's operands: groups 1..3 of the prologue are younger
-    FX_READ_A(0, 12, w0, x0) FX_WAIT_A(w0, x0)
-    int t = 0;
-    for (; t + 1 < tiles_per_wave; ++t) {
-        const int cur = FX_TT(t), nxt = FX_TT(t + 1);
-        FX_TILE(RN0_, RN1_, RN2_, RN3_, 8, 8, FX_READ_A(0, 8, w0, x0), FX_WAIT_A(w0, x0))
-    }
-    {
+    FX_LDX(0, 0)
+    FX_STAMP(1)
+#ifdef FX_STAMPS
+    unsigned long long phase_[3] = {0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
+    for (int t = 0; t < tiles_per_wave; ++t) {
         const int cur = FX_TT(t);
-        FX_TILE(RNONE_, RNONE_, RNONE_, RNONE_, 4, 0, FX_NOREAD(), FX_NOREAD())
+        const int nxt = FX_TT(t + 1 < tiles_per_wave ? t + 1 : t);  // after the last tile: three groups requested again, unused
+        FX_BLOCK_A(0, 0, 0, 3, 1, FX_MFMA_V0, FX_MFMA_V0)
+        FX_BLOCK_A(1, 1, 1, 0, 0, FX_MFMA_V, FX_MFMA_V)
+        FX_BLOCK_A(2, 2, 0, 1, 1, FX_MFMA_V, FX_MFMA_V)
+        FX_BLOCK_A(3, 3, 1, 2, 0, FX_MFMA_V, FX_MFMA_V)
+        FX_BLOCK_A(4, 0, 0, 3, 1, FX_MFMA_V, FX_MFMA_V)
+        FX_BLOCK_A(5, 1, 1, 0, 0, FX_MFMA_V, FX_MFMA_V)
+        FX_BLOCK_A(6, 2, 0, 1, 1, FX_MFMA_V, FX_MFMA_V)
+        FX_BLOCK_A7(3, 1, 2)
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(xh[0]), "+v"(xh[1]));  // MFMA results -> VALU
+        FX_PHASE(0)
+        FX_RELU_PACK(cur, 0)
+        FX_RELU_PACK(cur, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        FX_PHASE(1)
+        FX_BLOCK_BV(0, 0, 3, cur, 11, 2)
+        FX_BLOCK_BV(1, 1, 0, cur, 12, 3)
+        FX_BLOCK_B(2, 2, 1, cur, 13)
+        FX_BLOCK_B(3, 3, 2, cur, 14)
+        FX_BLOCK_B(4, 0, 3, cur, 15)
+        FX_BLOCK_B(5, 1, 0, nxt, 0)
+        FX_BLOCK_B(6, 2, 1, nxt, 1)
+        FX_LDX(0, 0)
+        FX_BLOCK_B(7, 3, 2, nxt, 2)
+        FX_PHASE(2)
     }
-#undef FX_TILE
-#undef FX_READ_A
-#undef FX_READ_B
-#undef FX_WAIT_A
-#undef FX_WAIT_B
+#ifdef FX_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 3; ++i) p.stamps[(blockIdx.x * 4 + wave) * 8 + 4 + i] = phase_[i];
+#endif
+    FX_STAMP(2)
+#undef FX_BLOCK_A
+#undef FX_BLOCK_A7
+#undef FX_BLOCK_B
+#undef FX_BLOCK_BV
 #undef FX_MFMA_A
 #undef FX_MFMA_B
 #undef FX_RELU_PACK
-#undef FX_ZERO_XH
-#undef FX_FILL
-#undef FX_DMA
+#undef FX_LDW
+#undef FX_LDX
 #undef FX_TT
 
     // ---- cross-wave reduction of the out^T partials (one 32-row M-tile at a time), + b2 + residual, next LayerNorm
@@ -336,10 +316,10 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
                 float ss = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ss = fmaf(v[j] - mean, v[j] - mean, ss);
-                const float denom = sqrtf(wave_sum(ss) / (float)(FX_D - 1)) + p.eps;
+                const float inv = 1.f / (sqrtf(wave_sum(ss) / (float)(FX_D - 1)) + p.eps);
                 float o[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = ng[j] * (v[j] - mean) / denom + nb[j];
+                for (int j = 0; j < 4; ++j) o[j] = ng[j] * (v[j] - mean) * inv + nb[j];
                 bf16x4 hi, lo;
                 cn_split4(o, hi, lo);
                 unsigned char* ob = p.xn_out + (long long)m * FX_D * 4 + cn_split_off((size_t)(4 * lane));
@@ -348,7 +328,17 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
             }
         }
     }
+    FX_STAMP(3)
 }
+
+#ifdef FX_STAMPS
+static unsigned long long* g_fx_stamps = nullptr;
+// copies the stamps of the last launch (n workgroups x 4 waves x 8) to the host
+extern "C" int cn_debug_ffn_x3_stamps(unsigned long long* out, int n_wg) {
+    if (!g_fx_stamps || n_wg > 4096) return -1;
+    return hipMemcpy(out, g_fx_stamps, (size_t)n_wg * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
 
 bool ffn_x3_applies(int d, int dff) { return d == FX_D && dff % 128 == 0 && dff >= 128 && dff <= 2048 && !getenv("CASSNAT_NO_FFN_X3"); }
 
@@ -373,6 +363,13 @@ int launch_ffn_x3(const FfnX3Args& a, hipStream_t s) {
     p.eps = a.eps;
     static const int rotate = getenv("CASSNAT_FFN_X3_ROTATE") ? atoi(getenv("CASSNAT_FFN_X3_ROTATE")) : 1;
     p.rotate = rotate;
+#ifdef FX_STAMPS
+    static unsigned long long* stamps_dev = nullptr;
+    if (!stamps_dev) CN_HIP_CHECK(hipMalloc(&stamps_dev, 4096 * 32 * sizeof(unsigned long long)));
+    if (cn_ceil_div(p.M, 32 * FX_MT) > 4096) return -1;
+    p.stamps = stamps_dev;
+    g_fx_stamps = stamps_dev;
+#endif
     static CnAttrOnce attr_once;
     int attr_dev;
     if (attr_once.need(&attr_dev)) {
