@@ -85,27 +85,42 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
     // workgroups then do not pull the same L2 lines at the same moment)
     const int rot = p.rotate ? (blockIdx.x * 7 + wave_u * 3) % tiles_per_wave : 0;
 #define FX_TT(t) (((t) + rot) % tiles_per_wave)
-    const bf16x8* wst = reinterpret_cast<const bf16x8*>(p.wst) + (long long)ft0 * 64 * 64 + lane;
+    // the wave's stream as a buffer resource: a request is descriptor + scalar offset of the group + lane offset + immediate,
+    // no vector arithmetic per request (flat addressing spent two VALU adds on each group)
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.wst)) + (size_t)ft0 * 64 * 1024, 0, tiles_per_wave * 64 * 1024, 0x00020000);
+    const int lane_off = lane * 16;
+#define FX_WFRAG(tile, g, j_)                                                                          \
+    __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off + (j_) * 1024, ((tile) * 64 + 4 * (g)) * 1024, 0))
 
     // Weight register sets: group g (0..15 of a hidden tile: 8 of W1, 8 of W2; four 1-KiB fragments = hi, lo, hi, lo) lives
-    // in set g & 3.  The stream is private to the wave and read once, so it goes global -> VGPR with no LDS hop (an LDS-DMA
+    // in set g & 7.  The stream is private to the wave and read once, so it goes global -> VGPR with no LDS hop (an LDS-DMA
     // ring was tried first: its requests cost 60-190 issue cycles apiece beside MFMAs, 4 per 12 MFMAs, and the kernel ran at
-    // 0.37 us per block whatever the ring depth, 4 or 6 groups).  Block g computes on set g & 3 and, in its MFMA gaps,
-    // requests group g + 3 into the set block g - 1 has just released.
+    // 0.37 us per block whatever the ring depth, 4 or 6 groups).  Block g computes on set g & 7 and, in its MFMA gaps,
+    // requests group g + 7 into the set block g - 1 has just released: seven groups (28 KiB per wave) in flight.
     bf16x8 w0a, w0b, w0c, w0d, w1a, w1b, w1c, w1d, w2a, w2b, w2c, w2d, w3a, w3b, w3c, w3d;
+    bf16x8 w4a, w4b, w4c, w4d, w5a, w5b, w5c, w5d, w6a, w6b, w6c, w6d, w7a, w7b, w7c, w7d;
 #define FX_LDW(S_, tile, g)                                                                            \
     {                                                                                                  \
-        const bf16x8* s_ = wst + ((long long)(tile) * 64 + 4 * (g)) * 64;                              \
-        w##S_##a = s_[0]; w##S_##b = s_[64]; w##S_##c = s_[128]; w##S_##d = s_[192];                    \
+        w##S_##a = FX_WFRAG(tile, g, 0); w##S_##b = FX_WFRAG(tile, g, 1); w##S_##c = FX_WFRAG(tile, g, 2); w##S_##d = FX_WFRAG(tile, g, 3); \
     }
-    // prologue: the first three groups go in flight before the LayerNorm below
+    // the workgroup's rows (wave w: rows w, w + 4, ...), all requested before anything else: they are needed first
+    f32x4 xrow[32 * FX_MT / 4];
+#pragma unroll
+    for (int i = 0; i < 32 * FX_MT / 4; ++i) {
+        int m = m0 + wave + 4 * i;
+        if (m >= p.M) m = p.M - 1;
+        xrow[i] = *reinterpret_cast<const f32x4*>(p.x + (long long)m * FX_D + 4 * lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // prologue: the first seven groups go in flight before the LayerNorm below
     {
         const int t0 = FX_TT(0);
-        FX_LDW(0, t0, 0) FX_LDW(1, t0, 1) FX_LDW(2, t0, 2)
+        FX_LDW(0, t0, 0) FX_LDW(1, t0, 1) FX_LDW(2, t0, 2) FX_LDW(3, t0, 3) FX_LDW(4, t0, 4) FX_LDW(5, t0, 5) FX_LDW(6, t0, 6)
     }
     for (int i = tid; i < p.dff; i += 256) b1_s[i] = p.b1[i];
 
-    // ---- LayerNorm of the workgroup's rows -> hi / lo bf16 fragments in LDS (wave w: rows w, w+4, ...)
+    // ---- LayerNorm of the workgroup's rows -> hi / lo bf16 fragments in LDS
     {
         const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_a + 4 * lane);
         const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * lane);
@@ -114,9 +129,7 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
 #pragma unroll
         for (int i = 0; i < 32 * FX_MT / 4; ++i) {
             const int r = wave + 4 * i;
-            int m = m0 + r;
-            if (m >= p.M) m = p.M - 1;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (long long)m * FX_D + 4 * lane);
+            const f32x4 v = xrow[i];
             const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)FX_D;
             float ss = 0.f;
 #pragma unroll
@@ -153,8 +166,12 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
     x##S_##e = FX_XFRAG(16384 + (2 * (AI_) + 0) * 1024);     x##S_##f = FX_XFRAG(FX_PLANE + 16384 + (2 * (AI_) + 0) * 1024);  \
     x##S_##g = FX_XFRAG(16384 + (2 * (AI_) + 1) * 1024);     x##S_##h = FX_XFRAG(FX_PLANE + 16384 + (2 * (AI_) + 1) * 1024);
     // the hi and lo fragment of k-step 2 a + q, M-tile at byte offset mo
+#if defined(FX_STAMPS) && defined(FX_EXP_NO_XREAD)  // timing experiment: the W1 blocks without their activation reads
+#define FX_LDX2(S_, F0_, F1_, AI_, q, mo)
+#else
 #define FX_LDX2(S_, F0_, F1_, AI_, q, mo)                                                              \
     x##S_##F0_ = FX_XFRAG((mo) + (2 * (AI_) + (q)) * 1024); x##S_##F1_ = FX_XFRAG(FX_PLANE + (mo) + (2 * (AI_) + (q)) * 1024);
+#endif
     // issue order inside a W2 block: three MFMAs, one weight request
 #define FX_PIN_B()                                                                                     \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
@@ -187,17 +204,23 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
     FX_MFMA(W_##a, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3)]);                                       \
     FX_MFMA(W_##c, pbh[1][(BI_) >> 2], acc[1][2 * ((BI_) & 3) + 1]);
     // W1 block a (weights in set WS, activations in XS): request group a + 3 into set WN, read block a + 1's activations into XN
-#define FX_LDW1(S_, F_, tile, g, j_) w##S_##F_ = wst[((long long)(tile) * 64 + 4 * (g) + (j_)) * 64];
+#if defined(FX_STAMPS) && defined(FX_EXP_NO_WLOAD)  // timing experiment: the main loop without its weight requests
+#define FX_LDW1(S_, F_, tile, g, j_)
+#define FX_LDW_LOOP(S_, tile, g)
+#else
+#define FX_LDW_LOOP(S_, tile, g) FX_LDW(S_, tile, g)
+#define FX_LDW1(S_, F_, tile, g, j_) w##S_##F_ = FX_WFRAG(tile, g, j_);
+#endif
 #define FX_BLOCK_A(AI_, WS, XS, WN, XN, M0, M1)                                                          \
     FX_MFMA_A(w##WS, x##XS, M0, M1,                                                                    \
-              FX_LDW1(WN, a, cur, (AI_) + 3, 0), FX_LDW1(WN, b, cur, (AI_) + 3, 1), FX_LDW1(WN, c, cur, (AI_) + 3, 2), FX_LDW1(WN, d, cur, (AI_) + 3, 3), \
+              FX_LDW1(WN, a, cur, (AI_) + 7, 0), FX_LDW1(WN, b, cur, (AI_) + 7, 1), FX_LDW1(WN, c, cur, (AI_) + 7, 2), FX_LDW1(WN, d, cur, (AI_) + 7, 3), \
               FX_LDX2(XN, a, b, (AI_) + 1, 0, 0), FX_LDX2(XN, c, d, (AI_) + 1, 1, 0), FX_LDX2(XN, e, f, (AI_) + 1, 0, 16384), FX_LDX2(XN, g, h, (AI_) + 1, 1, 16384))
 #define FX_BLOCK_A7(WS, XS, WN)                                                                        \
     FX_MFMA_A(w##WS, x##XS, FX_MFMA_V, FX_MFMA_V,                                                      \
-              FX_LDW1(WN, a, cur, 10, 0), FX_LDW1(WN, b, cur, 10, 1), FX_LDW1(WN, c, cur, 10, 2), FX_LDW1(WN, d, cur, 10, 3), , , , )
-    // W2 block b: request group 8 + b + 3 (of this tile, or 0..2 of the next) into set WN
+              FX_LDW1(WN, a, cur, 14, 0), FX_LDW1(WN, b, cur, 14, 1), FX_LDW1(WN, c, cur, 14, 2), FX_LDW1(WN, d, cur, 14, 3), , , , )
+    // W2 block b (group 8 + b): request group 15 + b (the last of this tile, or 0..6 of the next) into set WN
 #define FX_BLOCK_B(b, WS, WN, TILE, G)                                                                 \
-    FX_LDW(WN, TILE, G) FX_MFMA_B(b, w##WS) FX_PIN_B()                                                 \
+    FX_LDW_LOOP(WN, TILE, G) FX_MFMA_B(b, w##WS) FX_PIN_B()                                                 \
     __builtin_amdgcn_sched_barrier(0);
     // bias + ReLU on hidden units f = 32 tile + 8 g + 4 half + e, e = 0..3 (accumulator registers 4 g + e), split into the
     // hi / lo B operands of the W2 blocks: g = 0, 1 feed blocks 0..3 (s = 0), g = 2, 3 blocks 4..7
@@ -221,7 +244,7 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
         __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                                              \
     }
 #define FX_BLOCK_BV(b, WS, WN, TILE, G, RG)                                                            \
-    FX_LDW(WN, TILE, G) FX_RELU_PACK(cur, RG) FX_MFMA_B(b, w##WS) FX_PIN_BV()                          \
+    FX_LDW_LOOP(WN, TILE, G) FX_RELU_PACK(cur, RG) FX_MFMA_B(b, w##WS) FX_PIN_BV()                          \
     __builtin_amdgcn_sched_barrier(0);
     f32x16 xh[FX_MT];
     bf16x8 pbh[FX_MT][2], pbl[FX_MT][2];
@@ -232,30 +255,30 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
 #endif
     for (int t = 0; t < tiles_per_wave; ++t) {
         const int cur = FX_TT(t);
-        const int nxt = FX_TT(t + 1 < tiles_per_wave ? t + 1 : t);  // after the last tile: three groups requested again, unused
-        FX_BLOCK_A(0, 0, 0, 3, 1, FX_MFMA_V0, FX_MFMA_V0)
+        const int nxt = FX_TT(t + 1 < tiles_per_wave ? t + 1 : t);  // after the last tile: seven groups requested again, unused
+        FX_BLOCK_A(0, 0, 0, 7, 1, FX_MFMA_V0, FX_MFMA_V0)
         FX_BLOCK_A(1, 1, 1, 0, 0, FX_MFMA_V, FX_MFMA_V)
         FX_BLOCK_A(2, 2, 0, 1, 1, FX_MFMA_V, FX_MFMA_V)
         FX_BLOCK_A(3, 3, 1, 2, 0, FX_MFMA_V, FX_MFMA_V)
-        FX_BLOCK_A(4, 0, 0, 3, 1, FX_MFMA_V, FX_MFMA_V)
-        FX_BLOCK_A(5, 1, 1, 0, 0, FX_MFMA_V, FX_MFMA_V)
-        FX_BLOCK_A(6, 2, 0, 1, 1, FX_MFMA_V, FX_MFMA_V)
-        FX_BLOCK_A7(3, 1, 2)
+        FX_BLOCK_A(4, 4, 0, 3, 1, FX_MFMA_V, FX_MFMA_V)
+        FX_BLOCK_A(5, 5, 1, 4, 0, FX_MFMA_V, FX_MFMA_V)
+        FX_BLOCK_A(6, 6, 0, 5, 1, FX_MFMA_V, FX_MFMA_V)
+        FX_BLOCK_A7(7, 1, 6)
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(xh[0]), "+v"(xh[1]));  // MFMA results -> VALU
         FX_PHASE(0)
         FX_RELU_PACK(cur, 0)
         FX_RELU_PACK(cur, 1)
         __builtin_amdgcn_sched_barrier(0);
         FX_PHASE(1)
-        FX_BLOCK_BV(0, 0, 3, cur, 11, 2)
-        FX_BLOCK_BV(1, 1, 0, cur, 12, 3)
-        FX_BLOCK_B(2, 2, 1, cur, 13)
-        FX_BLOCK_B(3, 3, 2, cur, 14)
-        FX_BLOCK_B(4, 0, 3, cur, 15)
-        FX_BLOCK_B(5, 1, 0, nxt, 0)
-        FX_BLOCK_B(6, 2, 1, nxt, 1)
+        FX_BLOCK_BV(0, 0, 7, cur, 15, 2)
+        FX_BLOCK_BV(1, 1, 0, nxt, 0, 3)
+        FX_BLOCK_B(2, 2, 1, nxt, 1)
+        FX_BLOCK_B(3, 3, 2, nxt, 2)
+        FX_BLOCK_B(4, 4, 3, nxt, 3)
+        FX_BLOCK_B(5, 5, 4, nxt, 4)
+        FX_BLOCK_B(6, 6, 5, nxt, 5)
         FX_LDX(0, 0)
-        FX_BLOCK_B(7, 3, 2, nxt, 2)
+        FX_BLOCK_B(7, 7, 6, nxt, 6)
         FX_PHASE(2)
     }
 #ifdef FX_STAMPS
@@ -283,7 +306,16 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
     }
 #pragma unroll
     for (int mt = 0; mt < FX_MT; ++mt) {
-        __syncthreads();  // rings / xn fragments (mt == 0) or the previous round's partials are no longer read
+        // the residual rows of this round (wave w: rows w, w + 4, ... of the M-tile), requested before the partials go
+        // through LDS; everything below is branch-free so that the eight rows' chains interleave, only the stores are guarded
+        f32x4 xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int m = m0 + 32 * mt + wave + 4 * i;
+            if (m >= p.M) m = p.M - 1;
+            xv[i] = *reinterpret_cast<const f32x4*>(p.x + (long long)m * FX_D + 4 * lane);
+        }
+        __syncthreads();  // xn fragments (mt == 0) or the previous round's partials are no longer read
         float* mine = part + (wave * 32 + l31) * FX_P_STRIDE;
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt)
@@ -299,9 +331,8 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
         for (int i = 0; i < 8; ++i) {
             const int r = wave + 4 * i;
             const int m = m0 + 32 * mt + r;
-            if (m >= p.M) continue;  // wave-uniform
-            float* xr = p.x + (long long)m * FX_D + 4 * lane;
-            f32x4 v = *reinterpret_cast<const f32x4*>(xr);
+            const bool live = m < p.M;  // wave-uniform
+            f32x4 v = xv[i];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const f32x4 q = *reinterpret_cast<const f32x4*>(part + (w * 32 + r) * FX_P_STRIDE + 4 * lane);
@@ -310,7 +341,7 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += b2v[j];
-            *reinterpret_cast<f32x4*>(xr) = v;
+            if (live) *reinterpret_cast<f32x4*>(p.x + (long long)m * FX_D + 4 * lane) = v;
             if (p.nln_a) {
                 const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)FX_D;
                 float ss = 0.f;
@@ -322,9 +353,11 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
                 for (int j = 0; j < 4; ++j) o[j] = ng[j] * (v[j] - mean) * inv + nb[j];
                 bf16x4 hi, lo;
                 cn_split4(o, hi, lo);
-                unsigned char* ob = p.xn_out + (long long)m * FX_D * 4 + cn_split_off((size_t)(4 * lane));
-                *reinterpret_cast<bf16x4*>(ob) = hi;
-                *reinterpret_cast<bf16x4*>(ob + 64) = lo;
+                if (live) {
+                    unsigned char* ob = p.xn_out + (long long)m * FX_D * 4 + cn_split_off((size_t)(4 * lane));
+                    *reinterpret_cast<bf16x4*>(ob) = hi;
+                    *reinterpret_cast<bf16x4*>(ob + 64) = lo;
+                }
             }
         }
     }

@@ -3,7 +3,7 @@ the library (-DFX_STAMPS: four s_memtime stamps per wave) beside the product one
 benchmark shape and prints the medians of prologue (LayerNorm + first requests), main loop and epilogue (cross-wave sum,
 residual, next LayerNorm), in shader cycles (s_memtime; the counters of different XCDs are not aligned, so only per-wave differences mean anything).
 
-    python tools/ffn_x3_stamps.py [M] [dff]          (GPU box)
+    python tools/ffn_x3_stamps.py [M] [dff] [-DFX_EXP_...]         (GPU box)
 """
 import ctypes as C
 import os
@@ -20,7 +20,9 @@ def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
     dff = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
     out = os.environ.get("TMPDIR", "/tmp")
-    lib = B.build(extra_flags=["-DFX_STAMPS"], lib=os.path.join(out, "libcassnat_hip_stamps.so"), objdir=os.path.join(out, "cn_stamps_obj"))
+    extra = sys.argv[3:]  # e.g. -DFX_EXP_NO_WLOAD / -DFX_EXP_NO_XREAD: timing experiments (wrong results)
+    tag = "".join(c for c in "".join(extra) if c.isalnum())
+    lib = B.build(extra_flags=["-DFX_STAMPS"] + extra, lib=os.path.join(out, "libcassnat_hip_stamps%s.so" % tag), objdir=os.path.join(out, "cn_stamps_obj" + tag))
     L = C.CDLL(lib)
     L.cn_op_ffn_x3.argtypes = [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     L.cn_debug_ffn_x3_stamps.argtypes = [C.c_void_p, C.c_int32]
