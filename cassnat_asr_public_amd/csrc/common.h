@@ -132,6 +132,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += cn_dpp<0x143, 0xc, false>(0.f, v);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// N independent sums, step by step side by side: the DPP steps of one chain are each other's hazard distance for the next
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += cn_dpp<0xB1, 0xf, true>(0.f, v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += cn_dpp<0x4E, 0xf, true>(0.f, v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += cn_dpp<0x141, 0xf, true>(0.f, v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += cn_dpp<0x140, 0xf, true>(0.f, v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += cn_dpp<0x142, 0xa, false>(0.f, v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += cn_dpp<0x143, 0xc, false>(0.f, v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, cn_dpp<0xB1, 0xf, true>(v, v));
     v = fmaxf(v, cn_dpp<0x4E, 0xf, true>(v, v));

@@ -113,12 +113,18 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
         xrow[i] = *reinterpret_cast<const f32x4*>(p.x + (long long)m * FX_D + 4 * lane);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // prologue: the first seven groups go in flight before the LayerNorm below
+    // prologue: the first four groups go in flight before the LayerNorm below, three more after it (the rows' registers
+    // are free by then)
     {
         const int t0 = FX_TT(0);
-        FX_LDW(0, t0, 0) FX_LDW(1, t0, 1) FX_LDW(2, t0, 2) FX_LDW(3, t0, 3) FX_LDW(4, t0, 4) FX_LDW(5, t0, 5) FX_LDW(6, t0, 6)
+        FX_LDW(0, t0, 0) FX_LDW(1, t0, 1) FX_LDW(2, t0, 2) FX_LDW(3, t0, 3)
     }
-    for (int i = tid; i < p.dff; i += 256) b1_s[i] = p.b1[i];
+    // b1 -> LDS: eight floats per thread, requested now, stored after the LayerNorm (nothing waits for them in between)
+    f32x4 b1lo = {0.f, 0.f, 0.f, 0.f}, b1hi = {0.f, 0.f, 0.f, 0.f};
+    if (8 * tid < p.dff) {
+        b1lo = *reinterpret_cast<const f32x4*>(p.b1 + 8 * tid);
+        b1hi = *reinterpret_cast<const f32x4*>(p.b1 + 8 * tid + 4);
+    }
 
     // ---- LayerNorm of the workgroup's rows -> hi / lo bf16 fragments in LDS
     {
@@ -126,24 +132,44 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * lane);
         // element k = 4 lane + j of row r: fragment (mt = r >> 5, ks = k >> 4), lane slot 32 ((k >> 3) & 1) + (r & 31), byte 2 (k & 7)
         const int ks = lane >> 2, kh = (lane >> 1) & 1, kb = (lane & 1) * 8;
+        // four rows at a time, their reductions side by side
 #pragma unroll
-        for (int i = 0; i < 32 * FX_MT / 4; ++i) {
-            const int r = wave + 4 * i;
-            const f32x4 v = xrow[i];
-            const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)FX_D;
-            float ss = 0.f;
+        for (int i0 = 0; i0 < 32 * FX_MT / 4; i0 += 4) {
+            float mean[4], ss[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ss = fmaf(v[j] - mean, v[j] - mean, ss);
-            const float inv = 1.f / (sqrtf(wave_sum(ss) / (float)(FX_D - 1)) + p.eps);  // one division per row, not per element
-            float o[4];
+            for (int q = 0; q < 4; ++q) mean[q] = (xrow[i0 + q][0] + xrow[i0 + q][1]) + (xrow[i0 + q][2] + xrow[i0 + q][3]);
+            wave_sum_n(mean);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[j] - mean) * inv + bb[j];
-            bf16x4 hi, lo;
-            cn_split4(o, hi, lo);
-            unsigned char* dst = xn_s + (((r >> 5) * 16 + ks) * 64 + kh * 32 + (r & 31)) * 16 + kb;
-            *reinterpret_cast<bf16x4*>(dst) = hi;
-            *reinterpret_cast<bf16x4*>(dst + FX_PLANE) = lo;
+            for (int q = 0; q < 4; ++q) {
+                mean[q] /= (float)FX_D;
+                ss[q] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ss[q] = fmaf(xrow[i0 + q][j] - mean[q], xrow[i0 + q][j] - mean[q], ss[q]);
+            }
+            wave_sum_n(ss);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = wave + 4 * (i0 + q);
+                const float inv = 1.f / (sqrtf(ss[q] / (float)(FX_D - 1)) + p.eps);  // one division per row, not per element
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = g[j] * (xrow[i0 + q][j] - mean[q]) * inv + bb[j];
+                bf16x4 hi, lo;
+                cn_split4(o, hi, lo);
+                unsigned char* dst = xn_s + (((r >> 5) * 16 + ks) * 64 + kh * 32 + (r & 31)) * 16 + kb;
+                *reinterpret_cast<bf16x4*>(dst) = hi;
+                *reinterpret_cast<bf16x4*>(dst + FX_PLANE) = lo;
+            }
         }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const int t0 = FX_TT(0);
+        FX_LDW(4, t0, 4) FX_LDW(5, t0, 5) FX_LDW(6, t0, 6)
+    }
+    if (8 * tid < p.dff) {
+        *reinterpret_cast<f32x4*>(b1_s + 8 * tid) = b1lo;
+        *reinterpret_cast<f32x4*>(b1_s + 8 * tid + 4) = b1hi;
     }
     __syncthreads();
 
@@ -331,7 +357,6 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
         for (int i = 0; i < 8; ++i) {
             const int r = wave + 4 * i;
             const int m = m0 + 32 * mt + r;
-            const bool live = m < p.M;  // wave-uniform
             f32x4 v = xv[i];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -341,22 +366,38 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += b2v[j];
-            if (live) *reinterpret_cast<f32x4*>(p.x + (long long)m * FX_D + 4 * lane) = v;
-            if (p.nln_a) {
-                const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)FX_D;
-                float ss = 0.f;
+            if (m < p.M) *reinterpret_cast<f32x4*>(p.x + (long long)m * FX_D + 4 * lane) = v;  // wave-uniform
+            xv[i] = v;
+        }
+        if (p.nln_a) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ss = fmaf(v[j] - mean, v[j] - mean, ss);
-                const float inv = 1.f / (sqrtf(wave_sum(ss) / (float)(FX_D - 1)) + p.eps);
-                float o[4];
+            for (int i0 = 0; i0 < 8; i0 += 4) {
+                float mean[4], ss[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = ng[j] * (v[j] - mean) * inv + nb[j];
-                bf16x4 hi, lo;
-                cn_split4(o, hi, lo);
-                if (live) {
-                    unsigned char* ob = p.xn_out + (long long)m * FX_D * 4 + cn_split_off((size_t)(4 * lane));
-                    *reinterpret_cast<bf16x4*>(ob) = hi;
-                    *reinterpret_cast<bf16x4*>(ob + 64) = lo;
+                for (int q = 0; q < 4; ++q) mean[q] = (xv[i0 + q][0] + xv[i0 + q][1]) + (xv[i0 + q][2] + xv[i0 + q][3]);
+                wave_sum_n(mean);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    mean[q] /= (float)FX_D;
+                    ss[q] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ss[q] = fmaf(xv[i0 + q][j] - mean[q], xv[i0 + q][j] - mean[q], ss[q]);
+                }
+                wave_sum_n(ss);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = m0 + 32 * mt + wave + 4 * (i0 + q);
+                    const float inv = 1.f / (sqrtf(ss[q] / (float)(FX_D - 1)) + p.eps);
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = ng[j] * (xv[i0 + q][j] - mean[q]) * inv + nb[j];
+                    bf16x4 hi, lo;
+                    cn_split4(o, hi, lo);
+                    if (m < p.M) {
+                        unsigned char* ob = p.xn_out + (long long)m * FX_D * 4 + cn_split_off((size_t)(4 * lane));
+                        *reinterpret_cast<bf16x4*>(ob) = hi;
+                        *reinterpret_cast<bf16x4*>(ob + 64) = lo;
+                    }
                 }
             }
         }
