@@ -58,12 +58,15 @@ def main():
     ap.add_argument("--cpu-batches", type=int, default=3)
     ap.add_argument("--stage-profile", action="store_true", help="also print a per-kernel-tag table to stderr")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 path on one GPU")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=2,
                     help="decode pipelines per GPU (own engine handle, HIP stream and host thread each): keeps the GPU fed "
                          "across the two host syncs every batch needs (token count readback, hypotheses to host)")
-    ap.add_argument("--coalesce", type=int, default=3,
+    ap.add_argument("--coalesce", type=int, default=10,
                     help="batches of 32 a decode pipeline may take through ONE engine pass (wider launches; every batch's "
                          "hypotheses and scores stay exactly those of a pass of its own: cn_decode_opts.sub_batch)")
+    ap.add_argument("--exit-after-timed", action="store_true",
+                    help="tracing aid: print value / ms_per_step only and leave right after the timed region (so that it is the "
+                         "end of a kernel trace: tools/trace_tail.py)")
     ap.add_argument("--no-uncoalesced", action="store_true",
                     help="skip the extra measurement with one batch per engine pass (reported beside `value`)")
     a = ap.parse_args()
@@ -166,6 +169,13 @@ def main():
     run_steps(a.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    if a.exit_after_timed:
+        if rank == 0:
+            print(json.dumps({"value": round(a.steps * B * world / elapsed, 2), "ms_per_step": round(elapsed / a.steps * 1e3, 4), "steps": a.steps}))
+        pipes.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
     prof = {t: {"count": 0, "ms": 0.0, "flops": 0.0} for t in ROOF_TAGS}
     for e in engines[:1]:
         got = e.profile_end()
@@ -195,20 +205,21 @@ def main():
     # ---- extra (never `value`; N = 1 only): the same steps with one batch per engine pass
     uncoalesced = None
     if not a.no_uncoalesced and CO > 1 and world == 1:  # (like cpu_baseline: at N = 1 only)
-        pipes2 = DecodePipelines(model, NS, B, T, coalesce=1, share_from=engines[0])  # (the same device copy of the weights)
+        NS1 = max(NS, 3)  # one batch per pass needs more pipelines in flight than wide passes do
+        pipes2 = DecodePipelines(model, NS1, B, T, coalesce=1, share_from=engines[0])  # (the same device copy of the weights)
 
         def run2(n_steps):
             for _ in pipes2.decode([(feats, sizes, k) for k in range(n_steps)], args, sos=1, as_lists=False):
                 pass
 
-        run2(max(a.warmup, NS))
+        run2(max(a.warmup, NS1))
         fence()
         c0 = time.perf_counter()
         run2(a.steps)
         fence()
         el2 = time.perf_counter() - c0
         uncoalesced = {"value": round(a.steps * B * world / el2, 2), "unit": "utt/s", "ms_per_step": round(el2 / a.steps * 1e3, 4),
-                       "note": "same workload and step count with one batch of 32 per engine pass"}
+                       "decode_pipelines": NS1, "note": "same workload and step count with one batch of 32 per engine pass"}
         pipes2.close()
 
     if rank != 0:
@@ -233,7 +244,8 @@ def main():
         pmc_path = os.path.join(REPO, "profiles", f"pmc_{tag}.json")
         if os.path.exists(pmc_path):
             try:
-                pmc = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc_path))  # (counted on launches of a given width: quoted only beside launches of that width)
+                pmc = pj.get("hbm_bytes_per_launch") if pj.get("batches_per_engine_pass", 3) == CO else None
             except Exception:
                 pmc = None
         iso = stages.get(tag)
@@ -306,14 +318,15 @@ def main():
         with torch.no_grad():
             for k, p in mx.named_parameters():
                 p.copy_(torch.from_numpy(state[k]))
-        px = DecodePipelines(mx, NS, B, T, coalesce=1 if prec == "fp32" else CO)
+        nsx = max(NS, 3) if prec == "fp32" else NS  # (the f32-MFMA engine runs one batch per pass)
+        px = DecodePipelines(mx, nsx, B, T, coalesce=1 if prec == "fp32" else CO)
         got = {}
 
         def runx(n_steps):
             for _, h_, s_ in px.decode([(feats, sizes, k) for k in range(n_steps)], ax, sos=1, as_lists=False):
                 got[0] = h_
 
-        runx(max(2, NS))
+        runx(max(2, nsx * (1 if prec == "fp32" else CO)))
         fence()
         c0 = time.perf_counter()
         runx(a.steps)
@@ -322,7 +335,7 @@ def main():
         tk, ln = got[0]
         hx = [tk[b, : ln[b]].tolist() for b in range(tk.shape[0])]
         r = {"dtype": prec, "value": round(a.steps * B / el, 2), "unit": "utt/s", "ms_per_step": round(el / a.steps * 1e3, 4),
-             "steps": a.steps, "decode_pipelines": NS,
+             "steps": a.steps, "decode_pipelines": nsx, "batches_per_engine_pass": 1 if prec == "fp32" else CO,
              "hyp_agreement": None if ref is None else round(float(np.mean([h == list(q) for h, q in zip(hx, ref["hyps"])])), 3)}
         px.close()
         return r

@@ -35,9 +35,14 @@ class _NoStream:
 class _Job:
     """One ``records()`` call: the shared iterator and the bookkeeping its workers and its consumer meet on."""
 
-    def __init__(self, it, args, sos, n, total=None, coalesce=1):
+    def __init__(self, it, args, sos, n, total=None, coalesce=1, host=False):
         self.it, self.args, self.sos = it, args, sos
+        self.host = host  # the consumer wants the records on the host: the producing pipeline sends them itself, one copy per pass
         self.left = total  # batches not yet handed to a worker (None: unknown)
+        # a list of known length is cut into n x rounds passes of (nearly) equal size up front - 20 batches on 3 pipelines x 3
+        # per pass: 3 3 2 2 2 2 2 2 2, not 3 3 3 3 3 2 1 1 1 - so that the pipelines finish together without one-batch passes
+        c = max(1, coalesce)
+        self.passes_left = None if total is None else n * max(1, -(-total // (n * c)))
         self.lock = threading.Lock()
         self.cv = threading.Condition()
         self.slots = {}          # index -> queue of one (tag, records, event)
@@ -83,6 +88,7 @@ class DecodePipelines:
         self._threads = []
         self._inbox = []
         self._busy = threading.Lock()  # one records() call at a time
+        self._stage = [{} for _ in range(self.n)]  # per pipeline: merged-batch input buffers at full capacity, by shape
 
     # ------------------------------------------------------------------------------------------ workers
     def _start(self):
@@ -142,11 +148,12 @@ class DecodePipelines:
                     except StopIteration:
                         state["done"] = True
                         break
-                # further batches of the same shape ride along; another shape waits for the next pass.  Near the end of a
-                # list of known length the passes shrink so that the pipelines finish together
+                # further batches of the same shape ride along; another shape waits for the next pass.  A list of known length
+                # goes in passes of equal size (see _Job)
                 want = self.coalesce
                 if job.left is not None:
-                    want = min(want, max(1, -(-job.left // self.n)))
+                    want = min(want, max(1, -(-job.left // max(1, job.passes_left))))
+                    job.passes_left = max(1, job.passes_left - 1)
                 while len(items) < want:
                     try:
                         nxt = next(it)
@@ -168,13 +175,29 @@ class DecodePipelines:
             else:
                 nb = items[0][0].shape[0]
                 dev_ = torch.device("cuda", device) if on_gpu else None
-                feats = torch.cat([x[0].to(dev_) if on_gpu else x[0] for x in items], 0)
-                ratio = torch.cat([x[1].to(dev_) if on_gpu else x[1] for x in items], 0)
+                # the merged input lives in a buffer of the pipeline's full capacity, allocated the first time a shape is merged
+                # (any merged warm-up pass, whatever its size, leaves nothing to allocate for the later ones)
+                f0, r0 = items[0][0], items[0][1]
+                key = (tuple(f0.shape), f0.dtype, tuple(r0.shape), r0.dtype)
+                bufs = self._stage[k].get(key)
+                if bufs is None:
+                    bufs = (torch.empty((self.coalesce * nb,) + tuple(f0.shape[1:]), dtype=f0.dtype, device=dev_),
+                            torch.empty((self.coalesce * nb,) + tuple(r0.shape[1:]), dtype=r0.dtype, device=dev_))
+                    self._stage[k][key] = bufs
+                feats, ratio = bufs[0][: len(items) * nb], bufs[1][: len(items) * nb]
+                torch.cat([x[0].to(dev_) if on_gpu else x[0] for x in items], 0, out=feats)  # one launch, nothing allocated
+                torch.cat([x[1].to(dev_) if on_gpu else x[1] for x in items], 0, out=ratio)
                 hyp, hyp_len, score = self.model.decode_device(feats, ratio, job.args, job.sos, engine=self.engines[k], sub_batch=nb)
                 rec = cdist.pack_records(hyp, hyp_len, score)
                 recs = [rec[j * nb : (j + 1) * nb] for j in range(len(items))]
             ev = None
             if on_gpu:
+                if job.host:  # pinned buffer from torch's caching host allocator, asynchronous copy on this pipeline's stream
+                    whole = recs[0] if len(items) == 1 else rec
+                    hbuf = torch.empty(whole.shape, dtype=whole.dtype, device="cpu", pin_memory=True)
+                    hbuf.copy_(whole, non_blocking=True)
+                    nb_ = whole.shape[0] // len(items)
+                    recs = [hbuf[j * nb_ : (j + 1) * nb_] for j in range(len(items))]
                 ev = torch.cuda.Event()
                 ev.record(st)
             for j, item in enumerate(items):
@@ -198,14 +221,16 @@ class DecodePipelines:
         self.close()
         return False
 
-    def records(self, batches, args, sos=1):
+    def records(self, batches, args, sos=1, host=False):
         """``batches``: iterable of ``(feats (B,T,F), size_ratio (B,), tag)`` (host or device tensors).  Yields
         ``(tag, records)`` in the order of the iterable: ``records`` is the device tensor of ``dist.pack_records`` (per
         utterance: length, float64 score, [sos] + tokens), ready for ``dist.all_gather_records`` / ``unpack_records``.  The
-        consumer's current stream is made to wait for the producing pipeline's work."""
+        consumer's current stream is made to wait for the producing pipeline's work.  ``host=True``: the records arrive as
+        host tensors instead (pinned; sent by the producing pipeline on its own stream, one copy per engine pass, and complete when
+        they are yielded) - what a single-GPU consumer wants, which would otherwise pay one blocking copy per batch."""
         self._start()
         job = _Job(iter(batches), args, sos, self.n, total=len(batches) if hasattr(batches, "__len__") else None,
-                   coalesce=self.coalesce)
+                   coalesce=self.coalesce, host=host)
         state, lock = job.state, job.lock
         with self._busy:
             for q in self._inbox:
@@ -227,7 +252,10 @@ class DecodePipelines:
                     with job.cv:
                         job.slots.pop(i, None)
                     if ev is not None:
-                        ev.wait(torch.cuda.current_stream())
+                        if job.host:
+                            ev.synchronize()
+                        else:
+                            ev.wait(torch.cuda.current_stream())
                     job.ahead.release()
                     yield tag, rec
                     i += 1
@@ -242,7 +270,7 @@ class DecodePipelines:
         with ``sos`` (what ``beam_decode`` returns as ``['hyp']``), or with ``as_lists=False`` the arrays ``(tokens (N, S),
         lengths (N,))`` of ``dist.unpack_records``.  ``gather=True``: every record set goes through the per-batch all-gather
         of the multi-GPU path first (rank-major concatenation)."""
-        for tag, rec in self.records(batches, args, sos):
+        for tag, rec in self.records(batches, args, sos, host=not gather):
             if gather:
                 rec = cdist.all_gather_records(rec)
             hyps, scores = cdist.unpack_records(rec, as_lists=as_lists)

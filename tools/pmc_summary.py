@@ -1,7 +1,7 @@
 """Summarise rocprofv3 --pmc passes (separate runs for FETCH_SIZE and WRITE_SIZE, CSV output) into the per-launch HBM
 traffic figures bench.py's roofline objects quote.
 
-    python tools/pmc_summary.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <out dir (profiles/)> [<dir with the SQ pass>]
+    python tools/pmc_summary.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <out dir (profiles/)> [<dir with the SQ pass> [batches per engine pass]]
 
 The optional SQ pass (--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE)
 becomes pmc_mfma.json: per kernel, matrix-pipe busy cycles against the cycles its waves were resident and against the
@@ -32,8 +32,9 @@ def mfma_summary(sdir, out):
     acc = {n: per_kernel(sdir, n) for n in names}
     kernels = {"chain_kernel": "chain_kernel", "conv2_kernel<false>": "conv2_kernel (conv2)", "conv2_kernel<true>": "conv2_kernel<LINEAR> (linear_out)",
                "attention_kernel": "attention_kernel", "genmax_kernel": "genmax_kernel", "conv1_kernel": "conv1_kernel"}
-    rec = {"source": "rocprofv3 --pmc " + " ".join(names) + " (its own pass, --kernel-trace only), bench.py --steps 6 --warmup 3 --streams 1 "
-                     "(one pipeline, three batches of 32 per pass: the kernels have the GPU to themselves)",
+    c = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+    rec = {"source": "rocprofv3 --pmc " + " ".join(names) + f" (its own pass, --kernel-trace only), bench.py --steps {2 * c} --warmup {c} --streams 1 --coalesce {c} "
+                     f"(one pipeline, {c} batches of 32 per pass: the kernels have the GPU to themselves)",
            "units": "SQ_VALU_MFMA_BUSY_CYCLES: cycles, summed over SIMDs; SQ_WAVE_CYCLES / SQ_BUSY_CYCLES: quad-cycles (x4); "
                     "GRBM_GUI_ACTIVE: cycles summed over the 8 XCDs (/8); MOPS_BF16 x 512 = bf16 MFMA FLOPs",
            "kernels": {}}
@@ -59,9 +60,10 @@ def main():
     if len(sys.argv) > 4:
         mfma_summary(sys.argv[4], out)
     fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
-    targets = {"row_chain": ("chain_kernel", "chain_kernel (all 21 launches of an engine pass of three batches: 12 encoder at 24000 rows, 9 decoder-side)"),
-               "conv2": ("conv2_kernel<false>", "conv2_kernel<false> (LDS-DMA implicit GEMM, three batches of 32 x 1000 frames per launch)"),
-               "linear_out": ("conv2_kernel<true>", "conv2_kernel<true> (linear_out on the LDS-DMA tile kernel, 24000 x 5120 -> 256)")}
+    c = int(sys.argv[5]) if len(sys.argv) > 5 else 10  # batches of 32 x 1000 frames per engine pass in the profiled runs
+    targets = {"row_chain": ("chain_kernel", f"chain_kernel (all 21 launches of an engine pass of {c} batches: 12 encoder at {8000 * c} rows, 9 decoder-side)"),
+               "conv2": ("conv2_kernel<false>", f"conv2_kernel<false> (LDS-DMA implicit GEMM, {c} batches of 32 x 1000 frames per launch)"),
+               "linear_out": ("conv2_kernel<true>", f"conv2_kernel<true> (linear_out on the LDS-DMA tile kernel, {8000 * c} x 5120 -> 256)")}
     for tag, (needle, label) in targets.items():
         fk = [v for k, vs in fetch.items() if needle in k for v in vs]
         wk = [v for k, vs in write.items() if needle in k for v in vs]
@@ -70,8 +72,8 @@ def main():
             continue
         f_kb, w_kb = sum(fk) / len(fk), sum(wk) / len(wk)
         rec = {"kernel": label,
-               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 6 --warmup 3 --streams 1 (one pipeline, the default three batches of 32 per engine pass: launches as wide as the timed run's)",
-               "launches_sampled": len(fk), "FETCH_SIZE_KB_per_launch": round(f_kb), "WRITE_SIZE_KB_per_launch": round(w_kb),
+               "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps {2 * c} --warmup {c} --streams 1 --coalesce {c} (one pipeline, {c} batches of 32 per engine pass: launches as wide as the timed run's)",
+               "batches_per_engine_pass": c, "launches_sampled": len(fk), "FETCH_SIZE_KB_per_launch": round(f_kb), "WRITE_SIZE_KB_per_launch": round(w_kb),
                "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request for wide (16 B/lane) coalesced reads: doubled "
                              "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
                "hbm_bytes_per_launch": round((2 * f_kb + w_kb) * 1024)}
