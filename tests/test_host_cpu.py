@@ -294,3 +294,42 @@ def test_decode_pipelines_keep_submission_order_and_surface_errors():
             break
     gen.close()
     assert len(m3.seen) < 40
+
+
+def test_decode_pipelines_cut_a_list_of_known_length_into_equal_passes():
+    """pipeline._Job: with len(batches) known the passes are planned up front - n x rounds of them, sizes differing by at most
+    one, no one-batch tail - and the merged input of a pass is the batches in order."""
+    import torch as _torch
+
+    from cassnat_asr_public_amd.pipeline import DecodePipelines
+
+    class StubEngine:
+        def close(self):
+            pass
+
+    class StubModel:
+        def __init__(self):
+            self.passes = []
+
+        def new_engine(self, batch, frames, with_weights=True, share=None):
+            return StubEngine()
+
+        def decode_device(self, feats, ratio, args, sos, engine=None, sub_batch=0):
+            ks = [int(feats[j, 0, 0]) for j in range(feats.shape[0])]
+            self.passes.append(ks)
+            hyp = _torch.tensor([[sos, 10 + k, 0] for k in ks], dtype=_torch.int32)
+            return hyp, _torch.full((len(ks),), 2, dtype=_torch.int32), _torch.tensor([float(k) for k in ks], dtype=_torch.float64)
+
+    for n, c, total, want in ((3, 3, 20, [2, 2, 2, 2, 2, 2, 2, 3, 3]), (2, 10, 20, [10, 10]), (2, 10, 5, [2, 3]), (1, 4, 9, [3, 3, 3]),
+                              (3, 3, 200, None)):
+        m = StubModel()
+        items = [(_torch.full((1, 4, 2), float(k)), _torch.ones(1), k) for k in range(total)]
+        out = list(DecodePipelines(m, n, 1, 4, coalesce=c).decode(items, args=None, sos=1))
+        assert [t for t, _, _ in out] == list(range(total))
+        assert [h for _, h, _ in out] == [[[1, 10 + k]] for k in range(total)]
+        sizes = sorted(len(p) for p in m.passes)
+        assert sum(sizes) == total and sizes[-1] <= c, sizes
+        if want is not None:  # (a long list may also see passes cut short by the bound on decoded-but-unconsumed batches)
+            assert sizes == want, sizes
+        for p in m.passes:  # consecutive batches, in order
+            assert p == list(range(p[0], p[0] + len(p)))
