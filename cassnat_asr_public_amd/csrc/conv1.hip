@@ -5,12 +5,18 @@
 // (B,T1,F1,C) that the implicit-GEMM second convolution reads; a wave covers two full 512-B/1-KiB rows.
 #include "kernels.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
                                                     const float* __restrict__ bias, T* __restrict__ out, int B, int Tn,
                                                     int F, int T1, int F1, int C, int halo) {
-    // A thread keeps its 8 channels for the whole kernel, so the 72 tap weights + 8 biases live in registers; per
-    // output position it issues 9 (broadcast) loads, 72 FMAs and one 16-byte store.
+    // A thread keeps its 8 channels for the whole kernel, so the 72 tap weights + 8 biases live in registers (as pairs: the
+    // 72 multiply-adds of an output position are 36 v_pk_fma_f32).  The three input rows of an output row are staged once in
+    // LDS with their zero padding (index f + 1, f = -1 .. F), so a position's nine taps are nine unconditional LDS reads - the
+    // 32 lanes of a position read the same address - instead of nine predicated global loads, each in a branch of its own.
+    extern __shared__ float xs_all[];  // [2][3][F + 2]: double-buffered over the workgroup's rows (one barrier per row)
+    const int FW = F + 2;
     const int cg = C >> 3;
     // halo = 1: the image is written as [B][T1 + 2][F1 + 2][C] with a border of zeros (the padding of the second
     // convolution, conv2.hip): the grid then covers the border cells too.
@@ -23,46 +29,61 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
     const int T1p = T1 + 2 * halo, F1p = F1 + 2 * halo;
     const int c0 = (int)(threadIdx.x % cg) << 3;
     const int p0 = threadIdx.x / cg, pstep = 256 / cg;
-    float w[9][8], bz[8];
+    f32x2 w[9][4], bz[4];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[tap][j] = w9c[tap * C + c0 + j];
+        for (int j = 0; j < 4; ++j) w[tap][j] = f32x2{w9c[tap * C + c0 + 2 * j], w9c[tap * C + c0 + 2 * j + 1]};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bz[j] = bias[c0 + j];
+    for (int j = 0; j < 4; ++j) bz[j] = f32x2{bias[c0 + 2 * j], bias[c0 + 2 * j + 1]};
     const int rows = B * T1p;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    int buf = 0;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x, buf ^= 1) {
         const int b = row / T1p, t1 = row - b * T1p - halo;
         T* orow = out + (long long)row * F1p * C + (__is_same(T, split_t) ? 0 : c0);
         const bool row_in = t1 >= 0 && t1 < T1;
-        // the three input rows of this output row (null = outside the padded input)
-        const float* xr[3];
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int t = 2 * t1 - 1 + kh;
-            xr[kh] = (row_in && t >= 0 && t < Tn) ? x + ((long long)b * Tn + t) * F : nullptr;
+        float* xs = xs_all + buf * 3 * FW;
+        if (row_in) {
+            for (int i = threadIdx.x; i < 3 * FW; i += 256) {
+                const int kh = i / FW, f = i - kh * FW - 1, t = 2 * t1 - 1 + kh;
+                xs[i] = (t >= 0 && t < Tn && f >= 0 && f < F) ? x[((long long)b * Tn + t) * F + f] : 0.f;
+            }
         }
+        __syncthreads();  // (a buffer is rewritten two rows later: every thread has passed the barrier in between)
         for (int fp = p0; fp < F1p; fp += pstep) {
             const int f1 = fp - halo;
             T* dst = orow + (long long)fp * C;
-            if constexpr (__is_same(T, split_t)) {  // (no bordered image in this precision: halo == 0)
-                float o[8];
-                float acc[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = bz[j];
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const int f = 2 * f1 - 1 + kw;
-                        float v = 0.f;
-                        if (xr[kh] && f >= 0 && f < F) v = xr[kh][f];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, w[kh * 3 + kw][j], acc[j]);
-                    }
+            const bool cell_in = row_in && f1 >= 0 && f1 < F1;
+            if (!cell_in) {  // border cell (bordered images only)
+                if (skip_border) continue;
+                if constexpr (sizeof(T) == 2) {
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
+                } else if constexpr (!__is_same(T, split_t)) {
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(dst + 4) = make_uint4(0, 0, 0, 0);
                 }
+                continue;
+            }
+            f32x2 acc[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = fmaxf(acc[j], 0.f);
+            for (int j = 0; j < 4; ++j) acc[j] = bz[j];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float v = xs[kh * FW + 2 * f1 + kw];  // f = 2 f1 - 1 + kw at index f + 1
+                    const f32x2 vv = {v, v};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_elementwise_fma(vv, w[kh * 3 + kw][j], acc[j]);
+                }
+            }
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[2 * j] = fmaxf(acc[j][0], 0.f);
+                o[2 * j + 1] = fmaxf(acc[j][1], 0.f);
+            }
+            if constexpr (__is_same(T, split_t)) {  // (no bordered image in this precision: halo == 0)
                 bf16x8 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -72,43 +93,17 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
                 unsigned char* db = reinterpret_cast<unsigned char*>(dst) + cn_split_off((size_t)c0);
                 *reinterpret_cast<bf16x8*>(db) = hi;
                 *reinterpret_cast<bf16x8*>(db + 64) = lo;
-                continue;
-            }
-            if (!row_in || f1 < 0 || f1 >= F1) {  // border cell
-                if (skip_border) continue;
-                if constexpr (sizeof(T) == 2) {
-                    *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
-                } else {
-                    *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
-                    *reinterpret_cast<uint4*>(dst + 4) = make_uint4(0, 0, 0, 0);
-                }
-                continue;
-            }
-            float acc[8];
+            } else if constexpr (sizeof(T) == 2) {
+                bf16x8 ob;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = bz[j];
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int f = 2 * f1 - 1 + kw;
-                    float v = 0.f;
-                    if (xr[kh] && f >= 0 && f < F) v = xr[kh][f];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, w[kh * 3 + kw][j], acc[j]);
-                }
-            }
-            if constexpr (sizeof(T) == 2) {
-                bf16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf(acc[j], 0.f);
-                *reinterpret_cast<bf16x8*>(dst) = o;
+                for (int j = 0; j < 8; ++j) ob[j] = (bf16)o[j];
+                *reinterpret_cast<bf16x8*>(dst) = ob;
             } else {
                 f32x4 o0, o1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    o0[j] = fmaxf(acc[j], 0.f);
-                    o1[j] = fmaxf(acc[4 + j], 0.f);
+                    o0[j] = o[j];
+                    o1[j] = o[4 + j];
                 }
                 *reinterpret_cast<f32x4*>(dst) = o0;
                 *reinterpret_cast<f32x4*>(dst + 4) = o1;
@@ -126,7 +121,7 @@ int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, 
     long long blocks = (long long)B * (T1 + 2 * (halo ? 1 : 0));  // one image row per workgroup pass
     if (blocks > 256 * 8) blocks = 256 * 8;             // 8 workgroups per CU, grid-stride the rest
     if (blocks < 1) blocks = 1;
-    const size_t lds = 0;
+    const size_t lds = (size_t)2 * 3 * (F + 2) * sizeof(float);  // the rows being read and the next ones
     if (prec == CN_PREC_X3 && (halo || C % 32 != 0)) {
         cn_set_error("conv1: the split-bf16 image has no halo form and needs C % 32 == 0");
         return -1;
