@@ -439,6 +439,31 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     // REL: softmax(...).masked_fill(mask == 0, 0) leaves a row without any allowed key at zero (attention.py:133-134)
     const float inv = (REL && m_run == CN_NEG_FILL) ? 0.f : 1.f / l_tot;
+    if constexpr (sizeof(T) == 2) {
+        // bf16: a lane holds channels 8 g + 4 half + (0..3) of its row - sixteen 8-byte stores.  The two half-waves trade their odd /
+        // even groups (v_permlane32_swap: upper half of the first operand <-> lower half of the second), after which a lane owns
+        // 8 consecutive channels: eight 16-byte stores (the tail is bound by store instructions, not bytes).  The swap needs all
+        // 64 lanes, so it runs for rows past Lq too; only the stores are guarded.
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        T* orow = reinterpret_cast<T*>(p.O) + ((long long)b * p.Lq + qc) * p.ldo + h * 64 + 8 * half;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                bf16x4 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[e] = (bf16)(o_acc[d][8 * gp + e] * inv);
+                    o1[e] = (bf16)(o_acc[d][8 * gp + 4 + e] * inv);
+                }
+                const uint2 lo_ = __builtin_bit_cast(uint2, o0), hi_ = __builtin_bit_cast(uint2, o1);
+                const auto s0_ = __builtin_amdgcn_permlane32_swap(lo_.x, hi_.x, false, false);
+                const auto s1_ = __builtin_amdgcn_permlane32_swap(lo_.y, hi_.y, false, false);
+                if (q_row < p.Lq) *reinterpret_cast<u32x4*>(orow + 32 * d + 16 * gp) = u32x4{s0_[0], s1_[0], s0_[1], s1_[1]};
+            }
+        }
+        return;
+    }
     if (q_row < p.Lq) {
         T* orow = reinterpret_cast<T*>(p.O) + ((long long)b * p.Lq + q_row) * p.ldo + h * 64;
 #pragma unroll
