@@ -33,7 +33,7 @@ struct AttnParams {
     int H, Lq, Lk;
     const unsigned char* keymask;
     int kv_mod;  // > 0: keys / values / keymask of batch entry b live at entry b % kv_mod (several query sets per source)
-    int stamps;  // investigation aid (CASSNAT_ATTN_STAMPS): workgroup 0 / thread 0 records s_memtime at its phase boundaries
+    int stamps;  // investigation aid (CASSNAT_ATTN_STAMPS): the last workgroup's thread 0 records s_memtime at its phase boundaries
     const int* kv_index;  // non-null: ... at entry kv_index[b] (beam search: every hypothesis row names its utterance)
     const int* klen;
     const int* iv;
@@ -75,7 +75,8 @@ template <> struct AttnCfg<split_t> {   // split-bf16 rows: per head [32 hi][32 
 // REL: relative-position scores (RelMultiHeadedAttention): the query operand is q + u, and a per-query table
 // bd[i][r] = (q_i + v) . P[r] (r = clamp(j - i) + R, at most 63 entries) is built in LDS and added to every raw score.
 __device__ long long attn_stamps[8];
-#define AT_STAMP(i) if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) attn_stamps[i] = (long long)__builtin_amdgcn_s_memtime();
+// (the LAST workgroup of the grid: with more workgroups than CUs it runs among others in every phase, not in the launch's first burst)
+#define AT_STAMP(i) if (p.stamps && blockIdx.x == 0 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1 && threadIdx.x == 0) attn_stamps[i] = (long long)__builtin_amdgcn_s_memtime();
 
 template <typename T, int NW, bool RES, bool REL = false>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
@@ -262,55 +263,53 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
         }
         if (!wave_active) continue;
 
-        // ---- S^T[key][q] for the two 32-key sub-tiles
-        f32x16 sc[2];
+        // The 64-key tile is consumed as two 32-key sub-tiles, each with its own online-softmax step: 16 score registers live
+        // instead of 32, which is what lets the bf16 kernel run at 128 VGPRs - two 8-wave workgroups per CU, one loading
+        // while the other computes.
+        const bool plain = !REL && Mplain[RES ? kt : 0] != 0 && !p.iv && !p.causal;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
+            // ---- S^T[key][q] of the sub-tile
+            f32x16 sc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[sub][r] = 0.f;
-            const int row = sub * 32 + l31;
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+            {
+                const int row = sub * 32 + l31;
 #pragma unroll
-            for (int s = 0; s < NF; ++s) {
-                if constexpr (SPLIT) {
-                    const int chunk = (s >> 1) * 8 + 2 * (s & 1) + half;
-                    split_frag kf;
-                    kf.hi = as_frag<bf16>(ld16(Ks + row * KROW + ((chunk ^ Cfg::swz(row)) << 4)));
-                    kf.lo = as_frag<bf16>(ld16(Ks + row * KROW + (((chunk + 4) ^ Cfg::swz(row)) << 4)));
-                    sc[sub] = mfma_frag(kf, qf[s], sc[sub]);
-                } else {
-                    const int chunk = 2 * s + half;
-                    const frag_t kf = as_frag<T>(ld16(Ks + row * KROW + ((chunk ^ Cfg::swz(row)) << 4)));
-                    sc[sub] = mfma_frag(kf, qf[s], sc[sub]);
+                for (int s = 0; s < NF; ++s) {
+                    if constexpr (SPLIT) {
+                        const int chunk = (s >> 1) * 8 + 2 * (s & 1) + half;
+                        split_frag kf;
+                        kf.hi = as_frag<bf16>(ld16(Ks + row * KROW + ((chunk ^ Cfg::swz(row)) << 4)));
+                        kf.lo = as_frag<bf16>(ld16(Ks + row * KROW + (((chunk + 4) ^ Cfg::swz(row)) << 4)));
+                        sc = mfma_frag(kf, qf[s], sc);
+                    } else {
+                        const int chunk = 2 * s + half;
+                        const frag_t kf = as_frag<T>(ld16(Ks + row * KROW + ((chunk ^ Cfg::swz(row)) << 4)));
+                        sc = mfma_frag(kf, qf[s], sc);
+                    }
                 }
             }
-        }
-        // ---- scale + mask + online softmax.  Fast path (wave-uniform): no key of this tile is masked and there are no
-        // per-row intervals / causal limit -> one FMA + exp2 per score instead of ~15 VALU ops of mask logic.
-        const bool plain = !REL && Mplain[RES ? kt : 0] != 0 && !p.iv && !p.causal;
-        float psum = 0.f, alpha;
-        if (plain) {
-            float tmax = sc[0][0];
+            // ---- scale + mask + online softmax.  Fast path (wave-uniform): no key of this tile is masked and there are no
+            // per-row intervals / causal limit -> one FMA + exp2 per score instead of ~15 VALU ops of mask logic.
+            float psum = 0.f, alpha;
+            if (plain) {
+                float tmax = sc[0];
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[sub][r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * p.scale;
-            const float m_new = fmaxf(m_run, tmax);
-            alpha = __expf(m_run - m_new);
-            m_run = m_new;
-            const float c2 = p.scale * 1.44269504088896340736f, mb = m_new * 1.44269504088896340736f;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+                for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * p.scale;
+                const float m_new = fmaxf(m_run, tmax);
+                alpha = __expf(m_run - m_new);
+                m_run = m_new;
+                const float c2 = p.scale * 1.44269504088896340736f, mb = m_new * 1.44269504088896340736f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[sub][r], c2, -mb));
-                    sc[sub][r] = pv;
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -mb));
+                    sc[r] = pv;
                     psum += pv;
                 }
-        } else {
-            float tmax = -INFINITY;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
+            } else {
+                float tmax = -INFINITY;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const unsigned int mw = Ms[sub * 8 + 2 * g + half];
@@ -322,7 +321,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                         bool ok = code == 1u;
                         if (p.iv) ok = ok && ((key >= iv_s1 && key < iv_e1) || (key >= iv_s2 && key < iv_e2));
                         if (p.causal) ok = ok && key <= q_row;
-                        float v = sc[sub][r];
+                        float v = sc[r];
                         if constexpr (REL) {
                             int rd = key - q_row;
                             rd = rd < -p.rel_R ? -p.rel_R : (rd > p.rel_R ? p.rel_R : rd);
@@ -331,46 +330,41 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                         v *= p.scale;
                         v = ok ? v : CN_NEG_FILL;
                         v = code == 2u ? -INFINITY : v;
-                        sc[sub][r] = v;
+                        sc[r] = v;
                         tmax = fmaxf(tmax, v);
                     }
                 }
-            }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float m_new = fmaxf(m_run, tmax);
-            alpha = __expf(m_run - m_new);
-            m_run = m_new;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                const float m_new = fmaxf(m_run, tmax);
+                alpha = __expf(m_run - m_new);
+                m_run = m_new;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = __expf(sc[sub][r] - m_new);
-                    sc[sub][r] = pv;
+                    const float pv = __expf(sc[r] - m_new);
+                    sc[r] = pv;
                     psum += pv;
                 }
-        }
-        l_run = l_run * alpha + psum;
-        if (!__all(alpha == 1.f)) {
+            }
+            l_run = l_run * alpha + psum;
+            if (!__all(alpha == 1.f)) {
 #pragma unroll
-            for (int d = 0; d < 2; ++d)
+                for (int d = 0; d < 2; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
-        }
+                    for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+            }
 
-        // ---- O^T[dk][q] += V^T[dk][key] . P^T[key][q]
-        if constexpr (SPLIT) {
-            // as the bf16 form below, on the hi and lo planes of V and the hi / lo halves of P: three MFMAs per product
-            const int i16 = lane & 15, g1 = (lane >> 4) & 1;
-            typedef short s16x8 __attribute__((ext_vector_type(8)));
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
+            // ---- O^T[dk][q] += V^T[dk][key] . P^T[key][q]
+            if constexpr (SPLIT) {
+                // as the bf16 form below, on the hi and lo planes of V and the hi / lo halves of P: three MFMAs per product
+                const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     bf16x8 ph, pl;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        ph[j] = (bf16)sc[sub][8 * s + j];
-                        pl[j] = (bf16)(sc[sub][8 * s + j] - (float)ph[j]);
+                        ph[j] = (bf16)sc[8 * s + j];
+                        pl[j] = (bf16)(sc[8 * s + j] - (float)ph[j]);
                     }
                     const int key0 = sub * 32 + 16 * s + 4 * half + (i16 >> 2);
 #pragma unroll
@@ -391,16 +385,13 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                         o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], ph, o_acc[d], 0, 0, 0);
                     }
                 }
-            }
-        } else if constexpr (sizeof(T) == 2) {
-            const int i16 = lane & 15, g1 = (lane >> 4) & 1;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
+            } else if constexpr (sizeof(T) == 2) {
+                const int i16 = lane & 15, g1 = (lane >> 4) & 1;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     bf16x8 pb;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pb[j] = (bf16)sc[sub][8 * s + j];
+                    for (int j = 0; j < 8; ++j) pb[j] = (bf16)sc[8 * s + j];
                     const int key0 = sub * 32 + 16 * s + 4 * half + (i16 >> 2);
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
@@ -418,17 +409,14 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                         o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o_acc[d], 0, 0, 0);
                     }
                 }
-            }
-        } else {
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
+            } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key_local = sub * 32 + acc_row(r, lane);
                     const float* vrow = reinterpret_cast<const float*>(Vs + key_local * VROW);
 #pragma unroll
                     for (int d = 0; d < 2; ++d)
-                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * d + l31], sc[sub][r], o_acc[d], 0, 0, 0);
+                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * d + l31], sc[r], o_acc[d], 0, 0, 0);
                 }
             }
         }
