@@ -26,7 +26,8 @@
 //     stream through an 8-slot LDS ring by LDS-DMA (global_load_lds_dwordx4); each wave issues a quarter of every
 //     unit, waits for its own quarter with a counted vmcnt, and ONE s_barrier per unit publishes the slot.  A slot is
 //     refilled as soon as the barrier after its last read has passed, so 5-6 units (~90 KiB) stay in flight per CU;
-//     activations are read and written with the nt policy so that they do not evict the weight stream from L2.
+//     (the outputs were first written with the nt policy, to keep them from evicting the weight stream from L2: the stores then
+//     took so long to retire that the tail phase ran 40 % longer - plain stores now, see CH_TAIL_STORE.)
 //   * All LDS reads are issued from inline asm: hipcc drains vmcnt to 0 in front of any LDS access it can see while
 //     an LDS-DMA is outstanding.  Per-channel vectors (biases, LayerNorm gains) ride the same DMA into a 20-KiB table.
 #include <cstdio>
@@ -188,10 +189,17 @@ __device__ __forceinline__ void ch_add_channel(f32x16 (&acc)[8], unsigned tab_la
                           "ds_read_b128 %[" #n1 "], %[ra] offset:" CH_STR(((K) + 1) * 1024) "\n\t"
 #define CH_PRE_A "s_waitcnt lgkmcnt(0)\n\t"
 #define CH_PRE_B(M0OFF) "s_waitcnt vmcnt(20)\n\ts_barrier\n\ts_add_u32 m0, %[m0w], " CH_STR(M0OFF) "\n\ts_waitcnt lgkmcnt(0)\n\t"
+#ifdef CH_EXP_NO_DMA  // timing experiment (tools/chain_stamps.py): the blocks without their refill requests (stale ring: wrong results)
+#define CH_DMA0(SOFF) "v_add_u32 %[tv], " CH_STR(SOFF) ", %[vo]\n\t"
+#define CH_DMA1 ""
+#define CH_DMA2 ""
+#define CH_DMA3 ""
+#else
 #define CH_DMA0(SOFF) "v_add_u32 %[tv], " CH_STR(SOFF) ", %[vo]\n\tglobal_load_lds_dwordx4 %[tv], %[sb]\n\t"
 #define CH_DMA1 "global_load_lds_dwordx4 %[tv], %[sb] offset:1024\n\t"
 #define CH_DMA2 "global_load_lds_dwordx4 %[tv], %[sb] offset:2048\n\t"
 #define CH_DMA3 "global_load_lds_dwordx4 %[tv], %[sb] offset:3072\n\t"
+#endif
 // single accumulator (CIO/CC: "+"/"=&" and "v"/"a"; C0 = "0" starts the accumulation, "%[c]" continues it), eight B
 // operands B[BO..BO+7]; reads the next 8 fragments from RA at RK KiB
 #define CH_BLK1(CIO, CC, C0, acc, Fc, B, BO, Fn, RA, RK, PRE, D0, D1, D2, D3, SB, POST)                        \
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
                         bf16x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = bop[k][4 * q + e];
-                        __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(op + 16 * k + 8 * q));
+                        *reinterpret_cast<bf16x4*>(op + 16 * k + 8 * q) = o;
                     }
             }
         }
@@ -481,6 +489,9 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
             f32x16 q;
             f32x4 btv[4];
             ch_tab4_nowait(tb, btv[0], btv[1], btv[2], btv[3]);
+// (plain stores: with the nt policy the tail ran 40 % longer - 38k against 27k cycles for 24 positions at 63 workgroups, 79k
+// against 51k at 256, `tools/chain_stamps.py`; a tail without its stores takes 21k - and the whole benchmark 2.6 % longer)
+#define CH_TAIL_STORE(v, ptr) *(ptr) = (v)
 #define CH_S5(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB)                                                     \
             q = __builtin_shufflevector(__builtin_shufflevector(btv[0], btv[1], 0, 1, 2, 3, 4, 5, 6, 7),      \
                                         __builtin_shufflevector(btv[2], btv[3], 0, 1, 2, 3, 4, 5, 6, 7),      \
@@ -506,7 +517,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
                 }                                                                                             \
                 if (live && p.stamps != 2) {                                                                  \
                     _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                          \
-                        __builtin_nontemporal_store(w_[gp], reinterpret_cast<u32x4*>(op16 + 32 * (k) + 16 * gp)); \
+                        CH_TAIL_STORE(w_[gp], reinterpret_cast<u32x4*>(op16 + 32 * (k) + 16 * gp));           \
                 } else if (p.stamps == 2) { asm volatile("" :: "v"(w_[0]), "v"(w_[1])); }                     \
             }
             CH_POSITIONS(CH_S5)
