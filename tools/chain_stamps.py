@@ -25,7 +25,7 @@ def main():
     d, dff, tail = 256, 2048, 768
     g = torch.Generator().manual_seed(1)
     rn = lambda *s: torch.randn(*s, generator=g)
-    x = (rn(M, d) * 2).cuda()
+    x = (rn((M + 31) // 32 * 32, d) * 2).cuda()  # (blocked layout in and out, as between the engine's layers: any values do)
     ctx = rn(M, d).to(torch.bfloat16).cuda()
     host = [rn(d, d) / 16, 0.1 * rn(d), 1 + 0.1 * rn(d), 0.1 * rn(d), rn(dff, d) / 16, 0.1 * rn(dff), rn(d, dff) / 45, 0.1 * rn(d), 1 + 0.1 * rn(d),
             0.1 * rn(d), rn(tail, d) / 16, 0.1 * rn(tail)]
@@ -33,7 +33,7 @@ def main():
     outt = torch.empty(M, tail, dtype=torch.bfloat16, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr())
     for _ in range(2):
-        rc = L.cn_op_chain(p(x), p(ctx), d, *[p(t) for t in host], p(outt), tail, M, dff, tail, 1e-6, 0, None)
+        rc = L.cn_op_chain(p(x), p(ctx), d, *[p(t) for t in host], p(outt), tail, M, dff, tail, 1e-6, 3, None)
         assert rc == 0, rc
     torch.cuda.synchronize()
 
