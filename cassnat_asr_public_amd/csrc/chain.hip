@@ -185,10 +185,18 @@ __device__ __forceinline__ void ch_add_channel(f32x16 (&acc)[8], unsigned tab_la
 #define CH_MF "v_mfma_f32_32x32x16_bf16 "
 #define CH_DRAIN "s_nop 13\n\t"
 #define CH_NODRAIN ""
+#ifdef CH_EXP_NO_READ  // timing experiment: the blocks without their fragment reads (stale registers: wrong results)
+#define CH_RD2(n0, n1, K) ""
+#else
 #define CH_RD2(n0, n1, K) "ds_read_b128 %[" #n0 "], %[ra] offset:" CH_STR((K) * 1024) "\n\t"                   \
                           "ds_read_b128 %[" #n1 "], %[ra] offset:" CH_STR(((K) + 1) * 1024) "\n\t"
+#endif
 #define CH_PRE_A "s_waitcnt lgkmcnt(0)\n\t"
+#ifdef CH_EXP_NO_BARRIER  // timing experiment, only together with CH_EXP_NO_DMA and CH_EXP_NO_READ (nothing left to order)
+#define CH_PRE_B(M0OFF) "s_add_u32 m0, %[m0w], " CH_STR(M0OFF) "\n\ts_waitcnt lgkmcnt(0)\n\t"
+#else
 #define CH_PRE_B(M0OFF) "s_waitcnt vmcnt(20)\n\ts_barrier\n\ts_add_u32 m0, %[m0w], " CH_STR(M0OFF) "\n\ts_waitcnt lgkmcnt(0)\n\t"
+#endif
 #ifdef CH_EXP_NO_DMA  // timing experiment (tools/chain_stamps.py): the blocks without their refill requests (stale ring: wrong results)
 #define CH_DMA0(SOFF) "v_add_u32 %[tv], " CH_STR(SOFF) ", %[vo]\n\t"
 #define CH_DMA1 ""

@@ -178,7 +178,11 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
     // (inside the block: lgkmcnt) and for its share of step kt+1 (vmcnt), then the barrier publishes step kt+1 and
     // frees stage kt & 1, into which the block requests the A slab of step kt+2 while it prefetches the first fragments
     // of step kt+1.
+#ifdef C2_EXP_NO_VMWAIT  // timing experiment: the K loop without its wait for the next slabs (wrong results)
+#define C2_PRE3 "s_waitcnt lgkmcnt(0)\n\ts_barrier\n\t"
+#else
 #define C2_PRE3 "s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)\n\ts_barrier\n\t"
+#endif
     for (int kt = 0; kt < KSTEPS; ++kt) {
         const unsigned so = (unsigned)((kt & 1) * C2_STAGE), sn = (unsigned)(((kt + 1) & 1) * C2_STAGE);
         {
