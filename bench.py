@@ -196,6 +196,16 @@ def main():
         cdist.unpack_records(cdist.pack_records(*model.decode_device(feats, sizes, args, engine=eng)))
     stages = eng.profile_end()
     stage_ms = {k: round(v["ms"] / 3, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])}
+    # ... and the roofline kernels once more with the GPU to themselves at the WIDTH of the timed run (CO batches per pass)
+    stages_wide = {}
+    if CO > 1:
+        fw, sw = torch.cat([feats] * CO, 0), torch.cat([sizes] * CO, 0)
+        model.decode_device(fw, sw, args, 1, engine=eng, sub_batch=B)
+        eng.profile_begin(ROOF_TAGS)
+        for _ in range(2):
+            cdist.unpack_records(cdist.pack_records(*model.decode_device(fw, sw, args, 1, engine=eng, sub_batch=B)))
+        stages_wide = eng.profile_end()
+        del fw, sw
     if a.stage_profile and rank == 0:
         for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"]):
             tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0
@@ -250,13 +260,17 @@ def main():
                 pmc = None
         iso = stages.get(tag)
         iso_tf = round(iso["flops"] / (iso["ms"] * 1e-3) / 1e12, 2) if iso and iso["ms"] > 0 else None
+        isow = stages_wide.get(tag)
+        isow_tf = round(isow["flops"] / (isow["ms"] * 1e-3) / 1e12, 2) if isow and isow["ms"] > 0 else None
         r = {"kernel": kernel,
              "note": f"timed with HIP events inside the timed region while {NS} decode pipelines share the GPU; "
-                     "'isolated_achieved' is the same kernel with the GPU to itself (one pipeline, outside the timed region)",
+                     "'isolated_achieved' is the same kernel with the GPU to itself (one pipeline, one batch per pass, outside the "
+                     f"timed region), 'isolated_at_width_achieved' likewise at the timed run's {CO} batches per pass",
              "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
              "traffic": pmc, "flops_per_launch": round(pr["flops"] / pr["count"]), "avg_launch_us": round(avg_s * 1e6, 2),
              "launches_timed": pr["count"], "isolated_achieved": iso_tf,
-             "isolated_frac": None if iso_tf is None else round(iso_tf / peak, 4)}
+             "isolated_frac": None if iso_tf is None else round(iso_tf / peak, 4),
+             "isolated_at_width_achieved": isow_tf, "isolated_at_width_frac": None if isow_tf is None else round(isow_tf / peak, 4)}
         r.update(extra)
         return r
 
@@ -280,6 +294,9 @@ def main():
             if r_:
                 r_["peak"] = round(PEAK_BF16_DENSE_TFLOPS / 3, 1)
                 r_["frac"] = round(r_["achieved"] / r_["peak"], 4)
+                for k_ in ("isolated", "isolated_at_width"):
+                    if r_.get(k_ + "_achieved") is not None:
+                        r_[k_ + "_frac"] = round(r_[k_ + "_achieved"] / r_["peak"], 4)
 
     cpu, ref = None, None
     if not a.no_cpu_baseline and world == 1:
