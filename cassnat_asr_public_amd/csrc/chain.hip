@@ -192,6 +192,10 @@ __device__ __forceinline__ void ch_add_channel(f32x16 (&acc)[8], unsigned tab_la
                           "ds_read_b128 %[" #n1 "], %[ra] offset:" CH_STR(((K) + 1) * 1024) "\n\t"
 #endif
 #define CH_PRE_A "s_waitcnt lgkmcnt(0)\n\t"
+// first W2 block of a hidden tile: the eight fragment reads are older than the four bias-table reads of the NEXT tile that were
+// issued behind the ReLU section (LDS returns in order) - waiting for those as well exposed their whole latency once per tile
+// (FFN loop 95.9k -> 91.4k cycles)
+#define CH_PRE_A4 "s_waitcnt lgkmcnt(4)\n\t"
 #ifdef CH_EXP_NO_BARRIER  // timing experiment, only together with CH_EXP_NO_DMA and CH_EXP_NO_READ (nothing left to order)
 #define CH_PRE_B(M0OFF) "s_add_u32 m0, %[m0w], " CH_STR(M0OFF) "\n\ts_waitcnt lgkmcnt(0)\n\t"
 #else
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
             }
             // W2 unit at position K1: acc[nt] += W2 tile (s, nt) . relu(xh)
 #define CH_W2(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB, POST)                                               \
-            CH_BLK2(acc, Fa, pb[0], Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN);                  \
+            CH_BLK2(acc, Fa, pb[0], Fb, RA_A, RK_A, CH_PRE_A4, "", "", "", "", SB, CH_NODRAIN);                 \
             CH_BLK2(acc, Fb, pb[1], Fa, RA_B, RK_B, CH_PRE_B(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, CH_DMA3, SB, POST);
             CH_W1(0, ra0, 8, ra0, 16, 0x1C000, 0x1C000, sb_cur)
             CH_W2(1, ra0, 24, ra0, 32, 0x0, 0x0, sb_next, CH_NODRAIN)
