@@ -41,9 +41,11 @@ struct Conv2Params {
 };
 
 constexpr int C2_BM = 256, C2_N = 256, C2_C = 256, C2_ROWB = 128;
-constexpr int C2_STAGE = (C2_BM + C2_N) * C2_ROWB;  // 64 KiB: A rows then W rows, 128 bytes (64 channels) each
+constexpr int C2_SLAB = C2_BM * C2_ROWB;             // 32 KiB: 256 rows (of A, or of W) x 128 bytes (64 channels)
+constexpr int C2_WBASE = 3 * C2_SLAB;                // LDS: three A stages, then two W stages = the CU's whole 160 KiB
 constexpr int C2_OSTRIDE = 528;                      // epilogue image: 512-byte rows + 16 (LDS bank spread)
-constexpr int C2_LDS = C2_BM * C2_OSTRIDE > 2 * C2_STAGE ? C2_BM * C2_OSTRIDE : 2 * C2_STAGE;
+constexpr int C2_LDS = 5 * C2_SLAB;
+static_assert(C2_BM * C2_OSTRIDE <= C2_LDS && C2_BM == C2_N, "epilogue image fits; A and W slabs are the same size");
 static_assert(C2_LDS <= 160 * 1024, "LDS budget");
 constexpr int C2_KSTEPS = 9 * (C2_C / 64);
 
@@ -57,9 +59,18 @@ constexpr int C2_KSTEPS = 9 * (C2_C / 64);
 // output rows), 16 MFMAs; behind the first eight go the eight fragment reads of the NEXT sub-step (An from address an_:
 // + 4096 mt; Wn from wn_: + 4096 nt), behind the last eight up to eight LDS-DMA pieces of a later K step (DMA = the
 // instruction text; destination M0 = st_ + 4096 i, source = scalar base sb_ + per-piece lane offset vo[i]).
+#ifdef C2_EXP_NO_READ  // timing experiments (wrong results): the blocks without their fragment reads / their slab requests
+#define C2_RDA(i) ""
+#define C2_RDW(i) ""
+#else
 #define C2_RDA(i) "ds_read_b128 %[na" #i "], %[an] offset:" C2_STR(i * 4096) "\n\t"
 #define C2_RDW(i) "ds_read_b128 %[nw" #i "], %[wn] offset:" C2_STR(i * 4096) "\n\t"
+#endif
+#ifdef C2_EXP_NO_DMA
+#define C2_DMA_I(i) ""
+#else
 #define C2_DMA_I(i) "s_add_u32 m0, %[st], " C2_STR(i * 4096) "\n\tglobal_load_lds_dwordx4 %[vo" #i "], %[sb]\n\t"
+#endif
 #define C2_NODMA(i) ""
 #define C2_M(nt, mt) C2_MF "%[c" #nt #mt "], %[w" #nt "], %[a" #mt "], %[c" #nt #mt "]\n\t"
 #define C2_BLOCK(PRE, Ac, Wc, An, Wn, DMA, vo)                                                                 \
@@ -133,8 +144,9 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         const int cb = kt / 9, tap = kt - 9 * cb;
         return p.W + (long long)((tap * C2_C + cb * 64) * 2);
     };
-    auto a_dst = [&](int kt) -> unsigned { return m0_wave + (unsigned)((kt & 1) * C2_STAGE); };
-    auto w_dst = [&](int kt) -> unsigned { return m0_wave + (unsigned)((kt & 1) * C2_STAGE + C2_BM * C2_ROWB); };
+    // K step kt lives in A stage kt % 3 and W stage kt & 1
+    auto a_dst = [&](int k3) -> unsigned { return m0_wave + (unsigned)(k3 * C2_SLAB); };
+    auto w_dst = [&](int kt) -> unsigned { return m0_wave + (unsigned)(C2_WBASE + (kt & 1) * C2_SLAB); };
 #define C2_ISSUE8(dst, vo, sbase)                                                                             \
     {                                                                                                         \
         const unsigned d_ = (dst);                                                                            \
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
     // (address of sub-step 0) ^ (ks << 5)
     const unsigned off0 = (((unsigned)half) ^ (unsigned)((l31 >> 1) & 7)) << 4;
     const unsigned a_rd0 = lds0 + (unsigned)((wm * 128 + l31) * C2_ROWB) + off0;
-    const unsigned w_rd0 = lds0 + (unsigned)(C2_BM * C2_ROWB + (wnn * 128 + l31) * C2_ROWB) + off0;
+    const unsigned w_rd0 = lds0 + (unsigned)(C2_WBASE + (wnn * 128 + l31) * C2_ROWB) + off0;
 #define C2_RD(base, ks, stage_off) (((base) ^ (unsigned)((ks) << 5)) + (stage_off))
 
     f32x16 acc[16];  // acc[4 nt + mt]: channels wnn * 128 + 32 nt + (accumulator rows), output rows wm * 128 + 32 mt + (lanes)
@@ -159,10 +171,11 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     bf16x8 Ax[4], Wx[4], Ay[4], Wy[4];  // fragment sets X / Y alternate between sub-steps (4 per step: a step starts on X)
 
+    const int KL = KSTEPS - 1;
     C2_ISSUE8(a_dst(0), pa, a_base(0))
     C2_ISSUE8(w_dst(0), pw, w_base(0))
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    C2_ISSUE8(a_dst(1), pa, a_base(1))
+    C2_ISSUE8(a_dst(1), pa, a_base(min(1, KL)))
     {  // fragments of step 0, sub-step 0
         const unsigned an_ = a_rd0, wn_ = w_rd0;
         asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:4096\n\tds_read_b128 %2, %8 offset:8192\n\t"
@@ -173,63 +186,72 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
                      : "v"(an_), "v"(wn_)
                      : "memory");
     }
-    // K step kt: sub-step blocks 0..2 read on in stage kt & 1; block 0 also requests the W slab of step kt+1 (the other
-    // stage: free since the barrier that closed step kt-1).  Block 3 first waits for this wave's last fragments
-    // (inside the block: lgkmcnt) and for its share of step kt+1 (vmcnt), then the barrier publishes step kt+1 and
-    // frees stage kt & 1, into which the block requests the A slab of step kt+2 while it prefetches the first fragments
-    // of step kt+1.
+    // K step kt reads A stage kt % 3 and W stage kt & 1.  Block 0 requests the W slab of step kt + 1, block 1 the A slab of step
+    // kt + 2 - both into stages the barrier of step kt - 1 has freed, W first: block 3 waits for this wave's last fragments
+    // (lgkmcnt) and for its share of step kt + 1 with vmcnt(8), i.e. everything but the A slab just requested, then the barrier
+    // publishes step kt + 1.  The A slab comes from HBM: with two stages it had one K step (2048 cycles of MFMA) to arrive and
+    // the loop waited for it (without the wait: -10 %); now it has a step and a half.  W comes from L2.
 #ifdef C2_EXP_NO_VMWAIT  // timing experiment: the K loop without its wait for the next slabs (wrong results)
 #define C2_PRE3 "s_waitcnt lgkmcnt(0)\n\ts_barrier\n\t"
 #else
-#define C2_PRE3 "s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)\n\ts_barrier\n\t"
+#define C2_PRE3 "s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier\n\t"
 #endif
+#define C2_PRE3_ALL "s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)\n\ts_barrier\n\t"
+    // (LINEAR: branch-free, past the last K step the requests repeat the last slabs into stages nobody reads any more; the
+    // convolution branches instead - in the branch-free form hipcc spills the request offsets to scratch inside the loop)
+    int k3 = 0;  // kt % 3
     for (int kt = 0; kt < KSTEPS; ++kt) {
-        const unsigned so = (unsigned)((kt & 1) * C2_STAGE), sn = (unsigned)(((kt + 1) & 1) * C2_STAGE);
+        const int k3n = k3 == 2 ? 0 : k3 + 1, k3p = k3 == 0 ? 2 : k3 - 1;
+        const unsigned so_a = (unsigned)(k3 * C2_SLAB), so_w = (unsigned)((kt & 1) * C2_SLAB);
+        const unsigned sn_a = (unsigned)(k3n * C2_SLAB), sn_w = (unsigned)(((kt + 1) & 1) * C2_SLAB);
         {
-            const unsigned an_ = C2_RD(a_rd0, 1, so), wn_ = C2_RD(w_rd0, 1, so);
-            if (LINEAR || kt + 1 < KSTEPS) {  // LINEAR: branch-free, the last steps re-request their own slab
+            const unsigned an_ = C2_RD(a_rd0, 1, so_a), wn_ = C2_RD(w_rd0, 1, so_w);
+            const unsigned* vo = pw;
+            if (LINEAR || kt + 1 < KSTEPS) {
                 const unsigned st_ = w_dst(kt + 1);
-                const unsigned char* sb_ = w_base(LINEAR ? min(kt + 1, KSTEPS - 1) : kt + 1);
-                const unsigned* vo = pw;
+                const unsigned char* sb_ = w_base(LINEAR ? min(kt + 1, KL) : kt + 1);
                 C2_BLOCK("", Ax, Wx, Ay, Wy, C2_DMA_I, vo);
             } else {
                 const unsigned st_ = 0;
                 const unsigned char* sb_ = p.W;
-                const unsigned* vo = pw;
                 C2_BLOCK("", Ax, Wx, Ay, Wy, C2_NODMA, vo);
             }
         }
         {
-            const unsigned an_ = C2_RD(a_rd0, 2, so), wn_ = C2_RD(w_rd0, 2, so);
-            const unsigned st_ = 0;
-            const unsigned char* sb_ = p.W;
-            const unsigned* vo = pw;
-            C2_BLOCK("", Ay, Wy, Ax, Wx, C2_NODMA, vo);
+            const unsigned an_ = C2_RD(a_rd0, 2, so_a), wn_ = C2_RD(w_rd0, 2, so_w);
+            const unsigned* vo = pa;
+            if (LINEAR || kt + 2 < KSTEPS) {
+                const unsigned st_ = a_dst(k3p);  // (kt + 2) % 3
+                const unsigned char* sb_ = a_base(LINEAR ? min(kt + 2, KL) : kt + 2);
+                C2_BLOCK("", Ay, Wy, Ax, Wx, C2_DMA_I, vo);
+            } else {
+                const unsigned st_ = 0;
+                const unsigned char* sb_ = p.W;
+                C2_BLOCK("", Ay, Wy, Ax, Wx, C2_NODMA, vo);
+            }
         }
         {
-            const unsigned an_ = C2_RD(a_rd0, 3, so), wn_ = C2_RD(w_rd0, 3, so);
+            const unsigned an_ = C2_RD(a_rd0, 3, so_a), wn_ = C2_RD(w_rd0, 3, so_w);
             const unsigned st_ = 0;
             const unsigned char* sb_ = p.W;
             const unsigned* vo = pw;
             C2_BLOCK("", Ax, Wx, Ay, Wy, C2_NODMA, vo);
         }
         {
-            const unsigned an_ = a_rd0 + sn, wn_ = w_rd0 + sn;
-            if (LINEAR || kt + 2 < KSTEPS) {
-                const unsigned st_ = a_dst(kt + 2);
-                const unsigned char* sb_ = a_base(LINEAR ? min(kt + 2, KSTEPS - 1) : kt + 2);
-                const unsigned* vo = pa;
-                C2_BLOCK(C2_PRE3, Ay, Wy, Ax, Wx, C2_DMA_I, vo);
-            } else {
-                const unsigned st_ = 0;
-                const unsigned char* sb_ = p.W;
-                const unsigned* vo = pa;
+            const unsigned an_ = a_rd0 + sn_a, wn_ = w_rd0 + sn_w;
+            const unsigned st_ = 0;
+            const unsigned char* sb_ = p.W;
+            const unsigned* vo = pw;
+            if (LINEAR || kt + 2 < KSTEPS) {  // the A slab of step kt + 2 is this wave's eight youngest requests
                 C2_BLOCK(C2_PRE3, Ay, Wy, Ax, Wx, C2_NODMA, vo);
+            } else {
+                C2_BLOCK(C2_PRE3_ALL, Ay, Wy, Ax, Wx, C2_NODMA, vo);
             }
         }
+        k3 = k3n;
     }
     asm volatile("s_nop 13\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // MFMA results -> vector reads below
-    if constexpr (LINEAR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant requests of the last two steps
+    if constexpr (LINEAR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant requests of the last steps (they write this workgroup's LDS)
 
     if constexpr (LINEAR) {
         // ---- linear_out epilogue: (acc + bias) * scale + PE row, fp32, four consecutive channels of one row per store
