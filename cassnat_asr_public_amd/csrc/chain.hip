@@ -178,8 +178,9 @@ __device__ __forceinline__ void ch_add_channel(f32x16 (&acc)[8], unsigned tab_la
 //     source offsets of every block are compile-time constants, and the only per-group work is two base pointers;
 //   * a block = 8 MFMAs on the half-unit already in registers; the 8 ds_reads of the NEXT half-unit go two per gap
 //     behind MFMAs 0-3 (so their latency is covered by MFMAs 4-7), the wave's four refill DMAs behind MFMAs 4-7;
-//   * second-half blocks start with: own quarter of unit u+1 landed (counted vmcnt) -> s_barrier (publishes unit
-//     u+1; every wave has consumed unit u-1) -> M0 <- destination of this wave's quarter of unit u+7's slot.
+//   * second-half blocks of EVEN positions start with: own quarters of units u+1 and u+2 landed (counted vmcnt) ->
+//     s_barrier (publishes both; every wave has consumed unit u-1) -> M0 <- destination of this wave's quarter of unit
+//     u+7's slot; those of odd positions only set M0 (CH_PRE_BE / CH_PRE_BO).
 // The compiler pads its own MFMA -> vector-read sequences with wait states (s_nop 11 for this MFMA) but cannot see
 // into asm: a block whose accumulators the compiler may touch next ends with them itself (CH_DRAIN).
 #define CH_MF "v_mfma_f32_32x32x16_bf16 "
@@ -196,11 +197,24 @@ __device__ __forceinline__ void ch_add_channel(f32x16 (&acc)[8], unsigned tab_la
 // issued behind the ReLU section (LDS returns in order) - waiting for those as well exposed their whole latency once per tile
 // (FFN loop 95.9k -> 91.4k cycles)
 #define CH_PRE_A4 "s_waitcnt lgkmcnt(4)\n\t"
+// One barrier per TWO units (a barrier costs the matrix pipe ~80 cycles): the second-half block of an EVEN position waits for
+// this wave's quarters of the next two units (vmcnt(16): four units of requests may stay outstanding) and its barrier publishes
+// both; an odd position has neither.  Slot reuse needs no more: the requests of positions k and k + 1 go into the slots of units
+// whose last reads lie before position k's barrier.
+#define CH_PRE_BO(M0OFF) "s_add_u32 m0, %[m0w], " CH_STR(M0OFF) "\n\ts_waitcnt lgkmcnt(0)\n\t"
 #ifdef CH_EXP_NO_BARRIER  // timing experiment, only together with CH_EXP_NO_DMA and CH_EXP_NO_READ (nothing left to order)
-#define CH_PRE_B(M0OFF) "s_add_u32 m0, %[m0w], " CH_STR(M0OFF) "\n\ts_waitcnt lgkmcnt(0)\n\t"
+#define CH_PRE_BE(M0OFF) CH_PRE_BO(M0OFF)
 #else
-#define CH_PRE_B(M0OFF) "s_waitcnt vmcnt(20)\n\ts_barrier\n\ts_add_u32 m0, %[m0w], " CH_STR(M0OFF) "\n\ts_waitcnt lgkmcnt(0)\n\t"
+#define CH_PRE_BE(M0OFF) "s_waitcnt vmcnt(16)\n\ts_barrier\n\ts_add_u32 m0, %[m0w], " CH_STR(M0OFF) "\n\ts_waitcnt lgkmcnt(0)\n\t"
 #endif
+#define CH_PRE_B_0 CH_PRE_BE
+#define CH_PRE_B_1 CH_PRE_BO
+#define CH_PRE_B_2 CH_PRE_BE
+#define CH_PRE_B_3 CH_PRE_BO
+#define CH_PRE_B_4 CH_PRE_BE
+#define CH_PRE_B_5 CH_PRE_BO
+#define CH_PRE_B_6 CH_PRE_BE
+#define CH_PRE_B_7 CH_PRE_BO
 #ifdef CH_EXP_NO_DMA  // timing experiment (tools/chain_stamps.py): the blocks without their refill requests (stale ring: wrong results)
 #define CH_DMA0(SOFF) "v_add_u32 %[tv], " CH_STR(SOFF) ", %[vo]\n\t"
 #define CH_DMA1 ""
@@ -393,7 +407,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
         const uint4* sb_next = group_base(gpos + 1);
 #define CH_S1(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB)                                                     \
         CH_BLK1A(k, acc, Fa, bop, 0, Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN);                \
-        CH_BLK1A(k, acc, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, CH_DMA3, SB, CH_NODRAIN);
+        CH_BLK1A(k, acc, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B_##k(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, CH_DMA3, SB, CH_NODRAIN);
         asm volatile("s_nop 1" ::: "memory");  // the compiler's copies into the accumulators -> first MFMA
         CH_POSITIONS(CH_S1)
 #undef CH_S1
@@ -425,7 +439,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
                                          __builtin_shufflevector(b1v[2], b1v[3], 0, 1, 2, 3, 4, 5, 6, 7),      \
                                          0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);               \
             CH_BLK1("+", "v", "%[c]", xh, Fa, bop, 0, Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN); \
-            CH_BLK1("+", "v", "%[c]", xh, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, \
+            CH_BLK1("+", "v", "%[c]", xh, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_BE(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, \
                     CH_DMA3, SB, CH_DRAIN);                                                                    \
             {                                                                                                 \
                 /* (ReLU as an integer max on the fp32 bits, before the pack: a packed int16 max after it measured slower) */ \
@@ -443,7 +457,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
             // W2 unit at position K1: acc[nt] += W2 tile (s, nt) . relu(xh)
 #define CH_W2(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB, POST)                                               \
             CH_BLK2(acc, Fa, pb[0], Fb, RA_A, RK_A, CH_PRE_A4, "", "", "", "", SB, CH_NODRAIN);                 \
-            CH_BLK2(acc, Fb, pb[1], Fa, RA_B, RK_B, CH_PRE_B(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, CH_DMA3, SB, POST);
+            CH_BLK2(acc, Fb, pb[1], Fa, RA_B, RK_B, CH_PRE_BO(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, CH_DMA3, SB, POST);
             CH_W1(0, ra0, 8, ra0, 16, 0x1C000, 0x1C000, sb_cur)
             CH_W2(1, ra0, 24, ra0, 32, 0x0, 0x0, sb_next, CH_NODRAIN)
             CH_W1(2, ra0, 40, ra0, 48, 0x4000, 0x4000, sb_next)
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
                                         __builtin_shufflevector(btv[2], btv[3], 0, 1, 2, 3, 4, 5, 6, 7),      \
                                         0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);  /* bias = initial value */ \
             CH_BLK1("+", "v", "%[c]", q, Fa, bop, 0, Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN); \
-            CH_BLK1("+", "v", "%[c]", q, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, \
+            CH_BLK1("+", "v", "%[c]", q, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B_##k(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, \
                     CH_DMA3, SB, CH_DRAIN);                                                                    \
             {                                                                                                 \
                 bf16x4 o_[4];                                                                                 \
