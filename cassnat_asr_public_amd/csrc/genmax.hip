@@ -3,11 +3,15 @@
 // path: the (M, V) logits tensor (160 MB at M = 8000, V = 5000) never exists.  (Beam search and the capture mode, which
 // need full log-probability rows, keep the GEMM + row kernel.)
 //
-// Same streaming machinery as the fused FFN (fused.hip): a workgroup owns 32*MT rows; its activations sit in registers
-// as MFMA B fragments; every wave streams ITS quarter of the vocabulary as pre-tiled 1-KiB weight fragments by LDS-DMA
-// into a private 32-slot ring (2 vocabulary tiles of 32 rows x 16 k-steps) with counted vmcnt waits.  The product is
-// computed swapped (logits^T: vocabulary on accumulator rows, the row index on the lane) so the running max / arg-max /
-// sum-of-exponentials update is 16 in-lane values per tile; halves and waves are merged once at the end.
+// A workgroup owns 32*MT rows: their activations sit in LDS as MFMA B fragments (read two per MFMA, one group ahead); every
+// wave owns a quarter of the vocabulary and streams ITS pre-tiled 1-KiB weight fragments straight from L2 into four
+// rotating register sets (buffer loads: descriptor + scalar tile offset + lane offset; three groups of four fragments in
+// flight) - the stream is read once and by one wave, so an LDS hop buys nothing (the first version had a private LDS-DMA
+// ring per wave: two MFMAs per request at ~70 issue cycles a request, reads -> wait -> MFMAs in series: 3.9k cycles per
+// vocabulary tile of 32 MFMAs).  The product is computed swapped (logits^T: vocabulary on accumulator rows, the row index on
+// the lane) so the running max / arg-max / sum-of-exponentials update is 16 in-lane values per tile; halves and waves are
+// merged once at the end.  The kernel stays under 256 registers per lane: two workgroups share a CU, one's update
+// arithmetic runs beside the other's MFMAs.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -28,54 +32,49 @@ struct GenmaxParams {
     int tgt_U, tgt_ld;
 };
 
-constexpr int GM_RING_BYTES = 32 * 1024;
+constexpr int GM_MAX_VTW = 48;  // vocabulary tiles per wave (V <= 6144)
+template <int MT> constexpr int gm_lds_bytes() {
+    constexpr int main_ = MT * 16384 + 4 * GM_MAX_VTW * 32 * 4, merge_ = 4 * 32 * MT * 16;
+    return main_ > merge_ ? main_ : merge_;
+}
 
 // LSE = false: the arg-max alone (no exponentials, no log-sum-exp): what the CTC alignment of the greedy path needs
 template <int MT, bool GATHER, bool LSE = true>
-__global__ __launch_bounds__(256) void genmax_kernel(GenmaxParams p) {
+__global__ __launch_bounds__(256, 2) void genmax_kernel(GenmaxParams p) {
     constexpr int BM = 32 * MT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.x * BM;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    unsigned char* ring = smem + wave_u * GM_RING_BYTES;
-    float* merge = reinterpret_cast<float*>(smem);  // epilogue: [4 waves][BM][4] (aliases the rings)
+    unsigned char* xs = smem;                                         // [MT][16 k-steps][64 lanes][16 B]: B fragments of the rows
+    float* bias_s = reinterpret_cast<float*>(smem + MT * 16384);      // [4][vtw * 32]
+    float* merge = reinterpret_cast<float*>(smem);                    // epilogue: [4 waves][BM][4] (aliases the above)
 
-    const int nrt = p.vtw / 2;  // ring tiles (2 vocabulary tiles each) per wave
-    const uint4* w = p.wp + (long long)wave_u * p.vtw * 16 * 64 + lane;
-#define GM_DMA(src, slot)                                                                              \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
-                                     (__attribute__((address_space(3))) void*)(ring + (slot) * 1024), 16, 0, 0)
-    // biases of this wave in 2*ceil(vtw/2)... registers: register j, lane 32*p+i = bias of row i of vocabulary tile 2j+p
-    constexpr int NBQ = 24;  // up to 48 vocabulary tiles per wave (V <= 6144)
-    float bq[NBQ];
-#pragma unroll
-    for (int j = 0; j < NBQ; ++j) {
-        const int pos = 2 * j + half;
-        bq[j] = pos < p.vtw ? p.bp[(long long)wave_u * p.vtw * 32 + pos * 32 + l31] : 0.f;
-    }
-    // activations as B fragments: lane holds h[m = l31 (+32 mt)][16 ks + 8 half + j]
-    bf16x8 ef[MT][16];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int m = m0 + 32 * mt + l31;
+    // the wave's stream as a buffer resource: a request is descriptor + scalar offset of the fragment + lane offset
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.wp)) + (size_t)wave_u * p.vtw * 16384, 0, p.vtw * 16384, 0x00020000);
+    const int lane_off = lane * 16;
+#define GM_WFRAG(tile, ks) \
+    __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off, ((tile) * 16 + (ks)) * 1024, 0))
+    // group g (0..3) of a vocabulary tile = the fragments of k-steps 4g..4g+3, in register set g
+    bf16x8 w0a, w0b, w0c, w0d, w1a, w1b, w1c, w1d, w2a, w2b, w2c, w2d, w3a, w3b, w3c, w3d;
+#define GM_LDW(S_, tile, g)                                                                            \
+    w##S_##a = GM_WFRAG(tile, 4 * (g) + 0); w##S_##b = GM_WFRAG(tile, 4 * (g) + 1);                    \
+    w##S_##c = GM_WFRAG(tile, 4 * (g) + 2); w##S_##d = GM_WFRAG(tile, 4 * (g) + 3);
+    GM_LDW(0, 0, 0) GM_LDW(1, 0, 1) GM_LDW(2, 0, 2)
+
+    // activations -> LDS: 16-byte chunk c = 2 ks + half of row r at fragment (mt = r >> 5, ks), lane slot 32 half + (r & 31)
+    for (int c = tid; c < BM * 32; c += 256) {
+        const int r = c >> 5, ch = c & 31;
+        int m = m0 + r;
         if (m >= p.M) m = p.M - 1;
-        const unsigned char* row = reinterpret_cast<const unsigned char*>(p.h + (long long)m * 256) + 16 * half;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) ef[mt][ks] = __builtin_bit_cast(bf16x8, ld16(row + 32 * ks));
+        const uint4 v = ld16(reinterpret_cast<const unsigned char*>(p.h + (long long)m * 256) + 16 * ch);
+        st16(xs + ((((r >> 5) * 16 + (ch >> 1)) * 64) + (ch & 1) * 32 + (r & 31)) * 16, v);
     }
-    // keep the plain loads above out of the DMA-pipelined region (hipcc would drain the DMA queue for them)
-#pragma unroll
-    for (int j = 0; j < NBQ; ++j) asm volatile("" : "+v"(bq[j]));
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(ef[mt][ks]));
-#pragma unroll
-    for (int i = 0; i < 32; ++i) GM_DMA(w + (long long)i * 64, i);
+    for (int i = tid; i < 4 * p.vtw * 32; i += 256) bias_s[i] = p.bp[i];
+    __syncthreads();
 
-    const unsigned slot_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(ring + lane * 16);
     float m_run[MT], s_run[MT];
     int i_run[MT];
     int tg[MT];      // GATHER: this lane's rows' target labels and their logits once seen
@@ -94,99 +93,81 @@ __global__ __launch_bounds__(256) void genmax_kernel(GenmaxParams p) {
         }
     }
 
-#define GM_STR2(x) #x
-#define GM_STR(x) GM_STR2(x)
-    // group g (0-3: first vocabulary tile of the ring tile, 4-7: second): fragments of k-steps 4(g&3)..+3
-#define GM_GROUP(g, WAITN, REFILL)                                                                            \
-    {                                                                                                         \
-        bf16x8 wf0, wf1, wf2, wf3;                                                                            \
-        asm volatile("s_waitcnt vmcnt(" GM_STR(WAITN) ")\n\t"                                                 \
-                     "ds_read_b128 %0, %4 offset:" GM_STR((4 * (g) + 0) * 1024) "\n\t"                        \
-                     "ds_read_b128 %1, %4 offset:" GM_STR((4 * (g) + 1) * 1024) "\n\t"                        \
-                     "ds_read_b128 %2, %4 offset:" GM_STR((4 * (g) + 2) * 1024) "\n\t"                        \
-                     "ds_read_b128 %3, %4 offset:" GM_STR((4 * (g) + 3) * 1024)                                \
-                     : "=&v"(wf0), "=&v"(wf1), "=&v"(wf2), "=&v"(wf3)                                         \
-                     : "v"(slot_a)                                                                            \
-                     : "memory");                                                                             \
-        REFILL                                                                                                \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf0), "+v"(wf1), "+v"(wf2), "+v"(wf3) :: "memory");        \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                   \
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, ef[mt][4 * ((g) & 3) + 0], acc[mt], 0, 0, 0); \
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, ef[mt][4 * ((g) & 3) + 1], acc[mt], 0, 0, 0); \
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf2, ef[mt][4 * ((g) & 3) + 2], acc[mt], 0, 0, 0); \
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf3, ef[mt][4 * ((g) & 3) + 3], acc[mt], 0, 0, 0); \
-        }                                                                                                     \
-    }
-#define GM_REFILL(g) { _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
-        GM_DMA(w + ((long long)rnext * 32 + 4 * (g) + j) * 64, 4 * (g) + j); }
-#define GM_ZERO()                                                                                             \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-    // fold one finished vocabulary tile (position pos within this wave's slice) into the running statistics
-#define GM_FOLD(pos)                                                                                          \
-    {                                                                                                         \
-        const int src0 = 32 * ((pos) & 1) + 4 * half;                                                         \
-        const int vbase = 32 * (wave_u * p.vtw + (pos)) + 4 * half;                                           \
-        float bv[16];                                                                                         \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) _Pragma("unroll") for (int e = 0; e < 4; ++e)           \
-            bv[4 * g + e] = __shfl(bq[0], src0 + 8 * g + e);                                                  \
-        if ((pos) & 1) { _Pragma("unroll") for (int j = 0; j < NBQ - 1; ++j) bq[j] = bq[j + 1]; }             \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                   \
-            float tmax = -INFINITY;                                                                           \
-            int tidx = 0;                                                                                     \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
-                const float v = acc[mt][r] + bv[r];                                                           \
-                acc[mt][r] = v;                                                                               \
-                if (v > tmax) { tmax = v; tidx = vbase + (r & 3) + 8 * (r >> 2); }                            \
-                if constexpr (GATHER) { if (vbase + (r & 3) + 8 * (r >> 2) == tg[mt]) tv[mt] = v; }           \
-            }                                                                                                 \
-            if (tmax > m_run[mt]) {                                                                           \
-                if constexpr (LSE) s_run[mt] *= __expf(m_run[mt] - tmax);                                     \
-                m_run[mt] = tmax;                                                                             \
-                i_run[mt] = tidx;                                                                             \
-            }                                                                                                 \
-            if constexpr (LSE) {                                                                              \
-                float ps = 0.f;                                                                               \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) ps += __expf(acc[mt][r] - m_run[mt]);          \
-                s_run[mt] += ps;                                                                              \
-            }                                                                                                 \
-        }                                                                                                     \
+    // activation fragments of a group: xq[mt][j] = k-step 4g + j of M-tile mt; two sets, group g + 1's reads ride beside group g's MFMAs
+    const unsigned char* xfrag = xs + lane * 16;
+    bf16x8 x0[MT][4], x1[MT][4];
+#define GM_LDX(X_, g)                                                                                  \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int j = 0; j < 4; ++j)    \
+        X_[mt][j] = *reinterpret_cast<const bf16x8*>(xfrag + ((mt * 16 + 4 * (g) + j) * 64) * 16);
+    // group g: 4 MT MFMAs on set WS / XS; requests group g + 3 (set WN: of this tile, or 0..2 of the next) and reads group g + 1's
+    // activations (XN) in the MFMA gaps
+#define GM_GROUP(g, WS, XS, WN, XN, NT, NG)                                                            \
+    GM_LDX(XN, ((g) + 1) & 3) GM_LDW(WN, NT, NG)                                                       \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                \
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##a, XS[mt][0], acc[mt], 0, 0, 0);      \
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##b, XS[mt][1], acc[mt], 0, 0, 0);      \
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##c, XS[mt][2], acc[mt], 0, 0, 0);      \
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##d, XS[mt][3], acc[mt], 0, 0, 0);      \
+    }                                                                                                  \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
+        _Pragma("unroll") for (int r_ = 0; r_ < MT; ++r_) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+        }                                                                                              \
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                                              \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);
+    // fold one finished vocabulary tile into the running statistics
+#define GM_FOLD(tile)                                                                                  \
+    {                                                                                                  \
+        const int vbase = 32 * (wave_u * p.vtw + (tile)) + 4 * half;                                   \
+        const float* bt_ = bias_s + 32 * (wave_u * p.vtw + (tile)) + 4 * half;                         \
+        float bv[16];                                                                                  \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                \
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bt_ + 8 * g);                             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) bv[4 * g + e] = b4[e];                       \
+        }                                                                                              \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                            \
+            float tmax = -INFINITY;                                                                    \
+            int tidx = 0;                                                                              \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                           \
+                const float v = acc[mt][r] + bv[r];                                                    \
+                acc[mt][r] = v;                                                                        \
+                if (v > tmax) { tmax = v; tidx = vbase + (r & 3) + 8 * (r >> 2); }                     \
+                if constexpr (GATHER) { if (vbase + (r & 3) + 8 * (r >> 2) == tg[mt]) tv[mt] = v; }    \
+            }                                                                                          \
+            if (tmax > m_run[mt]) {                                                                    \
+                if constexpr (LSE) s_run[mt] *= __expf(m_run[mt] - tmax);                              \
+                m_run[mt] = tmax;                                                                      \
+                i_run[mt] = tidx;                                                                      \
+            }                                                                                          \
+            if constexpr (LSE) {                                                                       \
+                float ps = 0.f;                                                                        \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) ps += __expf(acc[mt][r] - m_run[mt]);   \
+                s_run[mt] += ps;                                                                       \
+            }                                                                                          \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;                           \
+        }                                                                                              \
     }
 
     f32x16 acc[MT];
-    int rt = 0, rnext = 0;
-    for (; rt + 1 < nrt; ++rt) {
-        GM_ZERO()
-        if (rt == 0) {
-            GM_GROUP(0, 28, )
-        } else {
-            GM_GROUP(0, 24, GM_REFILL(7))
-        }
-        rnext = rt + 1;
-        GM_GROUP(1, 24, GM_REFILL(0)) GM_GROUP(2, 24, GM_REFILL(1)) GM_GROUP(3, 24, GM_REFILL(2))
-        GM_FOLD(2 * rt)
-        GM_ZERO()
-        GM_GROUP(4, 24, GM_REFILL(3)) GM_GROUP(5, 24, GM_REFILL(4)) GM_GROUP(6, 24, GM_REFILL(5))
-        GM_GROUP(7, 24, GM_REFILL(6))
-        GM_FOLD(2 * rt + 1)
-    }
-    {
-        GM_ZERO()
-        if (rt == 0) {
-            GM_GROUP(0, 28, )
-        } else {
-            GM_GROUP(0, 24, GM_REFILL(7))
-        }
-        GM_GROUP(1, 24, ) GM_GROUP(2, 20, ) GM_GROUP(3, 16, )
-        GM_FOLD(2 * rt)
-        GM_ZERO()
-        GM_GROUP(4, 12, ) GM_GROUP(5, 8, ) GM_GROUP(6, 4, ) GM_GROUP(7, 0, )
-        GM_FOLD(2 * rt + 1)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    GM_LDX(x0, 0)
+    for (int t = 0; t < p.vtw; ++t) {
+        const int nxt = t + 1 < p.vtw ? t + 1 : t;  // after the last tile: three groups requested again, unused
+        GM_GROUP(0, 0, x0, 3, x1, t, 3)
+        GM_GROUP(1, 1, x1, 0, x0, nxt, 0)
+        GM_GROUP(2, 2, x0, 1, x1, nxt, 1)
+        GM_GROUP(3, 3, x1, 2, x0, nxt, 2)
+        GM_FOLD(t)
     }
 #undef GM_GROUP
-#undef GM_REFILL
-#undef GM_ZERO
 #undef GM_FOLD
-#undef GM_DMA
+#undef GM_LDX
+#undef GM_LDW
+#undef GM_WFRAG
 
     // ---- merge the two lane halves, then the four waves (ties: the lower vocabulary index wins, as torch.argmax)
 #pragma unroll
@@ -199,7 +180,7 @@ __global__ __launch_bounds__(256) void genmax_kernel(GenmaxParams p) {
         m_run[mt] = nm;
         if constexpr (GATHER) tv[mt] = fmaxf(tv[mt], __shfl_xor(tv[mt], 32));  // exactly one lane half of one wave saw it
     }
-    __syncthreads();  // all rings idle (last wait was vmcnt(0)); reuse LDS for the cross-wave merge
+    __syncthreads();  // every wave is done with the activation fragments and the bias table: reuse LDS for the cross-wave merge
     if (half == 0) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -237,11 +218,13 @@ __global__ __launch_bounds__(256) void genmax_kernel(GenmaxParams p) {
 }
 
 template <int MT, bool GATHER, bool LSE> static int launch_genmax_variant(const GenmaxParams& p, hipStream_t s) {
-    constexpr int lds = 4 * GM_RING_BYTES;
+    // (sized for this vocabulary, not for the largest one: at V = 5000 three workgroups fit a CU's LDS)
+    const int main_ = MT * 16384 + 4 * p.vtw * 32 * 4, merge_ = 4 * 32 * MT * 16;
+    const int lds = main_ > merge_ ? main_ : merge_;
     static CnAttrOnce attr_once;
     int attr_dev;
     if (attr_once.need(&attr_dev)) {
-        CN_HIP_CHECK(hipFuncSetAttribute((const void*)genmax_kernel<MT, GATHER, LSE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)genmax_kernel<MT, GATHER, LSE>, hipFuncAttributeMaxDynamicSharedMemorySize, gm_lds_bytes<MT>()));
         attr_once.mark(attr_dev);
     }
     hipLaunchKernelGGL((genmax_kernel<MT, GATHER, LSE>), dim3(cn_ceil_div(p.M, 32 * MT)), dim3(256), lds, s, p);
@@ -256,7 +239,7 @@ int genmax_vtw(int V) {
 
 int launch_genmax(const GenmaxArgs& a, hipStream_t s) {
     const int vtw = genmax_vtw(a.V);
-    if (a.d != 256 || a.V < 1 || vtw > 48) {
+    if (a.d != 256 || a.V < 1 || vtw > GM_MAX_VTW) {
         cn_set_error("genmax: needs d_model == 256 and V <= 6144");
         return -1;
     }
