@@ -62,7 +62,19 @@ __global__ __launch_bounds__(256, 2) void genmax_kernel(GenmaxParams p) {
 #define GM_LDW(S_, tile, g)                                                                            \
     w##S_##a = GM_WFRAG(tile, 4 * (g) + 0); w##S_##b = GM_WFRAG(tile, 4 * (g) + 1);                    \
     w##S_##c = GM_WFRAG(tile, 4 * (g) + 2); w##S_##d = GM_WFRAG(tile, 4 * (g) + 3);
-    GM_LDW(0, 0, 0) GM_LDW(1, 0, 1) GM_LDW(2, 0, 2)
+    // every workgroup walks its vocabulary tiles in a rotation of its own (ties go to the lower index whatever the order): the
+    // workgroups of a launch then do not pull the same L2 lines at the same moment
+    const int rot = (int)((blockIdx.x * 7u) % (unsigned)p.vtw);
+#define GM_TT(t) ((t) + rot >= p.vtw ? (t) + rot - p.vtw : (t) + rot)
+    {
+        const int t0 = GM_TT(0);
+        GM_LDW(0, t0, 0) GM_LDW(1, t0, 1) GM_LDW(2, t0, 2)
+    }
+#ifdef GM_EXP_NO_LOAD  // timing experiments (wrong results): the loop without its weight requests / without the update arithmetic
+#define GM_LDW_LOOP(S_, tile, g)
+#else
+#define GM_LDW_LOOP(S_, tile, g) GM_LDW(S_, tile, g)
+#endif
 
     // activations -> LDS: 16-byte chunk c = 2 ks + half of row r at fragment (mt = r >> 5, ks), lane slot 32 half + (r & 31)
     for (int c = tid; c < BM * 32; c += 256) {
@@ -102,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void genmax_kernel(GenmaxParams p) {
     // group g: 4 MT MFMAs on set WS / XS; requests group g + 3 (set WN: of this tile, or 0..2 of the next) and reads group g + 1's
     // activations (XN) in the MFMA gaps
 #define GM_GROUP(g, WS, XS, WN, XN, NT, NG)                                                            \
-    GM_LDX(XN, ((g) + 1) & 3) GM_LDW(WN, NT, NG)                                                       \
+    GM_LDX(XN, ((g) + 1) & 3) GM_LDW_LOOP(WN, NT, NG)                                                  \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                \
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##a, XS[mt][0], acc[mt], 0, 0, 0);      \
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##b, XS[mt][1], acc[mt], 0, 0, 0);      \
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void genmax_kernel(GenmaxParams p) {
                 if (v > tmax) { tmax = v; tidx = vbase + (r & 3) + 8 * (r >> 2); }                     \
                 if constexpr (GATHER) { if (vbase + (r & 3) + 8 * (r >> 2) == tg[mt]) tv[mt] = v; }    \
             }                                                                                          \
-            if (tmax > m_run[mt]) {                                                                    \
+            if (tmax > m_run[mt] || (tmax == m_run[mt] && tidx < i_run[mt])) {                         \
                 if constexpr (LSE) s_run[mt] *= __expf(m_run[mt] - tmax);                              \
                 m_run[mt] = tmax;                                                                      \
                 i_run[mt] = tidx;                                                                      \
@@ -156,18 +168,29 @@ __global__ __launch_bounds__(256, 2) void genmax_kernel(GenmaxParams p) {
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
     GM_LDX(x0, 0)
     for (int t = 0; t < p.vtw; ++t) {
-        const int nxt = t + 1 < p.vtw ? t + 1 : t;  // after the last tile: three groups requested again, unused
-        GM_GROUP(0, 0, x0, 3, x1, t, 3)
+        const int cur = GM_TT(t);
+        const int nxt = GM_TT(t + 1 < p.vtw ? t + 1 : t);  // after the last tile: three groups requested again, unused
+        GM_GROUP(0, 0, x0, 3, x1, cur, 3)
         GM_GROUP(1, 1, x1, 0, x0, nxt, 0)
         GM_GROUP(2, 2, x0, 1, x1, nxt, 1)
         GM_GROUP(3, 3, x1, 2, x0, nxt, 2)
-        GM_FOLD(t)
+#ifndef GM_EXP_NO_FOLD
+        GM_FOLD(cur)
+#else  // (one use of every accumulator keeps the products alive)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            m_run[mt] = fmaxf(m_run[mt], acc[mt][0]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        }
+#endif
     }
 #undef GM_GROUP
 #undef GM_FOLD
 #undef GM_LDX
 #undef GM_LDW
 #undef GM_WFRAG
+#undef GM_TT
 
     // ---- merge the two lane halves, then the four waves (ties: the lower vocabulary index wins, as torch.argmax)
 #pragma unroll
