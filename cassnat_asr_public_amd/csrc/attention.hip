@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                 float tmax = sc[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * p.scale;
+                tmax = xhalf_max(tmax) * p.scale;
                 const float m_new = fmaxf(m_run, tmax);
                 alpha = __expf(m_run - m_new);
                 m_run = m_new;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                         tmax = fmaxf(tmax, v);
                     }
                 }
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                tmax = xhalf_max(tmax);
                 const float m_new = fmaxf(m_run, tmax);
                 alpha = __expf(m_run - m_new);
                 m_run = m_new;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
 
     AT_STAMP(3)
     if (!wave_active) return;
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = xhalf_sum(l_run);
     // REL: softmax(...).masked_fill(mask == 0, 0) leaves a row without any allowed key at zero (attention.py:133-134)
     const float inv = (REL && m_run == CN_NEG_FILL) ? 0.f : 1.f / l_tot;
     if constexpr (sizeof(T) == 2) {

@@ -132,6 +132,26 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += cn_dpp<0x143, 0xc, false>(0.f, v);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Combine a value with its partner in the other half-wave (lane ^ 32) on the VALU: v_permlane32_swap of two copies leaves
+// {lo, lo} in one and {hi, hi} in the other, so every lane holds both halves' values - no LDS round trip as with ds_bpermute.
+// (Written out: given the same value twice, hipcc folds the builtin's two results into one.  s_nop 1 = the two wait states
+// between a VALU write of an operand and the swap.)  All 64 lanes must be active.
+__device__ __forceinline__ void xhalf_pair(float v, float& lo, float& hi) {
+    lo = v;
+    hi = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+}
+__device__ __forceinline__ float xhalf_max(float v) {
+    float lo, hi;
+    xhalf_pair(v, lo, hi);
+    return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    float lo, hi;
+    xhalf_pair(v, lo, hi);
+    return lo + hi;
+}
+
 // N independent sums, step by step side by side: the DPP steps of one chain are each other's hazard distance for the next
 template <int N>
 __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
