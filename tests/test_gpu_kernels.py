@@ -600,3 +600,28 @@ def test_generator_argmax_fused_bf16(M, V):
     assert (arg.cpu()[clear] == ref.argmax(-1)[clear].int()).all()
     assert (arg.cpu() >= 0).all() and (arg.cpu() < V).all()
     assert (mlp.cpu() - ref.max(-1).values).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("M,V", [(700, 5000), (40, 1028)])
+def test_generator_argmax_ties_go_to_the_lower_index(M, V):
+    """genmax.hip walks its vocabulary tiles in a rotation that differs per workgroup; among EXACTLY equal logits the lower
+    index wins whatever the order (torch.argmax: first maximum).  Every vocabulary row appears twice, far apart, with the same
+    bias: all products are bit-identical pairs (same operands, same accumulation order)."""
+    g = torch.Generator().manual_seed(V)
+    h = torch.randn(M, 256, generator=g)
+    half = V // 2
+    w0 = torch.randn(half, 256, generator=g) / 16
+    b0 = 0.1 * torch.randn(half, generator=g)
+    w = torch.cat([w0, w0, torch.zeros(V - 2 * half, 256)]).contiguous()
+    b = torch.cat([b0, b0, torch.full((V - 2 * half,), -30.0)]).contiguous()
+    ref = F.linear(rounded(h, "bf16"), rounded(w0, "bf16"), b0)
+    hd = dev(h, torch.bfloat16)
+    arg = torch.full((M,), -1, dtype=torch.int32, device="cuda")
+    mlp = torch.full((M,), float("nan"), dtype=torch.float32, device="cuda")
+    hip.check(hip.lib().cn_op_genmax(p(hd), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), M, V, p(arg), p(mlp), stream()))
+    torch.cuda.synchronize()
+    a = arg.cpu()
+    assert (a >= 0).all() and (a < half).all(), "a tie between v and v + V/2 must resolve to v"
+    top2 = torch.topk(ref, 2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert (a[clear] == ref.argmax(-1)[clear].int()).all()
