@@ -11,6 +11,7 @@ order.  ``bench.py`` measures exactly this object; ``tasks.cassnat_task.CassNATT
 The reference has no counterpart (it decodes batch after batch, src/tasks/cassnat_task.py:317-356); results are the same
 hypotheses in the same order.
 """
+import os
 import queue
 import threading
 
@@ -43,6 +44,9 @@ class _Job:
         # per pass: 3 3 2 2 2 2 2 2 2, not 3 3 3 3 3 2 1 1 1 - so that the pipelines finish together without one-batch passes
         c = max(1, coalesce)
         self.passes_left = None if total is None else n * max(1, -(-total // (n * c)))
+        # experiment hook (tools/scripts/r02_plan.sh): CASSNAT_PASS_PLAN="10,4,6" = explicit pass sizes, in the order they are taken
+        plan = os.environ.get("CASSNAT_PASS_PLAN")
+        self.plan = [int(x) for x in plan.split(",")] if plan else None
         self.lock = threading.Lock()
         self.cv = threading.Condition()
         self.slots = {}          # index -> queue of one (tag, records, event)
@@ -151,7 +155,9 @@ class DecodePipelines:
                 # further batches of the same shape ride along; another shape waits for the next pass.  A list of known length
                 # goes in passes of equal size (see _Job)
                 want = self.coalesce
-                if job.left is not None:
+                if job.plan:
+                    want = min(want, job.plan.pop(0))
+                elif job.left is not None:
                     want = min(want, max(1, -(-job.left // max(1, job.passes_left))))
                     job.passes_left = max(1, job.passes_left - 1)
                 while len(items) < want:
