@@ -247,6 +247,24 @@ def test_decode_pipelines_equal_the_plain_loop():
     for (tag, hyps, scores), (wh, ws) in zip(got2, want2):
         assert hyps == wh, tag
         assert list(scores) == ws, tag
+    # bench.py's width: up to ten batches per pass (a list of 13 equal shapes on two pipelines goes as 7 + 6)
+    wide, want3 = [], []
+    for k in range(13):
+        lens = sorted((int(x) for x in rng.integers(1, 78, size=4)), reverse=True)
+        lens[0] = 77
+        wide.append(synth.make_feats(4, 77, 80, lengths=lens, seed=500 + k))
+    for feats, sizes in wide:
+        src = torch.from_numpy(feats)
+        with torch.no_grad():
+            out, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, args)
+        want3.append(([s[0]["hyp"] for s in out], [s[0]["score"] for s in out]))
+    pipes3 = DecodePipelines(model, 2, 4, 90, coalesce=10)
+    got3 = list(pipes3.decode([(torch.from_numpy(f), torch.from_numpy(s), k) for k, (f, s) in enumerate(wide)], args, sos=1))
+    pipes3.close()
+    assert [t for t, _, _ in got3] == list(range(13))
+    for (tag, hyps, scores), (wh, ws) in zip(got3, want3):
+        assert hyps == wh, tag
+        assert list(scores) == ws, tag
 
 
 def test_lm_scoring_bf16_fast_path_against_the_fp32_engine():
