@@ -271,13 +271,40 @@ class DecodePipelines:
                 for _ in range(self.n):  # every worker has left the job (its stream is drained) before the next one starts
                     job.finished.acquire()
 
-    def decode(self, batches, args, sos=1, gather=False, as_lists=True):
+    def decode(self, batches, args, sos=1, gather=False, as_lists=True, gather_every=None):
         """Hypotheses on the host, in order: yields ``(tag, hyps, scores)`` with ``hyps`` a list of token lists starting
         with ``sos`` (what ``beam_decode`` returns as ``['hyp']``), or with ``as_lists=False`` the arrays ``(tokens (N, S),
-        lengths (N,))`` of ``dist.unpack_records``.  ``gather=True``: every record set goes through the per-batch all-gather
-        of the multi-GPU path first (rank-major concatenation)."""
-        for tag, rec in self.records(batches, args, sos, host=not gather):
-            if gather:
-                rec = cdist.all_gather_records(rec)
-            hyps, scores = cdist.unpack_records(rec, as_lists=as_lists)
-            yield tag, hyps, scores
+        lengths (N,))`` of ``dist.unpack_records``.  ``gather=True``: the multi-GPU path - every step's records of all ranks,
+        rank-major.  The all-gather (and the copy home) is issued once per ``gather_every`` consecutive steps of equal shape
+        (default: the pipelines' batches per pass; SURVEY 8e: "once per batch (or once per N batches)"), by step index - the
+        same sequence of collectives on every rank whatever the pipelines' timing; every rank must decode the same number of
+        steps."""
+        if not gather:
+            for tag, rec in self.records(batches, args, sos, host=True):
+                hyps, scores = cdist.unpack_records(rec, as_lists=as_lists)
+                yield tag, hyps, scores
+            return
+        group = max(1, int(gather_every or self.coalesce))
+        pending = []
+
+        def flush():
+            recs = [r for _, r in pending]
+            nb, width = recs[0].shape
+            everyone = cdist.all_gather_records(torch.cat(recs, 0) if len(recs) > 1 else recs[0]).cpu()  # one collective, one copy
+            world = everyone.shape[0] // (len(recs) * nb)
+            steps = everyone.view(world, len(recs), nb, width)
+            out = [(tag, cdist.unpack_records(steps[:, j].reshape(world * nb, width), as_lists=as_lists)) for j, (tag, _) in enumerate(pending)]
+            pending.clear()
+            return out
+
+        for tag, rec in self.records(batches, args, sos):
+            if pending and tuple(rec.shape) != tuple(pending[0][1].shape):
+                for t_, (h_, s_) in flush():
+                    yield t_, h_, s_
+            pending.append((tag, rec))
+            if len(pending) == group:
+                for t_, (h_, s_) in flush():
+                    yield t_, h_, s_
+        if pending:
+            for t_, (h_, s_) in flush():
+                yield t_, h_, s_

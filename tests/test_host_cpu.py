@@ -333,3 +333,58 @@ def test_decode_pipelines_cut_a_list_of_known_length_into_equal_passes():
             assert sizes == want, sizes
         for p in m.passes:  # consecutive batches, in order
             assert p == list(range(p[0], p[0] + len(p)))
+
+
+_WORKER_PIPES = r"""
+import os, sys, time, torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from cassnat_asr_public_amd.pipeline import DecodePipelines
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=rank, world_size=world)
+
+class StubEngine:
+    def close(self):
+        pass
+
+class StubModel:
+    def new_engine(self, batch, frames, with_weights=True, share=None):
+        return StubEngine()
+    def decode_device(self, feats, ratio, args, sos, engine=None, sub_batch=0):
+        ks = [int(feats[j, 0, 0]) for j in range(feats.shape[0])]
+        time.sleep(0.001 * (1 + rank))  # the ranks' pipelines run at different speeds
+        hyp = torch.tensor([[sos, 10 + k, 100 + rank] for k in ks], dtype=torch.int32)
+        return hyp, torch.full((len(ks),), 3, dtype=torch.int32), torch.tensor([float(k) + 0.25 * rank for k in ks], dtype=torch.float64)
+
+# 23 steps of two utterances each; steps 9..11 have another shape (the gather groups break there)
+items = []
+for k in range(23):
+    t = 6 if 9 <= k < 12 else 4
+    items.append((torch.stack([torch.full((t, 2), float(2 * k)), torch.full((t, 2), float(2 * k + 1))]), torch.ones(2), k))
+pipes = DecodePipelines(StubModel(), 2, 2, 6, coalesce=4)
+out = list(pipes.decode(items, args=None, sos=1, gather=True))
+pipes.close()
+assert [t for t, _, _ in out] == list(range(23))
+for k, hyps, scores in out:  # rank-major: rank 0's two utterances, then rank 1's
+    assert hyps == [[1, 10 + 2 * k, 100], [1, 11 + 2 * k, 100], [1, 10 + 2 * k, 101], [1, 11 + 2 * k, 101]], (k, hyps)
+    assert scores.tolist() == [2.0 * k, 2.0 * k + 1, 2.0 * k + 0.25, 2.0 * k + 1.25], (k, scores)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_process_gloo_decode_pipelines_gather(tmp_path):
+    """DecodePipelines.decode(gather=True): the all-gather is issued once per group of consecutive equal-shaped steps, by step
+    index - two ranks whose pipelines run at different speeds issue the same collectives and see every step rank-major."""
+    script = tmp_path / "worker_pipes.py"
+    script.write_text(_WORKER_PIPES)
+    port = str(31500 + os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script), REPO, port], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for r, pr in enumerate(procs):
+        out, _ = pr.communicate(timeout=180)
+        assert pr.returncode == 0, out
+        assert f"rank {r} ok" in out
