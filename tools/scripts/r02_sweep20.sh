@@ -1,10 +1,10 @@
 #!/bin/bash
-# pipelines x batches-per-pass at the driver's step count (20) and at 200
+# pipelines x batches-per-pass at 200 steps (and 20)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for cfg in "2 10" "3 7" "2 7" "4 5" "2 5" "1 20"; do
+for cfg in "2 10" "2 8" "2 12" "2 16" "2 10"; do
   set -- $cfg
-  for steps in 20 200; do
+  for steps in 200; do
     timeout -k 10 200 python bench.py --no-cpu-baseline --no-parity-engine --no-uncoalesced --streams $1 --coalesce $2 --steps $steps --warmup 5 2>/dev/null | \
       python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('pipelines', $1, 'coalesce', $2, 'steps', $steps, d['value'], d['ms_per_step'], d['roofline']['frac'])" || exit 1
   done
-done 2>&1 | tee gpurun_out/r02y_sweep20.txt
+done 2>&1 | tee gpurun_out/r03i_sweep.txt
