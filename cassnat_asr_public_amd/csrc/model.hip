@@ -1483,9 +1483,20 @@ int run_generator(cn_model* m, const Linear& g, const void* h, int M, int* arg, 
         a.d = d;
         return launch_genmax(a, s);
     }
-    CN_TRY(run_linear(m, "generator_proj", g, h, d, m->logits, V, 1, M, 0, nullptr, 0, s));
-    ProfScope ps(m, "logsoftmax_argmax", 0, (double)M * V * 4, s);
-    return launch_logsoftmax_argmax(m->logits, M, V, V, arg, maxlp, need_rows ? 1 : 0, s);
+    // the logits buffer holds B x (T' + 1) rows (one alignment per utterance); the decoder side of an ESA group brings G times
+    // that: the rows go through it in chunks (the engines without the fused kernel - fp32, bf16x3 - wrote past the buffer here)
+    const size_t cap_rows = (size_t)m->maxB * (m->maxTp + 1);
+    if ((size_t)M > cap_rows && need_rows) {
+        cn_set_error("generator: full log-probability rows (capture / beam_width > 1) of more rows than one alignment per utterance");
+        return -1;
+    }
+    for (size_t r0 = 0; r0 < (size_t)M; r0 += cap_rows) {
+        const int rows = (int)std::min(cap_rows, (size_t)M - r0);
+        CN_TRY(run_linear(m, "generator_proj", g, (const unsigned char*)h + r0 * d * m->es, d, m->logits, V, 1, rows, 0, nullptr, 0, s));
+        ProfScope ps(m, "logsoftmax_argmax", 0, (double)rows * V * 4, s);
+        CN_TRY(launch_logsoftmax_argmax(m->logits, rows, V, V, arg + r0, maxlp ? maxlp + r0 : nullptr, need_rows ? 1 : 0, s));
+    }
+    return 0;
 }
 
 int check_call(cn_model* m, int B, int T, int F) {

@@ -288,10 +288,11 @@ def test_bf16_production_path_against_golden(capsys):
 
 # ------------------------------------------------------------------------------------------- ESA + LM ranking (8f rank 3)
 @pytest.mark.parametrize("which,prec", [("esa_tiny", "fp32"), ("esa_config2", "fp32"), ("esa_config2", "bf16"),
+                                        ("esa_tiny", "bf16x3"), ("esa_config2", "bf16x3"),  # the split-bf16 engine: gated like fp32
                                         ("esa_conf_tiny", "fp32")])  # (conformer blocks under ESA: the shipped YAML's combination)
 def test_esa_sampling_with_lm_ranking(which, prec, capsys):
     """sample_num = 4 alignments per utterance (random draws = the fixture's, i.e. the reference's torch.randint stream),
-    TransformerLM ranking on the device.  fp32: hypotheses (up to the position the reference reads from a masked row, see
+    TransformerLM ranking on the device.  fp32 and bf16x3: hypotheses (up to the position the reference reads from a masked row, see
     tests/test_oracle_golden.py) and scores equal the reference's; bf16: reported."""
     from conftest import esa_case
     from cassnat_asr_public_amd.models.lm import make_model as make_lm
@@ -315,7 +316,7 @@ def test_esa_sampling_with_lm_ranking(which, prec, capsys):
         same += h[:n] == ref[:n] and len(h) == len(ref)
     with capsys.disabled():
         print(f"\n[ESA {prec}] {which}: {same}/{len(out)} hypotheses identical, scores {[round(s[0]['score'], 3) for s in out]} vs {np.round(g['score'], 3).tolist()}")
-    if prec == "fp32":
+    if prec in ("fp32", "bf16x3"):
         assert same == len(out)
         np.testing.assert_allclose([s[0]["score"] for s in out], g["score"], rtol=1e-5, atol=2e-3)
     if which in ("esa_tiny", "esa_conf_tiny"):  # the samples go through the decoder side in groups: any group size gives the same answer
@@ -348,3 +349,41 @@ def test_config5_fp8_encoder_products(capsys):
               + "; ".join(f"{k}: argmax flips {v['flips']:.4f}, max |d log-posterior| {v['err']:.4f}, hypotheses identical "
                           f"{v['hyp']}/{len(g['hyp'])}" for k, v in rows.items()))
     assert rows["fp8"]["flips"] < 0.25 and rows["fp8"]["err"] < 0.5
+
+
+def test_esa_group_rows_beyond_one_alignment_per_utterance():
+    """ESA at a size where the decoder side of one group (B x 16 alignments x U rows) has many times the B x (T' + 1) rows
+    the logits buffer holds: the engines without the fused generator kernel (fp32, bf16x3) take the rows through it in chunks
+    (they used to write past it).  No golden at this size: the two parity-grade engines must agree with each other - same
+    draws, same hypotheses, scores to fp32 accuracy."""
+    from cassnat_asr_public_amd import synth as sy
+    from cassnat_asr_public_amd.models.cassnat import make_model
+    from cassnat_asr_public_amd.models.lm import make_model as make_lm
+
+    B, T, samples = 4, 400, 16
+    got = {}
+    for prec in ("fp32", "bf16x3"):
+        args = sy.make_args("config2", sample_num=samples, rank_model="lm", threshold=0.9)
+        args.hip_precision = prec
+        args.hip_max_batch, args.hip_max_frames = B, T
+        lm_args = sy.make_args_lm("lm_small", vocab_size=args.vocab_size)
+        lm_args.hip_precision = prec
+        state = sy.make_state(args, seed=0, blank_bias=sy.BENCH_BLANK_BIAS)
+        lm_state = sy.make_state(lm_args, seed=9, gain=2.0)
+        model = make_model(args.input_size, args).cuda()
+        lm = make_lm(lm_args).cuda()
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                p.copy_(torch.from_numpy(state[k]))
+            for k, p in lm.named_parameters():
+                p.copy_(torch.from_numpy(lm_state[k]))
+        fh, sh = sy.make_feats(B, T, args.input_size, seed=77)
+        src, sizes = torch.from_numpy(fh).cuda(), torch.from_numpy(sh).cuda()
+        torch.manual_seed(3)
+        with torch.no_grad():
+            out, _ = model.beam_decode(src, (src[:, :, 0] != args.padding_idx).unsqueeze(1), sizes, Vocab, args, lm)
+        torch.cuda.synchronize()
+        got[prec] = ([o[0]["hyp"] for o in out], [o[0]["score"] for o in out])
+        assert max(len(h) for h in got[prec][0]) * 16 > T // 4 + 1  # the group's rows do exceed one alignment's capacity
+    assert got["fp32"][0] == got["bf16x3"][0]
+    np.testing.assert_allclose(got["fp32"][1], got["bf16x3"][1], rtol=1e-4, atol=5e-3)
