@@ -28,16 +28,26 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--same-seed", action="store_true", help="the same random draws in every repetition")
+    ap.add_argument("--rank", default="lm", choices=["lm", "at_baseline"],
+                    help="ranker: the TransformerLM (lm_small) or the autoregressive baseline (config 4 model, teacher-forced)")
     a = ap.parse_args()
-    args = synth.make_args("config2", sample_num=a.samples, rank_model="lm", threshold=0.9)
+    args = synth.make_args("config2", sample_num=a.samples, rank_model=a.rank, threshold=0.9)
     args.hip_precision = a.precision
     args.hip_max_batch, args.hip_max_frames = a.batch, a.frames
-    lm_args = synth.make_args_lm("lm_small", vocab_size=args.vocab_size)
+    if a.rank == "lm":
+        lm_args = synth.make_args_lm("lm_small", vocab_size=args.vocab_size)
+    else:
+        lm_args = synth.make_args_ast("config4", vocab_size=args.vocab_size)
     lm_args.hip_precision = a.precision
     state = synth.make_state(args, seed=0, blank_bias=synth.BENCH_BLANK_BIAS)
     lm_state = synth.make_state(lm_args, seed=9, gain=2.0)
     model = make_model(args.input_size, args).cuda()
-    lm = make_lm(lm_args).cuda()
+    if a.rank == "lm":
+        lm = make_lm(lm_args).cuda()
+    else:
+        from cassnat_asr_public_amd.models.transformer import make_model as make_ast
+
+        lm = make_ast(lm_args.input_size, lm_args).cuda()
     with torch.no_grad():
         for k, p in model.named_parameters():
             p.copy_(torch.from_numpy(state[k]))
@@ -55,7 +65,7 @@ def main():
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     best = min(times[1:])
-    print(json.dumps({"workload": f"ESA: config 2 model, sample_num {a.samples}, TransformerLM lm_small ranking",
+    print(json.dumps({"workload": f"ESA: config 2 model, sample_num {a.samples}, " + ("TransformerLM lm_small" if a.rank == "lm" else "autoregressive-baseline (config 4 model)") + " ranking",
                       "batch": a.batch, "frames": a.frames, "precision": a.precision, "sec_per_batch": round(best, 4),
                       "utt_per_sec": round(a.batch / best, 2), "rtf": round(best / (a.batch * a.frames * 0.01), 6),
                       "tokens_max": max(len(o[0]["hyp"]) for o in out) - 1, "all_runs_sec": [round(t, 4) for t in times]}))
