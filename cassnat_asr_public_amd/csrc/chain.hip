@@ -315,7 +315,15 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     // same L2 lines at the same moment] [tail projection: tail_tiles / 8 groups]
     const int G_OUT = p.ctx ? 1 : 0, G_FFN = p.ffn_tiles >> 2, G_TAIL = p.tail_tiles >> 3;
     const int NG = G_OUT + G_FFN + G_TAIL;
+    // (Every workgroup used to walk the FFN groups in a rotation of its own, to keep the workgroups from pulling the same L2
+    // lines at the same moment.  It bought nothing measurable (A/B on one box), and it made a row's fp32 accumulation order
+    // depend on which workgroup the row lands in - so a batch decoded in a merged engine pass differed in its scores' last
+    // digits from the same batch decoded alone.  CH_ROTATE keeps the old walk for experiments.)
+#ifdef CH_ROTATE
     const int rotg = G_FFN ? (int)((blockIdx.x * 5u) % (unsigned)G_FFN) : 0;
+#else
+    const int rotg = 0;
+#endif
     unsigned char* ring = smem + CH_TAB_BYTES;
     // stream group consumed at position g (past the end: the last group again - dummy refills keep the DMA queue depth,
     // and with it every vmcnt of the loop, constant; their slots are never read)

@@ -435,7 +435,8 @@ int launch_ffn_x3(const FfnX3Args& a, hipStream_t s) {
     p.M = a.M;
     p.dff = a.dff;
     p.eps = a.eps;
-    static const int rotate = getenv("CASSNAT_FFN_X3_ROTATE") ? atoi(getenv("CASSNAT_FFN_X3_ROTATE")) : 1;
+    // (off by default: the rotation made a row's accumulation order depend on its workgroup and measured no gain)
+    static const int rotate = getenv("CASSNAT_FFN_X3_ROTATE") ? atoi(getenv("CASSNAT_FFN_X3_ROTATE")) : 0;
     p.rotate = rotate;
 #ifdef FX_STAMPS
     static unsigned long long* stamps_dev = nullptr;

@@ -62,9 +62,14 @@ __global__ __launch_bounds__(256, 2) void genmax_kernel(GenmaxParams p) {
 #define GM_LDW(S_, tile, g)                                                                            \
     w##S_##a = GM_WFRAG(tile, 4 * (g) + 0); w##S_##b = GM_WFRAG(tile, 4 * (g) + 1);                    \
     w##S_##c = GM_WFRAG(tile, 4 * (g) + 2); w##S_##d = GM_WFRAG(tile, 4 * (g) + 3);
-    // every workgroup walks its vocabulary tiles in a rotation of its own (ties go to the lower index whatever the order): the
-    // workgroups of a launch then do not pull the same L2 lines at the same moment
+    // (GM_ROTATE: every workgroup walks its vocabulary tiles in a rotation of its own - ties go to the lower index whatever
+    // the order.  -6 % for the launch alone, nothing on the benchmark, and the log-sum-exp's accumulation order then depends
+    // on the workgroup a row lands in: off, so that a batch gives the same scores in a merged pass as alone.)
+#ifdef GM_ROTATE
     const int rot = (int)((blockIdx.x * 7u) % (unsigned)p.vtw);
+#else
+    const int rot = 0;
+#endif
 #define GM_TT(t) ((t) + rot >= p.vtw ? (t) + rot - p.vtw : (t) + rot)
     {
         const int t0 = GM_TT(0);

@@ -414,3 +414,34 @@ def test_randomised_shapes_bf16_fast_path_against_the_fp32_engine():
                 n = int(x["ylen"][i])
                 assert np.abs(x["dec_h"][i, :n] - y["dec_h"][i, :n]).max() < 0.08 * np.abs(x["dec_h"][i, :n]).max(), (case, B, T, i)
     assert same_path >= 4
+
+
+def test_merged_pass_equals_separate_passes_when_rows_change_workgroups():
+    """The config-2 model at a size where a merged engine pass puts an utterance's rows into other workgroups than a pass of
+    its own does (400 frames -> 100 rows per utterance, 128-row workgroups, three ragged batches of 4): hypotheses AND scores
+    are bitwise those of the separate passes.  (A per-workgroup rotation of the FFN / vocabulary tile order made the fp32
+    accumulation order depend on the workgroup: identical tokens, scores differing from the sixth digit on.)"""
+    from cassnat_asr_public_amd.pipeline import DecodePipelines
+
+    args = synth.make_args("config2")
+    args.hip_max_batch, args.hip_max_frames = 4, 400
+    state = synth.make_state(args, seed=0, blank_bias=synth.BENCH_BLANK_BIAS)
+    model = build(args, state, capture=False)
+    rng = np.random.default_rng(21)
+    data = []
+    for k in range(3):
+        lens = sorted((int(x) for x in rng.integers(150, 401, size=4)), reverse=True)
+        lens[0] = 400
+        data.append(synth.make_feats(4, 400, 80, lengths=lens, seed=700 + k))
+    want = []
+    for feats, sizes in data:
+        src = torch.from_numpy(feats)
+        with torch.no_grad():
+            out, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, args)
+        want.append(([s[0]["hyp"] for s in out], [s[0]["score"] for s in out]))
+    pipes = DecodePipelines(model, 1, 4, 400, coalesce=3)
+    got = list(pipes.decode([(torch.from_numpy(f), torch.from_numpy(s), k) for k, (f, s) in enumerate(data)], args, sos=1))
+    pipes.close()
+    for (tag, hyps, scores), (wh, ws) in zip(got, want):
+        assert hyps == wh, tag
+        assert list(scores) == ws, tag

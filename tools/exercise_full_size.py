@@ -62,5 +62,45 @@ def main():
         assert same >= 31, (name, same)
 
 
+def pipelines_ragged():
+    """Twelve ragged batches of the same padded shape through 2 pipelines x up to 10 batches per pass against the plain loop."""
+    from cassnat_asr_public_amd.pipeline import DecodePipelines
+
+    args = synth.make_args("config2")
+    args.hip_precision = "bf16"
+    args.hip_max_batch, args.hip_max_frames = 32, 1000
+    state = synth.make_state(args, seed=0, blank_bias=synth.BENCH_BLANK_BIAS)
+    model = make_model(args.input_size, args).cuda()
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.copy_(torch.from_numpy(state[k]))
+    rng = np.random.default_rng(11)
+    data = []
+    for k in range(12):
+        lens = sorted((int(x) for x in rng.integers(300, 1001, size=32)), reverse=True)
+        lens[0] = 1000
+        data.append(synth.make_feats(32, 1000, args.input_size, lengths=lens, seed=900 + k))
+    want = []
+    for fh, sh in data:
+        src = torch.from_numpy(fh).cuda()
+        with torch.no_grad():
+            out, _ = model.beam_decode(src, (src[:, :, 0] != 0).unsqueeze(1), torch.from_numpy(sh).cuda(), Vocab, args, None)
+        want.append(([o[0]["hyp"] for o in out], [o[0]["score"] for o in out]))
+    with DecodePipelines(model, 2, 32, 1000, coalesce=10) as pipes:
+        got = list(pipes.decode([(torch.from_numpy(f), torch.from_numpy(s), k) for k, (f, s) in enumerate(data)], args, sos=1))
+    bad = 0
+    for (tag, hyps, scores), (wh, ws) in zip(got, want):
+        for b in range(32):
+            if hyps[b] != wh[b] or scores[b] != ws[b]:
+                bad += 1
+                if bad <= 6:
+                    d = [i for i in range(min(len(hyps[b]), len(wh[b]))) if hyps[b][i] != wh[b][i]]
+                    print("batch %d utt %d: len %d vs %d, first token diffs at %s, score %.6f vs %.6f" % (tag, b, len(hyps[b]), len(wh[b]), d[:5], scores[b], ws[b]), flush=True)
+    assert bad == 0, "%d utterances differ" % bad
+    print("12 ragged batches of 32 x 1000 through 2 pipelines x 10 per pass: hypotheses and scores equal the plain loop's", flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if "--pipelines-only" not in sys.argv:
+        main()
+    pipelines_ragged()
