@@ -251,11 +251,13 @@ struct ChainWeights {  // host fp32, nn.Linear layout [out][in]; null members = 
 size_t chain_stream_units(int has_outproj, int dff, int tail_n);
 void pack_chain(const ChainWeights& w, uint16_t* stream, float* tab);
 
-// ---- fused generator tail, bf16 / d_model == 256: per-row argmax and max log-probability of log_softmax(W h + b)   (genmax.hip)
+// ---- fused generator tail, bf16 or split-bf16 / d_model == 256: per-row argmax and max log-probability of
+// log_softmax(W h + b)   (genmax.hip)
 struct GenmaxArgs {
-    const void* h = nullptr;   // [M][256] bf16
-    const void* wp = nullptr;  // pack_genmax weight fragments
-    const float* bp = nullptr; // pack_genmax biases
+    const void* h = nullptr;   // [M][256] bf16 (split-bf16 when x3)
+    const void* wp = nullptr;  // pack_genmax / pack_genmax_x3 weight fragments
+    const float* bp = nullptr; // pack_genmax / pack_genmax_x3 biases
+    bool x3 = false;           // split-bf16 operands, three MFMAs per product
     int* arg = nullptr;
     float* maxlp = nullptr;
     int M = 0, V = 0, d = 0;
@@ -268,6 +270,9 @@ struct GenmaxArgs {
 int launch_genmax(const GenmaxArgs& a, hipStream_t s);
 int genmax_vtw(int V);  // vocabulary tiles per wave; packed sizes: weights 4*vtw*16 KiB, biases 4*vtw*32 floats
 void pack_genmax(const float* w, const float* b, int V, uint16_t* wout, float* bout);
+int genmax_x3_vtw(int V);  // split-bf16: tiles per wave (8 waves); packed sizes: weights 8*vtw*32 KiB, biases 8*vtw*32 floats
+void pack_genmax_x3(const float* w, const float* b, int V, uint16_t* wout, float* bout);
+bool genmax_applies(int prec, int d, int V);
 
 // ---- autoregressive decoder step with KV cache + CTC prefix scorer (BASELINE config 4)             (ast.hip)
 int launch_ast_embed(const int* tok, const float* lut, const float* pe_row, float* x, int n, int d, float scale, hipStream_t s);

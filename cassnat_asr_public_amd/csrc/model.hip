@@ -641,15 +641,17 @@ struct Packer {
     // generator: the plain matrix (beam search / capture) plus the fused-argmax fragment stream when it applies
     Linear generator(const std::string& prefix, int64_t V, int64_t d) {
         Linear l = linear({prefix}, V, d);
-        if (m->prec == CN_PREC_BF16 && d == 256 && genmax_vtw((int)V) <= 48) {
-            const int vtw = genmax_vtw((int)V);
-            const size_t aw = reserve((size_t)4 * vtw * 16 * 1024), ab = reserve((size_t)4 * vtw * 32 * 4);
+        if (genmax_applies(m->prec, (int)d, (int)V)) {
+            const bool x3 = m->prec == CN_PREC_X3;
+            const int vtw = x3 ? genmax_x3_vtw((int)V) : genmax_vtw((int)V);
+            const size_t aw = reserve(x3 ? (size_t)8 * vtw * 32 * 1024 : (size_t)4 * vtw * 16 * 1024);
+            const size_t ab = reserve((size_t)(x3 ? 8 : 4) * vtw * 32 * 4);
             if (fill) {
                 const HostTensor* tw = find(prefix + ".weight", {V, d});
                 const HostTensor* tb = find(prefix + ".bias", {V});
                 if (tw && tb)
-                    pack_genmax(tw->data.data(), tb->data.data(), (int)V, reinterpret_cast<uint16_t*>(&host[aw]),
-                                reinterpret_cast<float*>(&host[ab]));
+                    (x3 ? pack_genmax_x3 : pack_genmax)(tw->data.data(), tb->data.data(), (int)V, reinterpret_cast<uint16_t*>(&host[aw]),
+                                                        reinterpret_cast<float*>(&host[ab]));
             }
             l.gm_w = reinterpret_cast<void*>(aw);
             l.gm_b = reinterpret_cast<float*>(ab);
@@ -1471,8 +1473,10 @@ int run_generator(cn_model* m, const Linear& g, const void* h, int M, int* arg, 
                   hipStream_t s) {
     const int d = m->cfg.d_model, V = m->cfg.vocab_size;
     if (g.gm_w && !need_rows) {
-        ProfScope ps(m, "generator_argmax_fused", 2.0 * M * V * d, (double)M * d * 2 + (double)V * d * 2, s);
+        const bool x3 = m->prec == CN_PREC_X3;
+        ProfScope ps(m, "generator_argmax_fused", (x3 ? 6.0 : 2.0) * M * V * d, ((double)M * d + (double)V * d) * (x3 ? 4 : 2), s);
         GenmaxArgs a;
+        a.x3 = x3;
         a.h = h;
         a.wp = g.gm_w;
         a.bp = g.gm_b;
@@ -2361,8 +2365,10 @@ extern "C" int cn_lm_score(cn_model* m, const int32_t* tok_dev, const int32_t* t
     }
     static const bool no_fused = getenv("CASSNAT_LM_NO_FUSED_TAIL") != nullptr;
     if (m->att_gen.gm_w && !no_fused) {  // bf16 / d_model 256: generator + log-softmax + gather in one kernel, no (M, V) tensor
-        ProfScope ps(m, "generator_gather_fused", 2.0 * M * V * d, (double)M * d * 2 + (double)V * d * 2, s);
+        const bool x3 = m->prec == CN_PREC_X3;
+        ProfScope ps(m, "generator_gather_fused", (x3 ? 6.0 : 2.0) * M * V * d, ((double)M * d + (double)V * d) * (x3 ? 4 : 2), s);
         GenmaxArgs a;
+        a.x3 = x3;
         a.h = m->enc_h;
         a.wp = m->att_gen.gm_w;
         a.bp = m->att_gen.gm_b;
@@ -3104,6 +3110,65 @@ extern "C" int cn_op_genmax(const void* h_dev, const float* w_host, const float*
 extern "C" int cn_op_genmax_gather(const void* h_dev, const float* w_host, const float* b_host, int32_t B, int32_t U, int32_t V,
                                    const int32_t* tgt_dev, int32_t ld, float* tgt_lp_dev, void* stream) {
     return op_genmax_impl(h_dev, w_host, b_host, B * U, V, nullptr, nullptr, tgt_dev, tgt_lp_dev, U, ld, stream);
+}
+
+// the split-bf16 form (CN_PRECISION_BF16X3): h_host fp32 [M][256] is split into hi + lo halves and uploaded by the call;
+// tgt_dev == NULL: arg-max (+ maxlp when maxlp_dev), else the target gather with M = rows, U per sequence, ld the target stride
+extern "C" int cn_op_genmax_x3(const float* h_host, const float* w_host, const float* b_host, int32_t M, int32_t V, int32_t* arg_dev,
+                               float* maxlp_dev, const int32_t* tgt_dev, int32_t U, int32_t ld, float* tgt_lp_dev, void* stream) {
+    if (!genmax_applies(CN_PREC_X3, 256, V) || M < 1) {
+        cn_set_error("cn_op_genmax_x3: V too large");
+        return -1;
+    }
+    const int vtw = genmax_x3_vtw(V);
+    std::vector<uint16_t> hw((size_t)8 * vtw * 16 * 1024);
+    std::vector<float> hb((size_t)8 * vtw * 32);
+    pack_genmax_x3(w_host, b_host, V, hw.data(), hb.data());
+    std::vector<unsigned char> hx((size_t)M * 1024);
+    for (size_t r = 0; r < (size_t)M; ++r)
+        for (size_t c = 0; c < 256; ++c) {
+            const float v = h_host[r * 256 + c];
+            const uint16_t hi = f32_to_bf16_host(v);
+            const uint32_t hbits = (uint32_t)hi << 16;
+            float hf;
+            std::memcpy(&hf, &hbits, 4);
+            const uint16_t lo = f32_to_bf16_host(v - hf);
+            std::memcpy(&hx[r * 1024 + cn_split_off(c)], &hi, 2);
+            std::memcpy(&hx[r * 1024 + cn_split_off(c) + 64], &lo, 2);
+        }
+    void *dw = nullptr, *db = nullptr, *dx = nullptr;
+    CN_HIP_CHECK(hipMalloc(&dw, hw.size() * 2));
+    CN_HIP_CHECK(hipMalloc(&db, hb.size() * 4));
+    CN_HIP_CHECK(hipMalloc(&dx, hx.size()));
+    CN_HIP_CHECK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    CN_HIP_CHECK(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    CN_HIP_CHECK(hipMemcpy(dx, hx.data(), hx.size(), hipMemcpyHostToDevice));
+    GenmaxArgs a;
+    a.x3 = true;
+    a.h = dx;
+    a.wp = dw;
+    a.bp = (const float*)db;
+    a.arg = arg_dev;
+    a.maxlp = maxlp_dev;
+    a.M = M;
+    a.V = V;
+    a.d = 256;
+    a.tgt = tgt_dev;
+    a.tgt_lp = tgt_lp_dev;
+    a.tgt_U = U;
+    a.tgt_ld = ld;
+    int rc = launch_genmax(a, (hipStream_t)stream);
+    if (const char* rep = getenv("CASSNAT_GENMAX_REPEAT"))  // timing runs only
+        for (int i = 1, n = atoi(rep); rc == 0 && i < n; ++i) rc = launch_genmax(a, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(dw);
+    (void)hipFree(db);
+    (void)hipFree(dx);
+    if (rc == 0 && e != hipSuccess) {
+        cn_set_error(std::string("cn_op_genmax_x3: ") + hipGetErrorString(e));
+        rc = -2;
+    }
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

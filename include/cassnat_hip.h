@@ -292,6 +292,11 @@ int cn_op_genmax(const void* h_dev, const float* w_host, const float* b_host, in
  * tgt_lp[b * ld + u] = log_softmax(W h[b * U + u] + b)[tgt[b * ld + u]] */
 int cn_op_genmax_gather(const void* h_dev, const float* w_host, const float* b_host, int32_t B, int32_t U, int32_t V,
                         const int32_t* tgt_dev, int32_t ld, float* tgt_lp_dev, void* stream);
+/* the generator tail in the split-bf16 precision (CN_PRECISION_BF16X3; three MFMAs per product): h_host fp32 [M][256] (split
+ * and uploaded by the call).  tgt_dev == NULL: arg-max (and maxlp when maxlp_dev != NULL); else M = B * U rows and
+ * tgt_lp[b * ld + u] = log_softmax(W h[b * U + u] + b)[tgt[b * ld + u]] */
+int cn_op_genmax_x3(const float* h_host, const float* w_host, const float* b_host, int32_t M, int32_t V, int32_t* arg_dev,
+                    float* maxlp_dev, const int32_t* tgt_dev, int32_t U, int32_t ld, float* tgt_lp_dev, void* stream);
 int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, int32_t* idx, float* val, void* stream);
 /* e4m3fn product (BASELINE config 5): A bf16 [M][lda] on the device is quantised at a_scale (saturating at 448 / a_scale),
  * W = HOST fp32 [N][K] at the largest power-of-two scale that fits (returned in *w_scale_out), as cn_model_finalize does for
