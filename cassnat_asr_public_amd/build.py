@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcassnat_hip.so")
-SOURCES = ["gemm.hip", "fbank.hip", "conv2.hip", "conv1.hip", "rowops.hip", "attention.hip", "ctc_align.hip", "ctc_beam.hip", "fused.hip", "fused_x3.hip", "genmax.hip", "conformer.hip", "chain.hip", "ast.hip", "model.hip"]
+SOURCES = ["gemm.hip", "fbank.hip", "conv2.hip", "conv1.hip", "rowops.hip", "attention.hip", "ctc_align.hip", "ctc_beam.hip", "fused.hip", "fused_x3.hip", "genmax.hip", "proj_x3.hip", "conformer.hip", "chain.hip", "ast.hip", "model.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -132,14 +132,31 @@ __global__ __launch_bounds__(256, 2) void genmax_kernel(GenmaxParams p) {
 #endif
 
     // activations -> LDS: 16-byte chunk c = 2 ks + half of row r at fragment (mt = r >> 5, ks), lane slot 32 half + (r & 31)
-    for (int c = tid; c < BM * 32; c += 256) {
-        const int r = c >> 5, ch = c & 31;
-        int m = m0 + r;
-        if (m >= p.M) m = p.M - 1;
-        const uint4 v = ld16(reinterpret_cast<const unsigned char*>(p.h + (long long)m * 256) + 16 * ch);
-        st16(xs + ((((r >> 5) * 16 + (ch >> 1)) * 64) + (ch & 1) * 32 + (r & 31)) * 16, v);
+    // (all requests - rows and bias table, 16 bytes each - before the first LDS write: written as copy loops, every chunk
+    // waited for its own round trip, 4 MT + 10 of them in series)
+    {
+        constexpr int NB = (4 * GM_MAX_VTW * 32 / 4 + 255) / 256;
+        const int nb16 = 4 * p.vtw * 32 / 4;
+        uint4 stage[BM / 8], bst[NB];
+#pragma unroll
+        for (int i = 0; i < BM / 8; ++i) {
+            const int c = tid + 256 * i, r = c >> 5, ch = c & 31;
+            int m = m0 + r;
+            if (m >= p.M) m = p.M - 1;
+            stage[i] = ld16(reinterpret_cast<const unsigned char*>(p.h + (long long)m * 256) + 16 * ch);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (tid + 256 * i < nb16) bst[i] = ld16(reinterpret_cast<const unsigned char*>(p.bp) + 16 * (tid + 256 * i));
+#pragma unroll
+        for (int i = 0; i < BM / 8; ++i) {
+            const int c = tid + 256 * i, r = c >> 5, ch = c & 31;
+            st16(xs + ((((r >> 5) * 16 + (ch >> 1)) * 64) + (ch & 1) * 32 + (r & 31)) * 16, stage[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (tid + 256 * i < nb16) st16(reinterpret_cast<unsigned char*>(bias_s) + 16 * (tid + 256 * i), bst[i]);
     }
-    for (int i = tid; i < 4 * p.vtw * 32; i += 256) bias_s[i] = p.bp[i];
     __syncthreads();
 
     float m_run[MT], s_run[MT];
@@ -284,15 +301,30 @@ __global__ __launch_bounds__(512, 1) void genmax_x3_kernel(GenmaxParams p) {
 
     // activations -> LDS.  A split-bf16 row is 8 groups of 32 elements, 64 B of hi halves then 64 B of lo halves: 16-byte
     // chunk ch = 8 q + 4 plane + sub holds k = 32 q + 8 sub .. + 7, i.e. k-step 2 q + (sub >> 1), lane half sub & 1
-    for (int c = tid; c < BM * 64; c += 512) {
-        const int r = c >> 6, ch = c & 63;
-        int m = m0 + r;
-        if (m >= p.M) m = p.M - 1;
-        const uint4 v = ld16(reinterpret_cast<const unsigned char*>(p.h) + (long long)m * 1024 + 16 * ch);
-        const int ks = 2 * (ch >> 3) + ((ch & 3) >> 1), pl = (ch >> 2) & 1;
-        st16(xs + ((((r >> 5) * 16 + ks) * 2 + pl) * 64 + (ch & 1) * 32 + (r & 31)) * 16, v);
+    {
+        constexpr int NB = (GM3_WAVES * GM3_MAX_VTW * 32 / 4 + 511) / 512;
+        const int nb16 = GM3_WAVES * p.vtw * 32 / 4;
+        uint4 stage[BM / 8], bst[NB];
+#pragma unroll
+        for (int i = 0; i < BM / 8; ++i) {
+            const int c = tid + 512 * i, r = c >> 6, ch = c & 63;
+            int m = m0 + r;
+            if (m >= p.M) m = p.M - 1;
+            stage[i] = ld16(reinterpret_cast<const unsigned char*>(p.h) + (long long)m * 1024 + 16 * ch);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (tid + 512 * i < nb16) bst[i] = ld16(reinterpret_cast<const unsigned char*>(p.bp) + 16 * (tid + 512 * i));
+#pragma unroll
+        for (int i = 0; i < BM / 8; ++i) {
+            const int c = tid + 512 * i, r = c >> 6, ch = c & 63;
+            const int ks = 2 * (ch >> 3) + ((ch & 3) >> 1), pl = (ch >> 2) & 1;
+            st16(xs + ((((r >> 5) * 16 + ks) * 2 + pl) * 64 + (ch & 1) * 32 + (r & 31)) * 16, stage[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (tid + 512 * i < nb16) st16(reinterpret_cast<unsigned char*>(bias_s) + 16 * (tid + 512 * i), bst[i]);
     }
-    for (int i = tid; i < GM3_WAVES * p.vtw * 32; i += 512) bias_s[i] = p.bp[i];
     __syncthreads();
 
     float m_run[MT], s_run[MT];

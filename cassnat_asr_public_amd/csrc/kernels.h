@@ -251,6 +251,25 @@ struct ChainWeights {  // host fp32, nn.Linear layout [out][in]; null members = 
 size_t chain_stream_units(int has_outproj, int dff, int tail_n);
 void pack_chain(const ChainWeights& w, uint16_t* stream, float* tab);
 
+// ---- d_model-deep projections of the split-bf16 engine (K = 256): C = A . W^T + bias, split-bf16 or fp32 (+ residual) output   (proj_x3.hip)
+struct ProjX3Args {
+    const void* A = nullptr;   // [M] rows of 256 split-bf16 elements, row stride lda elements
+    int lda = 256;
+    const void* wp = nullptr;  // pack_proj_x3 stream (N * 1024 bytes)
+    const float* bias = nullptr;
+    void* C = nullptr;         // fp32 [M][ldc] when c_f32, else split-bf16 rows of ldc elements
+    int ldc = 0;
+    int c_f32 = 0;
+    const float* resid = nullptr;  // fp32 output only: C = resid + resid_scale * (A . W^T + bias); may alias C
+    int ldr = 0;
+    float resid_scale = 1.f;
+    int M = 0, N = 0;
+};
+bool proj_x3_applies(int N, int K);
+int launch_proj_x3(const ProjX3Args& a, hipStream_t s);
+size_t proj_x3_off(int n, int k);  // byte offset of W[n][k]'s hi half in the packed stream; the lo half 1024 bytes further
+void pack_proj_x3(const float* w, int N, unsigned char* out);
+
 // ---- fused generator tail, bf16 or split-bf16 / d_model == 256: per-row argmax and max log-probability of
 // log_softmax(W h + b)   (genmax.hip)
 struct GenmaxArgs {

@@ -115,6 +115,8 @@ def lib():
                                       C.c_void_p, C.c_void_p]
     L.cn_op_genmax_x3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.cn_op_proj_x3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_void_p]
     L.cn_ast_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts), C.c_int32,
                                C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.cn_ast_step.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -297,6 +297,13 @@ int cn_op_genmax_gather(const void* h_dev, const float* w_host, const float* b_h
  * tgt_lp[b * ld + u] = log_softmax(W h[b * U + u] + b)[tgt[b * ld + u]] */
 int cn_op_genmax_x3(const float* h_host, const float* w_host, const float* b_host, int32_t M, int32_t V, int32_t* arg_dev,
                     float* maxlp_dev, const int32_t* tgt_dev, int32_t U, int32_t ld, float* tgt_lp_dev, void* stream);
+/* d_model-deep projection of the split-bf16 engine (proj_x3.hip; the nn.Linear layers around the attention kernel,
+ * src/models/modules/attention.py:57-66): a_host fp32 [M][256], w_host fp32 [N][256] (split into hi + lo halves, packed and
+ * uploaded by the call), bias_host [N]; N a multiple of 32, at most 1024.  split_out == 0: c_dev fp32 [M][N] = A . W^T + bias,
+ * or resid + resid_scale * (...) when resid_dev (fp32 [M][N], may alias c_dev);  split_out == 1: c_dev receives split-bf16
+ * rows (M * N * 4 bytes: per 32 columns 64 bytes of bf16 hi halves, then 64 bytes of lo halves) */
+int cn_op_proj_x3(const float* a_host, const float* w_host, const float* bias_host, const float* resid_dev, float resid_scale,
+                  void* c_dev, int32_t M, int32_t N, int32_t split_out, void* stream);
 int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, int32_t* idx, float* val, void* stream);
 /* e4m3fn product (BASELINE config 5): A bf16 [M][lda] on the device is quantised at a_scale (saturating at 448 / a_scale),
  * W = HOST fp32 [N][K] at the largest power-of-two scale that fits (returned in *w_scale_out), as cn_model_finalize does for

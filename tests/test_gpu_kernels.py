@@ -473,6 +473,39 @@ def test_generator_target_gather_fused_bf16(B, U, ld, V):
         assert torch.isnan(out.cpu()[:, U:]).all()  # nothing written outside the U scored positions
 
 
+# ---------------------------------------------------------------------------- split-bf16 projections (proj_x3.hip)
+def _unsplit(raw, M, N):
+    """split-bf16 rows (per 32 columns: 64 bytes of hi halves, 64 bytes of lo halves) -> float64 hi + lo"""
+    v = raw.cpu().view(torch.bfloat16).view(M, N // 32, 2, 32).double()
+    return (v[:, :, 0] + v[:, :, 1]).reshape(M, N)
+
+
+@pytest.mark.parametrize("M,N", [(8000, 256), (7969, 768), (33, 512), (1, 32), (32800, 256), (33000, 768), (70, 96)])
+def test_projection_bf16x3(M, N):
+    """The K = 256 projections of the split-bf16 engine against float64: fp32 output with and without the residual, and the
+    split-bf16 output (whose hi + lo carries 16 mantissa bits)."""
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, 256, generator=g).contiguous()
+    w = (torch.randn(N, 256, generator=g) / 16).contiguous()
+    b = (0.1 * torch.randn(N, generator=g)).contiguous()
+    x = torch.randn(M, N, generator=g)
+    ref = F.linear(a.double(), w.double(), b.double())
+    hp = lambda t: C.c_void_p(t.data_ptr())
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    hip.check(hip.lib().cn_op_proj_x3(hp(a), hp(w), hp(b), None, 1.0, p(out), M, N, 0, stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - ref).abs().max().item() < 5e-5
+    xd = dev(x)
+    hip.check(hip.lib().cn_op_proj_x3(hp(a), hp(w), hp(b), p(xd), 0.5, p(xd), M, N, 0, stream()))
+    torch.cuda.synchronize()
+    assert (xd.cpu().double() - (x.double() + 0.5 * ref)).abs().max().item() < 5e-5
+    raw = torch.zeros(M, N * 2, dtype=torch.int16, device="cuda")
+    hip.check(hip.lib().cn_op_proj_x3(hp(a), hp(w), hp(b), None, 1.0, p(raw), M, N, 1, stream()))
+    torch.cuda.synchronize()
+    got = _unsplit(raw, M, N)
+    assert ((got - ref).abs() / (1 + ref.abs())).max().item() < 5e-5
+
+
 # ----------------------------------------------------------------------------------------------- fused FFN sublayer
 @pytest.mark.parametrize("M,dff,with_next,nslice", [(8000, 2048, True, 1), (45, 256, False, 1), (2304, 2048, True, 1), (32, 128, True, 1),
                                                     (320, 2048, True, 8), (7, 2048, False, 16), (130, 1024, True, 4), (64, 256, True, 2)])
