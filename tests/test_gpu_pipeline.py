@@ -145,6 +145,30 @@ def test_fp32_parity_gate(case, name, strides, prec, capsys):
         print(f"\n[parity {prec}] {name}: {rep}")
 
 
+@pytest.mark.parametrize("case,name", [(config1_case, "config1"), (config2_b8_case, "config2_b8"), (config2_b32_case, "config2_b32")])
+def test_bf16x3_fused_path_matches_the_goldens(case, name):
+    """The gate above runs with the capture mode on, which keeps the generators on the GEMM + log-softmax kernels (full rows).
+    The throughput path of the bf16x3 engine - fused generator kernels (`genmax_x3_kernel`: no logits tensor), projection
+    kernel - must give the same integers: best path, shifted alignment, token counts, hypotheses; scores to 2e-2."""
+    g = load_golden(name)
+    args, state, feats, sizes = case()
+    model = build(args, state, "bf16x3", capture=False)
+    out = decode(model, args, feats, sizes)
+    eng = model._engine
+    flips = eng.fetch("best_paths") != g["best_paths"]
+    assert (g["margin"].astype(np.float32)[flips] < 1e-4).all()
+    if not flips.any():
+        np.testing.assert_array_equal(eng.fetch("aligned_seq_shift"), g["aligned_seq_shift"])
+        np.testing.assert_array_equal(eng.fetch("ylen"), g["ylen"])
+        U = int(g["ymax"])
+        aflip = eng.fetch("tok") != g["att_argmax"][:, :U] if "att_argmax" in g else np.zeros(1, bool)
+        if "att_argmax" in g:
+            assert (g["att_margin"].astype(np.float32)[:, :U][aflip] < 1e-4).all()
+        if not aflip.any():
+            assert [s[0]["hyp"] for s in out] == [g["hyp"][b, : g["hyp_len"][b]].tolist() for b in range(len(out))]
+            np.testing.assert_allclose([s[0]["score"] for s in out], g["score"], atol=2e-2)
+
+
 @pytest.mark.parametrize("case,name,strides", [
     (config2_b8_case, "config2_b8", (10, 50, 4)),
     (config2_b32_case, "config2_b32", (25, 100, 8)),
