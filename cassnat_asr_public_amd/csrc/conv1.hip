@@ -7,10 +7,12 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <typename T>
+// PLANES (T = bf16): the split-bf16 image as two bf16 images, the hi halves at `out` and the lo halves `lo_off` elements
+// further, both in the bordered layout - what the LDS-DMA conv2 kernel reads in its split form (conv2.hip, X3)
+template <typename T, bool PLANES = false>
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
                                                     const float* __restrict__ bias, T* __restrict__ out, int B, int Tn,
-                                                    int F, int T1, int F1, int C, int halo) {
+                                                    int F, int T1, int F1, int C, int halo, long long lo_off = 0) {
     // A thread keeps its 8 channels for the whole kernel, so the 72 tap weights + 8 biases live in registers (as pairs: the
     // 72 multiply-adds of an output position are 36 v_pk_fma_f32).  The three input rows of an output row are staged once in
     // LDS with their zero padding (index f + 1, f = -1 .. F), so a position's nine taps are nine unconditional LDS reads - the
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
                 if (skip_border) continue;
                 if constexpr (sizeof(T) == 2) {
                     *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
+                    if constexpr (PLANES) *reinterpret_cast<uint4*>(dst + lo_off) = make_uint4(0, 0, 0, 0);
                 } else if constexpr (!__is_same(T, split_t)) {
                     *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
                     *reinterpret_cast<uint4*>(dst + 4) = make_uint4(0, 0, 0, 0);
@@ -100,6 +103,12 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
                 // (streamed out past L2: the image is 345 MB per batch, written once and read once by conv2, whose weight slabs
                 // then stay resident - conv1 -4 %, conv2 -5 %, the benchmark +1.2 % A/B)
                 __builtin_nontemporal_store(ob, reinterpret_cast<bf16x8*>(dst));
+                if constexpr (PLANES) {
+                    bf16x8 lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) lo[j] = (bf16)(o[j] - (float)ob[j]);
+                    __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8*>(dst + lo_off));
+                }
             } else {
                 f32x4 o0, o1;
 #pragma unroll
@@ -137,6 +146,25 @@ int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, 
     else
         hipLaunchKernelGGL(conv1_kernel<bf16>, dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (bf16*)out, B, T,
                            F, T1, F1, C, halo);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// the split-bf16 engine's image for the LDS-DMA conv2 kernel: two bordered bf16 planes ([B][T1 + 2][F1 + 2][C] each; hi at
+// `out`, lo right behind it).  halo: 1 = write the border zeros, 2 = they are there already (launch_conv1)
+int launch_conv1_planes(const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1, int F1,
+                        int C, int halo, hipStream_t s) {
+    if (C % 8 != 0 || (256 % (C / 8)) != 0 || (halo != 1 && halo != 2)) {
+        cn_set_error("conv1 (planes): channel count must be a multiple of 8 with C/8 dividing 256; the image is always bordered");
+        return -1;
+    }
+    long long blocks = (long long)B * (T1 + 2);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    const size_t lds = (size_t)2 * 3 * (F + 2) * sizeof(float);
+    const long long plane = (long long)B * (T1 + 2) * (F1 + 2) * C;
+    hipLaunchKernelGGL((conv1_kernel<bf16, true>), dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (bf16*)out, B, T, F, T1,
+                       F1, C, halo, plane);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -27,8 +27,11 @@
 struct Conv2Params {
     const unsigned char* A;      // conv1 output with a zero halo [B][T1 + 2][F1 + 2][256] bf16
     const unsigned char* W;      // [256][9 * 256] bf16, k = (kh * 3 + kw) * 256 + ci
+    // X3 (template; split-bf16 engine): A and W are the planes of the hi halves, these the planes of the lo halves (same layouts)
+    const unsigned char* A_lo;
+    const unsigned char* W_lo;
     const float* bias;
-    bf16* out;                   // [M][256]
+    bf16* out;                   // [M][256] (X3: split-bf16 rows, 1 KiB each)
     int M, T1, F1, T2, F2, ntiles;
     // LINEAR mode (template): a plain [M][K] x [256][K]^T product with the embedding epilogue of linear_out
     // (embedding.py:118-119): out_f32[m][n] = (acc + bias[n]) * scale + pe[m % pe_period][n] (pe may be null)
@@ -92,8 +95,13 @@ constexpr int C2_KSTEPS = 9 * (C2_C / 64);
                  : "memory", "scc")
 
 // LINEAR = false: the 3x3 / stride-2 convolution; true: a plain K-major GEMM with N = 256 (same tiles, stream and blocks)
-template <bool LINEAR>
+// X3 (convolution only): the split-bf16 product.  conv1 wrote the image as two bf16 planes (hi, lo) and the weights come as two
+// matrices; every K step of the bf16 loop becomes three - (A_hi, W_lo), (A_lo, W_hi), (A_hi, W_hi): the small terms first, the hi
+// slab of A asked for twice in a row (the second time from L2) - on the same stages, blocks and accumulators: the kernel is the
+// bf16 kernel with 108 K steps and another epilogue (bias + ReLU + hi / lo split, split-bf16 rows).
+template <bool LINEAR, bool X3 = false>
 __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
+    static_assert(!(LINEAR && X3), "the split form exists for the convolution only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,17 +140,29 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const unsigned m0_wave = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
     // source bases / destinations of K step kt (channel block outermost, tap innermost), stage kt & 1
-    const int KSTEPS = LINEAR ? p.ksteps : C2_KSTEPS;
+    const int KSTEPS = LINEAR ? p.ksteps : (X3 ? 3 * C2_KSTEPS : C2_KSTEPS);
     auto a_base = [&](int kt) -> const unsigned char* {
         if constexpr (LINEAR) return p.A + (long long)kt * 128;
+        const unsigned char* plane = p.A;
+        if constexpr (X3) {
+            const int k = kt / 3;
+            if (kt - 3 * k == 1) plane = p.A_lo;
+            kt = k;
+        }
         const int cb = kt / 9, tap = kt - 9 * cb;
         const int kh = tap / 3, kw = tap - 3 * kh;
-        return p.A + (long long)((kh * F1p + kw) * (C2_C * 2) + cb * 128);
+        return plane + (long long)((kh * F1p + kw) * (C2_C * 2) + cb * 128);
     };
     auto w_base = [&](int kt) -> const unsigned char* {
         if constexpr (LINEAR) return p.W + (long long)kt * 128;
+        const unsigned char* plane = p.W;
+        if constexpr (X3) {
+            const int k = kt / 3;
+            if (kt - 3 * k == 0) plane = p.W_lo;
+            kt = k;
+        }
         const int cb = kt / 9, tap = kt - 9 * cb;
-        return p.W + (long long)((tap * C2_C + cb * 64) * 2);
+        return plane + (long long)((tap * C2_C + cb * 64) * 2);
     };
     // K step kt lives in A stage kt % 3 and W stage kt & 1
     auto a_dst = [&](int k3) -> unsigned { return m0_wave + (unsigned)(k3 * C2_SLAB); };
@@ -280,6 +300,49 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         }
         return;
     }
+    if constexpr (X3) {
+        // ---- split epilogue: + bias, ReLU, hi / lo split; a split-bf16 row is 1 KiB (per 32 channels 64 B of hi halves, then
+        // 64 B of lo halves), so the tile goes through LDS in two halves of 128 rows (the waves wm = 0, then wm = 1) and leaves
+        // as contiguous 1-KiB rows
+        constexpr int OST = 1024 + 16;
+        static_assert(128 * OST <= C2_LDS, "half a split tile fits");
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();
+            if (wm == pass) {
+                unsigned char* orow = smem + l31 * OST + (wnn * 4) * 128 + 8 * half;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    f32x4 bv[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(p.bias + wnn * 128 + 32 * nt + 8 * g + 4 * half);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float o[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = fmaxf(acc[4 * nt + mt][4 * g + e] + bv[g][e], 0.f);
+                            bf16x4 hi, lo;
+                            cn_split4(o, hi, lo);
+                            unsigned char* d = orow + mt * 32 * OST + nt * 128 + 16 * g;
+                            *reinterpret_cast<bf16x4*>(d) = hi;
+                            *reinterpret_cast<bf16x4*>(d + 64) = lo;
+                        }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 32; ++it) {
+                const int row = 4 * it + (tid >> 6), ch = tid & 63;
+                const int m = m0 + 128 * pass + row;
+                if (m < p.M)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + (long long)m * 1024 + ch * 16) =
+                        *reinterpret_cast<const uint4*>(smem + row * OST + ch * 16);
+            }
+        }
+        return;
+    }
     // ---- epilogue: + bias, ReLU, bf16, through LDS (row image of the tile), out as contiguous 512-byte rows
     __syncthreads();
     {
@@ -336,6 +399,41 @@ int launch_conv2_dma(const void* in, const void* w, const float* bias, void* out
     p.ntiles = cn_ceil_div(p.M, C2_BM);
     if (p.M <= 0) return 0;
     hipLaunchKernelGGL(conv2_kernel<false>, dim3(p.ntiles), dim3(256), C2_LDS, s, p);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// the split-bf16 engine's convolution on the same kernel: `in_hi` / `in_lo` are the haloed bf16 planes conv1 wrote
+// ([B][T1 + 2][F1 + 2][256] each), `w_hi` / `w_lo` the [256][9 * 256] matrices of the weights' halves; out: split-bf16 rows
+bool conv2_x3_applies(int prec, int C, int N) { return prec == CN_PREC_X3 && C == C2_C && N == C2_N && !getenv("CASSNAT_NO_CONV2_X3"); }
+
+int launch_conv2_x3(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias, void* out, int B,
+                    int T1, int F1, int T2, int F2, hipStream_t s) {
+    static CnAttrOnce attr_once;
+    int attr_dev;
+    if (attr_once.need(&attr_dev)) {
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)conv2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS));
+        attr_once.mark(attr_dev);
+    }
+    if ((long long)B * (T1 + 2) * (F1 + 2) * C2_C * 2 >= (1ll << 32)) {
+        cn_set_error("conv2_x3: an image plane exceeds the 32-bit lane offsets of the LDS-DMA kernel");
+        return -1;
+    }
+    Conv2Params p = {};
+    p.A = (const unsigned char*)in_hi;
+    p.A_lo = (const unsigned char*)in_lo;
+    p.W = (const unsigned char*)w_hi;
+    p.W_lo = (const unsigned char*)w_lo;
+    p.bias = bias;
+    p.out = (bf16*)out;
+    p.M = B * T2 * F2;
+    p.T1 = T1;
+    p.F1 = F1;
+    p.T2 = T2;
+    p.F2 = F2;
+    p.ntiles = cn_ceil_div(p.M, C2_BM);
+    if (p.M <= 0) return 0;
+    hipLaunchKernelGGL((conv2_kernel<false, true>), dim3(p.ntiles), dim3(256), C2_LDS, s, p);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -44,6 +44,9 @@ int launch_gemm(int prec, const GemmArgs& a, hipStream_t s);
 // x (B,T,F) fp32  ->  out (B,T1,F1,C) channels-last in model precision.  w is [9][C] (tap-major).
 int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1,
                  int F1, int C, int halo, hipStream_t s);
+// split-bf16 engine: the image as two bordered bf16 planes (hi, then lo), for launch_conv2_x3; halo 1 / 2 as above
+int launch_conv1_planes(const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1, int F1,
+                        int C, int halo, hipStream_t s);
 
 // ---- row kernels                                                                  (rowops.hip)
 // y = a_2 * (x - mean) / (std_unbiased + eps) + b_2 ; x fp32 [M][d] ; y model precision (or fp32 if y_f32)
@@ -213,6 +216,10 @@ int launch_fbank(const FbankOpts& o, const float* wave, const int* num_samples, 
 
 // ---- conv2 as an LDS-DMA implicit GEMM, bf16 / 256 -> 256 channels (conv2.hip); launch_gemm dispatches to it
 bool conv2_dma_applies(int prec, int C, int N);
+// split-bf16 form of the same kernel: image and weights as hi / lo bf16 planes, three K steps per K step of the bf16 loop
+bool conv2_x3_applies(int prec, int C, int N);
+int launch_conv2_x3(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias, void* out, int B,
+                    int T1, int F1, int T2, int F2, hipStream_t s);
 bool linear256_dma_applies(int prec, int N, int K);
 int launch_linear256_dma(const void* A, int lda, const void* W, const float* bias, float* out, int M, int K, float scale,
                          const float* pe, int pe_period, hipStream_t s);

@@ -143,6 +143,7 @@ struct cn_model {
     float* conv1_w = nullptr;  // [9][C]
     float* conv1_b = nullptr;
     Linear conv2;       // [C][9C] (kh,kw,cin)
+    void* conv2_x3w = nullptr;  // split-bf16 engine, 256 channels: the same matrix as two bf16 planes (hi, then lo) for conv2.hip's X3 form
     Linear linear_out;  // [d][F2*C] (f,c)
     std::vector<Layer> enc, extra, sad, mad;
     std::vector<ChainRef> enc_chain;  // one per encoder layer when the row-chain path applies, else empty
@@ -745,6 +746,27 @@ int build_weights(cn_model* m) {
                             pk.put_elem(at, co * 9 * C + tap * C + ci, t->data[(co * C + ci) * 9 + tap]);
         }
         m->conv2.W = reinterpret_cast<void*>(at);
+        if (conv2_x3_applies(m->prec, (int)C, (int)C)) {
+            const size_t plane = (size_t)C * 9 * C * 2, pat = pk.reserve(2 * plane);
+            if (pk.fill) {
+                const HostTensor* t = pk.find("src_embed.conv.2.weight", {C, C, 3, 3});
+                if (t)
+                    for (int64_t co = 0; co < C; ++co)
+                        for (int64_t ci = 0; ci < C; ++ci)
+                            for (int tap = 0; tap < 9; ++tap) {
+                                const float v = t->data[(co * C + ci) * 9 + tap];
+                                const uint16_t hi = f32_to_bf16_host(v);
+                                const uint32_t hb = (uint32_t)hi << 16;
+                                float hf;
+                                std::memcpy(&hf, &hb, 4);
+                                const uint16_t lo = f32_to_bf16_host(v - hf);
+                                const size_t o = pat + (size_t)(co * 9 * C + tap * C + ci) * 2;
+                                std::memcpy(&pk.host[o], &hi, 2);
+                                std::memcpy(&pk.host[o + plane], &lo, 2);
+                            }
+            }
+            m->conv2_x3w = reinterpret_cast<void*>(pat);
+        }
         m->conv2.b = pk.vec({"src_embed.conv.2.bias"}, C);
     }
     // linear_out: column c*F2+f of the reference (embedding.py:118) -> column f*C+c (the conv2 GEMM's natural output)
@@ -1004,6 +1026,7 @@ int build_weights(cn_model* m) {
     rebase(m->conv1_w, base);
     rebase(m->conv1_b, base);
     rebase_linear(m->conv2, base);
+    rebase(m->conv2_x3w, base);
     rebase_linear(m->linear_out, base);
     auto rebase_layers = [&](std::vector<Layer>& v) {
         for (auto& L : v) {
@@ -1610,13 +1633,18 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     m->U = 0;
     CN_TRY(launch_keymask(feats, B, T, F, Tp, 4, (float)o->padding_idx, m->keymask, s));
     // conv1 writes its image with a zero halo when the LDS-DMA conv2 kernel consumes it (captures want the plain image)
-    const int halo = (!cap && conv2_dma_applies(m->prec, d, d)) ? 1 : 0;
+    // (the split-bf16 engine: two bordered bf16 planes, hi and lo, for the same kernel's X3 form)
+    const bool x3_planes = !cap && m->conv2_x3w && conv2_x3_applies(m->prec, d, d);
+    const int halo = ((!cap && conv2_dma_applies(m->prec, d, d)) || x3_planes) ? 1 : 0;
     {
         // the halo cells of the image buffer are zero already when the previous haloed image had this very shape (and nothing
         // else wrote the buffer since): conv1 then writes the interior only (halo mode 2)
         const bool same = halo && m->c1_halo_B == B && m->c1_halo_T1 == T1;
         ProfScope ps(m, "conv1", 2.0 * 9 * B * T1 * F1 * d, (double)B * T * F * 4 + (double)B * T1 * F1 * d * m->es, s);
-        CN_TRY(launch_conv1(m->prec, feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : halo, s));
+        if (x3_planes)
+            CN_TRY(launch_conv1_planes(feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : 1, s));
+        else
+            CN_TRY(launch_conv1(m->prec, feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : halo, s));
         m->c1_halo_B = halo ? B : -1;
         m->c1_halo_T1 = halo ? T1 : -1;
     }
@@ -1642,7 +1670,13 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         g.cF2 = F2;
         ProfScope ps(m, "conv2", 2.0 * g.M * g.N * g.K,
                      ((double)B * T1 * F1 * d + (double)g.N * g.K + (double)g.M * g.N) * m->es, s);
-        CN_TRY(launch_gemm(m->prec, g, s));
+        if (x3_planes) {
+            const size_t img = (size_t)B * (T1 + 2) * (F1 + 2) * d * 2, wpl = (size_t)d * 9 * d * 2;
+            CN_TRY(launch_conv2_x3(m->c1, (const unsigned char*)m->c1 + img, m->conv2_x3w, (const unsigned char*)m->conv2_x3w + wpl,
+                                   m->conv2.b, m->c2, B, T1, F1, Tp, F2, s));
+        } else {
+            CN_TRY(launch_gemm(m->prec, g, s));
+        }
     }
     if (cap) CN_TRY(capture(m, "conv2", m->c2, true, CN_DTYPE_F32, {B, Tp, F2, d}, s));
     {

@@ -155,6 +155,12 @@ def test_bf16x3_fused_path_matches_the_goldens(case, name):
     model = build(args, state, "bf16x3", capture=False)
     out = decode(model, args, feats, sizes)
     eng = model._engine
+    # the encoder output of this path (conv2 on the LDS-DMA kernel's split form, projection kernel, fused FFN) against the
+    # same engine's capture run (generic GEMM kernels throughout): two roundings of the same fp32-grade arithmetic
+    ref_model = build(args, state, "bf16x3", capture=True)
+    decode(ref_model, args, feats, sizes)
+    enc_ref = ref_model._engine.fetch("enc_h")
+    assert maxerr(eng.fetch("enc_h_live"), enc_ref) < 2e-4 * max(1.0, float(np.abs(enc_ref).max()))
     flips = eng.fetch("best_paths") != g["best_paths"]
     assert (g["margin"].astype(np.float32)[flips] < 1e-4).all()
     if not flips.any():
