@@ -26,7 +26,9 @@ def ctc_beam_decode(model, src, src_mask, src_size, vocab, args, lm_model=None):
     ratio = src_size.to(dev, torch.float32).contiguous()
     B, T, _ = feats.shape
     eng = model.engine(B, T)
-    opts = hip.Engine.make_opts(args)
+    # (args.hip_capture as in CassNAT.beam_decode: a capture run keeps every stage on the kernels that leave full tensors behind,
+    # so that `ctc_out` fetched after a later call of the same engine is the tensor this search ran on)
+    opts = hip.Engine.make_opts(args, capture=getattr(args, "hip_capture", False))
     opts.sos = sos
     hyp, hlen, sc, pb, pnb, nb = eng.ctc_beam(feats, ratio, opts, int(args.ctc_beam), int(args.ctc_pruning), float(args.ctc_lp))
     hyp, hlen, sc, pb, pnb, nb = (t.cpu().numpy() for t in (hyp, hlen, sc, pb, pnb, nb))

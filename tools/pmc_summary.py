@@ -30,7 +30,7 @@ def per_kernel(path, counter):
 def mfma_summary(sdir, out):
     names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "GRBM_GUI_ACTIVE"]
     acc = {n: per_kernel(sdir, n) for n in names}
-    kernels = {"chain_kernel": "chain_kernel", "conv2_kernel<false>": "conv2_kernel (conv2)", "conv2_kernel<true>": "conv2_kernel<LINEAR> (linear_out)",
+    kernels = {"chain_kernel": "chain_kernel", "conv2_kernel<false, false>": "conv2_kernel (conv2)", "conv2_kernel<true, false>": "conv2_kernel<LINEAR> (linear_out)",
                "attention_kernel": "attention_kernel", "genmax_kernel": "genmax_kernel", "conv1_kernel": "conv1_kernel"}
     c = int(sys.argv[5]) if len(sys.argv) > 5 else 10
     rec = {"source": "rocprofv3 --pmc " + " ".join(names) + f" (its own pass, --kernel-trace only), bench.py --steps {2 * c} --warmup {c} --streams 1 --coalesce {c} "
@@ -62,8 +62,8 @@ def main():
     fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
     c = int(sys.argv[5]) if len(sys.argv) > 5 else 10  # batches of 32 x 1000 frames per engine pass in the profiled runs
     targets = {"row_chain": ("chain_kernel", f"chain_kernel (all 21 launches of an engine pass of {c} batches: 12 encoder at {8000 * c} rows, 9 decoder-side)"),
-               "conv2": ("conv2_kernel<false>", f"conv2_kernel<false> (LDS-DMA implicit GEMM, {c} batches of 32 x 1000 frames per launch)"),
-               "linear_out": ("conv2_kernel<true>", f"conv2_kernel<true> (linear_out on the LDS-DMA tile kernel, {8000 * c} x 5120 -> 256)")}
+               "conv2": ("conv2_kernel<false, false>", f"conv2_kernel<false, false> (LDS-DMA implicit GEMM, {c} batches of 32 x 1000 frames per launch)"),
+               "linear_out": ("conv2_kernel<true, false>", f"conv2_kernel<true, false> (linear_out on the LDS-DMA tile kernel, {8000 * c} x 5120 -> 256)")}
     for tag, (needle, label) in targets.items():
         fk = [v for k, vs in fetch.items() if needle in k for v in vs]
         wk = [v for k, vs in write.items() if needle in k for v in vs]
