@@ -18,8 +18,8 @@ class Vocab:
     word2index = {"blank": 0, "sos": 1, "eos": 2, "unk": 3}
 
 
-def build(args, state, capture=True):
-    args.hip_precision = "fp32"
+def build(args, state, capture=True, prec="fp32"):
+    args.hip_precision = prec
     args.hip_capture = capture
     model = make_model(args.input_size, args).cuda()
     with torch.no_grad():
@@ -416,7 +416,8 @@ def test_randomised_shapes_bf16_fast_path_against_the_fp32_engine():
     assert same_path >= 4
 
 
-def test_merged_pass_equals_separate_passes_when_rows_change_workgroups():
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3", "fp32"])
+def test_merged_pass_equals_separate_passes_when_rows_change_workgroups(prec):
     """The config-2 model at a size where a merged engine pass puts an utterance's rows into other workgroups than a pass of
     its own does (400 frames -> 100 rows per utterance, 128-row workgroups, three ragged batches of 4): hypotheses AND scores
     are bitwise those of the separate passes.  (A per-workgroup rotation of the FFN / vocabulary tile order made the fp32
@@ -426,7 +427,7 @@ def test_merged_pass_equals_separate_passes_when_rows_change_workgroups():
     args = synth.make_args("config2")
     args.hip_max_batch, args.hip_max_frames = 4, 400
     state = synth.make_state(args, seed=0, blank_bias=synth.BENCH_BLANK_BIAS)
-    model = build(args, state, capture=False)
+    model = build(args, state, capture=False, prec=prec)  # (bf16: row chain / generator kernels; bf16x3: FFN, projection, generator, conv2 kernels)
     rng = np.random.default_rng(21)
     data = []
     for k in range(3):
