@@ -69,6 +69,14 @@ def main():
                          "end of a kernel trace: tools/trace_tail.py)")
     ap.add_argument("--no-uncoalesced", action="store_true",
                     help="skip the extra measurement with one batch per engine pass (reported beside `value`)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 through the N > 1 code: a world-size-1 RCCL process group, the weight-blob broadcast and the "
+                         "all_gather_into_tensor of the hypothesis records (what the driver's multi-GPU command runs, on one GPU)")
+    ap.add_argument("--no-ragged-leg", action="store_true",
+                    help="skip the extra measurement on a length-sorted list of batches of DIFFERENT frame counts (300..1500), "
+                         "merged by workspace area as decode_asr does (reported beside `value`)")
+    ap.add_argument("--no-predict", action="store_true", help="decode every pass with the mid-pass host sync on the row count (round 2's form)")
+    ap.add_argument("--plan", default="", help="explicit pass sizes of the timed run, e.g. 8,8,4 (default: equal shares)")
     a = ap.parse_args()
 
     import numpy as np
@@ -92,8 +100,14 @@ def main():
         a.gpus = world
     local_rank = min(local_rank, torch.cuda.device_count() - 1)  # gloo rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dist_on = world > 1 or a.force_dist
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:  # --force-dist: a world of one rank on this GPU
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -123,13 +137,15 @@ def main():
     bcast = {"ms": None}
 
     def receive_weights(eng):
-        if world > 1:
+        if dist_on:
             t0 = time.perf_counter()
             cdist.broadcast_weights(eng, src=0)
             bcast["ms"] = (time.perf_counter() - t0) * 1e3
 
     CO = max(1, a.coalesce) if a.precision != "fp32" else 1
-    pipes = DecodePipelines(model, NS, B, T, with_weights=(rank == 0), after_engine=receive_weights, coalesce=CO)
+    pipes = DecodePipelines(model, NS, B, T, with_weights=(rank == 0), after_engine=receive_weights, coalesce=CO,
+                            predict_rows=not a.no_predict)
+    plan = [int(x) for x in a.plan.split(",")] if a.plan else None
     engines = pipes.engines
     bcast_ms = bcast["ms"]
     blob_bytes = engines[0].weight_blob()[1]
@@ -141,7 +157,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -152,11 +168,14 @@ def main():
         host happen here, in THIS thread only and in step order, so every rank issues the same sequence of collectives."""
         # (hypotheses reach the host as arrays - tokens, lengths, scores of all ranks' utterances - without per-utterance Python
         # work: at 8 ranks a step carries 256 of them)
-        for _, hyps_, scores_ in pipes.decode([(feats, sizes, k) for k in range(n_steps)], args, sos=1, gather=world > 1,
-                                              as_lists=False):
+        for _, hyps_, scores_ in pipes.decode([(feats, sizes, k) for k in range(n_steps)], args, sos=1, gather=dist_on,
+                                              as_lists=False, plan=list(plan) if plan and n_steps == a.steps else None):
             last[0] = (hyps_, scores_)
 
     run_steps(max(a.warmup, NS * CO))
+    if pipes.predict:  # (the first passes run exactly and teach the row-count predictor; one more, predicted, warms that form up)
+        run_steps(NS * CO)
+    stats0 = dict(pipes.stats)
     U = int(engines[0].fetch("ymax")[0])
     eng = engines[0]
     fence()
@@ -169,14 +188,15 @@ def main():
     run_steps(a.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    pass_stats = {k: pipes.stats[k] - stats0[k] for k in stats0}
     if a.exit_after_timed:
         if rank == 0:
             print(json.dumps({"value": round(a.steps * B * world / elapsed, 2), "ms_per_step": round(elapsed / a.steps * 1e3, 4), "steps": a.steps}))
         pipes.close()
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
-    prof = {t: {"count": 0, "ms": 0.0, "flops": 0.0} for t in ROOF_TAGS}
+    prof = {t: {"count": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0} for t in ROOF_TAGS}
     for e in engines[:1]:
         got = e.profile_end()
         for t in ROOF_TAGS:
@@ -185,7 +205,7 @@ def main():
                     prof[t][k] += got[t][k]
     (toks_, lens_), scores = last[0]
     hyps = [toks_[b, : lens_[b]].tolist() for b in range(toks_.shape[0])]  # the last step's hypotheses, as token lists
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -232,8 +252,46 @@ def main():
                        "decode_pipelines": NS1, "note": "same workload and step count with one batch of 32 per engine pass"}
         pipes2.close()
 
+    # ---- extra (never `value`; N = 1 only): what decode_asr meets - a length-sorted list of batches of DIFFERENT frame counts
+    # (300..1500, every batch padded to its own longest utterance), merged into engine passes by workspace area
+    ragged_leg = None
+    if not a.no_ragged_leg and world == 1 and not dist_on and a.precision in ("bf16", "bf16x3"):
+        rng = np.random.default_rng(99)
+        n_b = 48
+        lens = np.sort(rng.integers(300, 1501, size=n_b * B))[::-1]
+        rb = []
+        for k in range(n_b):
+            lk = [int(x) for x in lens[k * B:(k + 1) * B]]
+            fh, sh = synth.make_feats(B, lk[0], F, lengths=lk, seed=7000 + k)
+            rb.append((torch.from_numpy(fh).cuda(), torch.from_numpy(sh).cuda(), k))
+        audio_r = float(lens.sum()) * 0.01
+        pipes3 = DecodePipelines(model, NS, B, 1500, coalesce=-CO, share_from=engines[0], predict_rows=not a.no_predict)
+
+        def run3():
+            for _ in pipes3.decode(rb, args, sos=1, as_lists=False):
+                pass
+
+        run3()
+        st3 = dict(pipes3.stats)
+        fence()
+        c0 = time.perf_counter()
+        run3()
+        fence()
+        el3 = time.perf_counter() - c0
+        ragged_leg = {"value": round(n_b * B / el3, 2), "unit": "utt/s", "audio_seconds_per_second": round(audio_r / el3, 1),
+                      "batches": n_b, "frames_min_max": [int(lens.min()), int(lens.max())], "mean_frames": round(float(lens.mean()), 1),
+                      "engine_passes": pipes3.stats["passes"] - st3["passes"],
+                      "passes_mixing_frame_counts": pipes3.stats["merged_ragged"] - st3["merged_ragged"],
+                      "row_predictions_missed": pipes3.stats["missed"] - st3["missed"],
+                      "note": "length-sorted list of 48 batches of 32 utterances of 300..1500 frames, each batch padded to its own "
+                              "longest utterance; consecutive batches share an engine pass while they fit the workspace area "
+                              "(cn_decode_nast_merged: per-batch results identical to separate passes); compare "
+                              "audio_seconds_per_second with rtfx"}
+        pipes3.close()
+        del rb
+
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -254,10 +312,13 @@ def main():
         pmc_path = os.path.join(REPO, "profiles", f"pmc_{tag}.json")
         if os.path.exists(pmc_path):
             try:
-                pj = json.load(open(pmc_path))  # (counted on launches of a given width: quoted only beside launches of that width)
-                pmc = pj.get("hbm_bytes_per_launch") if pj.get("batches_per_engine_pass", 3) == CO else None
+                # counted in separate rocprofv3 --pmc passes on launches of a given width and grouped by launch width
+                # (tools/pmc_summary.py): the mean over the launches of a pass of that width, quoted only beside such launches
+                pj = json.load(open(pmc_path))
+                pmc = pj.get("hbm_bytes_per_launch") if pj.get("batches_per_engine_pass", 3) == CO and "by_grid" in pj else None
             except Exception:
                 pmc = None
+        alg_bytes = pr["bytes"] / pr["count"] if pr.get("bytes") else None
         iso = stages.get(tag)
         iso_tf = round(iso["flops"] / (iso["ms"] * 1e-3) / 1e12, 2) if iso and iso["ms"] > 0 else None
         isow = stages_wide.get(tag)
@@ -267,7 +328,9 @@ def main():
                      "'isolated_achieved' is the same kernel with the GPU to itself (one pipeline, one batch per pass, outside the "
                      f"timed region), 'isolated_at_width_achieved' likewise at the timed run's {CO} batches per pass",
              "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-             "traffic": pmc, "flops_per_launch": round(pr["flops"] / pr["count"]), "avg_launch_us": round(avg_s * 1e6, 2),
+             "traffic": pmc, "algorithmic_bytes_per_launch": None if alg_bytes is None else round(alg_bytes),
+             "traffic_over_algorithmic": None if (pmc is None or not alg_bytes) else round(pmc / alg_bytes, 3),
+             "flops_per_launch": round(pr["flops"] / pr["count"]), "avg_launch_us": round(avg_s * 1e6, 2),
              "launches_timed": pr["count"], "isolated_achieved": iso_tf,
              "isolated_frac": None if iso_tf is None else round(iso_tf / peak, 4),
              "isolated_at_width_achieved": isow_tf, "isolated_at_width_frac": None if isow_tf is None else round(isow_tf / peak, 4)}
@@ -275,13 +338,13 @@ def main():
         return r
 
     Tp_ = ((T - 1) // 2) // 2 + 1
-    enc_wgs = -(-B * Tp_ // 128)
+    enc_wgs = -(-B * Tp_ * CO // 128)  # 128-row workgroups over the merged pass's rows
     roofline = None
     if a.precision == "bf16":
         roofline = roof("row_chain",
                         "chain_kernel (per layer: attention out-projection + residual + LayerNorm + FFN + residual + next "
                         "LayerNorm + next Q|K|V projection; 21 launches per step: 12 encoder, 9 decoder-side)",
-                        {"workgroups_encoder_launch": enc_wgs * CO,
+                        {"workgroups_encoder_launch": enc_wgs,
                          "design_note": "a launch deliberately occupies ceil(rows / 128) CUs (63 of 256 for the encoder): its weight "
                                         "stream is bound per CU, so the remaining CUs are left to the other decode pipelines; "
                                         "'frac' is against the whole chip's peak all the same"})
@@ -380,19 +443,24 @@ def main():
                                "V 5000, greedy NAST; 32 utterances x 1000 frames x 80 fbank per GPU per step",
                    "batch_per_gpu": B, "frames": T, "feat_dim": F, "global_batch": B * world, "tokens_U_max": U,
                    "parallelism": f"utterance-sharded x{world}", "decode_pipelines_per_gpu": NS,
-                   "batches_per_engine_pass": CO,
+                   "batches_per_engine_pass": CO, "utterances_per_engine_pass": B * CO,
+                   "regime": "the package's own test-set decoder (pipeline.DecodePipelines, decode_asr's defaults: 2 pipelines, "
+                             "consecutive batches merged into engine passes by workspace area with per-batch results unchanged, "
+                             "decoder side launched on a predicted row count and verified)",
+                   "engine_passes_timed": pass_stats["passes"], "row_predictions": pass_stats["predicted"],
+                   "row_predictions_missed": pass_stats["missed"], "collectives": "rccl" if dist_on and a.backend == "nccl" else (a.backend if dist_on else None),
                    "blank_bias": synth.BENCH_BLANK_BIAS},
         "rtf": round(elapsed / audio_s, 8), "rtfx": round(audio_s / elapsed, 1),
         "gflop_per_utt": round(flops / B / 1e9, 3),
         # algorithmic FLOP/s of the whole path against the chip's peak for this precision's products (bf16x3: three MFMAs each)
         "mfma_frac_end_to_end": round(flops / B * value / (world * peak * 1e12 / (3.0 if a.precision == "bf16x3" else 1.0)), 5),
         "roofline": roofline, "roofline_conv2": roofline_conv2, "cpu_baseline": cpu, "parity_engine": parity_engine,
-        "fp32_engine": fp32_engine, "one_batch_per_pass": uncoalesced,
+        "fp32_engine": fp32_engine, "one_batch_per_pass": uncoalesced, "ragged_set": ragged_leg,
         "stage_ms": stage_ms,
         "weight_blob_mb": round(blob_bytes / 1e6, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
     }
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

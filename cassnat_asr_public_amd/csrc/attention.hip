@@ -36,6 +36,8 @@ struct AttnParams {
     int stamps;  // investigation aid (CASSNAT_ATTN_STAMPS): the last workgroup's thread 0 records s_memtime at its phase boundaries
     const int* kv_index;  // non-null: ... at entry kv_index[b] (beam search: every hypothesis row names its utterance)
     const int* klen;
+    const int* kcap;  // keys the K / V entry's own batch has (merged passes; null: Lk) - later keys get -inf, not the float-min fill
+    int kcap_stride;
     const int* iv;
     int iv_stride;
     int causal;
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
     // ---- staging registers for the next K/V tile
     uint4 k_reg[ST_IT], v_reg[ST_IT];
     const int bk = p.kv_index ? p.kv_index[b] : (p.kv_mod > 0 ? b % p.kv_mod : b);
+    const int kcap = p.kcap ? p.kcap[(long long)bk * p.kcap_stride] : p.Lk;
     const unsigned char* kbase = p.K + (long long)bk * p.Lk * p.ldk_b + (long long)h * KROW;
     const unsigned char* vbase = p.V + (long long)bk * p.Lk * p.ldv_b + (long long)h * KROW;
     auto load_tile = [&](int kt) {
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
         if (tid < 64) {
             const int key = kt * 64 + tid;
             unsigned char code = 2;
-            if (key < p.Lk) {
+            if (key < kcap) {
                 bool ok = key < klen;
                 if (p.keymask) ok = ok && p.keymask[(long long)bk * p.Lk + key] != 0;
                 code = ok ? 1 : 0;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
         __syncthreads();
         for (int i = tid; i < nkt * 64; i += NT) {
             unsigned char code = 2;
-            if (i < p.Lk) {
+            if (i < kcap) {
                 bool ok = i < klen;
                 if (p.keymask) ok = ok && p.keymask[(long long)bk * p.Lk + i] != 0;
                 code = ok ? 1 : 0;
@@ -513,6 +516,8 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     p.stamps = stamps;
     p.kv_index = a.kv_index;
     p.klen = a.klen;
+    p.kcap = a.kcap;
+    p.kcap_stride = a.kcap_stride;
     p.iv = a.intervals;
     p.iv_stride = a.iv_stride;
     p.causal = a.causal;

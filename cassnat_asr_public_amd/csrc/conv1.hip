@@ -12,7 +12,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <typename T, bool PLANES = false>
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
                                                     const float* __restrict__ bias, T* __restrict__ out, int B, int Tn,
-                                                    int F, int T1, int F1, int C, int halo, long long lo_off = 0) {
+                                                    int F, int T1, int F1, int C, int halo, long long lo_off = 0,
+                                                    const UttMeta* __restrict__ utt_meta = nullptr) {
     // A thread keeps its 8 channels for the whole kernel, so the 72 tap weights + 8 biases live in registers (as pairs: the
     // 72 multiply-adds of an output position are 36 v_pk_fma_f32).  The three input rows of an output row are staged once in
     // LDS with their zero padding (index f + 1, f = -1 .. F), so a position's nine taps are nine unconditional LDS reads - the
@@ -43,12 +44,16 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
     for (int row = blockIdx.x; row < rows; row += gridDim.x, buf ^= 1) {
         const int b = row / T1p, t1 = row - b * T1p - halo;
         T* orow = out + (long long)row * F1p * C + (__is_same(T, split_t) ? 0 : c0);
-        const bool row_in = t1 >= 0 && t1 < T1;
+        // merged pass: the utterance's own batch is `tl` frames long - later frames are zero padding, later image rows zeros
+        const int tl = utt_meta ? utt_meta[b].frames : Tn;
+        const int t1_own = utt_meta ? (tl - 1) / 2 + 1 : T1;
+        const bool row_in = t1 >= 0 && t1 < t1_own;
+        const bool past_own = t1 >= t1_own && t1 < T1;  // an interior row of the merged image that the own batch does not have
         float* xs = xs_all + buf * 3 * FW;
         if (row_in) {
             for (int i = threadIdx.x; i < 3 * FW; i += 256) {
                 const int kh = i / FW, f = i - kh * FW - 1, t = 2 * t1 - 1 + kh;
-                xs[i] = (t >= 0 && t < Tn && f >= 0 && f < F) ? x[((long long)b * Tn + t) * F + f] : 0.f;
+                xs[i] = (t >= 0 && t < tl && f >= 0 && f < F) ? x[((long long)b * Tn + t) * F + f] : 0.f;
             }
         }
         __syncthreads();  // (a buffer is rewritten two rows later: every thread has passed the barrier in between)
@@ -56,14 +61,18 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
             const int f1 = fp - halo;
             T* dst = orow + (long long)fp * C;
             const bool cell_in = row_in && f1 >= 0 && f1 < F1;
-            if (!cell_in) {  // border cell (bordered images only)
-                if (skip_border) continue;
+            if (!cell_in) {  // border cell (bordered images only), or a row past the utterance's own batch (written as zeros)
+                if (skip_border && !past_own) continue;
                 if constexpr (sizeof(T) == 2) {
                     *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
                     if constexpr (PLANES) *reinterpret_cast<uint4*>(dst + lo_off) = make_uint4(0, 0, 0, 0);
                 } else if constexpr (!__is_same(T, split_t)) {
                     *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
                     *reinterpret_cast<uint4*>(dst + 4) = make_uint4(0, 0, 0, 0);
+                } else {  // split-bf16 (no bordered form: only rows past the utterance's own batch come here): hi and lo halves
+                    unsigned char* db = reinterpret_cast<unsigned char*>(dst) + cn_split_off((size_t)c0);
+                    *reinterpret_cast<uint4*>(db) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(db + 64) = make_uint4(0, 0, 0, 0);
                 }
                 continue;
             }
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
 }
 
 int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1,
-                 int F1, int C, int halo, hipStream_t s) {
+                 int F1, int C, int halo, hipStream_t s, const UttMeta* utt_meta) {
     if (C % 8 != 0 || (256 % (C / 8)) != 0) {
         cn_set_error("conv1: channel count must be a multiple of 8 with C/8 dividing 256");
         return -1;
@@ -139,13 +148,13 @@ int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, 
     }
     if (prec == CN_PREC_F32)
         hipLaunchKernelGGL(conv1_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (float*)out, B, T,
-                           F, T1, F1, C, halo);
+                           F, T1, F1, C, halo, 0ll, utt_meta);
     else if (prec == CN_PREC_X3)
         hipLaunchKernelGGL(conv1_kernel<split_t>, dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (split_t*)out, B, T,
-                           F, T1, F1, C, halo);
+                           F, T1, F1, C, halo, 0ll, utt_meta);
     else
         hipLaunchKernelGGL(conv1_kernel<bf16>, dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (bf16*)out, B, T,
-                           F, T1, F1, C, halo);
+                           F, T1, F1, C, halo, 0ll, utt_meta);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -153,7 +162,7 @@ int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, 
 // the split-bf16 engine's image for the LDS-DMA conv2 kernel: two bordered bf16 planes ([B][T1 + 2][F1 + 2][C] each; hi at
 // `out`, lo right behind it).  halo: 1 = write the border zeros, 2 = they are there already (launch_conv1)
 int launch_conv1_planes(const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1, int F1,
-                        int C, int halo, hipStream_t s) {
+                        int C, int halo, hipStream_t s, const UttMeta* utt_meta) {
     if (C % 8 != 0 || (256 % (C / 8)) != 0 || (halo != 1 && halo != 2)) {
         cn_set_error("conv1 (planes): channel count must be a multiple of 8 with C/8 dividing 256; the image is always bordered");
         return -1;
@@ -164,7 +173,7 @@ int launch_conv1_planes(const float* x, const float* w9c, const float* bias, voi
     const size_t lds = (size_t)2 * 3 * (F + 2) * sizeof(float);
     const long long plane = (long long)B * (T1 + 2) * (F1 + 2) * C;
     hipLaunchKernelGGL((conv1_kernel<bf16, true>), dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (bf16*)out, B, T, F, T1,
-                       F1, C, halo, plane);
+                       F1, C, halo, plane, utt_meta);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -120,33 +120,39 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
     // The input image carries a one-cell zero halo ([B][T1+2][F1+2][256], written by conv1), so no tap is ever out of
     // range: the source of a row is (its fixed byte offset, a VGPR) + (a per-step, wave-uniform offset, the scalar base
     // of the DMA): the address arithmetic of a K step is two scalar adds.
+    // Lane offsets are 32-bit and RELATIVE to the tile's first row (a wave-uniform 64-bit base, part of the scalar base of
+    // every request): the rows of a tile are consecutive (b, t2, f2) positions, so they span a few image rows however large
+    // the image (a merged engine pass of many batches exceeds 4 GiB; with absolute 32-bit offsets the reads wrapped silently)
     const int F1p = p.F1 + 2;
+    auto a_off = [&](int mm) -> long long {
+        if constexpr (LINEAR) return (long long)mm * p.lda_bytes;
+        const int f2 = mm % p.F2, bt = mm / p.F2;
+        const int t2 = bt % p.T2, b = bt / p.T2;
+        return (((long long)b * (p.T1 + 2) + 2 * t2) * F1p + 2 * f2) * (C2_C * 2);
+    };
+    const long long tile_off = a_off(m0);  // (m0 < M: the grid has ceil(M / 256) workgroups)
     unsigned pa[8], pw[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int row = 8 * (wave + 4 * i) + r8;
         const int m = m0 + row;
         const int mc = m < p.M ? m : p.M - 1;  // rows past M compute on the last row's data and are never stored
-        const int f2 = mc % p.F2, bt = mc / p.F2;
-        const int t2 = bt % p.T2, b = bt / p.T2;
-        if constexpr (LINEAR) {
-            pa[i] = (unsigned)((long long)mc * p.lda_bytes) + sw;
+        pa[i] = (unsigned)(a_off(mc) - tile_off) + sw;
+        if constexpr (LINEAR)
             pw[i] = (unsigned)(row * (p.ksteps * 128)) + sw;
-        } else {
-            pa[i] = (unsigned)(((b * (p.T1 + 2) + 2 * t2) * F1p + 2 * f2) * (C2_C * 2)) + sw;
+        else
             pw[i] = (unsigned)(row * (9 * C2_C * 2)) + sw;
-        }
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const unsigned m0_wave = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
     // source bases / destinations of K step kt (channel block outermost, tap innermost), stage kt & 1
     const int KSTEPS = LINEAR ? p.ksteps : (X3 ? 3 * C2_KSTEPS : C2_KSTEPS);
     auto a_base = [&](int kt) -> const unsigned char* {
-        if constexpr (LINEAR) return p.A + (long long)kt * 128;
-        const unsigned char* plane = p.A;
+        if constexpr (LINEAR) return p.A + tile_off + (long long)kt * 128;
+        const unsigned char* plane = p.A + tile_off;
         if constexpr (X3) {
             const int k = kt / 3;
-            if (kt - 3 * k == 1) plane = p.A_lo;
+            if (kt - 3 * k == 1) plane = p.A_lo + tile_off;
             kt = k;
         }
         const int cb = kt / 9, tap = kt - 9 * cb;
@@ -377,6 +383,18 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
 // bf16, 256 -> 256 channels only; everything else stays on the generic implicit GEMM (gemm.hip)
 bool conv2_dma_applies(int prec, int C, int N) { return prec == CN_PREC_BF16 && C == C2_C && N == C2_N && !getenv("CASSNAT_NO_CONV2_DMA"); }
 
+// The lane offsets of a tile are relative to its first row: what has to fit 32 bits is the span of 256 consecutive output
+// positions in the image - (256 / F2 + 2) output rows of two image rows each, plus a batch boundary's two halo rows
+static bool conv2_tile_span_too_large(int T1, int F1, int F2) {
+    const long long span = ((256ll / (F2 > 0 ? F2 : 1) + 3) * 2 + 4) * (F1 + 2) * C2_C * 2;
+    if (span >= (1ll << 32)) {
+        cn_set_error("conv2: one 256-row tile spans more than 4 GiB of the image (feature dimension too wide for the LDS-DMA kernel)");
+        return true;
+    }
+    (void)T1;
+    return false;
+}
+
 // `in`: conv1 output WITH the zero halo, [B][T1 + 2][F1 + 2][256] bf16
 int launch_conv2_dma(const void* in, const void* w, const float* bias, void* out, int B, int T1, int F1, int T2, int F2,
                      hipStream_t s) {
@@ -398,6 +416,7 @@ int launch_conv2_dma(const void* in, const void* w, const float* bias, void* out
     p.F2 = F2;
     p.ntiles = cn_ceil_div(p.M, C2_BM);
     if (p.M <= 0) return 0;
+    if (conv2_tile_span_too_large(T1, F1, F2)) return -1;
     hipLaunchKernelGGL(conv2_kernel<false>, dim3(p.ntiles), dim3(256), C2_LDS, s, p);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
@@ -415,10 +434,7 @@ int launch_conv2_x3(const void* in_hi, const void* in_lo, const void* w_hi, cons
         CN_HIP_CHECK(hipFuncSetAttribute((const void*)conv2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS));
         attr_once.mark(attr_dev);
     }
-    if ((long long)B * (T1 + 2) * (F1 + 2) * C2_C * 2 >= (1ll << 32)) {
-        cn_set_error("conv2_x3: an image plane exceeds the 32-bit lane offsets of the LDS-DMA kernel");
-        return -1;
-    }
+    if (conv2_tile_span_too_large(T1, F1, F2)) return -1;
     Conv2Params p = {};
     p.A = (const unsigned char*)in_hi;
     p.A_lo = (const unsigned char*)in_lo;
@@ -452,8 +468,8 @@ int launch_linear256_dma(const void* A, int lda, const void* W, const float* bia
         attr_once.mark(attr_dev);
     }
     if (M <= 0) return 0;
-    if ((long long)M * lda * 2 >= (1ll << 32)) {
-        cn_set_error("linear256: A exceeds the 32-bit lane offsets of the LDS-DMA kernel");
+    if (256ll * lda * 2 >= (1ll << 32)) {
+        cn_set_error("linear256: a 256-row tile of A exceeds the 32-bit lane offsets of the LDS-DMA kernel");
         return -1;
     }
     Conv2Params p = {};

@@ -19,15 +19,18 @@ __global__ __launch_bounds__(256) void ctc_align_kernel(AlignArgs a) {
     int* s_lo = s_carry + 4;                     // [Tp+1] first valid frame of row u
     int* s_hi = s_lo + (a.Tp + 1);               // [Tp+1] one past the last valid frame of row u
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int Tp = a.Tp;
-    const int* best = a.best + (long long)b * Tp;
+    const int Tw = a.Tp;  // row width of the call's buffers
+    const int* best = a.best + (long long)b * Tw;
     const int bs = a.src_mod > 0 ? b % a.src_mod : b;
-    const unsigned char* km = a.keymask + (long long)bs * Tp;
-    int* shift = a.shift + (long long)b * Tp;
-    int* iv = a.intervals + (long long)b * (Tp + 1) * 4;
+    const unsigned char* km = a.keymask + (long long)bs * Tw;
+    int* shift = a.shift + (long long)b * Tw;
+    int* iv = a.intervals + (long long)b * (Tw + 1) * 4;
+    // merged pass: the utterance's own batch has fewer frames than the call - ITS width is what the reference's tensors had
+    // (frames at or past it do not exist: keymask is 0 there, and the shift below must not carry a token onto them)
+    const int Tp = a.utt_meta ? a.utt_meta[bs].tp : Tw;
 
     // rows start empty: (INT_MAX, 0) is the identity of (min, max)
-    for (int u = tid; u <= Tp; u += 256) {
+    for (int u = tid; u <= Tw; u += 256) {
         s_lo[u] = 0x7fffffff;
         s_hi[u] = 0;
     }
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(256) void ctc_align_kernel(AlignArgs a) {
 
     // path[t] = keymask ? argmax : 0 ; collapsed[t] = path[t]==path[t-1] ? 0 : path[t] (path[-1]=0)
     // shift[t] = collapsed[t-1], shift[0] = 0 ; c[t] = #{t' <= t : shift[t'] != blank}
-    for (int base = 0; base < Tp; base += 256) {
+    for (int base = 0; base < Tw; base += 256) {
         const int t = base + tid;
         int sh = 0;
         if (t < Tp && t >= 1) {
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256) void ctc_align_kernel(AlignArgs a) {
             const int p2 = (t >= 2) ? ((a.raw_path || km[t - 2]) ? best[t - 2] : 0) : 0;
             sh = (p1 == p2) ? 0 : p1;
         }
-        if (t < Tp) shift[t] = sh;
+        if (t < Tw) shift[t] = sh;
         const int nz = (t < Tp && sh != a.blank) ? 1 : 0;
         // inclusive block scan
         s_scan[tid] = nz;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void ctc_align_kernel(AlignArgs a) {
         a.ylen[b] = ylen0 + 1;
         atomicMax(a.ymax, ylen0 + 1);
     }
-    for (int u = tid; u <= Tp; u += 256) {
+    for (int u = tid; u <= Tw; u += 256) {
         int s1 = s_lo[u], e1 = s_hi[u], s2 = 0, e2 = 0;
         if (s1 == 0x7fffffff) {
             s1 = 0;
@@ -125,15 +128,24 @@ int launch_ctc_align(const AlignArgs& a, hipStream_t s) {
 // the largest ylen of ITS batch (what U would have been had that batch been decoded alone), so its hypothesis is the same.
 __global__ void greedy_pack_kernel(const int* __restrict__ tok, const float* __restrict__ val,
                                    const int* __restrict__ ylen, int B, int U, int sos, int hyp_stride,
-                                   int* __restrict__ hyp, int* __restrict__ hyp_len, double* __restrict__ score, int sub) {
+                                   int* __restrict__ hyp, int* __restrict__ hyp_len, double* __restrict__ score, int sub,
+                                   const UttMeta* __restrict__ utt_meta, const int* __restrict__ ymax_dev) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     int ulim = U;
-    if (sub > 0 && sub < B) {
-        const int b0 = (b / sub) * sub, b1 = b0 + sub < B ? b0 + sub : B;
-        ulim = 0;
-        for (int j = b0; j < b1; ++j) ulim = ylen[j] > ulim ? ylen[j] : ulim;
-        if (ulim > U) ulim = U;
+    if (ymax_dev && *ymax_dev < ulim) ulim = *ymax_dev;  // U was a prediction: the reference's row count is the true maximum
+    if (utt_meta || (sub > 0 && sub < B)) {
+        int b0, b1;
+        if (utt_meta) {
+            b0 = utt_meta[b].sub_lo;
+            b1 = utt_meta[b].sub_hi;
+        } else {
+            b0 = (b / sub) * sub;
+            b1 = b0 + sub < B ? b0 + sub : B;
+        }
+        int um = 0;
+        for (int j = b0; j < b1; ++j) um = ylen[j] > um ? ylen[j] : um;
+        if (um < ulim) ulim = um;
     }
     int n = ylen[b] + 1;
     if (n > ulim) n = ulim;
@@ -151,10 +163,10 @@ __global__ void greedy_pack_kernel(const int* __restrict__ tok, const float* __r
 }
 
 int launch_greedy_pack(const int* tok, const float* val, const int* ylen, int B, int U, int sos, int hyp_stride,
-                       int* hyp, int* hyp_len, double* score, hipStream_t s, int sub) {
+                       int* hyp, int* hyp_len, double* score, hipStream_t s, int sub, const UttMeta* utt_meta, const int* ymax_dev) {
     if (B <= 0) return 0;
     hipLaunchKernelGGL(greedy_pack_kernel, dim3(cn_ceil_div(B, 64)), dim3(64), 0, s, tok, val, ylen, B, U, sos,
-                       hyp_stride, hyp, hyp_len, score, sub);
+                       hyp_stride, hyp, hyp_len, score, sub, utt_meta, ymax_dev);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -42,11 +42,29 @@ int launch_gemm(int prec, const GemmArgs& a, hipStream_t s);
 
 // ---- first subsampling convolution, 1 -> C channels, 3x3 stride 2 pad 1, + ReLU   (conv1.hip)
 // x (B,T,F) fp32  ->  out (B,T1,F1,C) channels-last in model precision.  w is [9][C] (tap-major).
+// utt_meta (may be null): per-utterance records of a MERGED engine pass (see UttMeta below) - utterance b then belongs to a
+// reference batch of utt_meta[b].frames <= T frames: input frames at or past that count read as the convolution's zero padding
+// and image rows at or past (frames - 1) / 2 + 1 are written as zeros (what the second convolution's padding is in a pass of
+// that batch alone).
+struct UttMeta {
+    int frames;    // T of the utterance's own reference batch (collate pads a batch to ITS longest utterance, speech_loader.py:327-356)
+    int tp;        // its subsampled length T' = ((frames - 1) / 2 + 1 - 1) / 2 + 1
+    int sub_lo;    // first utterance of that batch in the merged call
+    int sub_hi;    // one past its last utterance
+};
 int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1,
-                 int F1, int C, int halo, hipStream_t s);
+                 int F1, int C, int halo, hipStream_t s, const UttMeta* utt_meta = nullptr);
 // split-bf16 engine: the image as two bordered bf16 planes (hi, then lo), for launch_conv2_x3; halo 1 / 2 as above
 int launch_conv1_planes(const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1, int F1,
-                        int C, int halo, hipStream_t s);
+                        int C, int halo, hipStream_t s, const UttMeta* utt_meta = nullptr);
+// the UttMeta records of a merged pass from its (rows, frames) list: n_sub <= CN_MAX_SUB batches, given by value
+constexpr int CN_MAX_SUB = 64;
+struct SubList {
+    int n;
+    int rows[CN_MAX_SUB];
+    int frames[CN_MAX_SUB];
+};
+int launch_expand_meta(const SubList& subs, UttMeta* meta, int B, hipStream_t s);
 
 // ---- row kernels                                                                  (rowops.hip)
 // y = a_2 * (x - mean) / (std_unbiased + eps) + b_2 ; x fp32 [M][d] ; y model precision (or fp32 if y_f32)
@@ -88,6 +106,11 @@ struct AttnArgs {
     int kv_mod = 0;  // > 0: K / V / keymask of batch entry b are those of entry b % kv_mod (ESA: many alignments per utterance)
     const int* kv_index = nullptr;  // non-null: ... those of entry kv_index[b] (AST beam search: the row's utterance)
     const int* klen = nullptr;               // [B] or null: key j valid iff j < klen[b]
+    // merged passes of batches with different frame counts: K / V entry e holds only kcap[e * kcap_stride] <= Lk keys of its own
+    // batch; the rest are the merged pass's padding and get -inf like tile padding (NOT the float-min fill of a masked key: a
+    // row whose keys are all masked attends uniformly over the keys its own batch has, attention.py:19-21).  Null: Lk keys
+    const int* kcap = nullptr;
+    int kcap_stride = 1;
     const int* intervals = nullptr;          // [B][iv_stride][4] (s1,e1,s2,e2) per query row, or null
     int iv_stride = 0;
     int causal = 0;  // key j allowed only if j <= i
@@ -124,6 +147,9 @@ struct AlignArgs {
     // path, which are NOT zeroed on masked frames, and the label counts are the given ones (align_to_mask forces row ylens[b])
     int raw_path = 0;
     const int* ylen_in = nullptr;  // [B] or null
+    // merged pass (null otherwise): utterance b's own batch has utt_meta[b].tp <= Tp frames - the width of its ctc_out in the
+    // reference: the shift drops a token that starts on ITS last frame, src_size = (ratio * tp).long(), rows wrap at tp
+    const UttMeta* utt_meta = nullptr;
 };
 int launch_ctc_align(const AlignArgs& a, hipStream_t s);
 
@@ -156,8 +182,11 @@ struct ViterbiArgs {
 };
 int launch_ctc_viterbi(const ViterbiArgs& a, hipStream_t s);
 // hyp[b] = [sos] + tok[b][0 .. min(ylen[b]+1, U)) ; score = sequential double sum of val
+// sub > 0: equal-sized coalesced batches of `sub` utterances; utt_meta: the batches of a merged pass (any sizes); ymax_dev
+// (may be null): the true row count of the call when U is a prediction (hypotheses are limited by min(U, *ymax_dev))
 int launch_greedy_pack(const int* tok, const float* val, const int* ylen, int B, int U, int sos, int hyp_stride,
-                       int* hyp, int* hyp_len, double* score, hipStream_t s, int sub = 0);
+                       int* hyp, int* hyp_len, double* score, hipStream_t s, int sub = 0, const UttMeta* utt_meta = nullptr,
+                       const int* ymax_dev = nullptr);
 // per row top-k (k <= 16) of log-probs [M][V] -> idx/val [M][k], sorted descending (ties: lower index first)
 int launch_topk(const float* logp, int M, int V, int ldl, int k, int* idx, float* val, hipStream_t s);
 // log_softmax(logits / T) and its per-row top-k in one pass (the (M, V) log-probabilities are not written)

@@ -155,7 +155,20 @@ struct cn_model {
 
     // geometry of the workspace
     int maxB = 0, maxT = 0, maxT1 = 0, maxTp = 0, F1 = 0, F2 = 0;
+    int maxU = 0;  // utterances a call may carry at most (buffers with one entry per utterance are sized for it): a merged pass
+                   // of short utterances fits more of them than max_batch into the workspace's max_batch x max_frames area
     std::vector<void*> allocs;
+    std::map<std::string, size_t> ws_cap;  // bytes allocated per workspace buffer: every call is checked against it (ws_check)
+    // merged engine pass (cn_decode_nast_merged): per-utterance records of the reference batches it carries
+    UttMeta* utt_meta = nullptr;
+    bool ragged = false;       // the current call has them
+    bool ragged_next = false;  // set by cn_decode_nast_merged right before its encoder stage
+    bool u_predicted = false;  // the current call's decoder side runs on a predicted row count (>= the true one, or the ticket says so)
+    // row-count prediction (cn_decode_nast_merged, u_hint): the decoder side ran on `ticket_U` rows before the true count was
+    // known; the count lands in one of four page-locked words (a ticket names its word) for cn_decode_ticket
+    int* ymax_ring = nullptr;  // [4], page-locked
+    int ticket_U[4] = {0, 0, 0, 0};
+    long long ticket_seq = 0;
     unsigned char* keymask = nullptr;
     void *c1 = nullptr, *c2 = nullptr;
     float* x = nullptr;
@@ -1085,50 +1098,131 @@ int build_weights(cn_model* m) {
     return 0;
 }
 
-int build_workspace(cn_model* m) {
-    if (m->keymask) return 0;
+// Bytes every workspace buffer needs for a call of B utterances (Bu: for the buffers with one entry per utterance) whose
+// conv1 image has T1 rows and whose encoder has Tp frames, with G alignments per utterance on the decoder side.  The ONE place
+// these sizes are written: build_workspace allocates them for the configured maxima, ws_check holds every call against what
+// was allocated (round 2's GPU fault was a generator that wrote B x G x U rows into a buffer sized for B x (T' + 1): a
+// capacity that only existed implicitly).
+struct WsDims {
+    size_t B, Bu, T1, Tp, G;
+};
+typedef std::vector<std::pair<const char*, size_t>> WsList;
+void ws_needs(const cn_model* m, const WsDims& v, WsList& out) {
     const cn_config& c = m->cfg;
     const size_t es = m->es;
-    const size_t B = m->maxB, T1 = m->maxT1, Tp = m->maxTp, F1 = m->F1, F2 = m->F2, d = c.d_model, V = c.vocab_size;
-    const size_t G = (size_t)std::max(1, c.esa_group);  // alignments per utterance the decoder side takes in one pass
-    const size_t M0 = B * (Tp + 1);                     // decoder rows can reach B*(T'+1) per alignment
+    const size_t B = v.B, T1 = v.T1, Tp = v.Tp, F1 = m->F1, F2 = m->F2, d = c.d_model, V = c.vocab_size, G = v.G;
+    const size_t M0 = B * (Tp + 1);  // decoder rows can reach B*(T'+1) per alignment
     const size_t M = M0 * G;
     const size_t dff = std::max(std::max(c.d_encff, c.d_decff), c.d_ff);  // (d_ff: the conformer extractor's FFN width)
-    CN_TRY(dev_alloc(m, (void**)&m->keymask, B * Tp));
+    out.clear();
+    out.push_back({"keymask", B * Tp});
     if (c.ast != 2) {  // (the LM has no convolutional front-end)
-        CN_TRY(dev_alloc(m, &m->c1, B * (T1 + 2) * (F1 + 2) * d * es));  // room for the zero halo the bf16 conv2 kernel wants
-        CN_TRY(dev_alloc(m, &m->c2, B * Tp * F2 * d * es));
+        out.push_back({"c1", B * (T1 + 2) * (F1 + 2) * d * es});  // room for the zero halo the bf16 conv2 kernel wants
+        out.push_back({"c2", B * Tp * F2 * d * es});
     }
-    CN_TRY(dev_alloc(m, (void**)&m->x, (M + 32) * d * 4));  // + one 32-row block: the chain kernel's blocked layout rounds up
-    CN_TRY(dev_alloc(m, &m->xn, M * d * es));
-    CN_TRY(dev_alloc(m, &m->qkv, M * 3 * d * es));
-    CN_TRY(dev_alloc(m, &m->ctx, M * d * es));
-    CN_TRY(dev_alloc(m, &m->hbuf, M * dff * es));
-    CN_TRY(dev_alloc(m, &m->enc_h, M0 * d * es));
-    CN_TRY(dev_alloc(m, &m->kvm, M0 * 2 * d * es));
-    if (m->kv_cols > 0) CN_TRY(dev_alloc(m, &m->kv_all, M0 * (size_t)m->kv_cols * es));
-    CN_TRY(dev_alloc(m, &m->qd, M * d * es));
-    CN_TRY(dev_alloc(m, &m->dec_h, M * d * es));
-    CN_TRY(dev_alloc(m, (void**)&m->xd, (M + 32) * d * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->xd2, (M + 32) * d * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->logits, M0 * V * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->best, M * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->ctc_maxlp, M0 * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->shift, M * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->src_size, B * G * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->ylen, B * G * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->ymax, 256));
-    CN_TRY(dev_alloc(m, (void**)&m->intervals, B * G * (Tp + 1) * 16));
-    CN_TRY(dev_alloc(m, (void**)&m->tok, M * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->val, M * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->topk_idx, M0 * 16 * 4));
-    CN_TRY(dev_alloc(m, (void**)&m->topk_val, M0 * 16 * 4));
+    out.push_back({"x", (M + 32) * d * 4});  // + one 32-row block: the chain kernel's blocked layout rounds up
+    out.push_back({"xn", M * d * es});
+    out.push_back({"qkv", M * 3 * d * es});
+    out.push_back({"ctx", M * d * es});
+    out.push_back({"hbuf", M * dff * es});
+    out.push_back({"enc_h", M0 * d * es});
+    out.push_back({"kvm", M0 * 2 * d * es});
+    if (m->kv_cols > 0) out.push_back({"kv_all", M0 * (size_t)m->kv_cols * es});
+    out.push_back({"qd", M * d * es});
+    out.push_back({"dec_h", M * d * es});
+    out.push_back({"xd", (M + 32) * d * 4});
+    out.push_back({"xd2", (M + 32) * d * 4});
+    out.push_back({"logits", M0 * V * 4});
+    out.push_back({"best", M * 4});
+    out.push_back({"ctc_maxlp", M0 * 4});
+    out.push_back({"shift", M * 4});
+    out.push_back({"src_size", v.Bu * G * 4});
+    out.push_back({"ylen", v.Bu * G * 4});
+    out.push_back({"utt_meta", v.Bu * sizeof(UttMeta)});
+    out.push_back({"ymax", 256});
+    out.push_back({"intervals", B * G * (Tp + 1) * 16});
+    out.push_back({"tok", M * 4});
+    out.push_back({"val", M * 4});
+    out.push_back({"topk_idx", M0 * 16 * 4});
+    out.push_back({"topk_val", M0 * 16 * 4});
     if (c.conf_enc || c.conf_dec) {  // convolution module: pointwise-conv output [M][2d], depthwise output fp32, GroupNorm sums
-        CN_TRY(dev_alloc(m, &m->cv_a, M * 2 * d * es));
-        CN_TRY(dev_alloc(m, (void**)&m->cv_f, M * d * 4));
-        CN_TRY(dev_alloc(m, (void**)&m->gn_stats, B * G * 2 * 8));
+        out.push_back({"cv_a", M * 2 * d * es});
+        out.push_back({"cv_f", M * d * 4});
+        out.push_back({"gn_stats", v.Bu * G * 2 * 8});
     }
+}
+
+int build_workspace(cn_model* m) {
+    if (m->keymask) return 0;
+    WsList needs;
+    ws_needs(m, {(size_t)m->maxB, (size_t)m->maxU, (size_t)m->maxT1, (size_t)m->maxTp, (size_t)std::max(1, m->cfg.esa_group)}, needs);
+    std::map<std::string, void*> at;
+    for (auto& kv : needs) {
+        void* p = nullptr;
+        CN_TRY(dev_alloc(m, &p, kv.second));
+        at[kv.first] = p;
+        m->ws_cap[kv.first] = kv.second;
+    }
+    auto get = [&](const char* n) -> void* {
+        auto it = at.find(n);
+        return it == at.end() ? nullptr : it->second;
+    };
+    m->keymask = (unsigned char*)get("keymask");
+    m->c1 = get("c1");
+    m->c2 = get("c2");
+    m->x = (float*)get("x");
+    m->xn = get("xn");
+    m->qkv = get("qkv");
+    m->ctx = get("ctx");
+    m->hbuf = get("hbuf");
+    m->enc_h = get("enc_h");
+    m->kvm = get("kvm");
+    m->kv_all = get("kv_all");
+    m->qd = get("qd");
+    m->dec_h = get("dec_h");
+    m->xd = (float*)get("xd");
+    m->xd2 = (float*)get("xd2");
+    m->logits = (float*)get("logits");
+    m->best = (int*)get("best");
+    m->ctc_maxlp = (float*)get("ctc_maxlp");
+    m->shift = (int*)get("shift");
+    m->src_size = (int*)get("src_size");
+    m->ylen = (int*)get("ylen");
+    m->utt_meta = (UttMeta*)get("utt_meta");
+    m->ymax = (int*)get("ymax");
+    m->intervals = (int*)get("intervals");
+    m->tok = (int*)get("tok");
+    m->val = (float*)get("val");
+    m->topk_idx = (int*)get("topk_idx");
+    m->topk_val = (float*)get("topk_val");
+    m->cv_a = get("cv_a");
+    m->cv_f = (float*)get("cv_f");
+    m->gn_stats = (double*)get("gn_stats");
     CN_HIP_CHECK(hipHostMalloc((void**)&m->ymax_pinned, 64, hipHostMallocDefault));
+    CN_HIP_CHECK(hipHostMalloc((void**)&m->ymax_ring, 64, hipHostMallocDefault));
+    return 0;
+}
+
+// Every buffer of the workspace against what a call of (B utterances, T frames, G alignments per utterance) needs: an error,
+// never a write past a buffer.  The workspace is an AREA (max_batch x max_frames): more, shorter utterances fit as well.
+int ws_check(cn_model* m, int B, int T, int G, const char* what) {
+    const int T1 = (T - 1) / 2 + 1, Tp = (T1 - 1) / 2 + 1;
+    WsList needs;
+    ws_needs(m, {(size_t)B, (size_t)B, (size_t)T1, (size_t)Tp, (size_t)std::max(1, G)}, needs);
+    for (auto& kv : needs) {
+        auto it = m->ws_cap.find(kv.first);
+        if (it == m->ws_cap.end() || kv.second > it->second) {
+            cn_set_error(std::string(what) + ": workspace buffer '" + kv.first + "' holds " +
+                         std::to_string(it == m->ws_cap.end() ? 0 : it->second) + " bytes, the call (B=" + std::to_string(B) + " T=" +
+                         std::to_string(T) + " alignments=" + std::to_string(G) + ") needs " + std::to_string(kv.second) +
+                         " (workspace: max_batch " + std::to_string(m->maxB) + " x max_frames " + std::to_string(m->maxT) + ")");
+            return -1;
+        }
+    }
+    if (Tp + 1 > m->pe_rows) {
+        cn_set_error(std::string(what) + ": more subsampled frames than the positional table has rows");
+        return -1;
+    }
     return 0;
 }
 
@@ -1269,6 +1363,10 @@ int run_self_attn_core(cn_model* m, int B, int Lseq, const unsigned char* keymas
     a.Lq = a.Lk = Lseq;
     a.keymask = keymask;
     a.klen = klen;
+    if (m->ragged && keymask == m->keymask) {  // encoder self-attention of a merged pass
+        a.kcap = &m->utt_meta[0].tp;
+        a.kcap_stride = (int)(sizeof(UttMeta) / sizeof(int));
+    }
     a.causal = causal;
     a.scale = 1.0f / sqrtf((float)(d / m->cfg.n_head));
     ProfScope ps(m, "self_attention", 4.0 * B * a.H * (double)Lseq * Lseq * 64, (double)M * 4 * d * m->es, s);
@@ -1515,6 +1613,10 @@ int run_src_attn_core(cn_model* m, const Layer& L, int B, int U, int Tp, const i
     a.Lq = U;
     a.Lk = Tp;
     a.keymask = m->keymask;
+    if (m->ragged) {
+        a.kcap = &m->utt_meta[0].tp;
+        a.kcap_stride = (int)(sizeof(UttMeta) / sizeof(int));
+    }
     a.intervals = intervals;
     a.iv_stride = Tp + 1;
     a.scale = 1.0f / sqrtf((float)(d / m->cfg.n_head));
@@ -1569,17 +1671,19 @@ int run_generator(cn_model* m, const Linear& g, const void* h, int M, int* arg, 
     return 0;
 }
 
-int check_call(cn_model* m, int B, int T, int F) {
+// `area`: the call may carry more utterances than max_batch (or longer ones than max_frames) as long as every buffer holds
+// it (the greedy NAT decode, whose kernels take any B x T; the other entry points keep the configured bounds)
+int check_call(cn_model* m, int B, int T, int F, bool area = false) {
     if (!m || !m->finalized) {
         cn_set_error("model not finalized");
         return -1;
     }
-    if (F != m->cfg.input_size || B < 1 || B > m->maxB || T < 1 || T > m->maxT) {
+    if (F != m->cfg.input_size || B < 1 || T < 1 || (!area && (B > m->maxB || T > m->maxT))) {
         cn_set_error("decode: batch/frames/feature dims outside the configured workspace (B=" + std::to_string(B) +
                      " T=" + std::to_string(T) + " F=" + std::to_string(F) + ")");
         return -1;
     }
-    return 0;
+    return ws_check(m, B, T, 1, "decode");
 }
 
 int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_decode_opts* o, hipStream_t s);
@@ -1609,6 +1713,7 @@ int stage_encode_align(cn_model* m, const float* feats, const float* ratio, int 
     al.ylen = m->ylen;
     al.ymax = m->ymax;
     al.intervals = m->intervals;
+    al.utt_meta = m->ragged ? m->utt_meta : nullptr;
     {
         ProfScope ps(m, "ctc_align", 0, (double)B * Tp * 9 + (double)B * (Tp + 1) * 16, s);
         CN_TRY(launch_ctc_align(al, s));
@@ -1625,6 +1730,9 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     const bool cap = o->capture != 0;
     m->B = B;
     ++m->call_id;
+    if (!m->ragged_next) m->ragged = false;  // (only cn_decode_nast_merged announces per-utterance records, for its own call)
+    m->ragged_next = false;
+    m->u_predicted = false;
     m->dec_group = 1;
     m->kv_ready = false;
     m->T = T;
@@ -1641,10 +1749,11 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         // else wrote the buffer since): conv1 then writes the interior only (halo mode 2)
         const bool same = halo && m->c1_halo_B == B && m->c1_halo_T1 == T1;
         ProfScope ps(m, "conv1", 2.0 * 9 * B * T1 * F1 * d, (double)B * T * F * 4 + (double)B * T1 * F1 * d * m->es, s);
+        const UttMeta* um = m->ragged ? m->utt_meta : nullptr;
         if (x3_planes)
-            CN_TRY(launch_conv1_planes(feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : 1, s));
+            CN_TRY(launch_conv1_planes(feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : 1, s, um));
         else
-            CN_TRY(launch_conv1(m->prec, feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : halo, s));
+            CN_TRY(launch_conv1(m->prec, feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : halo, s, um));
         m->c1_halo_B = halo ? B : -1;
         m->c1_halo_T1 = halo ? T1 : -1;
     }
@@ -1778,10 +1887,12 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
     const int d = c.d_model, B = m->B * m->dec_group, Tp = m->Tp, MU = B * U;
     const bool cap = o->capture != 0;
     m->U = U;
-    if (U > m->pe_rows) {
-        cn_set_error("decode: token count exceeds the positional table");
+    if (U > m->pe_rows || U < 1 || U > Tp + 1) {
+        cn_set_error("decode: token count exceeds the positional table / the frames of the batch");
         return -1;
     }
+    // every decoder-side buffer against B x alignments-per-utterance x rows (host-side, before anything is launched)
+    CN_TRY(ws_check(m, m->B, m->T, m->dec_group, "decoder side"));
     CN_TRY(launch_fill_queries(m->pe, m->xd, B, U, d, s));
     // The LayerNorm that follows an FFN is produced by that FFN (-> m->xn); `pending` says whether the next
     // sublayer may skip its own LayerNorm.  use_unimask shifts the stream between SAD and MAD, so no carry there.
@@ -1962,7 +2073,9 @@ int stage_decode_tail(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp,
         CN_TRY(launch_topk(m->logits, MU, c.vocab_size, c.vocab_size, k, m->topk_idx, m->topk_val, s));
         m->last_k = k;
     }
-    if (hyp) CN_TRY(launch_greedy_pack(m->tok, m->val, m->ylen, B, U, o->sos, hyp_stride, hyp, hyp_len, score, s, o->sub_batch));
+    if (hyp)
+        CN_TRY(launch_greedy_pack(m->tok, m->val, m->ylen, B, U, o->sos, hyp_stride, hyp, hyp_len, score, s, o->sub_batch,
+                                  m->ragged ? m->utt_meta : nullptr, m->u_predicted ? m->ymax : nullptr));
     return 0;
 }
 
@@ -2014,6 +2127,7 @@ extern "C" int cn_model_create(const cn_config* cfg, cn_model** out) {
     m->maxT = c.max_frames;
     m->maxT1 = (c.max_frames - 1) / 2 + 1;
     m->maxTp = (m->maxT1 - 1) / 2 + 1;
+    m->maxU = 16 * c.max_batch;
     m->F1 = (c.input_size - 1) / 2 + 1;
     m->F2 = (m->F1 - 1) / 2 + 1;
     *out = m;
@@ -2052,6 +2166,7 @@ extern "C" void cn_model_destroy(cn_model* m) {
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->ymax_pinned) (void)hipHostFree(m->ymax_pinned);
+    if (m->ymax_ring) (void)hipHostFree(m->ymax_ring);
     for (void* q : m->ast_allocs) (void)hipFree(q);
     for (auto& kv : m->scratch)
         if (kv.second.first) (void)hipFree(kv.second.first);
@@ -2131,29 +2246,114 @@ extern "C" int cn_encode_align(cn_model* m, const float* feats_dev, const float*
     return 0;
 }
 
-extern "C" int cn_decode_nast(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T,
-                              int32_t F, const cn_decode_opts* opts, int32_t* hyp_out_dev, int32_t hyp_stride,
-                              int32_t* hyp_len_dev, double* score_dev, void* stream) {
-    CN_TRY(check_call(m, B, T, F));
+namespace {
+// greedy NAT decode of one call; subs != null: a merged pass (see cn_decode_nast_merged); u_hint > 0: predicted row count
+int decode_nast_impl(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,
+                     const cn_decode_opts* opts, const SubList* subs, int32_t u_hint, int32_t* hyp_out_dev, int32_t hyp_stride,
+                     int32_t* hyp_len_dev, double* score_dev, void* stream, int32_t* ticket_out) {
+    CN_TRY(check_call(m, B, T, F, /*area=*/true));
     if (!opts || opts->beam_width < 1 || opts->beam_width > 16) {
         cn_set_error("cn_decode_nast: beam_width must be in [1,16]");
         return -1;
     }
     hipStream_t s = (hipStream_t)stream;
     CN_HIP_CHECK(hipSetDevice(m->cfg.device));  // callers may decode from several host threads (one handle each)
-    CN_TRY(stage_encode_align(m, feats_dev, size_ratio_dev, B, T, F, opts, s));
-    CN_HIP_CHECK(hipMemcpyAsync(m->ymax_pinned, m->ymax, sizeof(int), hipMemcpyDeviceToHost, s));
-    CN_HIP_CHECK(hipStreamSynchronize(s));  // U is data dependent
-    const int ymax = *m->ymax_pinned;
-    if (ymax < 1 || ymax > m->Tp + 1) {
-        cn_set_error("cn_decode_nast: alignment produced an impossible token count");
-        return -3;
+    if (subs) {
+        if (m->cfg.conf_enc || m->cfg.conf_dec) {
+            cn_set_error("cn_decode_nast_merged: transformer blocks only (a conformer's GroupNorm sees the padded rows of the merged pass)");
+            return -1;
+        }
+        if (opts->capture || opts->beam_width != 1 || opts->sub_batch) {
+            cn_set_error("cn_decode_nast_merged: greedy decode without capture; sub_batch is implied by the batch list");
+            return -1;
+        }
+        CN_TRY(launch_expand_meta(*subs, m->utt_meta, B, s));
+        m->ragged = true;
+        m->ragged_next = true;
     }
-    if (hyp_out_dev && hyp_stride < ymax + 1) {
-        cn_set_error("cn_decode_nast: hyp_stride " + std::to_string(hyp_stride) + " < ymax+1 = " + std::to_string(ymax + 1));
+    CN_TRY(stage_encode_align(m, feats_dev, size_ratio_dev, B, T, F, opts, s));
+    const int slot = (int)(m->ticket_seq & 3);
+    if (u_hint > 0 && opts->beam_width == 1 && !opts->capture) {
+        // No mid-pass host sync: the decoder side is launched on the predicted row count.  Results do not depend on U as long
+        // as U >= the true maximum (rows past an utterance's own count are masked keys that contribute exactly zero, and the
+        // finish is limited by the device-side counts); the true maximum lands in the ticket's page-locked word and the caller
+        // checks it once the stream has drained (cn_decode_ticket) - on a miss the pass is decoded again.
+        const int U = std::min(std::max(u_hint, 1), m->Tp + 1);
+        if (hyp_out_dev && hyp_stride < U + 1) {
+            cn_set_error("cn_decode_nast: hyp_stride " + std::to_string(hyp_stride) + " < predicted rows + 1 = " + std::to_string(U + 1));
+            return -1;
+        }
+        m->u_predicted = true;
+        CN_HIP_CHECK(hipMemcpyAsync(m->ymax_ring + slot, m->ymax, sizeof(int), hipMemcpyDeviceToHost, s));
+        m->ticket_U[slot] = U;
+        CN_TRY(stage_decode(m, U, opts, hyp_out_dev, hyp_stride, hyp_len_dev, score_dev, s));
+    } else {
+        CN_HIP_CHECK(hipMemcpyAsync(m->ymax_ring + slot, m->ymax, sizeof(int), hipMemcpyDeviceToHost, s));
+        CN_HIP_CHECK(hipStreamSynchronize(s));  // U is data dependent
+        const int ymax = m->ymax_ring[slot];
+        *m->ymax_pinned = ymax;
+        if (ymax < 1 || ymax > m->Tp + 1) {
+            cn_set_error("cn_decode_nast: alignment produced an impossible token count");
+            return -3;
+        }
+        if (hyp_out_dev && hyp_stride < ymax + 1) {
+            cn_set_error("cn_decode_nast: hyp_stride " + std::to_string(hyp_stride) + " < ymax+1 = " + std::to_string(ymax + 1));
+            return -1;
+        }
+        m->ticket_U[slot] = ymax;
+        CN_TRY(stage_decode(m, ymax, opts, hyp_out_dev, hyp_stride, hyp_len_dev, score_dev, s));
+    }
+    if (ticket_out) *ticket_out = slot;
+    ++m->ticket_seq;
+    return 0;
+}
+}  // namespace
+
+extern "C" int cn_decode_nast(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T,
+                              int32_t F, const cn_decode_opts* opts, int32_t* hyp_out_dev, int32_t hyp_stride,
+                              int32_t* hyp_len_dev, double* score_dev, void* stream) {
+    return decode_nast_impl(m, feats_dev, size_ratio_dev, B, T, F, opts, nullptr, 0, hyp_out_dev, hyp_stride, hyp_len_dev, score_dev,
+                            stream, nullptr);
+}
+
+extern "C" int cn_decode_nast_merged(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,
+                                     const cn_decode_opts* opts, int32_t n_sub, const int32_t* sub_rows_host,
+                                     const int32_t* sub_frames_host, int32_t u_hint, int32_t* hyp_out_dev, int32_t hyp_stride,
+                                     int32_t* hyp_len_dev, double* score_dev, void* stream, int32_t* ticket_out) {
+    if (n_sub < 0 || n_sub > CN_MAX_SUB || (n_sub > 0 && (!sub_rows_host || !sub_frames_host))) {
+        cn_set_error("cn_decode_nast_merged: between 0 and " + std::to_string(CN_MAX_SUB) + " batches per pass");
         return -1;
     }
-    CN_TRY(stage_decode(m, ymax, opts, hyp_out_dev, hyp_stride, hyp_len_dev, score_dev, s));
+    if (n_sub == 0)
+        return decode_nast_impl(m, feats_dev, size_ratio_dev, B, T, F, opts, nullptr, u_hint, hyp_out_dev, hyp_stride, hyp_len_dev,
+                                score_dev, stream, ticket_out);
+    SubList subs;
+    subs.n = n_sub;
+    long long rows = 0;
+    for (int k = 0; k < n_sub; ++k) {
+        if (sub_rows_host[k] < 1 || sub_frames_host[k] < 1 || sub_frames_host[k] > T) {
+            cn_set_error("cn_decode_nast_merged: every batch needs >= 1 utterance and 1 <= frames <= T");
+            return -1;
+        }
+        subs.rows[k] = sub_rows_host[k];
+        subs.frames[k] = sub_frames_host[k];
+        rows += sub_rows_host[k];
+    }
+    if (rows != B) {
+        cn_set_error("cn_decode_nast_merged: the batches' utterance counts must add up to B");
+        return -1;
+    }
+    return decode_nast_impl(m, feats_dev, size_ratio_dev, B, T, F, opts, &subs, u_hint, hyp_out_dev, hyp_stride, hyp_len_dev, score_dev,
+                            stream, ticket_out);
+}
+
+extern "C" int cn_decode_ticket(cn_model* m, int32_t ticket, int32_t* ymax_host, int32_t* rows_used_host) {
+    if (!m || !m->ymax_ring || ticket < 0 || ticket > 3) {
+        cn_set_error("cn_decode_ticket: bad ticket");
+        return -1;
+    }
+    if (ymax_host) *ymax_host = m->ymax_ring[ticket];
+    if (rows_used_host) *rows_used_host = m->ticket_U[ticket];
     return 0;
 }
 

@@ -400,6 +400,29 @@ int launch_keymask(const float* feats, int B, int T, int F, int Tp, int stride, 
     return 0;
 }
 
+// The per-utterance records of a merged engine pass (kernels.h: UttMeta) from the pass's list of reference batches.
+__global__ void expand_meta_kernel(SubList subs, UttMeta* __restrict__ meta, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int lo = 0, k = 0;
+    for (; k < subs.n - 1 && b >= lo + subs.rows[k]; ++k) lo += subs.rows[k];
+    const int T = subs.frames[k];
+    const int T1 = (T - 1) / 2 + 1;
+    UttMeta mrec;
+    mrec.frames = T;
+    mrec.tp = (T1 - 1) / 2 + 1;
+    mrec.sub_lo = lo;
+    mrec.sub_hi = lo + subs.rows[k];
+    meta[b] = mrec;
+}
+
+int launch_expand_meta(const SubList& subs, UttMeta* meta, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(expand_meta_kernel, dim3(cn_ceil_div(B, 256)), dim3(256), 0, s, subs, meta, B);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // extractor queries: pe[:ymax] repeated over the batch (src/models/cassnat.py:481)
 __global__ void fill_queries_kernel(const float* __restrict__ table, float* __restrict__ out, int B, int U, int d) {
     const long long n4 = (long long)B * U * d / 4;

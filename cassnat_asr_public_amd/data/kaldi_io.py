@@ -47,6 +47,19 @@ def load_mat(rxspecifier):
         return _read_matrix(f)
 
 
+def mat_rows(rxspecifier):
+    """Number of rows (frames) of an .scp entry from its 15-byte header alone - what `feat-to-len` gives."""
+    path, _, off = rxspecifier.rpartition(":")
+    if not path or not off.isdigit():
+        return load_mat(rxspecifier).shape[0]
+    with open(path, "rb") as f:
+        f.seek(int(off))
+        head = f.read(10)
+    if head[:2] != b"\0B" or head[2:5] not in _DTYPES or head[5:6] != b"\x04":
+        raise ValueError("not a binary Kaldi matrix at %s" % rxspecifier)
+    return struct.unpack("<i", head[6:10])[0]
+
+
 def read_scp(scp_path):
     """-> list of (utt, rxspecifier) in file order."""
     out = []

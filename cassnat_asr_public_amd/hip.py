@@ -102,6 +102,10 @@ def lib():
     L.cn_model_weight_blob.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.cn_decode_nast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                  C.POINTER(CnDecodeOpts), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cn_decode_nast_merged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts),
+                                        C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    L.cn_decode_ticket.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.cn_encode_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(CnDecodeOpts), C.POINTER(C.c_int32), C.c_void_p]
     L.cn_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
@@ -239,6 +243,28 @@ class Engine:
         B, T, F = feats.shape
         check(self.L.cn_decode_nast(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts), _ptr(hyp),
                                     hyp.shape[1], _ptr(hyp_len), _ptr(score), current_stream()), "cn_decode_nast")
+
+    def decode_merged(self, feats, size_ratio, opts, sub_rows, sub_frames, hyp, hyp_len, score, u_hint=0):
+        """One engine pass over several reference batches (``cn_decode_nast_merged``): ``feats`` (B, T, F) holds the batches one
+        after the other, batch k = ``sub_rows[k]`` utterances of ``sub_frames[k]`` <= T frames (padded to T with padding_idx
+        frames); every utterance's result is that of a pass of its own batch.  ``sub_rows`` empty / None: a plain call.
+        ``u_hint`` > 0: no mid-pass host sync - the decoder side runs on that many rows; returns the ticket whose
+        ``ticket(t) -> (ymax, rows_used)`` the caller reads once the stream has drained (rows_used < ymax: decode again)."""
+        B, T, F = feats.shape
+        n = len(sub_rows) if sub_rows is not None else 0
+        rows = (C.c_int32 * max(1, n))(*[int(x) for x in (sub_rows or [])])
+        frames = (C.c_int32 * max(1, n))(*[int(x) for x in (sub_frames or [])])
+        ticket = C.c_int32(-1)
+        check(self.L.cn_decode_nast_merged(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts), n, rows, frames,
+                                           int(u_hint), _ptr(hyp), hyp.shape[1], _ptr(hyp_len), _ptr(score), current_stream(),
+                                           C.byref(ticket)), "cn_decode_nast_merged")
+        return ticket.value
+
+    def ticket(self, t):
+        """(true row count, rows the decoder side ran on) of the pass that returned ticket ``t``; valid once its stream work is done."""
+        ymax, used = C.c_int32(), C.c_int32()
+        check(self.L.cn_decode_ticket(self.handle, int(t), C.byref(ymax), C.byref(used)), "cn_decode_ticket")
+        return ymax.value, used.value
 
     def encode_align(self, feats, size_ratio, opts):
         B, T, F = feats.shape

@@ -377,9 +377,13 @@ class CassNAT(nn.Module):
             raise NotImplementedError("use_unimask with the conformer decoder: the reference itself cannot run it "
                                       "(cassnat.py:486-488 indexes the (x, pos_embed) tuple)")
 
-    def decode_device(self, src, src_size, args, sos=1, engine=None, sub_batch=0):
+    def decode_device(self, src, src_size, args, sos=1, engine=None, sub_batch=0, sub_rows=None, sub_frames=None, u_hint=0,
+                      want_ticket=False):
         """The device half of beam_decode: returns cuda tensors (hyp (B,S) int32, hyp_len (B,) int32, score (B,) f64).
-        ``engine``: run on this handle (a decode pipeline's) instead of the model's own."""
+        ``engine``: run on this handle (a decode pipeline's) instead of the model's own.
+        ``sub_rows`` / ``sub_frames``: the call is a merged pass over that many reference batches of those frame counts
+        (``hip.Engine.decode_merged``); ``u_hint`` > 0: predicted row count, no mid-pass host sync; ``want_ticket``: also return
+        the ticket (the caller checks ``engine.ticket(t)`` once the stream has drained)."""
         dev = torch.device("cuda", getattr(self, "_device", torch.cuda.current_device()))
         feats = src.to(dev, torch.float32).contiguous()
         ratio = src_size.to(dev, torch.float32).contiguous()
@@ -392,6 +396,9 @@ class CassNAT(nn.Module):
         hyp = torch.empty(B, stride, dtype=torch.int32, device=dev)
         hyp_len = torch.empty(B, dtype=torch.int32, device=dev)
         score = torch.empty(B, dtype=torch.float64, device=dev)
+        if sub_rows or u_hint or want_ticket:
+            t = eng.decode_merged(feats, ratio, opts, sub_rows, sub_frames, hyp, hyp_len, score, u_hint=u_hint)
+            return (hyp, hyp_len, score, t) if want_ticket else (hyp, hyp_len, score)
         eng.decode(feats, ratio, opts, hyp, hyp_len, score)
         return hyp, hyp_len, score
 

@@ -1,16 +1,26 @@
 """Decode pipelines: keep one GPU busy with greedy CASS-NAT decoding of many batches.
 
-One ``beam_decode`` call needs the host twice - the token count U of the batch is data dependent (the decoder side is
-launched after it is read back) and the hypotheses themselves have to reach the host - and most of its kernels occupy a
-fraction of the chip (a row-chain launch of a 32-utterance batch sits on 63 of 256 CUs).  So the throughput form of the path
-is N independent pipelines per GPU: each owns an engine handle (a workspace; the packed weights are ONE device copy shared
-by all of them), a HIP stream and a persistent host thread (ctypes releases the GIL inside the C call), pulls the next batch from a shared iterator - so
-feature loading and collation run in the workers too - and hands back device-resident hypothesis records in submission
-order.  ``bench.py`` measures exactly this object; ``tasks.cassnat_task.CassNATTask.decode`` uses it for test sets.
+The reference decodes batch after batch, each collated to its own longest utterance (src/data/speech_loader.py:327-356,
+loop src/tasks/cassnat_task.py:317-356), and reads the data-dependent token count back in the middle of every batch
+(src/models/cassnat.py:387 `.item()`).  A 32-utterance batch fills a fraction of an MI355X, so the throughput form of the path
+is:
 
-The reference has no counterpart (it decodes batch after batch, src/tasks/cassnat_task.py:317-356); results are the same
-hypotheses in the same order.
+  * **merged engine passes**: a worker takes consecutive batches - of DIFFERENT frame counts - through ONE engine pass
+    (``cn_decode_nast_merged``): every utterance's hypothesis and score are exactly those of a pass of its own batch (its frames
+    past the batch's length are the convolutions' zero padding, `src_size`, the alignment's shift and the forced EOS frame use
+    the batch's own T', keys past it do not exist for the softmax, the greedy finish is limited by the batch's own row count).
+    A pass is bounded by the engine's workspace AREA (utterances x frames), not by a batch count: short utterances come in
+    larger numbers;
+  * **no mid-pass host sync**: the decoder side is launched on a PREDICTED row count (from the passes seen so far, with a
+    margin); results do not depend on it as long as it covers the true count, which the worker checks when the pass has
+    drained - on a miss (rare) the pass is decoded again exactly.  A worker keeps two passes in flight;
+  * **N pipelines per GPU**: engine handle (a workspace; the packed weights are ONE device copy shared by all), HIP stream and
+    persistent host thread each (ctypes releases the GIL inside the C call); the workers pull batches from a shared iterator -
+    so feature loading and collation run in the workers too - and hand back hypothesis records in submission order.
+
+``bench.py`` measures exactly this object; ``tasks.cassnat_task.CassNATTask.decode`` uses it for test sets.
 """
+import math
 import os
 import queue
 import threading
@@ -18,6 +28,11 @@ import threading
 import torch
 
 from . import dist as cdist
+
+
+def subsampled(T):
+    """T' of T frames after the two stride-2 convolutions (embedding.py:102-108)."""
+    return ((T - 1) // 2 + 1 - 1) // 2 + 1
 
 
 class _NoStream:
@@ -36,7 +51,7 @@ class _NoStream:
 class _Job:
     """One ``records()`` call: the shared iterator and the bookkeeping its workers and its consumer meet on."""
 
-    def __init__(self, it, args, sos, n, total=None, coalesce=1, host=False):
+    def __init__(self, it, args, sos, n, total=None, coalesce=1, host=False, plan=None, per_pass=None):
         self.it, self.args, self.sos = it, args, sos
         self.host = host  # the consumer wants the records on the host: the producing pipeline sends them itself, one copy per pass
         self.left = total  # batches not yet handed to a worker (None: unknown)
@@ -45,13 +60,15 @@ class _Job:
         c = max(1, coalesce)
         self.passes_left = None if total is None else n * max(1, -(-total // (n * c)))
         # experiment hook (tools/scripts/r02_plan.sh): CASSNAT_PASS_PLAN="10,4,6" = explicit pass sizes, in the order they are taken
-        plan = os.environ.get("CASSNAT_PASS_PLAN")
-        self.plan = [int(x) for x in plan.split(",")] if plan else None
+        env = os.environ.get("CASSNAT_PASS_PLAN")
+        self.plan = [int(x) for x in env.split(",")] if env else plan
         self.lock = threading.Lock()
         self.cv = threading.Condition()
         self.slots = {}          # index -> queue of one (tag, records, event)
         self.state = {"next": 0, "done": False, "err": None, "held": None}
-        self.ahead = threading.Semaphore(2 * n * max(1, coalesce) + 2)  # batches decoded but not yet consumed (bounds device memory held by records)
+        # batches taken but not yet consumed (bounds the device memory held by records): two passes in flight per pipeline plus
+        # as many waiting for the consumer
+        self.ahead = threading.Semaphore(4 * n * max(1, per_pass or coalesce) + 2)
         self.finished = threading.Semaphore(0)       # released once by every worker when it has left the job
 
     def slot(self, i):
@@ -61,38 +78,95 @@ class _Job:
             return self.slots[i]
 
 
+class _Pass:
+    """One engine pass in flight: what is needed to hand its results out - or to decode it again when the predicted row
+    count turns out too small."""
+
+    __slots__ = ("items", "first", "feats", "ratio", "rows", "frames", "ticket", "u_hint", "rec", "recs", "ev", "tp")
+
+
 class DecodePipelines:
-    def __init__(self, model, n_pipelines, batch, frames, with_weights=True, after_engine=None, coalesce=1, share_from=None):
-        """``model``: a CassNAT holding the parameters; ``batch`` / ``frames``: workspace size of every pipeline.
+    def __init__(self, model, n_pipelines, batch, frames, with_weights=True, after_engine=None, coalesce=1, share_from=None,
+                 ragged=0.75, predict_rows=True, area_frames=None):
+        """``model``: a CassNAT holding the parameters; ``batch`` x ``frames``: the largest single batch a pipeline must take.
         The pipelines of one GPU share ONE device copy of the packed weights (``cn_model_create_shared``): the first engine
         packs them - or, with ``with_weights=False`` + ``after_engine(engine)`` (multi-GPU start-up), receives them by RCCL
         broadcast (``dist.broadcast_weights``), once per rank - and the others only get a workspace of their own.
-        The worker threads and their HIP streams are created once (at the first call) and live until ``close()``: a short
-        run is not thread start-up.
-        ``coalesce`` = c > 1: a worker takes up to c consecutive batches of the same shape through ONE engine pass (wider
-        launches: the command processor keeps only about three kernels in flight, so width is what fills the chip) with the
-        greedy finish limited per original batch (``cn_decode_opts.sub_batch``) - every batch's hypotheses and scores are
-        exactly those of a pass of its own.  When the number of batches is known (``len(batches)``) the last passes are
-        cut so that every pipeline gets a similar share of the tail.  Transformer blocks only (a conformer's GroupNorm sees
-        the padded rows of the merged batch).
-        ``share_from``: an engine of the same model whose device copy of the weights ALL pipelines of this object use."""
+        The worker threads and their HIP streams are created once (at the first call) and live until ``close()``.
+
+        ``coalesce`` = c > 1: a worker takes up to c consecutive batches through ONE engine pass (wider launches: width is what
+        fills the chip) with every batch's hypotheses and scores exactly those of a pass of its own.  ``ragged`` = r: batches
+        of different frame counts share a pass while the shortest is at least r times the longest (0 < r <= 1; 1 = equal shapes
+        only); a pass holds what fits the engine's workspace AREA, ``area_frames`` utterance-frames (default: c batches of
+        ``batch`` x min(frames, 1024) - a pass of short batches carries more than c of them when ``coalesce`` is given as a
+        negative number -c, "by area only").  ``predict_rows``: launch the decoder side on a predicted row count instead of
+        waiting for the true one in the middle of the pass (verified afterwards; a miss is decoded again).
+        Transformer blocks only (a conformer's GroupNorm sees the padded rows of a merged pass): conformer models run one batch
+        per pass.  ``share_from``: an engine of the same model whose device copy of the weights ALL pipelines of this object use."""
         self.model = model
         self.n = max(1, int(n_pipelines))
-        self.coalesce = max(1, int(coalesce)) if (not getattr(model, "_conf_dec", False)
-                                                  and not getattr(model, "_hyper", {}).get("conf_enc")) else 1
+        conformer = bool(getattr(model, "_conf_dec", False) or getattr(model, "_hyper", {}).get("conf_enc"))
+        self.by_area = int(coalesce) < 0
+        self.coalesce = 1 if conformer else max(1, abs(int(coalesce)))
+        self.ragged = 1.0 if conformer else min(1.0, max(0.05, float(ragged)))
+        self.predict = bool(predict_rows) and not conformer
+        self.batch, self.frames = int(batch), int(frames)
+        area = int(area_frames) if area_frames else self.batch * self.coalesce * min(self.frames, 1024)
+        area = max(area, self.batch * self.frames)
+        # the engine's workspace is max_batch x max_frames; max_frames = the longest utterance, max_batch = what gives the area
+        self.max_batch = max(self.batch, -(-area // self.frames) + (1 if self.coalesce > 1 else 0))
+        self.max_utts = 16 * self.max_batch  # (the library sizes its per-utterance buffers for that many)
         if share_from is not None:
-            first = model.new_engine(batch * self.coalesce, frames, share=share_from)
+            first = model.new_engine(self.max_batch, frames, share=share_from)
         else:
-            first = model.new_engine(batch * self.coalesce, frames, with_weights=with_weights)
+            first = model.new_engine(self.max_batch, frames, with_weights=with_weights)
             if after_engine is not None:
                 after_engine(first)
         self.engines = [first]
         for _ in range(self.n - 1):
-            self.engines.append(model.new_engine(batch * self.coalesce, frames, share=first))
+            self.engines.append(model.new_engine(self.max_batch, frames, share=first))
+        cfg = getattr(first, "cfg", None)
+        if cfg is not None:  # (what the engine was really created with: the model may round the workspace up)
+            self.max_batch, self.frames_cap = int(cfg.max_batch), int(cfg.max_frames)
+            self.max_utts = 16 * self.max_batch
+        else:
+            self.frames_cap = self.frames
         self._threads = []
         self._inbox = []
         self._busy = threading.Lock()  # one records() call at a time
-        self._stage = [{} for _ in range(self.n)]  # per pipeline: merged-batch input buffers at full capacity, by shape
+        self._stage = [{} for _ in range(self.n)]  # per pipeline: merged-batch input buffers (two: two passes in flight), by kind
+        self._rows = {"ratio": None}  # row-count predictor shared by the pipelines: largest tokens-per-frame ratio seen
+        self._rows_lock = threading.Lock()
+        self.stats = {"passes": 0, "batches": 0, "predicted": 0, "missed": 0, "merged_ragged": 0}
+
+    # ------------------------------------------------------------------------------------------ capacity
+    def fits(self, rows, T):
+        """Does a pass of ``rows`` utterances x ``T`` frames fit the engines' workspace?  (The library's own check, ws_check in
+        csrc/model.hip, restated: every buffer scales with one of these products.)"""
+        T1 = (T - 1) // 2 + 1
+        Tp = (T1 - 1) // 2 + 1
+        mT1 = (self.frames_cap - 1) // 2 + 1
+        mTp = (mT1 - 1) // 2 + 1
+        B = self.max_batch
+        return (rows <= self.max_utts and rows * (Tp + 1) <= B * (mTp + 1) and rows * (T1 + 2) <= B * (mT1 + 2)
+                and rows * Tp <= B * mTp)
+
+    def _hint(self, T):
+        """Predicted row count for a pass whose longest batch has T frames (0: no prediction yet - decode exactly)."""
+        if not self.predict:
+            return 0
+        with self._rows_lock:
+            r = self._rows["ratio"]
+        if r is None:
+            return 0
+        tp = subsampled(T)
+        return min(tp + 1, int(math.ceil(r * 1.15 * (tp + 1))) + 4)
+
+    def _learn(self, ymax, T):
+        with self._rows_lock:
+            r = ymax / float(subsampled(T) + 1)
+            if self._rows["ratio"] is None or r > self._rows["ratio"]:
+                self._rows["ratio"] = r
 
     # ------------------------------------------------------------------------------------------ workers
     def _start(self):
@@ -123,6 +197,10 @@ class DecodePipelines:
                             job.state["err"] = e
                         with job.cv:
                             job.cv.notify_all()
+                        try:  # the failed pass may still have kernels queued against this pipeline's buffers
+                            st.synchronize()
+                        except BaseException:
+                            pass
                     finally:
                         job.finished.release()
 
@@ -132,83 +210,164 @@ class DecodePipelines:
         for _ in self._threads:
             ready.acquire()
 
-    def _work(self, k, st, job):
-        state, lock, ahead, it = job.state, job.lock, job.ahead, job.it
-        on_gpu, device = self._on_gpu, self._device
-        while True:
-            while not ahead.acquire(timeout=0.05):  # the consumer is behind: wait, but notice a shutdown
-                if state["done"] or state["err"] is not None:
-                    break
-            with lock:
-                if state["done"] or state["err"] is not None:
-                    break
-                items = []
-                if state["held"] is not None:
-                    items.append(state["held"])
-                    state["held"] = None
-                else:
-                    try:
-                        items.append(next(it))
-                    except StopIteration:
-                        state["done"] = True
-                        break
-                # further batches of the same shape ride along; another shape waits for the next pass.  A list of known length
-                # goes in passes of equal size (see _Job)
-                want = self.coalesce
-                if job.plan:
-                    want = min(want, job.plan.pop(0))
-                elif job.left is not None:
-                    want = min(want, max(1, -(-job.left // max(1, job.passes_left))))
-                    job.passes_left = max(1, job.passes_left - 1)
-                while len(items) < want:
-                    try:
-                        nxt = next(it)
-                    except StopIteration:
-                        break  # (the next worker to look finds the iterator exhausted)
-                    if tuple(nxt[0].shape) == tuple(items[0][0].shape) and ahead.acquire(blocking=False):
-                        items.append(nxt)
-                    else:
-                        state["held"] = nxt
-                        break
-                if job.left is not None:
-                    job.left = max(0, job.left - len(items))
-                i = state["next"]
-                state["next"] += len(items)
-            if len(items) == 1:
-                feats, ratio, tag = items[0]
-                hyp, hyp_len, score = self.model.decode_device(feats, ratio, job.args, job.sos, engine=self.engines[k])
-                recs = [cdist.pack_records(hyp, hyp_len, score)]
+    def _take(self, job):
+        """Under the job's lock: the next pass = consecutive batches that may share an engine pass.  None: nothing left."""
+        state, it, ahead = job.state, job.it, job.ahead
+        items = []
+        if state["held"] is not None:
+            items.append(state["held"])
+            state["held"] = None
+        else:
+            try:
+                items.append(next(it))
+            except StopIteration:
+                state["done"] = True
+                return None
+        # further batches ride along while the pass fits the workspace and their frame counts are close enough; anything else
+        # waits for the next pass.  A list of known length goes in passes of equal size (see _Job)
+        want = 64 if self.by_area else self.coalesce
+        if job.plan:
+            want = min(want, job.plan.pop(0))
+        elif job.left is not None and not self.by_area:
+            want = min(want, max(1, -(-job.left // max(1, job.passes_left))))
+            job.passes_left = max(1, job.passes_left - 1)
+        f0 = items[0][0]
+        rows, tmax, tmin = int(f0.shape[0]), int(f0.shape[1]), int(f0.shape[1])
+        while len(items) < want:
+            try:
+                nxt = next(it)
+            except StopIteration:
+                break  # (the next worker to look finds the iterator exhausted)
+            f = nxt[0]
+            T = int(f.shape[1])
+            hi, lo = max(tmax, T), min(tmin, T)
+            ok = (tuple(f.shape[2:]) == tuple(f0.shape[2:]) and f.dtype == f0.dtype and nxt[1].dtype == items[0][1].dtype
+                  and lo >= self.ragged * hi and self.fits(rows + int(f.shape[0]), hi))
+            if ok and ahead.acquire(blocking=False):
+                items.append(nxt)
+                rows, tmax, tmin = rows + int(f.shape[0]), hi, lo
             else:
-                nb = items[0][0].shape[0]
-                dev_ = torch.device("cuda", device) if on_gpu else None
-                # the merged input lives in a buffer of the pipeline's full capacity, allocated the first time a shape is merged
-                # (any merged warm-up pass, whatever its size, leaves nothing to allocate for the later ones)
-                f0, r0 = items[0][0], items[0][1]
-                key = (tuple(f0.shape), f0.dtype, tuple(r0.shape), r0.dtype)
-                bufs = self._stage[k].get(key)
-                if bufs is None:
-                    bufs = (torch.empty((self.coalesce * nb,) + tuple(f0.shape[1:]), dtype=f0.dtype, device=dev_),
-                            torch.empty((self.coalesce * nb,) + tuple(r0.shape[1:]), dtype=r0.dtype, device=dev_))
-                    self._stage[k][key] = bufs
-                feats, ratio = bufs[0][: len(items) * nb], bufs[1][: len(items) * nb]
-                torch.cat([x[0].to(dev_) if on_gpu else x[0] for x in items], 0, out=feats)  # one launch, nothing allocated
-                torch.cat([x[1].to(dev_) if on_gpu else x[1] for x in items], 0, out=ratio)
-                hyp, hyp_len, score = self.model.decode_device(feats, ratio, job.args, job.sos, engine=self.engines[k], sub_batch=nb)
-                rec = cdist.pack_records(hyp, hyp_len, score)
-                recs = [rec[j * nb : (j + 1) * nb] for j in range(len(items))]
-            ev = None
-            if on_gpu:
-                if job.host:  # pinned buffer from torch's caching host allocator, asynchronous copy on this pipeline's stream
-                    whole = recs[0] if len(items) == 1 else rec
-                    hbuf = torch.empty(whole.shape, dtype=whole.dtype, device="cpu", pin_memory=True)
-                    hbuf.copy_(whole, non_blocking=True)
-                    nb_ = whole.shape[0] // len(items)
-                    recs = [hbuf[j * nb_ : (j + 1) * nb_] for j in range(len(items))]
-                ev = torch.cuda.Event()
-                ev.record(st)
-            for j, item in enumerate(items):
-                job.slot(i + j).put((item[2], recs[j], ev))
-        st.synchronize()
+                state["held"] = nxt
+                break
+        if job.left is not None:
+            job.left = max(0, job.left - len(items))
+        i = state["next"]
+        state["next"] += len(items)
+        return i, items
+
+    def _stage_inputs(self, k, slot, items, pad):
+        """The merged input of a pass: the batches one after the other, padded to the longest with padding frames, in a buffer
+        of the pipeline's full capacity (two of them: two passes in flight), allocated at the first merged pass."""
+        on_gpu, device = self._on_gpu, self._device
+        dev_ = torch.device("cuda", device) if on_gpu else None
+        f0, r0 = items[0][0], items[0][1]
+        rows = sum(int(x[0].shape[0]) for x in items)
+        tmax = max(int(x[0].shape[1]) for x in items)
+        feat_dim = int(f0.shape[2])
+        key = (slot, feat_dim, f0.dtype, r0.dtype)
+        bufs = self._stage[k].get(key)
+        need = rows * tmax * feat_dim
+        if bufs is None or bufs[0].numel() < need or bufs[1].numel() < rows:
+            cap = max(need, self.max_batch * self.frames_cap * feat_dim)
+            bufs = (torch.empty(cap, dtype=f0.dtype, device=dev_), torch.empty(max(rows, self.max_utts), dtype=r0.dtype, device=dev_))
+            self._stage[k][key] = bufs
+        feats = bufs[0][:need].view(rows, tmax, feat_dim)
+        ratio = bufs[1][:rows]
+        if all(int(x[0].shape[1]) == tmax for x in items):
+            torch.cat([x[0].to(dev_) if on_gpu else x[0] for x in items], 0, out=feats)  # one launch, nothing allocated
+        else:
+            feats.fill_(float(pad))
+            o = 0
+            for x in items:
+                nb, t = int(x[0].shape[0]), int(x[0].shape[1])
+                feats[o:o + nb, :t].copy_(x[0], non_blocking=True)
+                o += nb
+        torch.cat([x[1].to(dev_) if on_gpu else x[1] for x in items], 0, out=ratio)
+        return feats, ratio
+
+    def _launch(self, k, st, job, p, exact=False):
+        """Enqueue the engine pass of ``p`` (and the trip of its records to the host) on this pipeline's stream."""
+        items = p.items
+        p.u_hint = 0 if exact else self._hint(max(p.frames))
+        single = len(items) == 1
+        out = self.model.decode_device(p.feats, p.ratio, job.args, job.sos, engine=self.engines[k],
+                                       sub_rows=None if single else p.rows, sub_frames=None if single else p.frames,
+                                       u_hint=p.u_hint, want_ticket=True)
+        hyp, hyp_len, score, p.ticket = out
+        rec = cdist.pack_records(hyp, hyp_len, score)
+        if self._on_gpu and job.host:  # pinned buffer from torch's caching host allocator, asynchronous copy on this pipeline's stream
+            hbuf = torch.empty(rec.shape, dtype=rec.dtype, device="cpu", pin_memory=True)
+            hbuf.copy_(rec, non_blocking=True)
+            rec = hbuf
+        o, p.recs = 0, []
+        for nb in p.rows:
+            p.recs.append(rec[o:o + nb])
+            o += nb
+        p.ev = None
+        if self._on_gpu:
+            p.ev = torch.cuda.Event()
+            p.ev.record(st)
+
+    def _retire(self, k, st, job, p):
+        """The pass has drained: check the predicted row count (decode again on a miss), learn from the true one, hand out."""
+        if p.ev is not None:
+            p.ev.synchronize()
+        if p.ticket is not None and p.ticket >= 0:
+            ymax, used = self.engines[k].ticket(p.ticket)
+            self.stats["passes"] += 1
+            self.stats["batches"] += len(p.items)
+            if p.u_hint:
+                self.stats["predicted"] += 1
+            if used < ymax:  # the prediction fell short: this pass again, exactly (its inputs are still in their staging slot)
+                self.stats["missed"] += 1
+                self._learn(ymax, max(p.frames))
+                self._launch(k, st, job, p, exact=True)
+                if p.ev is not None:
+                    p.ev.synchronize()
+            else:
+                self._learn(ymax, max(p.frames))
+        for j, item in enumerate(p.items):
+            job.slot(p.first + j).put((item[2], p.recs[j], p.ev))
+
+    def _work(self, k, st, job):
+        state, lock, ahead = job.state, job.lock, job.ahead
+        on_gpu, device = self._on_gpu, self._device
+        pad = float(getattr(job.args, "padding_idx", 0))
+        inflight = []
+        n_pass = 0
+        try:
+            while True:
+                while not ahead.acquire(timeout=0.05):  # the consumer is behind: wait, but notice a shutdown
+                    if state["done"] or state["err"] is not None:
+                        break
+                    if inflight:  # ... and do not sit on finished work meanwhile
+                        self._retire(k, st, job, inflight.pop(0))
+                with lock:
+                    if state["done"] or state["err"] is not None:
+                        break
+                    got = self._take(job)
+                if got is None:
+                    break
+                p = _Pass()
+                p.first, p.items = got
+                p.rows = [int(x[0].shape[0]) for x in p.items]
+                p.frames = [int(x[0].shape[1]) for x in p.items]
+                p.ticket = None
+                if len(p.items) == 1:
+                    p.feats, p.ratio = p.items[0][0], p.items[0][1]
+                else:
+                    p.feats, p.ratio = self._stage_inputs(k, n_pass & 1, p.items, pad)
+                    if len(set(p.frames)) > 1:
+                        self.stats["merged_ragged"] += 1
+                n_pass += 1
+                self._launch(k, st, job, p)
+                inflight.append(p)
+                if len(inflight) >= 2:  # two passes in flight: this one's launches are queued behind the older one's kernels
+                    self._retire(k, st, job, inflight.pop(0))
+            while inflight and state["err"] is None:
+                self._retire(k, st, job, inflight.pop(0))
+        finally:
+            st.synchronize()
 
     def close(self):
         for q in self._inbox:
@@ -227,18 +386,21 @@ class DecodePipelines:
         self.close()
         return False
 
-    def records(self, batches, args, sos=1, host=False):
+    def records(self, batches, args, sos=1, host=False, plan=None):
         """``batches``: iterable of ``(feats (B,T,F), size_ratio (B,), tag)`` (host or device tensors).  Yields
         ``(tag, records)`` in the order of the iterable: ``records`` is the device tensor of ``dist.pack_records`` (per
         utterance: length, float64 score, [sos] + tokens), ready for ``dist.all_gather_records`` / ``unpack_records``.  The
         consumer's current stream is made to wait for the producing pipeline's work.  ``host=True``: the records arrive as
         host tensors instead (pinned; sent by the producing pipeline on its own stream, one copy per engine pass, and complete when
-        they are yielded) - what a single-GPU consumer wants, which would otherwise pay one blocking copy per batch."""
+        they are yielded) - what a single-GPU consumer wants, which would otherwise pay one blocking copy per batch.
+        ``plan``: explicit pass sizes (batches per pass, in the order the passes are taken)."""
         self._start()
         job = _Job(iter(batches), args, sos, self.n, total=len(batches) if hasattr(batches, "__len__") else None,
-                   coalesce=self.coalesce, host=host)
+                   coalesce=self.coalesce, host=host, plan=list(plan) if plan else None, per_pass=64 if self.by_area else None)
         state, lock = job.state, job.lock
-        with self._busy:
+        if not self._busy.acquire(timeout=60.0):
+            raise RuntimeError("DecodePipelines.records(): the previous records() iterator was never finished or closed")
+        try:
             for q in self._inbox:
                 q.put(job)
             i = 0
@@ -268,10 +430,16 @@ class DecodePipelines:
             finally:
                 with lock:
                     state["done"] = True
+                stuck = 0
                 for _ in range(self.n):  # every worker has left the job (its stream is drained) before the next one starts
-                    job.finished.acquire()
+                    if not job.finished.acquire(timeout=300.0):
+                        stuck += 1
+                if stuck:
+                    raise RuntimeError(f"DecodePipelines: {stuck} pipeline(s) did not leave the job within 300 s (stuck inside a device call?)")
+        finally:
+            self._busy.release()
 
-    def decode(self, batches, args, sos=1, gather=False, as_lists=True, gather_every=None):
+    def decode(self, batches, args, sos=1, gather=False, as_lists=True, gather_every=None, plan=None):
         """Hypotheses on the host, in order: yields ``(tag, hyps, scores)`` with ``hyps`` a list of token lists starting
         with ``sos`` (what ``beam_decode`` returns as ``['hyp']``), or with ``as_lists=False`` the arrays ``(tokens (N, S),
         lengths (N,))`` of ``dist.unpack_records``.  ``gather=True``: the multi-GPU path - every step's records of all ranks,
@@ -280,7 +448,7 @@ class DecodePipelines:
         same sequence of collectives on every rank whatever the pipelines' timing; every rank must decode the same number of
         steps."""
         if not gather:
-            for tag, rec in self.records(batches, args, sos, host=True):
+            for tag, rec in self.records(batches, args, sos, host=True, plan=plan):
                 hyps, scores = cdist.unpack_records(rec, as_lists=as_lists)
                 yield tag, hyps, scores
             return
@@ -297,7 +465,7 @@ class DecodePipelines:
             pending.clear()
             return out
 
-        for tag, rec in self.records(batches, args, sos):
+        for tag, rec in self.records(batches, args, sos, plan=plan):
             if pending and tuple(rec.shape) != tuple(pending[0][1].shape):
                 for t_, (h_, s_) in flush():
                     yield t_, h_, s_

@@ -68,16 +68,33 @@ class CassNATTask(BaseTask):
         assert args.input_size == (args.left_ctx + args.right_ctx + 1) // args.skip_frame * args.n_features
         self.model = make_cassnat_model(args.input_size, args)
 
+    def _lengths(self, args, need):
+        """Frame counts of the utterance list: `utt2num_frames` (test_paths entry, or the file beside the scp) when there is
+        one, else - when `need`ed - the matrix headers of the ark entries; zeros otherwise."""
+        from ..data import kaldi_io
+
+        scp = args.test_paths[0]["scp_path"]
+        entries = kaldi_io.read_scp(scp)
+        u2n = args.test_paths[0].get("utt2num_frames") or os.path.join(os.path.dirname(scp), "utt2num_frames")
+        if os.path.exists(u2n):
+            table = dict((ln.split()[0], int(ln.split()[1])) for ln in open(u2n) if ln.strip())
+            if all(utt in table for utt, _ in entries):
+                return np.array([table[utt] for utt, _ in entries])
+        if need:
+            return np.array([kaldi_io.mat_rows(spec) for _, spec in entries])
+        return np.zeros(len(entries))
+
     def _shard(self, args):
-        """Indices of this rank's utterances (None = all).  Lengths come from utt2num_frames when given."""
+        """Indices of this rank's utterances, in decoding order (None = all, file order).  Ranks get a length-sorted snake deal;
+        `--hip_bucket 1` sorts a single process's list by length too (longest first: batches of similar frame counts, which pad
+        little and share engine passes well - the reference's own batching is file order)."""
         self._order = None
-        if self.world == 1:
+        bucket = bool(int(getattr(args, "hip_bucket", 0)))
+        if self.world == 1 and not bucket:
             return None
-        n = sum(1 for _ in open(args.test_paths[0]["scp_path"]))
-        lengths = np.zeros(n)
-        u2n = args.test_paths[0].get("utt2num_frames")
-        if u2n:
-            lengths = np.array([int(line.split()[1]) for line in open(u2n)])
+        lengths = self._lengths(args, need=bucket)
+        if self.world == 1:
+            return np.argsort(-lengths, kind="stable")
         return cdist.shard_indices(lengths, self.world, self.rank)
 
     def load_lm_model(self, args):
@@ -157,9 +174,11 @@ class CassNATTask(BaseTask):
         sos = self.vocab.word2index["sos"]
         first = next(iter(self.test_loader))
         max_frames = max(getattr(args, "hip_max_frames", 4096), first[1].shape[1])
+        # consecutive batches share an engine pass while they fit the workspace area (hip_coalesce batches of batch_size x 1024
+        # frames) and their frame counts are within hip_ragged of each other; passes are filled by area, not by a batch count
         pipes = DecodePipelines(self.model, n_pipes, args.batch_size, max_frames, with_weights=(self.rank == 0),
                                 after_engine=(lambda e: cdist.broadcast_weights(e, src=0)) if self.world > 1 else None,
-                                coalesce=int(getattr(args, "hip_coalesce", 3)))  # (equal-shaped neighbours share a pass)
+                                coalesce=-max(1, int(getattr(args, "hip_coalesce", 10))), ragged=float(getattr(args, "hip_ragged", 0.75)))
         meta, frames, i, end = {}, 0, -1, time.time()
 
         def batches():
@@ -176,6 +195,7 @@ class CassNATTask(BaseTask):
             end = time.time()
             if i % args.print_freq == 0 and self.rank == 0:
                 progress.print(i)
+        self.pipeline_stats = dict(pipes.stats)
         pipes.close()
         return frames, i
 
@@ -183,8 +203,8 @@ class CassNATTask(BaseTask):
         batch_time = util.AverageMeter("Time", ":6.3f")
         progress = util.ProgressMeter(len(self.test_loader), batch_time)
         results = {}
-        # args.hip_pipelines (default 3, each taking up to args.hip_coalesce = 3 equal-shaped batches per engine pass; 1 = the plain loop): beam search, ESA and capture runs keep the plain loop
-        n_pipes = int(getattr(args, "hip_pipelines", 3))
+        # args.hip_pipelines (default 2; 1 = the plain loop): beam search, ESA and capture runs keep the plain loop
+        n_pipes = int(getattr(args, "hip_pipelines", 2))
         plain_greedy = (args.beam_width == 1 and getattr(args, "sample_num", 0) <= 1 and not getattr(args, "hip_capture", False)
                         and args.decode_type == "att_only")
         # Both branches issue the same collectives (one weight broadcast; the result gather below), and the choice is made from

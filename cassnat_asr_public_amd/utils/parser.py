@@ -24,10 +24,19 @@ class DecodeParser(object):
         p.add_argument("--hip_precision", default="bf16", choices=["bf16", "fp32", "fp8", "bf16x3"],
                        help="bf16 MFMA (throughput) or exact-f32 MFMA (parity with the reference CPU path)")
         p.add_argument("--hip_max_frames", default=4096, type=int, help="workspace size in input frames")
-        p.add_argument("--hip_pipelines", default=3, type=int,
-                       help="decode pipelines per GPU for greedy decoding of a test set (1 = batch after batch)")
-        p.add_argument("--hip_coalesce", default=3, type=int,
-                       help="equal-shaped batches a decode pipeline may take through one engine pass (hypotheses per batch unchanged)")
+        p.add_argument("--hip_pipelines", default=2, type=int,
+                       help="decode pipelines per GPU for greedy decoding of a test set (1 = batch after batch, the reference's loop)")
+        p.add_argument("--hip_coalesce", default=10, type=int,
+                       help="sizes a pipeline's workspace: the area of that many batches of batch_size x 1024 frames; consecutive "
+                            "batches - of different frame counts too - share one engine pass while they fit it (every batch's "
+                            "hypotheses and scores stay exactly those of a pass of its own)")
+        p.add_argument("--hip_ragged", default=0.75, type=float,
+                       help="batches share an engine pass while the shortest has at least this fraction of the longest one's frames "
+                            "(1 = equal shapes only)")
+        p.add_argument("--hip_bucket", default=0, type=int,
+                       help="1: form the batches from the utterance list sorted by length (frame counts from <scp dir>/utt2num_frames "
+                            "or the ark headers) instead of file order - less padding per batch, neighbours that merge well; the "
+                            "result file stays in file order.  0 (default): the reference's batches")
         p.add_argument("--hip_dist_backend", default="nccl", choices=["nccl", "gloo"],
                        help="torch.distributed backend under torch.distributed.run (nccl = RCCL over xGMI; gloo: rehearsal of the "
                             "N-rank path, also with several ranks on one GPU)")

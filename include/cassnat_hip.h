@@ -97,10 +97,33 @@ int cn_model_weight_blob(cn_model* m, void** dev_ptr, int64_t* bytes);
  *   size_ratio_dev (B) fp32 length ratios (SuperviseLoader.collate_fn, src/data/speech_loader.py:354)
  *   hyp_out_dev    (B,hyp_stride) int32: [sos, tok...]; hyp_len_dev (B); score_dev (B) float64
  * All stages through the greedy pack run on `stream`; the call synchronises the stream once (the token
- * count U is data dependent). */
+ * count U is data dependent).  Workspace: every buffer is checked against the call before anything is launched. */
 int cn_decode_nast(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,
                    const cn_decode_opts* opts, int32_t* hyp_out_dev, int32_t hyp_stride, int32_t* hyp_len_dev,
                    double* score_dev, void* stream);
+
+/* One engine pass over SEVERAL reference batches, each with its own frame count (the reference collates every batch to its own
+ * longest utterance, src/data/speech_loader.py:327-356, and decodes batch after batch, src/tasks/cassnat_task.py:317-356):
+ * feats_dev holds the batches one after the other, every utterance padded with padding_idx frames to the call's T = the largest
+ * sub_frames; batch k has sub_rows_host[k] utterances of sub_frames_host[k] frames (size_ratio relative to THAT count, as
+ * collate_fn computes it).  Every utterance's hypothesis and score are exactly those of a cn_decode_nast call on its own batch:
+ * its frames past sub_frames are treated as the convolutions' zero padding, src_size = (ratio * T'_own).long()
+ * (src/models/cassnat.py:436), the alignment's shift and the forced EOS frame (:355-365, 378-389) use T'_own, keys past T'_own do
+ * not exist for the softmax (a row without any allowed key attends uniformly over T'_own keys, attention.py:19-21), and the
+ * greedy finish is limited by the row count of the own batch.  n_sub == 0: a plain call (sub_rows / sub_frames unused).
+ * Transformer blocks, beam_width 1, no capture.  At most 64 batches per pass.
+ * The workspace is an AREA: a pass fits when every buffer holds it (B x T' rows etc. against max_batch x max_frames), so a pass of
+ * short utterances may carry more of them than max_batch (up to 16 x max_batch); the error names the buffer that is too small.
+ * u_hint > 0: the decoder side is launched on min(u_hint, T' + 1) rows WITHOUT waiting for the data-dependent row count (the
+ * reference's `.item()` sync, src/models/cassnat.py:387): nothing in the call blocks the host.  Results equal the exact call's
+ * whenever u_hint >= the true count; *ticket_out names the page-locked word that receives the true count - once the stream has
+ * drained, cn_decode_ticket(ticket) returns it beside the rows used, and on rows_used < ymax the caller decodes the pass again
+ * (u_hint 0 = exact: the call synchronises the stream once, as cn_decode_nast). */
+int cn_decode_nast_merged(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,
+                          const cn_decode_opts* opts, int32_t n_sub, const int32_t* sub_rows_host, const int32_t* sub_frames_host,
+                          int32_t u_hint, int32_t* hyp_out_dev, int32_t hyp_stride, int32_t* hyp_len_dev, double* score_dev,
+                          void* stream, int32_t* ticket_out);
+int cn_decode_ticket(cn_model* m, int32_t ticket, int32_t* ymax_host, int32_t* rows_used_host);
 
 /* stage-level entry: src_embed + encoder + ctc_generator + alignment only (src/models/cassnat.py:431-468) */
 int cn_encode_align(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,

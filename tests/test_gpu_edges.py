@@ -446,3 +446,180 @@ def test_merged_pass_equals_separate_passes_when_rows_change_workgroups(prec):
     for (tag, hyps, scores), (wh, ws) in zip(got, want):
         assert hyps == wh, tag
         assert list(scores) == ws, tag
+
+
+# ------------------------------------------------------------------------------- merged passes of different frame counts
+def _separate(model, args, data):
+    want = []
+    for feats, sizes in data:
+        src = torch.from_numpy(feats)
+        with torch.no_grad():
+            out, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, args)
+        want.append(([s[0]["hyp"] for s in out], [s[0]["score"] for s in out]))
+    return want
+
+
+def _ragged_batches(rng, shapes, seed0, holes=False):
+    data = []
+    for k, (B, T) in enumerate(shapes):
+        lens = sorted((int(x) for x in rng.integers(1, T + 1, size=B)), reverse=True)
+        lens[0] = T  # collate pads a batch to ITS longest utterance (speech_loader.py:327-356)
+        f, s = synth.make_feats(B, T, 80, lengths=lens, seed=seed0 + k)
+        if holes and T > 24:  # zeroed frames inside an utterance: masked keys in the middle, possibly a trigger row without any key
+            f[0, 8:21] = 0.0
+        data.append((f, s))
+    return data
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])
+def test_merged_pass_of_different_frame_counts_equals_separate_passes(prec):
+    """cn_decode_nast_merged: batches of DIFFERENT frame counts (every residue of the two stride-2 subsamplings, different
+    utterance counts, very short utterances, zeroed frames inside an utterance) through ONE engine pass give, per batch, exactly
+    the hypotheses and scores of a pass of their own - the reference collates every batch to its own longest utterance
+    (speech_loader.py:327-356) and decodes batch after batch (cassnat_task.py:317-356).  Also with the decoder side launched on a
+    predicted row count (no mid-pass sync), including a prediction that falls short (the pass is decoded again)."""
+    from cassnat_asr_public_amd.pipeline import DecodePipelines
+
+    args = synth.make_args("tiny")
+    args.hip_max_batch, args.hip_max_frames = 4, 96
+    state = synth.make_state(args, seed=0, gain=2.0)
+    model = build(args, state, capture=False, prec=prec)
+    rng = np.random.default_rng(31)
+    shapes = [(3, 61), (4, 64), (2, 62), (1, 63), (3, 65), (4, 57), (2, 41), (3, 44), (1, 43), (4, 42), (3, 9), (2, 12), (4, 10), (1, 1),
+              (2, 5), (3, 96), (2, 90), (4, 77), (3, 80)]
+    data = _ragged_batches(rng, shapes, 1200, holes=True)
+    want = _separate(model, args, data)
+    items = [(torch.from_numpy(f), torch.from_numpy(s), k) for k, (f, s) in enumerate(data)]
+    for predict in (False, True):
+        with DecodePipelines(model, 2, 4, 96, coalesce=5, ragged=0.5, predict_rows=predict) as pipes:
+            got = list(pipes.decode(items, args, sos=1))
+            assert pipes.stats["merged_ragged"] >= 3, pipes.stats
+            if predict:
+                assert pipes.stats["predicted"] >= 1, pipes.stats
+        assert [t for t, _, _ in got] == list(range(len(shapes)))
+        for (tag, hyps, scores), (wh, ws) in zip(got, want):
+            assert hyps == wh, (predict, tag, shapes[tag])
+            assert list(scores) == ws, (predict, tag, shapes[tag])
+    # a prediction that is too small: detected when the pass has drained, the pass runs again exactly
+    with DecodePipelines(model, 1, 4, 96, coalesce=5, ragged=0.5) as pipes:
+        pipes._rows["ratio"] = 0.01
+        pipes._learn = lambda ymax, T: None  # (keep the predictor wrong for the whole list)
+        got = list(pipes.decode(items, args, sos=1))
+        assert pipes.stats["missed"] >= 3, pipes.stats
+    for (tag, hyps, scores), (wh, ws) in zip(got, want):
+        assert hyps == wh and list(scores) == ws, tag
+
+
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+def test_merged_ragged_pass_config2_size(prec):
+    """The same equality on the config-2 model at sizes where the fast kernels run (row chain, LDS-DMA convolution, fused
+    generator; 128-/256-row tiles cut across batches of 100-, 91- and 78-row utterances)."""
+    from cassnat_asr_public_amd.pipeline import DecodePipelines
+
+    args = synth.make_args("config2")
+    args.hip_max_batch, args.hip_max_frames = 4, 400
+    state = synth.make_state(args, seed=0, blank_bias=synth.BENCH_BLANK_BIAS)
+    model = build(args, state, capture=False, prec=prec)
+    rng = np.random.default_rng(41)
+    shapes = [(4, 400), (3, 363), (4, 310), (2, 397), (4, 333), (1, 301)]
+    data = []
+    for k, (B, T) in enumerate(shapes):
+        lens = sorted((int(x) for x in rng.integers(120, T + 1, size=B)), reverse=True)
+        lens[0] = T
+        data.append(synth.make_feats(B, T, 80, lengths=lens, seed=1500 + k))
+    want = _separate(model, args, data)
+    items = [(torch.from_numpy(f), torch.from_numpy(s), k) for k, (f, s) in enumerate(data)]
+    with DecodePipelines(model, 1, 4, 400, coalesce=6, ragged=0.7) as pipes:
+        got = list(pipes.decode(items, args, sos=1, plan=[3, 3]))
+        assert pipes.stats["merged_ragged"] == 2 and pipes.stats["passes"] == 2, pipes.stats
+    for (tag, hyps, scores), (wh, ws) in zip(got, want):
+        assert hyps == wh, tag
+        assert list(scores) == ws, tag
+
+
+def test_workspace_is_an_area_and_every_buffer_is_checked():
+    """The engine's workspace is max_batch x max_frames of AREA: a call with more, shorter utterances runs (and gives the plain
+    call's results); a call that does not fit is refused with the name of the buffer that is too small, before anything is
+    launched - capacities used to be implicit per buffer (round 2's GPU fault: decoder rows written past a logits buffer)."""
+    from cassnat_asr_public_amd import hip
+
+    args = synth.make_args("tiny")
+    args.hip_max_batch, args.hip_max_frames = 2, 64
+    state = synth.make_state(args, seed=0, gain=2.0)
+    model = build(args, state, capture=False)
+    f, s = synth.make_feats(5, 20, 80, lengths=[20, 17, 11, 5, 1], seed=77)
+    eng = model.engine(2, 64)
+    assert (eng.cfg.max_batch, eng.cfg.max_frames) == (2, 64)
+    hyp, hyp_len, score = model.decode_device(torch.from_numpy(f), torch.from_numpy(s), args, engine=eng)  # 5 x 20 fits 2 x 64
+    args2 = synth.make_args("tiny")
+    args2.hip_max_batch, args2.hip_max_frames = 8, 64
+    big = build(args2, state, capture=False)
+    h2, l2, s2 = big.decode_device(torch.from_numpy(f), torch.from_numpy(s), args2)
+    assert torch.equal(hyp_len, l2) and torch.equal(score, s2)
+    assert all(torch.equal(hyp[b, : int(l2[b])], h2[b, : int(l2[b])]) for b in range(5))
+    f3, s3 = synth.make_feats(3, 64, 80, seed=78)
+    with pytest.raises(hip.HipError, match="workspace buffer '"):
+        model.decode_device(torch.from_numpy(f3), torch.from_numpy(s3), args, engine=eng)  # 3 x 64 does not
+    f4, s4 = synth.make_feats(40, 4, 80, seed=79)
+    with pytest.raises(hip.HipError, match="workspace buffer '"):
+        model.decode_device(torch.from_numpy(f4), torch.from_numpy(s4), args, engine=eng)  # 40 one-row utterances do not either
+
+
+def test_bench_size_merged_pass_and_esa_50_in_every_precision(capsys):
+    """Once, at the benchmark's size (32 x 1000 frames, config-2 model): a ten-batch merged engine pass - the bench's launch
+    width, 80,000 encoder rows - and ESA with sample_num 50 (the shipped decode YAML) in bf16, bf16x3 and fp32.  No golden exists
+    at this size; the checks are the ones that found round 2's bugs: every buffer's capacity is checked on the host (ws_check),
+    the merged pass equals a plain call bitwise, and the two parity-grade engines agree with each other."""
+    from cassnat_asr_public_amd.models.lm import make_model as make_lm
+    from cassnat_asr_public_amd.pipeline import DecodePipelines
+
+    B, T = 32, 1000
+    hyps = {}
+    for prec in ("bf16", "bf16x3", "fp32"):
+        args = synth.make_args("config2")
+        args.hip_max_batch, args.hip_max_frames = B, T
+        state = synth.make_state(args, seed=0, blank_bias=synth.BENCH_BLANK_BIAS)
+        model = build(args, state, capture=False, prec=prec)
+        rng = np.random.default_rng(3)
+        data = []
+        for k in range(10):
+            lens = sorted((int(x) for x in rng.integers(400, T + 1, size=B)), reverse=True)
+            lens[0] = T
+            data.append(synth.make_feats(B, T, 80, lengths=lens, seed=2000 + k))
+        want = _separate(model, args, data[:2])
+        model._engine.close()
+        model._engine = None
+        with DecodePipelines(model, 1, B, T, coalesce=10) as pipes:
+            got = list(pipes.decode([(torch.from_numpy(f), torch.from_numpy(s), k) for k, (f, s) in enumerate(data)], args, sos=1, plan=[10]))
+            assert pipes.stats["passes"] == 1 and pipes.stats["batches"] == 10, pipes.stats
+        for (tag, h, sc), (wh, ws) in zip(got[:2], want):
+            assert h == wh and list(sc) == ws, (prec, tag)
+        hyps[prec] = [h for _, h, _ in got]
+        # ESA, sample_num 50 in groups of 16: B x 16 x U decoder rows per group against every buffer's capacity
+        a2 = synth.make_args("config2", sample_num=50, rank_model="lm", threshold=0.9)
+        a2.hip_precision, a2.hip_max_batch, a2.hip_max_frames = prec, B, T
+        lm_args = synth.make_args_lm("lm_small", vocab_size=a2.vocab_size)
+        lm_args.hip_precision = prec
+        lm_state = synth.make_state(lm_args, seed=9, gain=2.0)
+        m2, lm = build(a2, state, capture=False, prec=prec), make_lm(lm_args).cuda()
+        with torch.no_grad():
+            for k, p in lm.named_parameters():
+                p.copy_(torch.from_numpy(lm_state[k]))
+        src, sizes = torch.from_numpy(data[0][0]).cuda(), torch.from_numpy(data[0][1]).cuda()
+        torch.manual_seed(3)
+        with torch.no_grad():
+            out, _ = m2.beam_decode(src, (src[:, :, 0] != 0).unsqueeze(1), sizes, Vocab, a2, lm)
+        torch.cuda.synchronize()
+        assert len(out) == B and all(np.isfinite(o[0]["score"]) for o in out)
+        hyps[prec + "/esa"] = [o[0]["hyp"] for o in out]
+        for x in (m2, lm, model):
+            if getattr(x, "_engine", None) is not None:
+                x._engine.close()
+                x._engine = None
+    same = sum(a == b for x, y in zip(hyps["fp32"], hyps["bf16x3"]) for a, b in zip(x, y))
+    same_esa = sum(a == b for a, b in zip(hyps["fp32/esa"], hyps["bf16x3/esa"]))
+    same_bf = sum(a == b for x, y in zip(hyps["fp32"], hyps["bf16"]) for a, b in zip(x, y))
+    with capsys.disabled():
+        print(f"\n[bench size] merged ten-batch pass: bf16x3 == fp32 on {same}/320 hypotheses, bf16 == fp32 on {same_bf}/320; "
+              f"ESA 50: bf16x3 == fp32 on {same_esa}/32")
+    assert same >= 316 and same_esa >= 30

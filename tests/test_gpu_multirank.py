@@ -149,10 +149,37 @@ def _run_cli(tmp, cli, world, backend, tag):
         procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                                                 MASTER_PORT=port), cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
                  for r in range(world)]
-        for pr in procs:
-            text, _ = pr.communicate(timeout=600)
-            assert pr.returncode == 0, text[-4000:]
+        try:
+            for pr in procs:
+                text, _ = pr.communicate(timeout=600)
+                assert pr.returncode == 0, text[-4000:]
+        finally:  # a failed or timed-out rank must not leave its peer blocked in a collective, holding the GPU and the port
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+                    pr.wait()
     return open(result).read().splitlines()
+
+
+def test_rccl_branch_world_size_one():
+    """BASELINE configs[2]'s collectives on the one GPU a test box has: `init_process_group("nccl", device_id=...)`, the RCCL
+    broadcast of the packed weight blob and the `all_gather_into_tensor` branch of `dist.all_gather_records` through
+    `DecodePipelines.decode(gather=True)`, in a world of size 1 (tests/_nccl_world1.py, a child process) - so that the driver's
+    8-GPU command executes nothing for the first time.  Hypotheses and scores equal the non-distributed pipelines'."""
+    import json
+
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    for prec in ("bf16", "bf16x3"):
+        out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_nccl_world1.py"), prec], env=env, cwd=REPO,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        info = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert info["ok"] and info["backend"] == "nccl" and info["all_gather_into_tensor_calls"] >= 1
+        assert info["blob_bytes"] > 1e6 and info["weight_broadcast_ms"] > 0
+        print(f"[rccl world-size-1 {prec}] {info}")
 
 
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])

@@ -187,8 +187,10 @@ def test_bf16_agreement_report(case, name, strides, capsys):
     rep = check_against_golden(model, args, feats, sizes, g, *strides, fp32=False)
     with capsys.disabled():
         print(f"\n[agreement bf16] {name}: {rep}")
-    assert rep["flips"] / rep["frames"] < 0.10  # SURVEY 7 measured 0.65-2.8 % for bf16 rounding alone
-    assert rep["ctc_logit_err"] < 0.1
+    # gates at 2x what this build measures (GPUTEST_r02: 0.65-0.67 % flips, 5.2e-3 / 5.8e-3): a regression of the bf16 kernels'
+    # rounding (an accumulation moved to bf16, a dropped fp32 residual) shows here; SURVEY 7 predicts 0.65-2.8 % for bf16 alone
+    assert rep["flips"] / rep["frames"] < 0.015
+    assert rep["ctc_logit_err"] < 1.2e-2
 
 
 def test_full_size_properties_bf16():
@@ -221,7 +223,7 @@ def test_decode_rejects_oversize_batch():
     eng.load_state(state, torch.zeros(5000, args.d_model))
     f = torch.from_numpy(feats).cuda()
     hyp = torch.empty(3, 40, dtype=torch.int32, device="cuda")
-    with pytest.raises(hip.HipError, match="outside the configured workspace"):
+    with pytest.raises(hip.HipError, match="workspace buffer .* needs"):
         eng.decode(f, torch.from_numpy(sizes).cuda(), hip.Engine.make_opts(args), hyp,
                    torch.empty(3, dtype=torch.int32, device="cuda"), torch.empty(3, dtype=torch.float64, device="cuda"))
 
@@ -349,6 +351,8 @@ def test_esa_sampling_with_lm_ranking(which, prec, capsys):
     if prec in ("fp32", "bf16x3"):
         assert same == len(out)
         np.testing.assert_allclose([s[0]["score"] for s in out], g["score"], rtol=1e-5, atol=2e-3)
+    else:  # bf16: another of the sampled alignments may win the ranking; its score stays within a few percent (measured: 1.6 %)
+        np.testing.assert_allclose([s[0]["score"] for s in out], g["score"], rtol=0.05, atol=0.5)
     if which in ("esa_tiny", "esa_conf_tiny"):  # the samples go through the decoder side in groups: any group size gives the same answer
         for group in (1, 3):
             args.hip_esa_group = group
@@ -378,7 +382,9 @@ def test_config5_fp8_encoder_products(capsys):
         print(f"\n[config 5] V={args.vocab_size}, {g['best_paths'].size} frames, against the fp32 reference: "
               + "; ".join(f"{k}: argmax flips {v['flips']:.4f}, max |d log-posterior| {v['err']:.4f}, hypotheses identical "
                           f"{v['hyp']}/{len(g['hyp'])}" for k, v in rows.items()))
-    assert rows["fp8"]["flips"] < 0.25 and rows["fp8"]["err"] < 0.5
+    # 2x the measured values (fp8: 8.8 % flips, 0.081; bf16 on the same weights: 0.67 %, 5.8e-3)
+    assert rows["fp8"]["flips"] < 0.18 and rows["fp8"]["err"] < 0.17
+    assert rows["bf16"]["flips"] < 0.015 and rows["bf16"]["err"] < 1.2e-2
 
 
 def test_esa_group_rows_beyond_one_alignment_per_utterance():

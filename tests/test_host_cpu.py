@@ -247,7 +247,10 @@ def test_decode_pipelines_keep_submission_order_and_surface_errors():
         def new_engine(self, batch, frames, with_weights=True, share=None):
             return StubEngine()
 
-        def decode_device(self, feats, ratio, args, sos, engine=None, sub_batch=0):
+        def decode_device(self, feats, ratio, args, sos, engine=None, sub_batch=0, sub_rows=None, sub_frames=None, u_hint=0,
+                          want_ticket=False):
+            if want_ticket:  # (the pipelines' call: a fourth value, the ticket - none for a stub)
+                return self.decode_device(feats, ratio, args, sos) + (-1,)
             if feats.shape[0] > 1:  # a coalesced pair: one pass, records of both in order
                 parts = [self.decode_device(feats[j : j + 1], ratio[j : j + 1], args, sos) for j in range(feats.shape[0])]
                 self.pairs += 1
@@ -309,16 +312,19 @@ def test_decode_pipelines_cut_a_list_of_known_length_into_equal_passes():
 
     class StubModel:
         def __init__(self):
-            self.passes = []
+            self.passes, self.subs = [], []
 
         def new_engine(self, batch, frames, with_weights=True, share=None):
             return StubEngine()
 
-        def decode_device(self, feats, ratio, args, sos, engine=None, sub_batch=0):
+        def decode_device(self, feats, ratio, args, sos, engine=None, sub_batch=0, sub_rows=None, sub_frames=None, u_hint=0,
+                          want_ticket=False):
             ks = [int(feats[j, 0, 0]) for j in range(feats.shape[0])]
             self.passes.append(ks)
+            self.subs.append((sub_rows, sub_frames, tuple(feats.shape)))
             hyp = _torch.tensor([[sos, 10 + k, 0] for k in ks], dtype=_torch.int32)
-            return hyp, _torch.full((len(ks),), 2, dtype=_torch.int32), _torch.tensor([float(k) for k in ks], dtype=_torch.float64)
+            out = (hyp, _torch.full((len(ks),), 2, dtype=_torch.int32), _torch.tensor([float(k) for k in ks], dtype=_torch.float64))
+            return out + (-1,) if want_ticket else out
 
     for n, c, total, want in ((3, 3, 20, [2, 2, 2, 2, 2, 2, 2, 3, 3]), (2, 10, 20, [10, 10]), (2, 10, 5, [2, 3]), (1, 4, 9, [3, 3, 3]),
                               (3, 3, 200, None)):
@@ -333,6 +339,68 @@ def test_decode_pipelines_cut_a_list_of_known_length_into_equal_passes():
             assert sizes == want, sizes
         for p in m.passes:  # consecutive batches, in order
             assert p == list(range(p[0], p[0] + len(p)))
+
+
+def test_decode_pipelines_merge_batches_of_different_frame_counts():
+    """pipeline.DecodePipelines: consecutive batches whose frame counts are close enough share ONE engine pass - the merged
+    input holds them one after the other, each padded with padding frames to the longest, and the call names every batch's
+    utterance and frame counts (cn_decode_nast_merged); a batch that is too short waits for the next pass; a pass never
+    exceeds the engines' workspace area."""
+    import torch as _torch
+
+    from cassnat_asr_public_amd.pipeline import DecodePipelines
+
+    class StubEngine:
+        def close(self):
+            pass
+
+    class StubModel:
+        def __init__(self):
+            self.calls = []
+
+        def new_engine(self, batch, frames, with_weights=True, share=None):
+            return StubEngine()
+
+        def decode_device(self, feats, ratio, args, sos, engine=None, sub_batch=0, sub_rows=None, sub_frames=None, u_hint=0,
+                          want_ticket=False):
+            self.calls.append((sub_rows, sub_frames, feats.clone(), ratio.clone()))
+            n = feats.shape[0]
+            ks = [int(feats[j, 0, 0]) for j in range(n)]
+            hyp = _torch.tensor([[sos, 10 + k, 0] for k in ks], dtype=_torch.int32)
+            return hyp, _torch.full((n,), 2, dtype=_torch.int32), _torch.tensor([float(k) for k in ks], dtype=_torch.float64), -1
+
+    class Args:
+        padding_idx = 0
+
+    # (utterances, frames) per batch; values = 100 * batch + utterance so that every row is recognisable
+    shapes = [(3, 40), (3, 36), (2, 33), (3, 20), (3, 19), (1, 40)]
+    items = []
+    for k, (nb, t) in enumerate(shapes):
+        f = _torch.stack([_torch.full((t, 2), float(100 * k + j + 1)) for j in range(nb)])
+        items.append((f, _torch.full((nb,), 1.0 - 0.01 * k), k))
+    m = StubModel()
+    pipes = DecodePipelines(m, 1, 3, 40, coalesce=4, ragged=0.8)
+    out = list(pipes.decode(items, Args(), sos=1, plan=[4, 4, 4]))
+    pipes.close()
+    assert [t for t, _, _ in out] == list(range(len(shapes)))
+    got = [(r, f) for r, f, _, _ in m.calls]
+    # 40 / 36 / 33 frames merge (33 >= 0.8 * 40); 20 does not (it waits and opens the next pass, with 19); the last one is alone
+    assert got == [([3, 3, 2], [40, 36, 33]), ([3, 3], [20, 19]), (None, None)], got
+    feats, ratio = m.calls[0][2], m.calls[0][3]
+    assert tuple(feats.shape) == (8, 40, 2)
+    assert _torch.all(feats[3:6, :36] != 0) and _torch.all(feats[3:6, 36:] == 0) and _torch.all(feats[6:8, 33:] == 0)
+    assert [int(feats[j, 0, 0]) for j in range(8)] == [1, 2, 3, 101, 102, 103, 201, 202]
+    assert _torch.allclose(ratio, _torch.tensor([1.0] * 3 + [0.99] * 3 + [0.98] * 2))
+    for k, hyps, _ in out:
+        assert hyps == [[1, 10 + 100 * k + j + 1] for j in range(shapes[k][0])]
+    # the area bound: a workspace of 3 x 40 frames (coalesce 1: no extra room) never takes 3 + 3 utterances of 36+ frames at once
+    m2 = StubModel()
+    p2 = DecodePipelines(m2, 1, 3, 40, coalesce=2, ragged=0.5, area_frames=3 * 40)
+    assert p2.fits(3, 40) and not p2.fits(6, 36) and p2.fits(6, 19)
+    list(p2.decode(items, Args(), sos=1))
+    p2.close()
+    assert all(r is None or sum(r) * max(f) <= 4 * 41 for r, f, _, _ in m2.calls)
+    assert any(r == [3, 3] and f == [20, 19] for r, f, _, _ in m2.calls)
 
 
 _WORKER_PIPES = r"""
@@ -350,11 +418,12 @@ class StubEngine:
 class StubModel:
     def new_engine(self, batch, frames, with_weights=True, share=None):
         return StubEngine()
-    def decode_device(self, feats, ratio, args, sos, engine=None, sub_batch=0):
+    def decode_device(self, feats, ratio, args, sos, engine=None, sub_batch=0, sub_rows=None, sub_frames=None, u_hint=0, want_ticket=False):
         ks = [int(feats[j, 0, 0]) for j in range(feats.shape[0])]
         time.sleep(0.001 * (1 + rank))  # the ranks' pipelines run at different speeds
         hyp = torch.tensor([[sos, 10 + k, 100 + rank] for k in ks], dtype=torch.int32)
-        return hyp, torch.full((len(ks),), 3, dtype=torch.int32), torch.tensor([float(k) + 0.25 * rank for k in ks], dtype=torch.float64)
+        out = (hyp, torch.full((len(ks),), 3, dtype=torch.int32), torch.tensor([float(k) + 0.25 * rank for k in ks], dtype=torch.float64))
+        return out + (-1,) if want_ticket else out
 
 # 23 steps of two utterances each; steps 9..11 have another shape (the gather groups break there)
 items = []

@@ -32,9 +32,15 @@ def run_cli(cli, result, world=1):
         procs = [subprocess.Popen(cmd + ["--hip_dist_backend", "gloo"],
                                   env=dict(env, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29733"),
                                   cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
-        for pr in procs:
-            text, _ = pr.communicate(timeout=900)
-            assert pr.returncode == 0, text[-4000:]
+        try:
+            for pr in procs:
+                text, _ = pr.communicate(timeout=900)
+                assert pr.returncode == 0, text[-4000:]
+        finally:  # never leave a rank blocked in a collective behind a failed peer
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+                    pr.wait()
     return open(result).read().splitlines(), time.perf_counter() - t0
 
 

@@ -55,30 +55,63 @@ def mfma_summary(sdir, out):
     print("mfma", json.dumps(rec["kernels"]))
 
 
+def by_grid(path, counter, needle):
+    """{Grid_Size (threads): [counter values]} of the kernels whose name contains `needle`."""
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and needle in r["Kernel_Name"]:
+                acc[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+    return acc
+
+
 def main():
+    """Traffic per launch, grouped by launch width (Grid_Size).  A kernel runs at several widths in one engine pass (the chain
+    kernel: 12 encoder launches at B x T' rows, 9 decoder-side ones at B x U) and, unless the profiled command is
+    `bench.py --exit-after-timed`, at the widths of the one-batch passes bench.py adds after its timed region: a mean over all
+    launches of a kernel mixes them (round 2's pmc_row_chain.json did: 194 MB where the 80,000-row launch moves 375).  Here:
+    `by_grid` = every width seen; `widest_launch` = the encoder-sized launch; `hbm_bytes_per_launch` = the mean over the launches
+    of the passes of the given width only (grids that occur in a ten-batch pass), i.e. per launch like bench.py's `achieved`."""
     fdir, wdir, out = sys.argv[1:4]
-    if len(sys.argv) > 4:
+    if len(sys.argv) > 4 and sys.argv[4] not in ("", "-"):
         mfma_summary(sys.argv[4], out)
-    fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
     c = int(sys.argv[5]) if len(sys.argv) > 5 else 10  # batches of 32 x 1000 frames per engine pass in the profiled runs
-    targets = {"row_chain": ("chain_kernel", f"chain_kernel (all 21 launches of an engine pass of {c} batches: 12 encoder at {8000 * c} rows, 9 decoder-side)"),
-               "conv2": ("conv2_kernel<false, false>", f"conv2_kernel<false, false> (LDS-DMA implicit GEMM, {c} batches of 32 x 1000 frames per launch)"),
-               "linear_out": ("conv2_kernel<true, false>", f"conv2_kernel<true, false> (linear_out on the LDS-DMA tile kernel, {8000 * c} x 5120 -> 256)")}
-    for tag, (needle, label) in targets.items():
-        fk = [v for k, vs in fetch.items() if needle in k for v in vs]
-        wk = [v for k, vs in write.items() if needle in k for v in vs]
-        if not fk or not wk:
+    rows_per_batch = int(sys.argv[6]) if len(sys.argv) > 6 else 8000
+    targets = {"row_chain": ("chain_kernel", 128, f"chain_kernel (21 launches per engine pass: 12 encoder launches at {rows_per_batch * c} rows, 9 decoder-side)"),
+               "conv2": ("conv2_kernel<false, false>", 256, f"conv2_kernel<false, false> (LDS-DMA implicit GEMM, {c} batches of 32 x 1000 frames per launch)"),
+               "linear_out": ("conv2_kernel<true, false>", 256, f"conv2_kernel<true, false> (linear_out on the LDS-DMA tile kernel, {rows_per_batch * c} x 5120 -> 256)")}
+    for tag, (needle, wg_rows, label) in targets.items():
+        fg, wg = by_grid(fdir, "FETCH_SIZE", needle), by_grid(wdir, "WRITE_SIZE", needle)
+        if not fg or not wg:
             print("no samples for", needle)
             continue
-        f_kb, w_kb = sum(fk) / len(fk), sum(wk) / len(wk)
+        grids = {}
+        for g in sorted(set(fg) & set(wg), reverse=True):
+            f_kb, w_kb = sum(fg[g]) / len(fg[g]), sum(wg[g]) / len(wg[g])
+            grids[g] = {"workgroups": g // 256, "launches_sampled": len(fg[g]), "FETCH_SIZE_KB": round(f_kb), "WRITE_SIZE_KB": round(w_kb),
+                        "hbm_bytes": round((2 * f_kb + w_kb) * 1024)}
+        widest = max(grids)
+        # launches that belong to a pass of `c` batches: the widest grid, and every grid that occurs as often per widest launch
+        # as a pass prescribes and is not also the widest grid of a one-batch pass (chain: 625 encoder / 63 one-batch encoder workgroups)
+        one_batch = {g for g in grids if c > 1 and abs(g // 256 - -(-(widest // 256 * wg_rows // c) // wg_rows)) <= 1}
+        wide = [g for g in grids if g not in one_batch and (c == 1 or g * c >= widest or g == widest)]
+        if tag == "row_chain" and c > 1:  # decoder-side launches of the wide pass: c times the rows of the one-batch pass's
+            small = sorted(g for g in grids if g not in one_batch and g != widest)
+            wide = [widest] + [g for g in small if any(abs(g - c * h) <= 256 * c for h in small if h < g) or len(small) == 1]
+        n = sum(grids[g]["launches_sampled"] for g in wide)
+        mean = sum(grids[g]["hbm_bytes"] * grids[g]["launches_sampled"] for g in wide) / max(1, n)
         rec = {"kernel": label,
-               "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps {2 * c} --warmup {c} --streams 1 --coalesce {c} (one pipeline, {c} batches of 32 per engine pass: launches as wide as the timed run's)",
-               "batches_per_engine_pass": c, "launches_sampled": len(fk), "FETCH_SIZE_KB_per_launch": round(f_kb), "WRITE_SIZE_KB_per_launch": round(w_kb),
+               "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, program directly after --), bench.py --streams 1 --coalesce {c} "
+                         f"(one pipeline, {c} batches of 32 per engine pass: launches as wide as the timed run's), grouped by Grid_Size",
+               "batches_per_engine_pass": c,
                "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request for wide (16 B/lane) coalesced reads: doubled "
-                             "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
-               "hbm_bytes_per_launch": round((2 * f_kb + w_kb) * 1024)}
+                             "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; both in KB of 1024 B",
+               "by_grid": {str(g): v for g, v in grids.items()},
+               "widest_launch": dict(grids[widest], grid=widest),
+               "grids_of_the_wide_pass": wide,
+               "hbm_bytes_per_launch": round(mean)}
         json.dump(rec, open(os.path.join(out, f"pmc_{tag}.json"), "w"), indent=2)
-        print(tag, rec)
+        print(tag, json.dumps({k: rec[k] for k in ("widest_launch", "grids_of_the_wide_pass", "hbm_bytes_per_launch")}))
 
 
 if __name__ == "__main__":
