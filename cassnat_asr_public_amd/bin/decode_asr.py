@@ -54,6 +54,8 @@ def main(argv=None):
     task = task_dict[args.task]("test", args)
     task.load_lm_model(args)
     task.decode(args)
+    if hasattr(task, "close"):
+        task.close()  # (decode pipelines: engine workspaces and worker threads)
     if world > 1:
         torch.distributed.destroy_process_group()
     return 0

@@ -286,6 +286,19 @@ __device__ __forceinline__ void ch_add_channel(f32x16 (&acc)[8], unsigned tab_la
                    [f5] "v"(Fc[5]), [f6] "v"(Fc[6]), [f7] "v"(Fc[7]), [pb] "v"(pbv), [ra] "v"(RA),             \
                    [m0w] "s"(m0_wave), [vo] "v"(voff), [sb] "s"(SB)                                            \
                  : "memory", "scc")
+// One MFMA per asm statement (single accumulator X in VGPRs), optionally with the two fragment reads that go into its gap: the
+// first-half block of a W1 position is written as eight of these with pieces of C++ (the previous hidden tile's ReLU + bf16 pack)
+// between them - sched_barrier(0) on both sides of every piece pins the instruction order, so the VALU work of tile t rides in the
+// MFMA gaps of tile t + 1 instead of sitting, with the matrix pipe idle, between the two products of tile t (320 cycles per 1024
+// of MFMA in round 2's stamps).
+#define CH_M1R(PRE, X, F, B, N0, N1, RA, K)                                                                    \
+    asm volatile(PRE CH_MF "%[c], %[f], %[b], %[c]\n\t" CH_RD2(n0, n1, K)                                      \
+                 : [c] "+v"(X), [n0] "=&v"(N0), [n1] "=&v"(N1)                                                 \
+                 : [f] "v"(F), [b] "v"(B), [ra] "v"(RA)                                                        \
+                 : "memory")
+#define CH_M1(X, F, B) asm volatile(CH_MF "%[c], %[f], %[b], %[c]" : [c] "+v"(X) : [f] "v"(F), [b] "v"(B) : "memory")
+#define CH_SB0 __builtin_amdgcn_sched_barrier(0)
+
 // Position k of a group: its second half lives in slot k (first-half blocks read it), the first half of the next unit
 // in slot k+1; while unit k is consumed, unit k+7 of the stream is requested into slot k-1 - i.e. unit 7 of THIS group
 // for k = 0 and unit k-1 of the NEXT group otherwise.  Slots 0-3 are addressed from ra0, 4-7 from ra1 = ra0 + 64 KiB.
@@ -426,58 +439,123 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     }
     CH_STAMP(3)
 
-    // ---- S3: feed-forward sublayer, four hidden tiles (W1 unit, W2 unit each) per group
+    // ---- S3: feed-forward sublayer.  Unit order (pack_chain): W1(0), then W1(t + 1), W2(t) for t = 0 .. n - 2, then W2(n - 1) -
+    // software-pipelined by one hidden tile: tile t's bias + ReLU + bf16 pack (VALU) is issued in the MFMA gaps of W1(t + 1), whose
+    // accumulator is the other one of two (xh0 / xh1), so W2(t) starts with its operand ready and no MFMA -> VALU drain.  In a
+    // group of 8 units the odd positions are W1 products (tiles 4 g + 1 .. 4 g + 4), the even ones W2 (tiles 4 g - 1 .. 4 g + 2);
+    // the first group opens with W1(0), the last one ends with W2(n - 1) in place of a W1.
     if (p.ffn_tiles) {
         ch_layernorm_pack(acc, tab_lane, CT_LN1A, CT_LN1B, p.eps, bop);
         ch_add_channel(acc, tab_lane, CT_B2);  // b2 once; the W2 products accumulate on top of x + b2
         CH_STAMP(4)
-        for (int g = 0; g < G_FFN; ++g, ++gpos) {
-            const uint4* sb_cur = group_base(gpos);
-            const uint4* sb_next = group_base(gpos + 1);
-            const unsigned tb = tab_lane + (unsigned)((CT_B1 + 128 * ffn_group(g)) * 4);  // b1 of the group's 128 hidden units
-            f32x16 xh;
-            f32x4 b1v[4];
-            bf16x8 pb[2];
-            ch_tab4_nowait(tb, b1v[0], b1v[1], b1v[2], b1v[3]);
-            // W1 unit at position K0: xh = W1 tile . xn ; then bias + ReLU + pack (next tile's bias read goes out first:
-            // it is older than every fragment read that follows, so the waits of the next blocks cover it)
-#define CH_W1(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB)                                                     \
-            /* the accumulation starts from the tile's bias (the 16 table values ARE the accumulator's initial value) */ \
-            xh = __builtin_shufflevector(__builtin_shufflevector(b1v[0], b1v[1], 0, 1, 2, 3, 4, 5, 6, 7),      \
-                                         __builtin_shufflevector(b1v[2], b1v[3], 0, 1, 2, 3, 4, 5, 6, 7),      \
-                                         0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);               \
-            CH_BLK1("+", "v", "%[c]", xh, Fa, bop, 0, Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN); \
-            CH_BLK1("+", "v", "%[c]", xh, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_BE(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, \
-                    CH_DMA3, SB, CH_DRAIN);                                                                    \
-            {                                                                                                 \
-                /* (ReLU as an integer max on the fp32 bits, before the pack: a packed int16 max after it measured slower) */ \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
-                    if constexpr (SWISH) {                                                                    \
-                        const float v_ = xh[r];                                                               \
-                        pb[r >> 3][r & 7] = (bf16)(v_ * (1.f / (1.f + __expf(-v_))));                          \
-                    } else {                                                                                  \
-                        const int bits = __float_as_int(xh[r]);                                               \
-                        pb[r >> 3][r & 7] = (bf16)__int_as_float(bits > 0 ? bits : 0);                        \
-                    }                                                                                         \
-                }                                                                                             \
-                ch_tab4_nowait(tb + ((k) / 2 + 1 < 4 ? ((k) / 2 + 1) * 128 : 0), b1v[0], b1v[1], b1v[2], b1v[3]); \
-            }
-            // W2 unit at position K1: acc[nt] += W2 tile (s, nt) . relu(xh)
-#define CH_W2(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB, POST)                                               \
-            CH_BLK2(acc, Fa, pb[0], Fb, RA_A, RK_A, CH_PRE_A4, "", "", "", "", SB, CH_NODRAIN);                 \
-            CH_BLK2(acc, Fb, pb[1], Fa, RA_B, RK_B, CH_PRE_BO(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, CH_DMA3, SB, POST);
-            CH_W1(0, ra0, 8, ra0, 16, 0x1C000, 0x1C000, sb_cur)
-            CH_W2(1, ra0, 24, ra0, 32, 0x0, 0x0, sb_next, CH_NODRAIN)
-            CH_W1(2, ra0, 40, ra0, 48, 0x4000, 0x4000, sb_next)
-            CH_W2(3, ra0, 56, ra1, 0, 0x8000, 0x8000, sb_next, CH_NODRAIN)
-            CH_W1(4, ra1, 8, ra1, 16, 0xC000, 0xC000, sb_next)
-            CH_W2(5, ra1, 24, ra1, 32, 0x10000, 0x10000, sb_next, CH_NODRAIN)
-            CH_W1(6, ra1, 40, ra1, 48, 0x14000, 0x14000, sb_next)
-            CH_W2(7, ra1, 56, ra0, 0, 0x18000, 0x18000, sb_next, CH_DRAIN)
-#undef CH_W1
-#undef CH_W2
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]) :: "memory");  // the wrap-around bias read (unused)
+        const int NTL = p.ffn_tiles;
+        f32x16 xh0, xh1;
+        f32x4 b1v[4];
+        bf16x8 pb[2];
+        auto tabb = [&](int t) -> unsigned { return tab_lane + (unsigned)((CT_B1 + 32 * (t < NTL ? t : NTL - 1)) * 4); };
+        ch_tab4_nowait(tabb(0), b1v[0], b1v[1], b1v[2], b1v[3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]) :: "memory");
+        // bias + activation + pack of values 2 i, 2 i + 1 of the finished tile XO (ReLU as an integer max on the fp32 bits)
+#define CH_ACT_PIECE(XO, i)                                                                                    \
+        {                                                                                                      \
+            if constexpr (SWISH) {                                                                             \
+                const float v0_ = XO[2 * (i)], v1_ = XO[2 * (i) + 1];                                          \
+                pb[(i) >> 2][2 * ((i) & 3)] = (bf16)(v0_ * (1.f / (1.f + __expf(-v0_))));                      \
+                pb[(i) >> 2][2 * ((i) & 3) + 1] = (bf16)(v1_ * (1.f / (1.f + __expf(-v1_))));                  \
+            } else {                                                                                           \
+                const int b0_ = __float_as_int(XO[2 * (i)]), b1_ = __float_as_int(XO[2 * (i) + 1]);            \
+                pb[(i) >> 2][2 * ((i) & 3)] = (bf16)__int_as_float(b0_ > 0 ? b0_ : 0);                         \
+                pb[(i) >> 2][2 * ((i) & 3) + 1] = (bf16)__int_as_float(b1_ > 0 ? b1_ : 0);                     \
+            }                                                                                                  \
+            asm volatile("" : "+v"(pb[(i) >> 2]));  /* the packed pair is produced HERE, not where W2 first reads it */ \
         }
+#define CH_ACT_GAP(HAS_OLD, XO, i)                                                                             \
+        CH_SB0;                                                                                                \
+        if constexpr (HAS_OLD) CH_ACT_PIECE(XO, i)                                                             \
+        CH_SB0;
+        // W1 position: XN = W1 tile . xn on top of the tile's bias (the 16 table values ARE the accumulator's initial value),
+        // the previous tile XO activated and packed into pb in the first block's gaps; then the next W1 tile's bias read goes
+        // out (younger than the fragment reads of the W2 block that follows, which waits with lgkmcnt(4))
+#define CH_W1N(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB, XN, XO, HAS_OLD, TNEXT)                             \
+        XN = __builtin_shufflevector(__builtin_shufflevector(b1v[0], b1v[1], 0, 1, 2, 3, 4, 5, 6, 7),          \
+                                     __builtin_shufflevector(b1v[2], b1v[3], 0, 1, 2, 3, 4, 5, 6, 7),          \
+                                     0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);                   \
+        CH_M1R(CH_PRE_A, XN, Fa[0], bop[0], Fb[0], Fb[1], RA_A, (RK_A) + 0);                                   \
+        CH_ACT_GAP(HAS_OLD, XO, 0)                                                                             \
+        CH_M1R("", XN, Fa[1], bop[1], Fb[2], Fb[3], RA_A, (RK_A) + 2);                                         \
+        CH_ACT_GAP(HAS_OLD, XO, 1)                                                                             \
+        CH_M1R("", XN, Fa[2], bop[2], Fb[4], Fb[5], RA_A, (RK_A) + 4);                                         \
+        CH_ACT_GAP(HAS_OLD, XO, 2)                                                                             \
+        CH_M1R("", XN, Fa[3], bop[3], Fb[6], Fb[7], RA_A, (RK_A) + 6);                                         \
+        CH_ACT_GAP(HAS_OLD, XO, 3)                                                                             \
+        CH_M1(XN, Fa[4], bop[4]);                                                                              \
+        CH_ACT_GAP(HAS_OLD, XO, 4)                                                                             \
+        CH_M1(XN, Fa[5], bop[5]);                                                                              \
+        CH_ACT_GAP(HAS_OLD, XO, 5)                                                                             \
+        CH_M1(XN, Fa[6], bop[6]);                                                                              \
+        CH_ACT_GAP(HAS_OLD, XO, 6)                                                                             \
+        CH_M1(XN, Fa[7], bop[7]);                                                                              \
+        CH_ACT_GAP(HAS_OLD, XO, 7)                                                                             \
+        CH_BLK1("+", "v", "%[c]", XN, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B_##k(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, \
+                CH_DMA3, SB, CH_NODRAIN);                                                                      \
+        ch_tab4_nowait(tabb(TNEXT), b1v[0], b1v[1], b1v[2], b1v[3]);
+        // W2 position: acc[nt] += W2 tile (s, nt) . act(xh); PREA = CH_PRE_A4 right after a W1 position (its bias read is younger
+        // than the eight fragment reads), CH_PRE_A otherwise
+#define CH_W2N(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB, PREA, POST)                                        \
+        CH_BLK2(acc, Fa, pb[0], Fb, RA_A, RK_A, PREA, "", "", "", "", SB, CH_NODRAIN);                         \
+        CH_BLK2(acc, Fb, pb[1], Fa, RA_B, RK_B, CH_PRE_B_##k(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, CH_DMA3, SB, POST);
+        // One group of 8 units.  FIRST / LAST are compile-time: the three forms are separate straight-line regions (a branch inside
+        // the loop body made hipcc shuffle all 128 accumulator registers at its join, every iteration)
+#define CH_FFN_GROUP(FIRST, LAST)                                                                              \
+        {                                                                                                      \
+            const uint4* sb_cur = group_base(gpos);                                                            \
+            const uint4* sb_next = group_base(gpos + 1);                                                       \
+            const int t0 = 4 * g;                                                                              \
+            if constexpr (FIRST) {                                                                             \
+                CH_W1N(0, ra0, 8, ra0, 16, 0x1C000, 0x1C000, sb_cur, xh0, xh1, false, 1)                       \
+                /* two W1 positions in a row: this bias read is consumed by the very next block - wait for it here; and the */ \
+                /* activation pieces of the next position read xh0 one MFMA after its last product was issued (everywhere   */ \
+                /* else a whole W2 position lies in between): the MFMA -> VALU wait states the compiler cannot see           */ \
+                asm volatile("s_nop 13\n\ts_nop 13\n\ts_waitcnt lgkmcnt(0)" : "+v"(xh0), "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]), "+v"(Fa[0]), \
+                             "+v"(Fa[1]), "+v"(Fa[2]), "+v"(Fa[3]), "+v"(Fa[4]), "+v"(Fa[5]), "+v"(Fa[6]), "+v"(Fa[7]) :: "memory"); \
+            } else {                                                                                           \
+                CH_W2N(0, ra0, 8, ra0, 16, 0x1C000, 0x1C000, sb_cur, CH_PRE_A4, CH_NODRAIN)                    \
+            }                                                                                                  \
+            CH_W1N(1, ra0, 24, ra0, 32, 0x0, 0x0, sb_next, xh1, xh0, true, t0 + 2)                             \
+            CH_W2N(2, ra0, 40, ra0, 48, 0x4000, 0x4000, sb_next, CH_PRE_A4, CH_NODRAIN)                        \
+            CH_W1N(3, ra0, 56, ra1, 0, 0x8000, 0x8000, sb_next, xh0, xh1, true, t0 + 3)                        \
+            CH_W2N(4, ra1, 8, ra1, 16, 0xC000, 0xC000, sb_next, CH_PRE_A4, CH_NODRAIN)                         \
+            CH_W1N(5, ra1, 24, ra1, 32, 0x10000, 0x10000, sb_next, xh1, xh0, true, t0 + 4)                     \
+            CH_W2N(6, ra1, 40, ra1, 48, 0x14000, 0x14000, sb_next, CH_PRE_A4, CH_NODRAIN)                      \
+            if constexpr (!(LAST)) {                                                                           \
+                CH_W1N(7, ra1, 56, ra0, 0, 0x18000, 0x18000, sb_next, xh0, xh1, true, t0 + 5)                  \
+            } else {                                                                                           \
+                /* the last hidden tile has no W1 product behind it to hide in: activation + pack on its own, then its W2.   */ \
+                /* (xh1 is re-defined HERE: without it the compiler is free to hoist this arithmetic above the W2 position  */ \
+                /* before it, right behind the MFMAs that produce xh1 - whose wait states it cannot see)                      */ \
+                asm volatile("" : "+v"(xh1));                                                                  \
+                CH_SB0;                                                                                        \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) CH_ACT_PIECE(xh1, i)                             \
+                CH_SB0;                                                                                        \
+                CH_W2N(7, ra1, 56, ra0, 0, 0x18000, 0x18000, sb_next, CH_PRE_A, CH_DRAIN)                      \
+            }                                                                                                  \
+            ++g;                                                                                               \
+            ++gpos;                                                                                            \
+        }
+        int g = 0;
+        if (G_FFN == 1) {
+            CH_FFN_GROUP(true, true)
+        } else {
+            CH_FFN_GROUP(true, false)
+            while (g < G_FFN - 1) CH_FFN_GROUP(false, false)
+            CH_FFN_GROUP(false, true)
+        }
+#undef CH_FFN_GROUP
+#undef CH_W1N
+#undef CH_W2N
+#undef CH_ACT_GAP
+#undef CH_ACT_PIECE
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]) :: "memory");  // the last (unused) bias read
     }
     CH_STAMP(5)
 
@@ -660,10 +738,14 @@ void pack_chain(const ChainWeights& w, uint16_t* stream, float* tab) {
     size_t u = 0;
     if (w.wo)
         for (int rt = 0; rt < 8; ++rt) ch_pack_rows(w.wo, CH_D, rt, false, stream + unit * u++);
-    for (int t = 0; t < w.dff / 32; ++t) {
-        ch_pack_rows(w.w1, CH_D, t, true, stream + unit * u++);
+    // software-pipelined by one hidden tile (chain_kernel, S3): W1(0), then W1(t + 1), W2(t) for t = 0 .. n - 2, then W2(n - 1)
+    const int nt_ffn = w.dff / 32;
+    if (nt_ffn > 0) ch_pack_rows(w.w1, CH_D, 0, true, stream + unit * u++);
+    for (int t = 0; t + 1 < nt_ffn; ++t) {
+        ch_pack_rows(w.w1, CH_D, t + 1, true, stream + unit * u++);
         ch_pack_w2(w.w2, w.dff, t, stream + unit * u++);
     }
+    if (nt_ffn > 0) ch_pack_w2(w.w2, w.dff, nt_ffn - 1, stream + unit * u++);
     for (int jt = 0; jt < w.tail_n / 32; ++jt) ch_pack_rows(w.wt, CH_D, jt, true, stream + unit * u++);
     memset(tab, 0, sizeof(float) * CH_TAB_FLOATS);
     auto put = [&](int off, const float* src, int n) {

@@ -9,7 +9,8 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcassnat_hip.so")
+# (CASSNAT_HIP_LIB: another build of the same library - A/B measurements of kernel variants, tools/scripts/ab_bench.sh)
+LIB_PATH = os.environ.get("CASSNAT_HIP_LIB") or os.path.join(_HERE, "libcassnat_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cassnat_hip.h")
 
 PRECISION = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp8": 2, "bf16x3": 3}

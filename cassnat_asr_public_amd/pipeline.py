@@ -160,7 +160,7 @@ class DecodePipelines:
         if r is None:
             return 0
         tp = subsampled(T)
-        return min(tp + 1, int(math.ceil(r * 1.15 * (tp + 1))) + 4)
+        return min(tp + 1, int(math.ceil(r * 1.3 * (tp + 1))) + 8)  # (a generous margin: extra decoder rows cost ~0.1 % each, a miss a whole pass)
 
     def _learn(self, ymax, T):
         with self._rows_lock:

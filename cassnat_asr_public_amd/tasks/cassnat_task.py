@@ -176,9 +176,16 @@ class CassNATTask(BaseTask):
         max_frames = max(getattr(args, "hip_max_frames", 4096), first[1].shape[1])
         # consecutive batches share an engine pass while they fit the workspace area (hip_coalesce batches of batch_size x 1024
         # frames) and their frame counts are within hip_ragged of each other; passes are filled by area, not by a batch count
-        pipes = DecodePipelines(self.model, n_pipes, args.batch_size, max_frames, with_weights=(self.rank == 0),
-                                after_engine=(lambda e: cdist.broadcast_weights(e, src=0)) if self.world > 1 else None,
-                                coalesce=-max(1, int(getattr(args, "hip_coalesce", 10))), ragged=float(getattr(args, "hip_ragged", 0.75)))
+        key = (n_pipes, args.batch_size, max_frames, int(getattr(args, "hip_coalesce", 10)), float(getattr(args, "hip_ragged", 0.75)))
+        pipes = getattr(self, "_pipes", None)
+        if pipes is None or self._pipes_key != key:  # (kept for further decode() calls on this task: engines, threads, streams)
+            if pipes is not None:
+                pipes.close()
+            pipes = DecodePipelines(self.model, n_pipes, args.batch_size, max_frames, with_weights=(self.rank == 0),
+                                    after_engine=(lambda e: cdist.broadcast_weights(e, src=0)) if self.world > 1 else None,
+                                    coalesce=-max(1, key[3]), ragged=key[4])
+            self._pipes, self._pipes_key = pipes, key
+        stats0 = dict(pipes.stats)
         meta, frames, i, end = {}, 0, -1, time.time()
 
         def batches():
@@ -195,9 +202,21 @@ class CassNATTask(BaseTask):
             end = time.time()
             if i % args.print_freq == 0 and self.rank == 0:
                 progress.print(i)
-        self.pipeline_stats = dict(pipes.stats)
-        pipes.close()
+        self.pipeline_stats = {k: pipes.stats[k] - stats0[k] for k in stats0}
         return frames, i
+
+    def close(self):
+        """Release the decode pipelines (engine workspaces, worker threads) a pipelined decode() left in place."""
+        pipes = getattr(self, "_pipes", None)
+        if pipes is not None:
+            pipes.close()
+            self._pipes = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def decode(self, args):
         batch_time = util.AverageMeter("Time", ":6.3f")
