@@ -36,6 +36,8 @@ struct AttnParams {
     int stamps;  // investigation aid (CASSNAT_ATTN_STAMPS): the last workgroup's thread 0 records s_memtime at its phase boundaries
     const int* kv_index;  // non-null: ... at entry kv_index[b] (beam search: every hypothesis row names its utterance)
     const int* klen;
+    int q_blk, kv_blk;  // bf16: Q / K|V are blocked matrices (cn_blk16_off) of q_n / kv_n columns, head 0 at column q_col / k_col / v_col
+    int q_col, k_col, v_col, q_n, kv_n;
     const int* kcap;  // keys the K / V entry's own batch has (merged passes; null: Lk) - later keys get -inf, not the float-min fill
     int kcap_stride;
     const int* iv;
@@ -117,6 +119,10 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                 qf[s].hi = as_frag<bf16>(ld16(c));
                 qf[s].lo = as_frag<bf16>(ld16(c + 64));
             }
+        } else if (p.q_blk) {
+            const long long qm = (long long)b * p.Lq + qc;
+#pragma unroll
+            for (int s = 0; s < NF; ++s) qf[s] = as_frag<T>(ld16(p.Q + cn_blk16_off(qm, p.q_col + h * 64 + (2 * s + half) * 8, p.q_n)));
         } else {
 #pragma unroll
             for (int s = 0; s < NF; ++s) qf[s] = as_frag<T>(ld16(qp + (2 * s + half) * 16));
@@ -179,8 +185,14 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
             const int row = cidx / CPR, ch = cidx % CPR;
             const int key = kt * 64 + row;
             if (key < p.Lk) {
-                k_reg[i] = ld16(kbase + (long long)key * p.ldk_b + ch * 16);
-                v_reg[i] = ld16(vbase + (long long)key * p.ldv_b + ch * 16);
+                if (p.kv_blk) {
+                    const long long km = (long long)bk * p.Lk + key;
+                    k_reg[i] = ld16(p.K + cn_blk16_off(km, p.k_col + h * 64 + ch * 8, p.kv_n));
+                    v_reg[i] = ld16(p.V + cn_blk16_off(km, p.v_col + h * 64 + ch * 8, p.kv_n));
+                } else {
+                    k_reg[i] = ld16(kbase + (long long)key * p.ldk_b + ch * 16);
+                    v_reg[i] = ld16(vbase + (long long)key * p.ldv_b + ch * 16);
+                }
             } else {
                 k_reg[i] = make_uint4(0, 0, 0, 0);
                 v_reg[i] = make_uint4(0, 0, 0, 0);
@@ -227,9 +239,12 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
             const int row = 8 * j + r8;
             int key = kt2 * 64 + row;
             if (key >= p.Lk) key = p.Lk - 1;  // finite filler; its probability is exactly 0 (mask code 2)
-            const unsigned char* src =
-                is_v ? vbase + (long long)key * p.ldv_b + ((cp ^ (((row >> 1) & 1) << 2)) << 4)
-                     : kbase + (long long)key * p.ldk_b + ((cp ^ Cfg::swz(row)) << 4);
+            const int chunk = is_v ? (cp ^ (((row >> 1) & 1) << 2)) : (cp ^ Cfg::swz(row));
+            const unsigned char* src;
+            if (p.kv_blk)
+                src = (is_v ? p.V : p.K) + cn_blk16_off((long long)bk * p.Lk + key, (is_v ? p.v_col : p.k_col) + h * 64 + chunk * 8, p.kv_n);
+            else
+                src = is_v ? vbase + (long long)key * p.ldv_b + (chunk << 4) : kbase + (long long)key * p.ldk_b + (chunk << 4);
             unsigned char* dst = (is_v ? Vs_all + kt2 * VT_BYTES : Ks_all + kt2 * KT_BYTES) + j * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -518,6 +533,18 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     p.klen = a.klen;
     p.kcap = a.kcap;
     p.kcap_stride = a.kcap_stride;
+    p.q_blk = a.q_blocked;
+    p.kv_blk = a.kv_blocked;
+    p.q_col = a.q_col;
+    p.k_col = a.k_col;
+    p.v_col = a.v_col;
+    p.q_n = a.q_n;
+    p.kv_n = a.kv_n;
+    if ((a.q_blocked || a.kv_blocked) && (sizeof(T) != 2 || __is_same(T, split_t) || a.rel_pos || (a.q_blocked && a.q_n % 32) ||
+                                          (a.kv_blocked && a.kv_n % 32))) {
+        cn_set_error("attention: blocked operands exist for the bf16 kernels without relative positions; column counts % 32 == 0");
+        return -1;
+    }
     p.iv = a.intervals;
     p.iv_stride = a.iv_stride;
     p.causal = a.causal;

@@ -67,6 +67,7 @@ struct ChainParams {
     float eps;
     int stamps;
     int x_in_blk, x_out_blk, store_x;
+    int out_blk;  // tail projection in the blocked layout (cn_blk16_off): every store instruction writes 1 KiB contiguous
 };
 
 #define CH_STR2(x) #x
@@ -598,6 +599,8 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
             const uint4* sb_next = group_base(gpos + 1);
             const unsigned tb = tab_lane + (unsigned)((CT_BT + 256 * g) * 4);
             bf16* op16 = p.out + (long long)m * p.ldo + 256 * g + 8 * half;  // after the half-wave exchange (below)
+            // blocked: tile (row block rb, column tile 8 g + k) is 2 KiB = [16-column half gp][lane][16 B]
+            unsigned char* ob16 = reinterpret_cast<unsigned char*>(p.out) + ((long long)rb * (p.ldo >> 5) + 8 * g) * 2048 + lane * 16;
             f32x16 q;
             f32x4 btv[4];
             ch_tab4_nowait(tb, btv[0], btv[1], btv[2], btv[3]);
@@ -627,7 +630,12 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
                     const auto s1_ = __builtin_amdgcn_permlane32_swap(lo_.y, hi_.y, false, false);            \
                     w_[gp] = u32x4{s0_[0], s1_[0], s0_[1], s1_[1]};                                           \
                 }                                                                                             \
-                if (live && p.stamps != 2) {                                                                  \
+                if (p.out_blk) {                                                                              \
+                    if (rb < nrb && p.stamps != 2) {  /* whole tiles: rows past M land in the buffer's padding */ \
+                        _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                      \
+                            CH_TAIL_STORE(w_[gp], reinterpret_cast<u32x4*>(ob16 + (k) * 2048 + gp * 1024));   \
+                    } else if (p.stamps == 2) { asm volatile("" :: "v"(w_[0]), "v"(w_[1])); }                 \
+                } else if (live && p.stamps != 2) {                                                           \
                     _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                          \
                         CH_TAIL_STORE(w_[gp], reinterpret_cast<u32x4*>(op16 + 32 * (k) + 16 * gp));           \
                 } else if (p.stamps == 2) { asm volatile("" :: "v"(w_[0]), "v"(w_[1])); }                     \
@@ -685,6 +693,11 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
     p.x_in_blk = a.x_in_blocked;
     p.x_out_blk = a.x_out_blocked;
     p.store_x = a.store_x && (a.ctx || a.dff);
+    p.out_blk = a.out_blocked && a.tail_n > 0;
+    if (p.out_blk && a.ldo % 32 != 0) {
+        cn_set_error("chain: a blocked tail output needs ldo % 32 == 0");
+        return -1;
+    }
     static CnAttrOnce attr_once;
     int attr_dev;
     if (attr_once.need(&attr_dev)) {

@@ -26,6 +26,14 @@ struct split_t {
 // byte offset of element c's hi half inside its row (the lo half sits 64 bytes further)
 __host__ __device__ static inline size_t cn_split_off(size_t c) { return (c >> 5) * 128 + (c & 31) * 2; }
 
+// Blocked bf16 matrix [M][N] (N % 32 == 0, the buffer holds ceil(M / 32) * 32 rows): 32-row x 32-column tiles of 2 KiB, each
+// [16-column half gp][lane = 32 * h + (row & 31)][8 bf16] with h = bit 3 of the column - the order in which the row-chain kernel's
+// lanes hold a projection tile after the half-wave exchange (chain.hip, S5), so that each of its store instructions writes 1 KiB
+// contiguous instead of thirty-two 32-byte row segments.  Byte offset of the 16-byte chunk that starts at column c (c % 8 == 0):
+__host__ __device__ static inline long long cn_blk16_off(long long m, int c, int N) {
+    return ((((m >> 5) * (long long)(N >> 5) + (c >> 5)) << 1) + ((c >> 4) & 1)) * 1024 + ((((c >> 3) & 1) << 5) + (int)(m & 31)) * 16;
+}
+
 #define CN_WAVE 64
 #define CN_NEG_FILL (-3.4028234663852886e38f) /* float32 min: the reference's masked_fill value */
 

@@ -111,6 +111,11 @@ struct AttnArgs {
     // row whose keys are all masked attends uniformly over the keys its own batch has, attention.py:19-21).  Null: Lk keys
     const int* kcap = nullptr;
     int kcap_stride = 1;
+    // bf16 only: Q (q_blocked) / K and V (kv_blocked) live in a blocked matrix (common.h: cn_blk16_off) of q_n / kv_n columns -
+    // what the row-chain kernel's tail writes; Q / K / V then point at the matrix itself and q_col / k_col / v_col give the
+    // first column of head 0 (ldq / ldk / ldv are unused for a blocked operand)
+    int q_blocked = 0, kv_blocked = 0;
+    int q_col = 0, k_col = 0, v_col = 0, q_n = 0, kv_n = 0;
     const int* intervals = nullptr;          // [B][iv_stride][4] (s1,e1,s2,e2) per query row, or null
     int iv_stride = 0;
     int causal = 0;  // key j allowed only if j <= i
@@ -274,6 +279,7 @@ struct ChainArgs {
     // (row % 32) + 32 half holds channels 32 nt + 8 g + 4 half + (0..3) - each load/store instruction moves 1 KiB contiguous
     // (buffer must hold ceil(M / 32) * 32 rows).  store_x = 0: x is not written back (nothing reads it afterwards)
     int x_in_blocked = 0, x_out_blocked = 0, store_x = 1;
+    int out_blocked = 0;  // the tail projection `out` is written as a blocked bf16 matrix of ldo columns (common.h: cn_blk16_off)
     int swish = 0;  // feed-forward activation: x * sigmoid(x) instead of ReLU (conformer)
     float eps = 1e-6f;
 };

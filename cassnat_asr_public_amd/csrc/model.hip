@@ -182,6 +182,7 @@ struct cn_model {
     void* kv_all = nullptr;   // [M][kv_cols] bf16: cross-attention K|V of every decoder-side layer, projected by the last encoder
     int kv_cols = 0;          // chain launch's tail (0: each layer projects its own into kvm)
     bool kv_ready = false;    // ... and that launch ran for the current batch
+    bool kv_blocked = false;  // ... writing the blocked layout (common.h: cn_blk16_off)
     long long call_id = 0;  // counts encoder passes: a captured tensor is only served for the call that wrote it
     int c1_halo_B = -1, c1_halo_T1 = -1;  // shape of the haloed conv1 image the buffer currently holds (-1: none)
     bool ctc_maxlp_valid = false;  // the fused arg-max-only CTC generator does not produce it
@@ -1122,13 +1123,13 @@ void ws_needs(const cn_model* m, const WsDims& v, WsList& out) {
     }
     out.push_back({"x", (M + 32) * d * 4});  // + one 32-row block: the chain kernel's blocked layout rounds up
     out.push_back({"xn", M * d * es});
-    out.push_back({"qkv", M * 3 * d * es});
+    out.push_back({"qkv", (M + 32) * 3 * d * es});  // (+ 32 rows: the chain kernel writes whole 32-row blocks of its blocked output)
     out.push_back({"ctx", M * d * es});
     out.push_back({"hbuf", M * dff * es});
     out.push_back({"enc_h", M0 * d * es});
     out.push_back({"kvm", M0 * 2 * d * es});
-    if (m->kv_cols > 0) out.push_back({"kv_all", M0 * (size_t)m->kv_cols * es});
-    out.push_back({"qd", M * d * es});
+    if (m->kv_cols > 0) out.push_back({"kv_all", (M0 + 32) * (size_t)m->kv_cols * es});
+    out.push_back({"qd", (M + 32) * d * es});
     out.push_back({"dec_h", M * d * es});
     out.push_back({"xd", (M + 32) * d * 4});
     out.push_back({"xd2", (M + 32) * d * 4});
@@ -1348,13 +1349,21 @@ int run_ffn(cn_model* m, const Layer& L, const Norm& n, float* x, int M, const N
 
 // ctx <- Attn(q, k, v) on the fused [M][3d] projection buffer m->qkv
 int run_self_attn_core(cn_model* m, int B, int Lseq, const unsigned char* keymask, const int* klen, int causal,
-                       hipStream_t s) {
+                       hipStream_t s, bool blocked = false) {
     const int d = m->cfg.d_model, M = B * Lseq;
     AttnArgs a;
     const size_t es = m->es;
     a.Q = m->qkv;
     a.K = (const unsigned char*)m->qkv + (size_t)d * es;
     a.V = (const unsigned char*)m->qkv + (size_t)2 * d * es;
+    if (blocked) {  // m->qkv as the row-chain kernel's tail wrote it: a blocked [M][3d] matrix
+        a.K = a.V = m->qkv;
+        a.q_blocked = a.kv_blocked = 1;
+        a.q_col = 0;
+        a.k_col = d;
+        a.v_col = 2 * d;
+        a.q_n = a.kv_n = 3 * d;
+    }
     a.O = m->ctx;
     a.ldq = a.ldk = a.ldv = 3 * d;
     a.ldo = d;
@@ -1390,7 +1399,7 @@ int run_self_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B,
 // x_mode: CHX_* bits - the fp32 stream is read / written row-major or in the kernel's blocked tile layout, or not written
 enum { CHX_IN_BLK = 1, CHX_OUT_BLK = 2, CHX_NO_STORE = 4 };
 int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ldo, bool with_next, int x_mode,
-              hipStream_t s, void* ln_out = nullptr, int ld_ln = 0) {
+              hipStream_t s, void* ln_out = nullptr, int ld_ln = 0, bool out_blocked = false) {
     const int d = m->cfg.d_model;
     const int tail_n = with_next ? r.tail_n : 0;
     const double macs = (r.has_wo ? (double)d * d : 0.0) + 2.0 * d * r.dff + (double)d * tail_n;
@@ -1414,6 +1423,7 @@ int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ld
     a.x_out_blocked = (x_mode & CHX_OUT_BLK) != 0;
     a.store_x = (x_mode & CHX_NO_STORE) == 0;
     a.swish = r.swish ? 1 : 0;
+    a.out_blocked = out_blocked ? 1 : 0;
     return launch_chain(a, s);
 }
 
@@ -1562,7 +1572,7 @@ int run_conformer_self_layer(cn_model* m, const Layer& L, float* x, int B, int L
 
 int run_src_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B, int U, int Tp, const int* intervals,
                  hipStream_t s);
-int run_src_attn_core(cn_model* m, const Layer& L, int B, int U, int Tp, const int* intervals, hipStream_t s);
+int run_src_attn_core(cn_model* m, const Layer& L, int B, int U, int Tp, const int* intervals, hipStream_t s, bool q_blocked = false);
 
 // A conformer layer on the row-chain kernel (chains packed by conf_layer_chains in build_weights): A -> relative-position
 // attention -> B -> GLU / depthwise conv / GroupNorm + Swish -> C [-> source attention -> D for a mixed-attention layer].
@@ -1590,21 +1600,33 @@ int run_conformer_layer_chain(cn_model* m, const Layer& L, float* x, int B, int 
 }
 
 // ctx <- Attn(m->qd, enc_h Wk, enc_h Wv) with the padding mask and (optionally) trigger intervals
-int run_src_attn_core(cn_model* m, const Layer& L, int B, int U, int Tp, const int* intervals, hipStream_t s) {
+int run_src_attn_core(cn_model* m, const Layer& L, int B, int U, int Tp, const int* intervals, hipStream_t s, bool q_blocked) {
     const int d = m->cfg.d_model;
     // (B counts query sets: dec_group of them share the keys / values of one utterance)
     AttnArgs a;
     if (m->kv_ready && L.kv_slot >= 0) {  // projected by the last encoder chain launch
         a.K = (const unsigned char*)m->kv_all + (size_t)L.kv_slot * 2 * d * m->es;
         a.ldk = a.ldv = m->kv_cols;
+        if (m->kv_blocked) {  // ... into a blocked [M][kv_cols] matrix
+            a.K = m->kv_all;
+            a.kv_blocked = 1;
+            a.k_col = L.kv_slot * 2 * d;
+            a.v_col = a.k_col + d;
+            a.kv_n = m->kv_cols;
+        }
     } else {
         CN_TRY(run_linear(m, "src_kv_proj", L.src_kv, m->enc_h, d, m->kvm, 2 * d, 0, m->B * Tp, 0, nullptr, 0, s));
         a.K = m->kvm;
         a.ldk = a.ldv = 2 * d;
     }
-    a.V = (const unsigned char*)a.K + (size_t)d * m->es;
+    a.V = a.kv_blocked ? a.K : (const unsigned char*)a.K + (size_t)d * m->es;
     a.kv_mod = m->dec_group > 1 ? m->B : 0;
     a.Q = m->qd;
+    if (q_blocked) {
+        a.q_blocked = 1;
+        a.q_col = 0;
+        a.q_n = d;
+    }
     a.O = m->ctx;
     a.ldq = d;
     a.ldo = d;
@@ -1843,10 +1865,14 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     }
     static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
     const bool chain = !m->enc.empty() && m->enc_chain.size() == m->enc.size() && !no_chain;
+    // the projections a chain launch writes for the attention kernel (Q|K|V, and the decoder side's K|V) go out in the blocked
+    // layout: 1-KiB store instructions instead of thirty-two 32-byte row segments (the tail phase was store-bound)
+    static const bool blk = getenv("CASSNAT_NO_BLOCKED_QKV") == nullptr;
+    m->kv_blocked = false;
     if (chain) {  // bf16 / d_model 256: LN + QKV of layer 0 (an entry chain launch: no FFN, x left alone), then per layer
                   // attention -> row-chain kernel
         if (m->enc_entry.w) {
-            CN_TRY(run_chain(m, m->enc_entry, m->x, M, m->qkv, 3 * d, true, CHX_NO_STORE, s));
+            CN_TRY(run_chain(m, m->enc_entry, m->x, M, m->qkv, 3 * d, true, CHX_NO_STORE, s, nullptr, 0, blk));
         } else {
             CN_TRY(run_ln(m, m->enc[0].n[0], m->x, m->xn, M, s));
             CN_TRY(run_linear(m, "qkv_proj", m->enc[0].qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
@@ -1856,15 +1882,17 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         const Layer& L = m->enc[n];
         const bool last = n + 1 == m->enc.size();
         if (chain) {
-            CN_TRY(run_self_attn_core(m, B, Tp, m->keymask, nullptr, 0, s));
+            CN_TRY(run_self_attn_core(m, B, Tp, m->keymask, nullptr, 0, s, (n > 0 || m->enc_entry.w) && blk));
             // between chain launches the residual stream lives in the kernel's blocked layout; the last layer's x is
             // consumed by nobody (enc_h is the output).  Captures read x row-major.
             const int xm = cap ? 0 : ((n > 0 ? CHX_IN_BLK : 0) | (last ? CHX_NO_STORE : CHX_OUT_BLK));
             if (last && m->kv_cols > 0) {  // enc_h and, from the same registers, every decoder-side layer's K|V
-                CN_TRY(run_chain(m, m->enc_chain[n], m->x, M, m->kv_all, m->kv_cols, true, xm, s, m->enc_h, d));
+                CN_TRY(run_chain(m, m->enc_chain[n], m->x, M, m->kv_all, m->kv_cols, true, xm, s, m->enc_h, d, blk));
                 m->kv_ready = true;
+                m->kv_blocked = blk;
             } else {
-                CN_TRY(run_chain(m, m->enc_chain[n], m->x, M, last ? m->enc_h : m->qkv, last ? d : 3 * d, true, xm, s));
+                CN_TRY(run_chain(m, m->enc_chain[n], m->x, M, last ? m->enc_h : m->qkv, last ? d : 3 * d, true, xm, s, nullptr, 0,
+                                 blk && !last));
             }
         } else {
             CN_TRY(run_self_attn(m, L, n == 0 ? &L.n[0] : nullptr, m->x, B, Tp, m->keymask, nullptr, 0, s));
@@ -1992,17 +2020,18 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
                     xdec = m->xd2;
                 }
             }
+            static const bool blkd = getenv("CASSNAT_NO_BLOCKED_QKV") == nullptr;
             if (k == 0 || (first_mad && uni)) {
                 void* out;
                 int ldo;
                 proj_out(st, out, ldo);
-                CN_TRY(run_chain(m, st.entry, xdec, MU, out, ldo, true, CHX_NO_STORE, s));  // reads row-major x, writes none
+                CN_TRY(run_chain(m, st.entry, xdec, MU, out, ldo, true, CHX_NO_STORE, s, nullptr, 0, blkd));  // reads row-major x, writes none
             }
             if (st.self)
-                CN_TRY(run_self_attn_core(m, B, U, nullptr, m->ylen, (st.stack == 2 && uni) ? 1 : 0, s));
+                CN_TRY(run_self_attn_core(m, B, U, nullptr, m->ylen, (st.stack == 2 && uni) ? 1 : 0, s, blkd));
             else
                 CN_TRY(run_src_attn_core(m, L, B, U, Tp,
-                                         st.stack == 0 ? m->intervals : (o->src_trigger ? m->intervals : nullptr), s));
+                                         st.stack == 0 ? m->intervals : (o->src_trigger ? m->intervals : nullptr), s, blkd));
             const bool final = k + 1 == n;
             // use_unimask shifts the stream between the last SAD layer and the first MAD layer: nothing carries over
             const bool carry = final || !(uni && m->dec_steps[k + 1].stack == 2 && m->dec_steps[k + 1].layer == 0 &&
@@ -2015,7 +2044,7 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
             const bool in_rm = k == 0 || (first_mad && uni);
             const bool out_rm = !final && !carry;
             const int xm = cap ? 0 : ((in_rm ? 0 : CHX_IN_BLK) | (final ? CHX_NO_STORE : (out_rm ? 0 : CHX_OUT_BLK)));
-            CN_TRY(run_chain(m, st.chain, xdec, MU, out, ldo, carry, xm, s));
+            CN_TRY(run_chain(m, st.chain, xdec, MU, out, ldo, carry, xm, s, nullptr, 0, blkd && !final));
             if (cap && st.stack == 0 && (k + 1 == n || m->dec_steps[k + 1].stack != 0))
                 CN_TRY(capture(m, "ac_embed", m->xd, false, CN_DTYPE_F32, {B, U, d}, s));
         }
@@ -3314,6 +3343,7 @@ extern "C" int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, con
     a.x_out_blocked = (x_mode & 2) != 0;
     a.store_x = (x_mode & 4) == 0;
     a.swish = (x_mode & 8) != 0;
+    a.out_blocked = (x_mode & 16) != 0;
     int rc = launch_chain(a, (hipStream_t)stream);
     if (const char* rep = getenv("CASSNAT_CHAIN_REPEAT")) {  // timing runs only: x keeps being updated
         // CASSNAT_CHAIN_STREAMS = n: the repeats go round-robin onto n private streams (how do concurrent launches share

@@ -230,7 +230,9 @@ int cn_profile_end(cn_model* m, char* json_out, int64_t cap);
  * (src/models/modules/attention.py:44-66, utils.py:23-32, positionff.py:15-16, norm.py:15-18).  Weights are host fp32
  * in nn.Linear layout and are packed on every call: a test entry point, the model keeps its packed copies.
  * x_mode bits: 1 = x_dev is read in the kernel's blocked layout, 2 = written in it, 4 = not written back, 8 = the feed-forward
- * activation is Swish (x * sigmoid(x), the conformer's macaron halves) instead of ReLU.  Blocked: 32-row
+ * activation is Swish (x * sigmoid(x), the conformer's macaron halves) instead of ReLU, 16 = the tail projection out_dev is
+ * written as a blocked bf16 matrix of ldo columns (ceil(M / 32) * 32 rows; 32 x 32 tiles of 2 KiB, each [16-column half][lane =
+ * 32 * (bit 3 of the column) + row % 32][8 bf16]: what the attention kernel reads as `blocked` Q / K / V).  Blocked x: 32-row
  * blocks of [32 pieces i][64 lanes][4 floats], lane = row % 32 + 32 h holding channels 32 (i / 4) + 8 (i % 4) + 4 h + (0..3);
  * the buffer then holds ceil(M / 32) * 32 rows. */
 int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, const float* wo_host, const float* bo_host,

@@ -505,7 +505,7 @@ def test_merged_pass_of_different_frame_counts_equals_separate_passes(prec):
         pipes._rows["ratio"] = 0.01
         pipes._learn = lambda ymax, T: None  # (keep the predictor wrong for the whole list)
         got = list(pipes.decode(items, args, sos=1))
-        assert pipes.stats["missed"] >= 3, pipes.stats
+        assert pipes.stats["missed"] >= 1, pipes.stats
     for (tag, hyps, scores), (wh, ws) in zip(got, want):
         assert hyps == wh and list(scores) == ws, tag
 

@@ -556,7 +556,14 @@ def _from_blocked(xb, M):
     return xb.view(nrb, 8, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(nrb * 32, 256)[:M].contiguous()
 
 
-@pytest.mark.parametrize("x_mode", [0, 3, 1, 2, 8, 11])  # (bit 8: Swish feed-forward)
+def _from_blocked16(buf, M, N):
+    """The chain kernel's blocked bf16 matrix (include/cassnat_hip.h, cn_op_chain, x_mode bit 16) -> row-major [M][N]."""
+    nrb = (M + 31) // 32
+    t = buf.view(nrb, N // 32, 2, 2, 32, 8)  # [row block][column tile][16-column half][bit 3 of the column][row][8]
+    return t.permute(0, 4, 1, 2, 3, 5).reshape(nrb * 32, N)[:M]
+
+
+@pytest.mark.parametrize("x_mode", [0, 3, 1, 2, 8, 11, 16, 19])  # (bit 8: Swish feed-forward; bit 16: blocked tail output)
 @pytest.mark.parametrize("M,dff,tail_n,with_ctx,with_next", [
     (8000, 2048, 768, True, True),    # encoder layer at config 2: out-proj + FFN + next layer's QKV
     (8000, 2048, 0, True, True),      # last encoder layer: the stack's final LayerNorm is the output
@@ -595,7 +602,8 @@ def test_chain_bf16(M, dff, tail_n, with_ctx, with_next, x_mode):
         xd = torch.cat([xd, torch.zeros(32, d, device="cuda")])
     ctxd = dev(ctx, torch.bfloat16) if with_ctx else None
     ldo = tail_n if tail_n else d
-    out = torch.full((M, ldo), float("nan"), dtype=torch.bfloat16, device="cuda") if with_next else None
+    rows_out = (M + 31) // 32 * 32 if x_mode & 16 else M
+    out = torch.full((rows_out, ldo), float("nan"), dtype=torch.bfloat16, device="cuda") if with_next else None
     hip.check(hip.lib().cn_op_chain(p(xd), p(ctxd) if with_ctx else None, d, _hp(wo), _hp(bo), _hp(a1), _hp(b1n), _hp(w1),
                                     _hp(b1), _hp(w2), _hp(b2), _hp(na) if with_next else None, _hp(nb) if with_next else None,
                                     _hp(wt), _hp(bt), p(out) if with_next else None, ldo, M, dff, tail_n, 1e-6, x_mode, stream()))
@@ -605,9 +613,11 @@ def test_chain_bf16(M, dff, tail_n, with_ctx, with_next, x_mode):
     xo = _from_blocked(xo.view(nrb, 32, 64, 4), M) if x_mode & 2 else xo.view(-1, d)[:M]
     if not with_ctx and not dff:
         xo = x  # nothing to store: the kernel leaves x alone (in whatever layout it came)
-    # (max-error metric: a hidden activation that rounds to the other bf16 neighbour than the reference's shifts a 2048-term
-    # sum by ~4e-5; the Swish form has no exact zeros and sits at 1.9e-3 .. 2.2e-3 depending on the compiler's schedule)
-    assert relerr(xo, ref) < (3e-3 if x_mode & 8 else 2e-3)
+    assert relerr(xo, ref) < 2e-3
+    if with_next and x_mode & 16 and tail_n:
+        out = _from_blocked16(out.cpu(), M, ldo)
+    elif with_next:
+        out = out[:M]
     if with_next:
         y = layer_norm(xo, na, nb)
         if tail_n:

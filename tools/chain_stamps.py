@@ -30,10 +30,10 @@ def main():
     host = [rn(d, d) / 16, 0.1 * rn(d), 1 + 0.1 * rn(d), 0.1 * rn(d), rn(dff, d) / 16, 0.1 * rn(dff), rn(d, dff) / 45, 0.1 * rn(d), 1 + 0.1 * rn(d),
             0.1 * rn(d), rn(tail, d) / 16, 0.1 * rn(tail)]
     host = [t.contiguous() for t in host]
-    outt = torch.empty(M, tail, dtype=torch.bfloat16, device="cuda")
+    outt = torch.empty((M + 31) // 32 * 32, tail, dtype=torch.bfloat16, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr())
     for _ in range(2):
-        rc = L.cn_op_chain(p(x), p(ctx), d, *[p(t) for t in host], p(outt), tail, M, dff, tail, 1e-6, 3, None)
+        rc = L.cn_op_chain(p(x), p(ctx), d, *[p(t) for t in host], p(outt), tail, M, dff, tail, 1e-6, int(os.environ.get("CHAIN_X_MODE", "19")), None)  # 19: blocked x in and out + blocked tail output (the engine's form)
         assert rc == 0, rc
     torch.cuda.synchronize()
 
