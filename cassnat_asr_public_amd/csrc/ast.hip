@@ -44,7 +44,7 @@ int launch_ast_kv_append(int prec, const void* qkv, void* ck, void* cv, int n, i
     if (n <= 0) return 0;
     const int per = d * (int)cn_elem_size(prec) / 16;
     const dim3 grid(cn_ceil_div(n * per, 256));
-    if (prec == CN_PREC_F32)
+    if (prec == CN_PREC_F32 || prec == CN_PREC_X3)  // (split-bf16: d columns are d * 4 contiguous bytes of a row, whole 128-byte groups)
         hipLaunchKernelGGL(ast_kv_append_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, (float*)ck, (float*)cv, n, d, slots, pos);
     else
         hipLaunchKernelGGL(ast_kv_append_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)qkv, (bf16*)ck, (bf16*)cv, n, d, slots, pos);
@@ -79,15 +79,39 @@ struct GatherAttnParams {
     int append_pos;
 };
 
+// element c of a row that starts at byte pointer `row` (c counted from the row's first column; for split-bf16 rows the start
+// must be a multiple of 32 columns): fp32 / bf16 elements are contiguous, a split-bf16 element is a bf16 hi half at
+// cn_split_off(c) and its lo half 64 bytes further
+template <typename T> __device__ __forceinline__ float ga_load(const unsigned char* row, int c) {
+    if constexpr (__is_same(T, split_t)) {
+        const unsigned char* e = row + cn_split_off((size_t)c);
+        return (float)*reinterpret_cast<const bf16*>(e) + (float)*reinterpret_cast<const bf16*>(e + 64);
+    } else {
+        return to_f32(reinterpret_cast<const T*>(row)[c]);
+    }
+}
+template <typename T> __device__ __forceinline__ void ga_store(unsigned char* row, int c, float v) {
+    if constexpr (__is_same(T, split_t)) {
+        unsigned char* e = row + cn_split_off((size_t)c);
+        const bf16 hi = (bf16)v;
+        *reinterpret_cast<bf16*>(e) = hi;
+        *reinterpret_cast<bf16*>(e + 64) = (bf16)(v - (float)hi);
+    } else {
+        reinterpret_cast<T*>(row)[c] = from_f32<T>(v);
+    }
+}
+
 template <typename T, int MODE>
 __global__ void ast_gather_attn_kernel(GatherAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int h = blockIdx.x, lane = threadIdx.x & 63, hd = threadIdx.x >> 6;
     float* sc = reinterpret_cast<float*>(smem) + (long long)hd * p.nkeys;
-    const T* qrow = reinterpret_cast<const T*>(p.q) + (long long)h * p.ldq + hd * 64;
+    constexpr int ES = __is_same(T, split_t) ? 4 : (int)sizeof(T);  // bytes per element (a split-bf16 pair is 4)
+    // rows as byte pointers: head hd of a row is 64 consecutive columns = 64 * ES contiguous bytes in every layout
+    const unsigned char* qrow = reinterpret_cast<const unsigned char*>(p.q) + ((long long)h * p.ldq + hd * 64) * ES;
     float q[64];
 #pragma unroll
-    for (int i = 0; i < 64; ++i) q[i] = to_f32(qrow[i]);
+    for (int i = 0; i < 64; ++i) q[i] = ga_load<T>(qrow, i);
     const int u = MODE == 1 ? p.utt[h] : 0;
     auto row_of = [&](int j) -> long long {
         if (MODE == 0) return (long long)j * p.slots + p.anc[(long long)h * p.table_stride + j];
@@ -95,19 +119,26 @@ __global__ void ast_gather_attn_kernel(GatherAttnParams p) {
     };
     const int kstride = MODE == 0 ? p.d : 2 * p.d;
     const bool append = MODE == 0 && p.append_pos >= 0;
-    const T* new_k = qrow + p.d;      // (head hd of this row's K | V in the fused projection)
-    const T* new_v = qrow + 2 * p.d;
-    if (append) {
-        const long long crow = ((long long)p.append_pos * p.slots + h) * p.d + hd * 64 + lane;
-        const_cast<T*>(reinterpret_cast<const T*>(p.k))[crow] = new_k[lane];
-        const_cast<T*>(reinterpret_cast<const T*>(p.v))[crow] = new_v[lane];
+    const unsigned char* new_k = qrow + (long long)p.d * ES;      // (head hd of this row's K | V in the fused projection)
+    const unsigned char* new_v = qrow + (long long)2 * p.d * ES;
+    const unsigned char* kb = reinterpret_cast<const unsigned char*>(p.k);
+    const unsigned char* vb = reinterpret_cast<const unsigned char*>(p.v);
+    if (append) {  // the head's 64 * ES bytes of K and of V, ES bytes per lane (a byte copy: any element layout)
+        const long long crow = (((long long)p.append_pos * p.slots + h) * p.d + hd * 64) * ES + lane * ES;
+        if constexpr (ES == 4) {
+            *reinterpret_cast<unsigned*>(const_cast<unsigned char*>(kb) + crow) = *reinterpret_cast<const unsigned*>(new_k + lane * 4);
+            *reinterpret_cast<unsigned*>(const_cast<unsigned char*>(vb) + crow) = *reinterpret_cast<const unsigned*>(new_v + lane * 4);
+        } else {
+            *reinterpret_cast<unsigned short*>(const_cast<unsigned char*>(kb) + crow) = *reinterpret_cast<const unsigned short*>(new_k + lane * 2);
+            *reinterpret_cast<unsigned short*>(const_cast<unsigned char*>(vb) + crow) = *reinterpret_cast<const unsigned short*>(new_v + lane * 2);
+        }
     }
     float lmax = -INFINITY;
     for (int j = lane; j < p.nkeys; j += 64) {
-        const T* kr = (append && j == p.append_pos) ? new_k : reinterpret_cast<const T*>(p.k) + row_of(j) * kstride + hd * 64;
+        const unsigned char* kr = (append && j == p.append_pos) ? new_k : kb + (row_of(j) * kstride + hd * 64) * ES;
         float dot = 0.f;
 #pragma unroll
-        for (int i = 0; i < 64; ++i) dot = fmaf(q[i], to_f32(kr[i]), dot);
+        for (int i = 0; i < 64; ++i) dot = fmaf(q[i], ga_load<T>(kr, i), dot);
         const bool ok = MODE == 0 ? p.keyok[(long long)h * p.table_stride + j] != 0 : p.keymask[(long long)u * p.nkeys + j] != 0;
         const float s = ok ? dot * p.scale : CN_NEG_FILL;
         sc[j] = s;
@@ -126,10 +157,10 @@ __global__ void ast_gather_attn_kernel(GatherAttnParams p) {
     const float inv = 1.f / lsum;
     float acc = 0.f;
     for (int j = 0; j < p.nkeys; ++j) {
-        const T* vr = (append && j == p.append_pos) ? new_v : reinterpret_cast<const T*>(p.v) + row_of(j) * kstride + hd * 64;
-        acc = fmaf(sc[j], to_f32(vr[lane]), acc);
+        const unsigned char* vr = (append && j == p.append_pos) ? new_v : vb + (row_of(j) * kstride + hd * 64) * ES;
+        acc = fmaf(sc[j], ga_load<T>(vr, lane), acc);
     }
-    reinterpret_cast<T*>(p.o)[(long long)h * p.ldo + hd * 64 + lane] = from_f32<T>(acc * inv);
+    ga_store<T>(reinterpret_cast<unsigned char*>(p.o) + ((long long)h * p.ldo + hd * 64) * ES, lane, acc * inv);
 }
 
 int launch_ast_gather_attn(int prec, int mode, const GatherAttnArgs& a, hipStream_t s) {
@@ -166,6 +197,13 @@ int launch_ast_gather_attn(int prec, int mode, const GatherAttnArgs& a, hipStrea
     if (prec == CN_PREC_F32) {
         if (mode == 0) hipLaunchKernelGGL((ast_gather_attn_kernel<float, 0>), grid, block, lds, s, p);
         else hipLaunchKernelGGL((ast_gather_attn_kernel<float, 1>), grid, block, lds, s, p);
+    } else if (prec == CN_PREC_X3) {
+        if (a.ldq % 32 || a.ldo % 32 || a.d % 32) {
+            cn_set_error("ast_gather_attn: split-bf16 rows need strides that are multiples of 32 elements");
+            return -1;
+        }
+        if (mode == 0) hipLaunchKernelGGL((ast_gather_attn_kernel<split_t, 0>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((ast_gather_attn_kernel<split_t, 1>), grid, block, lds, s, p);
     } else {
         if (mode == 0) hipLaunchKernelGGL((ast_gather_attn_kernel<bf16, 0>), grid, block, lds, s, p);
         else hipLaunchKernelGGL((ast_gather_attn_kernel<bf16, 1>), grid, block, lds, s, p);

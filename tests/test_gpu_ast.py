@@ -40,12 +40,13 @@ def agreement(beams, g):
     return exact, total, top1
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])  # the two engines that claim the reference's tolerance
 @pytest.mark.parametrize("name,ov", [("ast_tiny_att", dict(ctc_weight=0.0)), ("ast_tiny_ctc", dict(ctc_weight=0.3)),
                                      ("ast_tiny_lp", dict(ctc_weight=0.5, length_penalty=0.2, T=1.3))])
-def test_ast_tiny_fp32_all_beams(name, ov):
+def test_ast_tiny_fp32_all_beams(name, ov, prec):
     g = load_golden(name)
     args, state, feats = ast_tiny_case(**ov)
-    beams = run(args, state, feats, "fp32")
+    beams = run(args, state, feats, prec)
     for b, utt in enumerate(beams):
         assert len(utt) == args.beam_width
         for j, s in enumerate(utt):
@@ -54,14 +55,17 @@ def test_ast_tiny_fp32_all_beams(name, ov):
             assert s["ys"].tolist() == [s["hyp"]]
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name,ov", [("ast_config4_ctc", dict(ctc_weight=0.3)), ("ast_config4_att", dict(ctc_weight=0.0))])
-def test_ast_config4_fp32_beam10(name, ov, capsys):
+def test_ast_config4_fp32_beam10(name, ov, prec, capsys):
+    """BASELINE config 4 (beam 10, 30 steps, with and without the CTC prefix scorer) in the exact-f32 engine and in the
+    split-bf16 engine (every product three bf16 MFMAs on hi + lo operands; the KV cache holds split-bf16 rows)."""
     g = load_golden(name)
     args, state, feats = ast_config4_case(**ov)
-    beams = run(args, state, feats, "fp32")
+    beams = run(args, state, feats, prec)
     exact, total, top1 = agreement(beams, g)
     with capsys.disabled():
-        print(f"\n[AST fp32] {name}: {exact}/{total} beams identical, top-1 identical for {top1}/{len(beams)} utterances")
+        print(f"\n[AST {prec}] {name}: {exact}/{total} beams identical, top-1 identical for {top1}/{len(beams)} utterances")
     # 30 steps x beam 10 with random weights: near-ties between beams can reorder on 1e-6 differences; the best
     # hypothesis and the bulk of the beam must match the reference exactly.
     assert top1 == len(beams)
