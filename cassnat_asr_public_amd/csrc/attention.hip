@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
     typedef AttnCfg<T> Cfg;
     typedef typename Frag<T>::type frag_t;
     constexpr bool SPLIT = __is_same(T, split_t);
-    static_assert(!SPLIT || (!RES && !REL), "split-bf16 attention: plain staged form only");
+    static_assert(!SPLIT || !RES, "split-bf16 attention: the staged forms only");
     constexpr int KROW = Cfg::KROW, CPR = Cfg::CPR;
     constexpr int VROW = RES ? 128 : Cfg::VROW;  // RES: unpadded rows, 64-byte halves swapped on rows with (row>>1)&1
     constexpr int KT_BYTES = 64 * KROW, VT_BYTES = (SPLIT ? 2 : 1) * 64 * VROW, NRES = RES ? 4 : 1;
@@ -131,28 +131,42 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
     constexpr int REL_N = REL ? 64 : 1;
     __shared__ float rel_tab[REL ? 64 * 64 : 1];        // P rows of this head: [2R+1][64]
     __shared__ float rel_bias[REL ? NW : 1][32][REL_N];  // bd[i][r] per wave
-    if constexpr (REL && !SPLIT) {
-        constexpr int E = Frag<T>::ELEMS;
+    if constexpr (REL) {
+        constexpr int E = SPLIT ? 8 : Frag<T>::ELEMS;
         const int nr = 2 * p.rel_R + 1;
         for (int i = tid; i < nr * 64; i += NT) rel_tab[i] = p.rel_pos[(long long)(i >> 6) * p.ld_pos + h * 64 + (i & 63)];
         __syncthreads();
-        // this lane holds dims {(2s + half) * E + j}: half of the query row; the partner lane (lane ^ 32) holds the rest
+        // this lane holds half of the query row - dims (2s + half) * E + j (split rows: k-step s holds dims 32 (s >> 1) +
+        // 16 (s & 1) + 8 half + j, hi and lo halves) - the partner lane (lane ^ 32) holds the rest
+        auto dim_of = [&](int s, int j) -> int {
+            if constexpr (SPLIT) return 32 * (s >> 1) + 16 * (s & 1) + 8 * half + j;
+            else return (2 * s + half) * E + j;
+        };
         float qv[NF][E];
 #pragma unroll
         for (int s = 0; s < NF; ++s)
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                const int dim = (2 * s + half) * E + j;
-                const float q = to_f32(qf[s][j]);
-                qv[s][j] = q + p.rel_v[h * 64 + dim];
-                qf[s][j] = from_f32<T>(q + p.rel_u[h * 64 + dim]);
+                const int dim = dim_of(s, j);
+                if constexpr (SPLIT) {
+                    const float q = (float)qf[s].hi[j] + (float)qf[s].lo[j];
+                    qv[s][j] = q + p.rel_v[h * 64 + dim];
+                    const float qu = q + p.rel_u[h * 64 + dim];
+                    const bf16 hi = (bf16)qu;
+                    qf[s].hi[j] = hi;
+                    qf[s].lo[j] = (bf16)(qu - (float)hi);
+                } else {
+                    const float q = to_f32(qf[s][j]);
+                    qv[s][j] = q + p.rel_v[h * 64 + dim];
+                    qf[s][j] = from_f32<T>(q + p.rel_u[h * 64 + dim]);
+                }
             }
         for (int r = 0; r < nr; ++r) {
             float acc = 0.f;
 #pragma unroll
             for (int s = 0; s < NF; ++s)
 #pragma unroll
-                for (int j = 0; j < E; ++j) acc = fmaf(qv[s][j], rel_tab[r * 64 + (2 * s + half) * E + j], acc);
+                for (int j = 0; j < E; ++j) acc = fmaf(qv[s][j], rel_tab[r * 64 + dim_of(s, j)], acc);
             acc += __shfl_xor(acc, 32);
             if (half == 0) rel_bias[wave][l31][r] = acc;
         }
@@ -554,7 +568,7 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     p.rel_v = a.rel_v;
     p.rel_R = a.rel_R;
     p.ld_pos = a.ld_pos;
-    if constexpr (!__is_same(T, split_t)) {
+    {
         if (a.rel_pos) {
             if (a.rel_R < 0 || a.rel_R > 31 || !a.rel_u || !a.rel_v || a.Lq != a.Lk) {
                 cn_set_error("attention: relative positions need self attention and max_relative_len <= 31");
@@ -599,8 +613,8 @@ int launch_attention(int prec, const AttnArgs& a, hipStream_t s) {
         return -1;
     }
     if (prec == CN_PREC_X3) {
-        if (a.rel_pos || a.ldq % 32 || a.ldk % 32 || a.ldv % 32 || a.ldo % 32) {
-            cn_set_error("attention: split-bf16 rows need strides that are multiples of 32 elements; no relative-position form");
+        if (a.ldq % 32 || a.ldk % 32 || a.ldv % 32 || a.ldo % 32) {
+            cn_set_error("attention: split-bf16 rows need strides that are multiples of 32 elements");
             return -1;
         }
         return run_attention<split_t>(a, s);

@@ -593,55 +593,113 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
                     }
             }
         }
-        // ---- S5: tail projection (acc-order k; B operands = LNn(x)), eight 32-column tiles per group, row-major bf16
-        for (int g = 0; g < G_TAIL; ++g, ++gpos) {
-            const uint4* sb_cur = group_base(gpos);
-            const uint4* sb_next = group_base(gpos + 1);
-            const unsigned tb = tab_lane + (unsigned)((CT_BT + 256 * g) * 4);
-            bf16* op16 = p.out + (long long)m * p.ldo + 256 * g + 8 * half;  // after the half-wave exchange (below)
-            // blocked: tile (row block rb, column tile 8 g + k) is 2 KiB = [16-column half gp][lane][16 B]
-            unsigned char* ob16 = reinterpret_cast<unsigned char*>(p.out) + ((long long)rb * (p.ldo >> 5) + 8 * g) * 2048 + lane * 16;
-            f32x16 q;
+        // ---- S5: tail projection (acc-order k; B operands = LNn(x)), eight 32-column tiles per group.  Software-pipelined like
+        // the feed-forward loop: tile tt accumulates in one of two accumulators (q0 / q1) while the previous tile's epilogue -
+        // bf16 pack, the half-wave exchange, two 16-byte stores - is issued in the MFMA gaps of its first block (from the third
+        // gap on: the MFMA -> VALU wait states of the previous tile's last product have passed by then), so no drain and no
+        // stretch of VALU + store issue with the matrix pipe idle between tiles.
+        if (G_TAIL > 0) {
+            f32x16 q0, q1;
             f32x4 btv[4];
-            ch_tab4_nowait(tb, btv[0], btv[1], btv[2], btv[3]);
+            bf16x4 o_[4];
+            u32x4 w_[2];
+            const int NTT = 8 * G_TAIL;
+            auto tabt = [&](int tt) -> unsigned { return tab_lane + (unsigned)((CT_BT + 32 * (tt < NTT ? tt : NTT - 1)) * 4); };
+            bf16* op16 = p.out + (long long)m * p.ldo + 8 * half;  // (row-major) tile tt: + 32 tt; after the half-wave exchange
+            // blocked: tile (row block rb, column tile tt) is 2 KiB = [16-column half gp][lane][16 B]
+            unsigned char* ob16 = reinterpret_cast<unsigned char*>(p.out) + (long long)rb * (p.ldo >> 5) * 2048 + lane * 16;
+            // one store form for both layouts (no branches between the MFMAs): base + tile stride + half stride
+            unsigned char* st_base = p.out_blk ? ob16 : reinterpret_cast<unsigned char*>(op16);
+            const int st_tile = p.out_blk ? 2048 : 64, st_half = p.out_blk ? 1024 : 32;
+            const bool st_on = (p.out_blk ? rb < nrb : live) && p.stamps != 2;  // (blocked: whole tiles, rows past M land in the padding)
+            ch_tab4_nowait(tabt(0), btv[0], btv[1], btv[2], btv[3]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(btv[0]), "+v"(btv[1]), "+v"(btv[2]), "+v"(btv[3]) :: "memory");
 // (plain stores: with the nt policy the tail ran 40 % longer - 38k against 27k cycles for 24 positions at 63 workgroups, 79k
 // against 51k at 256, `tools/chain_stamps.py`; a tail without its stores takes 21k - and the whole benchmark 2.6 % longer)
 #define CH_TAIL_STORE(v, ptr) *(ptr) = (v)
-#define CH_S5(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB)                                                     \
-            q = __builtin_shufflevector(__builtin_shufflevector(btv[0], btv[1], 0, 1, 2, 3, 4, 5, 6, 7),      \
-                                        __builtin_shufflevector(btv[2], btv[3], 0, 1, 2, 3, 4, 5, 6, 7),      \
-                                        0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);  /* bias = initial value */ \
-            CH_BLK1("+", "v", "%[c]", q, Fa, bop, 0, Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN); \
-            CH_BLK1("+", "v", "%[c]", q, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B_##k(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, \
-                    CH_DMA3, SB, CH_DRAIN);                                                                    \
-            {                                                                                                 \
-                bf16x4 o_[4];                                                                                 \
-                _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                              \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) o_[g_][e] = (bf16)q[4 * g_ + e];             \
-                ch_tab4_nowait(tb + ((k) + 1 < 8 ? ((k) + 1) * 128 : 0), btv[0], btv[1], btv[2], btv[3]);      \
-                /* a lane holds channels 8 g + 4 half + (0..3) of its row: the two half-waves trade their odd / even */ \
-                /* groups (v_permlane32_swap: upper half of the first operand <-> lower half of the second), after    */ \
-                /* which a lane owns 8 consecutive channels of groups (half, half + 2): two 16-byte stores, not four   */ \
-                /* 8-byte ones                                                                                         */ \
-                u32x4 w_[2];                                                                                  \
-                _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                            \
-                    const uint2 lo_ = __builtin_bit_cast(uint2, o_[2 * gp]), hi_ = __builtin_bit_cast(uint2, o_[2 * gp + 1]); \
-                    const auto s0_ = __builtin_amdgcn_permlane32_swap(lo_.x, hi_.x, false, false);            \
-                    const auto s1_ = __builtin_amdgcn_permlane32_swap(lo_.y, hi_.y, false, false);            \
-                    w_[gp] = u32x4{s0_[0], s1_[0], s0_[1], s1_[1]};                                           \
-                }                                                                                             \
-                if (p.out_blk) {                                                                              \
-                    if (rb < nrb && p.stamps != 2) {  /* whole tiles: rows past M land in the buffer's padding */ \
-                        _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                      \
-                            CH_TAIL_STORE(w_[gp], reinterpret_cast<u32x4*>(ob16 + (k) * 2048 + gp * 1024));   \
-                    } else if (p.stamps == 2) { asm volatile("" :: "v"(w_[0]), "v"(w_[1])); }                 \
-                } else if (live && p.stamps != 2) {                                                           \
-                    _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                          \
-                        CH_TAIL_STORE(w_[gp], reinterpret_cast<u32x4*>(op16 + 32 * (k) + 16 * gp));           \
-                } else if (p.stamps == 2) { asm volatile("" :: "v"(w_[0]), "v"(w_[1])); }                     \
+            // epilogue of tile TT held in QO, in four pieces
+#define CH_EPI_CVT(QO, g0)                                                                                     \
+            {                                                                                                  \
+                _Pragma("unroll") for (int g_ = (g0); g_ < (g0) + 2; ++g_)                                     \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) o_[g_][e] = (bf16)QO[4 * g_ + e];             \
+                asm volatile("" : "+v"(o_[g0]), "+v"(o_[(g0) + 1]));                                            \
             }
-            CH_POSITIONS(CH_S5)
-#undef CH_S5
+            // a lane holds channels 8 g + 4 half + (0..3) of its row: the two half-waves trade their odd / even groups
+            // (v_permlane32_swap: upper half of the first operand <-> lower half of the second), after which a lane owns 8
+            // consecutive channels of groups (half, half + 2): two 16-byte stores, not four 8-byte ones
+#define CH_EPI_OUT(TT, gp)                                                                                     \
+            {                                                                                                  \
+                const uint2 lo_ = __builtin_bit_cast(uint2, o_[2 * (gp)]), hi_ = __builtin_bit_cast(uint2, o_[2 * (gp) + 1]); \
+                const auto s0_ = __builtin_amdgcn_permlane32_swap(lo_.x, hi_.x, false, false);                 \
+                const auto s1_ = __builtin_amdgcn_permlane32_swap(lo_.y, hi_.y, false, false);                 \
+                w_[gp] = u32x4{s0_[0], s1_[0], s0_[1], s1_[1]};                                                \
+                if (st_on) CH_TAIL_STORE(w_[gp], reinterpret_cast<u32x4*>(st_base + (long long)(TT) * st_tile + (gp) * st_half)); \
+                else asm volatile("" :: "v"(w_[gp]));                                                          \
+            }
+#define CH_EPI_GAP(HAS_OLD, CODE)                                                                              \
+            CH_SB0;                                                                                            \
+            if constexpr (HAS_OLD) CODE                                                                        \
+            CH_SB0;
+            // position k of group g = tile tt = 8 g + k into QN; QO holds tile tt - 1
+#define CH_S5N(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB, QN, QO, HAS_OLD)                                    \
+            QN = __builtin_shufflevector(__builtin_shufflevector(btv[0], btv[1], 0, 1, 2, 3, 4, 5, 6, 7),      \
+                                         __builtin_shufflevector(btv[2], btv[3], 0, 1, 2, 3, 4, 5, 6, 7),      \
+                                         0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);  /* bias = initial value */ \
+            CH_M1R(CH_PRE_A, QN, Fa[0], bop[0], Fb[0], Fb[1], RA_A, (RK_A) + 0);                               \
+            CH_SB0;                                                                                            \
+            ch_tab4_nowait(tabt(8 * g + (k) + 1), btv[0], btv[1], btv[2], btv[3]);  /* the next tile's bias: landed by this position's second block */ \
+            CH_SB0;                                                                                            \
+            CH_M1R("", QN, Fa[1], bop[1], Fb[2], Fb[3], RA_A, (RK_A) + 2);                                     \
+            CH_SB0;                                                                                            \
+            CH_M1R("", QN, Fa[2], bop[2], Fb[4], Fb[5], RA_A, (RK_A) + 4);                                     \
+            CH_EPI_GAP(HAS_OLD, CH_EPI_CVT(QO, 0))                                                             \
+            CH_M1R("", QN, Fa[3], bop[3], Fb[6], Fb[7], RA_A, (RK_A) + 6);                                     \
+            CH_EPI_GAP(HAS_OLD, CH_EPI_CVT(QO, 2))                                                             \
+            CH_M1(QN, Fa[4], bop[4]);                                                                          \
+            CH_EPI_GAP(HAS_OLD, CH_EPI_OUT(8 * g + (k) - 1, 0))                                                \
+            CH_M1(QN, Fa[5], bop[5]);                                                                          \
+            CH_EPI_GAP(HAS_OLD, CH_EPI_OUT(8 * g + (k) - 1, 1))                                                \
+            CH_M1(QN, Fa[6], bop[6]);                                                                          \
+            CH_SB0;                                                                                            \
+            CH_M1(QN, Fa[7], bop[7]);                                                                          \
+            CH_SB0;                                                                                            \
+            CH_BLK1("+", "v", "%[c]", QN, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B_##k(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, \
+                    CH_DMA3, SB, CH_NODRAIN);
+#define CH_TAIL_GROUP(FIRST, LAST)                                                                             \
+            {                                                                                                  \
+                const uint4* sb_cur = group_base(gpos);                                                        \
+                const uint4* sb_next = group_base(gpos + 1);                                                   \
+                CH_S5N(0, ra0, 8, ra0, 16, 0x1C000, 0x1C000, sb_cur, q0, q1, !(FIRST))                         \
+                CH_S5N(1, ra0, 24, ra0, 32, 0x0, 0x0, sb_next, q1, q0, true)                                   \
+                CH_S5N(2, ra0, 40, ra0, 48, 0x4000, 0x4000, sb_next, q0, q1, true)                             \
+                CH_S5N(3, ra0, 56, ra1, 0, 0x8000, 0x8000, sb_next, q1, q0, true)                              \
+                CH_S5N(4, ra1, 8, ra1, 16, 0xC000, 0xC000, sb_next, q0, q1, true)                              \
+                CH_S5N(5, ra1, 24, ra1, 32, 0x10000, 0x10000, sb_next, q1, q0, true)                           \
+                CH_S5N(6, ra1, 40, ra1, 48, 0x14000, 0x14000, sb_next, q0, q1, true)                           \
+                CH_S5N(7, ra1, 56, ra0, 0, 0x18000, 0x18000, sb_next, q1, q0, true)                            \
+                if constexpr (LAST) {                                                                          \
+                    /* the last tile: drain (its products were just issued), then its epilogue on its own */   \
+                    asm volatile(CH_DRAIN : "+v"(q1));                                                         \
+                    CH_SB0;                                                                                    \
+                    CH_EPI_CVT(q1, 0) CH_EPI_CVT(q1, 2) CH_EPI_OUT(8 * g + 7, 0) CH_EPI_OUT(8 * g + 7, 1)      \
+                    CH_SB0;                                                                                    \
+                }                                                                                              \
+                ++g;                                                                                           \
+                ++gpos;                                                                                        \
+            }
+            int g = 0;
+            if (G_TAIL == 1) {
+                CH_TAIL_GROUP(true, true)
+            } else {
+                CH_TAIL_GROUP(true, false)
+                while (g < G_TAIL - 1) CH_TAIL_GROUP(false, false)
+                CH_TAIL_GROUP(false, true)
+            }
+#undef CH_TAIL_GROUP
+#undef CH_S5N
+#undef CH_EPI_GAP
+#undef CH_EPI_OUT
+#undef CH_EPI_CVT
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(btv[0]), "+v"(btv[1]), "+v"(btv[2]), "+v"(btv[3]) :: "memory");
         }
     }

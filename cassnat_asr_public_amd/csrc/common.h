@@ -112,6 +112,25 @@ __device__ __forceinline__ unsigned char cn_f32_to_fp8(float v) {
 template <> __device__ __forceinline__ fp8_t from_f32<fp8_t>(float v) { return fp8_t{cn_f32_to_fp8(v)}; }
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+// element (row, c) of a matrix of `ld` columns in any element type (split-bf16: ld % 32 == 0; hi + lo halves)
+template <typename T> __device__ __forceinline__ float cn_ld_elem(const void* base, long long row, int ld, int c) {
+    if constexpr (__is_same(T, split_t)) {
+        const unsigned char* e = reinterpret_cast<const unsigned char*>(base) + row * (long long)ld * 4 + cn_split_off((size_t)c);
+        return (float)*reinterpret_cast<const bf16*>(e) + (float)*reinterpret_cast<const bf16*>(e + 64);
+    } else {
+        return to_f32(reinterpret_cast<const T*>(base)[row * ld + c]);
+    }
+}
+template <typename T> __device__ __forceinline__ void cn_st_elem(void* base, long long row, int ld, int c, float v) {
+    if constexpr (__is_same(T, split_t)) {
+        unsigned char* e = reinterpret_cast<unsigned char*>(base) + row * (long long)ld * 4 + cn_split_off((size_t)c);
+        const bf16 hi = (bf16)v;
+        *reinterpret_cast<bf16*>(e) = hi;
+        *reinterpret_cast<bf16*>(e + 64) = (bf16)(v - (float)hi);
+    } else {
+        reinterpret_cast<T*>(base)[row * ld + c] = from_f32<T>(v);
+    }
+}
 
 // 16-byte global load / LDS store helpers on raw bytes.
 __device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }

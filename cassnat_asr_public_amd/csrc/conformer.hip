@@ -13,8 +13,8 @@ __global__ void glu_kernel(const T* __restrict__ in, T* __restrict__ out, long l
     if (i >= M * d) return;
     const long long m = i / d;
     const int c = (int)(i - m * d);
-    const float a = to_f32(in[m * 2 * d + c]), g = to_f32(in[m * 2 * d + d + c]);
-    out[i] = from_f32<T>(a * (1.f / (1.f + __expf(-g))));  // F.glu(dim=channels): first half * sigmoid(second half)
+    const float a = cn_ld_elem<T>(in, m, 2 * d, c), g = cn_ld_elem<T>(in, m, 2 * d, d + c);
+    cn_st_elem<T>(out, m, d, c, a * (1.f / (1.f + __expf(-g))));  // F.glu(dim=channels): first half * sigmoid(second half)
 }
 
 // y[b][t][c] = bias[c] + sum_k w[c][k] x[b][t + k - pad][c], zero outside [0, L)   (nn.Conv1d(groups = C), stride 1)
@@ -31,7 +31,7 @@ __global__ void dwconv_kernel(const T* __restrict__ x, const float* __restrict__
     float acc = bias[c];
     for (int j = 0; j < k; ++j) {
         const int tt = t + j - pad;
-        if (tt >= 0 && tt < L) acc = fmaf(w[c * k + j], to_f32(x[(b * L + tt) * d + c]), acc);
+        if (tt >= 0 && tt < L) acc = fmaf(w[c * k + j], cn_ld_elem<T>(x, b * L + tt, d, c), acc);
     }
     y[i] = acc;
 }
@@ -78,7 +78,7 @@ __global__ void groupnorm_swish_kernel(const float* __restrict__ x, const double
     const double var = stats[2 * b + 1] / (double)n - mean * mean;
     const float inv = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
     const float v = (x[i] - (float)mean) * inv * gw[c] + gb[c];
-    out[i] = from_f32<T>(v * (1.f / (1.f + __expf(-v))));
+    cn_st_elem<T>(out, i / d, d, c, v * (1.f / (1.f + __expf(-v))));
 }
 
 int launch_glu(int prec, const void* in, void* out, int M, int d, hipStream_t s) {
@@ -87,6 +87,8 @@ int launch_glu(int prec, const void* in, void* out, int M, int d, hipStream_t s)
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (prec == CN_PREC_F32)
         hipLaunchKernelGGL(glu_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)in, (float*)out, (long long)M, d);
+    else if (prec == CN_PREC_X3)
+        hipLaunchKernelGGL(glu_kernel<split_t>, dim3(blocks), dim3(256), 0, s, (const split_t*)in, (split_t*)out, (long long)M, d);
     else
         hipLaunchKernelGGL(glu_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)in, (bf16*)out, (long long)M, d);
     CN_HIP_CHECK(hipGetLastError());
@@ -110,12 +112,11 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const T* __restrict__
     const float bz = bias[c];
 #pragma unroll
     for (int o = 0; o < TT; ++o) acc[o] = bz;
-    const T* xb = x + (long long)b * L * d + c;
 #pragma unroll
     for (int tt = 0; tt < TT + K - 1; ++tt) {
         const int t = t0 + tt - pad;
         if (t >= 0 && t < L) {  // a frame outside the utterance contributes nothing (and is skipped by dwconv_kernel as well)
-            const float v = to_f32(xb[(long long)t * d]);
+            const float v = cn_ld_elem<T>(x, (long long)b * L + t, d, c);
 #pragma unroll
             for (int o = 0; o < TT; ++o) {
                 const int j = tt - o;
@@ -142,6 +143,7 @@ int launch_dwconv(int prec, const void* x, const float* w, const float* bias, fl
 #define DW_CASE(KK)                                                                                   \
     case KK:                                                                                          \
         if (prec == CN_PREC_F32) launch_dwconv_tiled<float, KK>(x, w, bias, y, B, L, d, s);           \
+        else if (prec == CN_PREC_X3) launch_dwconv_tiled<split_t, KK>(x, w, bias, y, B, L, d, s);     \
         else launch_dwconv_tiled<bf16, KK>(x, w, bias, y, B, L, d, s);                                \
         CN_HIP_CHECK(hipGetLastError());                                                              \
         return 0;
@@ -154,6 +156,8 @@ int launch_dwconv(int prec, const void* x, const float* w, const float* bias, fl
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (prec == CN_PREC_F32)
         hipLaunchKernelGGL(dwconv_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, w, bias, y, B, L, d, k);
+    else if (prec == CN_PREC_X3)
+        hipLaunchKernelGGL(dwconv_kernel<split_t>, dim3(blocks), dim3(256), 0, s, (const split_t*)x, w, bias, y, B, L, d, k);
     else
         hipLaunchKernelGGL(dwconv_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, w, bias, y, B, L, d, k);
     CN_HIP_CHECK(hipGetLastError());
@@ -168,6 +172,8 @@ int launch_groupnorm_swish(int prec, const float* x, double* stats, const float*
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (prec == CN_PREC_F32)
         hipLaunchKernelGGL(groupnorm_swish_kernel<float>, dim3(blocks), dim3(256), 0, s, x, stats, gw, gb, (float*)out, B, L, d, eps);
+    else if (prec == CN_PREC_X3)
+        hipLaunchKernelGGL(groupnorm_swish_kernel<split_t>, dim3(blocks), dim3(256), 0, s, x, stats, gw, gb, (split_t*)out, B, L, d, eps);
     else
         hipLaunchKernelGGL(groupnorm_swish_kernel<bf16>, dim3(blocks), dim3(256), 0, s, x, stats, gw, gb, (bf16*)out, B, L, d, eps);
     CN_HIP_CHECK(hipGetLastError());

@@ -2132,8 +2132,8 @@ extern "C" int cn_model_create(const cn_config* cfg, cn_model** out) {
         cn_set_error("cn_model_create: unknown precision");
         return -1;
     }
-    if (c.precision == CN_PRECISION_BF16X3 && (c.conf_enc || c.conf_dec || c.d_encff % 32 || c.d_decff % 32 || c.d_model % 32)) {
-        cn_set_error("cn_model_create: the split-bf16 (bf16x3) engine covers the transformer-block models (NAT, autoregressive, TransformerLM)");
+    if (c.precision == CN_PRECISION_BF16X3 && (c.d_encff % 32 || c.d_decff % 32 || c.d_model % 32 || c.d_ff % 32)) {
+        cn_set_error("cn_model_create: the split-bf16 (bf16x3) engine needs d_model and the feed-forward widths to be multiples of 32");
         return -1;
     }
     if (c.precision == CN_PRECISION_FP8 && (c.ast || c.conf_enc || c.d_model % 128 != 0 || c.d_encff % 128 != 0)) {

@@ -22,10 +22,11 @@ def test_conformer_parameter_names_match_reference():
         assert [k for k, _ in model.named_parameters()] == list(synth.param_shapes_conformer(args).keys())
 
 
-def test_conformer_tiny_fp32_every_stage():
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])  # the exact-f32 engine and the split-bf16 engine: the same gate
+def test_conformer_tiny_fp32_every_stage(prec):
     g = load_golden("conf_tiny")
     args, state, feats, sizes = conf_tiny_case()
-    model = build(args, state, "fp32", capture=True)
+    model = build(args, state, prec, capture=True)
     out = decode(model, args, feats, sizes)
     eng = model._engine
     for name in ["x_embed", "enc_layer0", "enc_layer1", "enc_h", "ctc_out", "ac_embed", "pred_embed", "dec_h", "att_out"]:
@@ -53,7 +54,7 @@ def test_conformer_tiny_variants_fp32(name, seed, ov):
                 assert s["hyp"] == g["beam_hyp"][b, j, : g["beam_len"][b, j]].tolist(), (b, j)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])
 def test_conformer_shipped_shape(prec, capsys):
     g = load_golden("conf_small")
     args, state, feats, sizes = conf_small_case()
@@ -67,7 +68,7 @@ def test_conformer_shipped_shape(prec, capsys):
     exact = sum(seqs[0]["hyp"] == g["hyp"][b, : g["hyp_len"][b]].tolist() for b, seqs in enumerate(out))
     with capsys.disabled():
         print(f"\n[conformer {prec}] conf_small: frames {int(clear.sum())}, flips {flips}, ctc_logit_err {ctc_err:.3g}, hyp_exact {exact}/{len(out)}")
-    if prec == "fp32":
+    if prec in ("fp32", "bf16x3"):  # (bf16x3: relative-position attention, GLU / depthwise conv / GroupNorm on split-bf16 rows)
         assert flips == 0 and ctc_err < LOGIT_TOL
         np.testing.assert_array_equal(eng.fetch("ylen"), g["ylen"])
         assert maxerr(eng.fetch("dec_h")[:, ::3, ::8], g["dec_sample"]) < 5e-4
