@@ -24,6 +24,7 @@ import math
 import os
 import queue
 import threading
+import time
 
 import torch
 
@@ -137,7 +138,9 @@ class DecodePipelines:
         self._stage = [{} for _ in range(self.n)]  # per pipeline: merged-batch input buffers (two: two passes in flight), by kind
         self._rows = {"ratio": None}  # row-count predictor shared by the pipelines: largest tokens-per-frame ratio seen
         self._rows_lock = threading.Lock()
-        self.stats = {"passes": 0, "batches": 0, "predicted": 0, "missed": 0, "merged_ragged": 0}
+        self.stats = {"passes": 0, "batches": 0, "predicted": 0, "missed": 0, "merged_ragged": 0,
+                      # host seconds of the worker threads, by what they were doing (summed over the pipelines)
+                      "s_take": 0.0, "s_stage": 0.0, "s_launch": 0.0, "s_retire_wait": 0.0}
 
     # ------------------------------------------------------------------------------------------ capacity
     def fits(self, rows, T):
@@ -178,12 +181,14 @@ class DecodePipelines:
             device = torch.cuda.current_device()
         self._device = device
         self._inbox = [queue.Queue() for _ in range(self.n)]
+        self._copy_streams = [None] * self.n
         ready = threading.Semaphore(0)
 
         def loop(k):
             if self._on_gpu:
                 torch.cuda.set_device(device)
             st = torch.cuda.Stream() if self._on_gpu else _NoStream()
+            self._copy_streams[k] = torch.cuda.Stream() if self._on_gpu else None  # host -> device staging of the NEXT pass
             ready.release()
             with (torch.cuda.stream(st) if self._on_gpu else st), torch.no_grad():
                 while True:
@@ -274,15 +279,19 @@ class DecodePipelines:
         feats = bufs[0][:need].view(rows, tmax, feat_dim)
         ratio = bufs[1][:rows]
         if all(int(x[0].shape[1]) == tmax for x in items):
-            torch.cat([x[0].to(dev_) if on_gpu else x[0] for x in items], 0, out=feats)  # one launch, nothing allocated
+            torch.cat([x[0].to(dev_, non_blocking=True) if on_gpu else x[0] for x in items], 0, out=feats)  # one launch
         else:
+            # a batch first lands on the device as it is (contiguous: a plain asynchronous DMA from pinned host memory), then a
+            # device-side copy spreads it over the padded rows (a host tensor copied straight into the strided view is staged
+            # synchronously by torch: 2 ms of blocked host per batch)
+            srcs = [x[0] if (not on_gpu or x[0].is_cuda) else x[0].to(dev_, non_blocking=True) for x in items]
             feats.fill_(float(pad))
             o = 0
-            for x in items:
+            for x, src in zip(items, srcs):
                 nb, t = int(x[0].shape[0]), int(x[0].shape[1])
-                feats[o:o + nb, :t].copy_(x[0], non_blocking=True)
+                feats[o:o + nb, :t].copy_(src, non_blocking=True)
                 o += nb
-        torch.cat([x[1].to(dev_) if on_gpu else x[1] for x in items], 0, out=ratio)
+        torch.cat([x[1].to(dev_, non_blocking=True) if on_gpu else x[1] for x in items], 0, out=ratio)
         return feats, ratio
 
     def _launch(self, k, st, job, p, exact=False):
@@ -311,7 +320,9 @@ class DecodePipelines:
     def _retire(self, k, st, job, p):
         """The pass has drained: check the predicted row count (decode again on a miss), learn from the true one, hand out."""
         if p.ev is not None:
+            t_ = time.perf_counter()
             p.ev.synchronize()
+            self.stats["s_retire_wait"] += time.perf_counter() - t_
         if p.ticket is not None and p.ticket >= 0:
             ymax, used = self.engines[k].ticket(p.ticket)
             self.stats["passes"] += 1
@@ -342,10 +353,12 @@ class DecodePipelines:
                         break
                     if inflight:  # ... and do not sit on finished work meanwhile
                         self._retire(k, st, job, inflight.pop(0))
+                t_ = time.perf_counter()
                 with lock:
                     if state["done"] or state["err"] is not None:
                         break
                     got = self._take(job)
+                self.stats["s_take"] += time.perf_counter() - t_
                 if got is None:
                     break
                 p = _Pass()
@@ -353,14 +366,29 @@ class DecodePipelines:
                 p.rows = [int(x[0].shape[0]) for x in p.items]
                 p.frames = [int(x[0].shape[1]) for x in p.items]
                 p.ticket = None
+                t_ = time.perf_counter()
                 if len(p.items) == 1:
                     p.feats, p.ratio = p.items[0][0], p.items[0][1]
                 else:
-                    p.feats, p.ratio = self._stage_inputs(k, n_pass & 1, p.items, pad)
+                    cs = self._copy_streams[k]
+                    if cs is not None and not p.items[0][0].is_cuda:
+                        # host batches: the copies (and the padding / scatter kernels behind them) go on a stream of their own,
+                        # so that this pass's inputs travel while the previous pass computes; the slot's last reader - the pass
+                        # two before this one - has been retired
+                        with torch.cuda.stream(cs):
+                            p.feats, p.ratio = self._stage_inputs(k, n_pass & 1, p.items, pad)
+                            ready_ev = torch.cuda.Event()
+                            ready_ev.record(cs)
+                        st.wait_event(ready_ev)
+                    else:
+                        p.feats, p.ratio = self._stage_inputs(k, n_pass & 1, p.items, pad)
                     if len(set(p.frames)) > 1:
                         self.stats["merged_ragged"] += 1
                 n_pass += 1
+                t1_ = time.perf_counter()
+                self.stats["s_stage"] += t1_ - t_
                 self._launch(k, st, job, p)
+                self.stats["s_launch"] += time.perf_counter() - t1_
                 inflight.append(p)
                 if len(inflight) >= 2:  # two passes in flight: this one's launches are queued behind the older one's kernels
                     self._retire(k, st, job, inflight.pop(0))

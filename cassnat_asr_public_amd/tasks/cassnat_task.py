@@ -42,6 +42,28 @@ def hyp_to_words(hyp, vocab, padding_idx):
     return words
 
 
+def hyps_to_words_batch(toks, lens, vocab, padding_idx, table=None):
+    """`hyp_to_words` for a whole batch of hypothesis records (tokens (N, S) int32, lengths (N,)): one pass of array
+    arithmetic instead of a Python loop over every token (at 40k utterances per second the per-token loop was most of the
+    host's time).  Returns a list of word lists."""
+    sos, eos = vocab.word2index["sos"], vocab.word2index["eos"]
+    if table is None:
+        table = np.array([vocab.index2word[i] for i in range(vocab.n_words)], dtype=object)
+    toks, lens = np.asarray(toks), np.asarray(lens)
+    pos = np.arange(toks.shape[1])[None, :]
+    valid = pos < lens[:, None]
+    is_eos = (toks == eos) & valid
+    first_eos = np.where(is_eos.any(1), is_eos.argmax(1), toks.shape[1])
+    keep = valid & (pos < first_eos[:, None]) & (toks != sos) & (toks != padding_idx)
+    flat = table[toks[keep]]
+    ends = np.cumsum(keep.sum(1))
+    out, o = [], 0
+    for e in ends.tolist():
+        out.append(flat[o:e].tolist())
+        o = e
+    return out
+
+
 class CassNATTask(BaseTask):
     def __init__(self, mode, args):
         for k, v in _DEFAULTS.items():
@@ -193,11 +215,13 @@ class CassNATTask(BaseTask):
                 meta[j] = (utt_list, labels, int(feats.shape[0] * feats.shape[1]))
                 yield feats, feat_sizes, j
 
-        for i, hyps, _scores in pipes.decode(batches(), args, sos=sos):
+        table = np.array([self.vocab.index2word[k] for k in range(self.vocab.n_words)], dtype=object)
+        for i, (toks, lens), _scores in pipes.decode(batches(), args, sos=sos, as_lists=False):
             utt_list, labels, nfr = meta.pop(i)
             frames += nfr
-            for utt, hyp, lab in zip(utt_list, hyps, labels):
-                results[utt] = (hyp_to_words(hyp, self.vocab, args.padding_idx), len(hyp) - len(lab))
+            words = hyps_to_words_batch(toks, lens, self.vocab, args.padding_idx, table)
+            for utt, w, n, lab in zip(utt_list, words, lens.tolist(), labels):
+                results[utt] = (w, n - len(lab))
             batch_time.update(time.time() - end)
             end = time.time()
             if i % args.print_freq == 0 and self.rank == 0:

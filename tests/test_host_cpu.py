@@ -457,3 +457,21 @@ def test_two_process_gloo_decode_pipelines_gather(tmp_path):
         out, _ = pr.communicate(timeout=180)
         assert pr.returncode == 0, out
         assert f"rank {r} ok" in out
+
+
+def test_batched_hypothesis_to_words_equals_the_per_utterance_rule():
+    """tasks.cassnat_task.hyps_to_words_batch (the pipelined decoder's form) against hyp_to_words, the reference's rule
+    (src/tasks/cassnat_task.py:346-353: skip sos and padding ids, stop at the first eos), on random records incl. empty ones."""
+    from cassnat_asr_public_amd.tasks.cassnat_task import hyp_to_words, hyps_to_words_batch
+
+    class V:
+        word2index = {"blank": 0, "sos": 1, "eos": 2, "unk": 3}
+        n_words = 40
+        index2word = {i: f"w{i}" for i in range(40)}
+
+    rng = np.random.default_rng(3)
+    toks = rng.integers(0, 40, size=(64, 25)).astype(np.int32)
+    toks[rng.random(toks.shape) < 0.2] = 2  # plenty of eos
+    lens = rng.integers(0, 26, size=64)
+    got = hyps_to_words_batch(toks, lens, V, 0)
+    assert got == [hyp_to_words(toks[b, : lens[b]].tolist(), V, 0) for b in range(64)]

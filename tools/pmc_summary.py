@@ -93,11 +93,14 @@ def main():
         widest = max(grids)
         # launches that belong to a pass of `c` batches: the widest grid, and every grid that occurs as often per widest launch
         # as a pass prescribes and is not also the widest grid of a one-batch pass (chain: 625 encoder / 63 one-batch encoder workgroups)
-        one_batch = {g for g in grids if c > 1 and abs(g // 256 - -(-(widest // 256 * wg_rows // c) // wg_rows)) <= 1}
-        wide = [g for g in grids if g not in one_batch and (c == 1 or g * c >= widest or g == widest)]
-        if tag == "row_chain" and c > 1:  # decoder-side launches of the wide pass: c times the rows of the one-batch pass's
-            small = sorted(g for g in grids if g not in one_batch and g != widest)
-            wide = [widest] + [g for g in small if any(abs(g - c * h) <= 256 * c for h in small if h < g) or len(small) == 1]
+        # Launches that belong to a pass of `c` batches: everything but the grids of a ONE-batch pass, which only occur when the
+        # profiled command was not `bench.py --exit-after-timed` (bench.py then adds one-batch passes after its timed region):
+        # the one-batch encoder-sized launch has 1 / c of the widest launch's rows, and its decoder-side launches are narrower still
+        one_wgs = -(-(widest // 256 * wg_rows // c) // wg_rows) if c > 1 else -1
+        has_one_batch_pass = any(abs(g // 256 - one_wgs) <= 1 for g in grids)
+        wide = [g for g in grids if not has_one_batch_pass or g // 256 > one_wgs + 1 or g == widest]
+        if has_one_batch_pass and tag == "row_chain":  # decoder-side launches of the wide pass: wider than the one-batch encoder launch
+            wide = [g for g in grids if g // 256 > one_wgs + 1]
         n = sum(grids[g]["launches_sampled"] for g in wide)
         mean = sum(grids[g]["hbm_bytes"] * grids[g]["launches_sampled"] for g in wide) / max(1, n)
         rec = {"kernel": label,

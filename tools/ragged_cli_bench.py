@@ -83,11 +83,13 @@ def main():
             yaml.safe_dump({k: v for k, v in conf.items() if k != "test_paths"}, f)
         out["setup_s"] = round(time.perf_counter() - t0, 1)
         base = ["--task", "cassnat", "--test_config", cfg, "--data_path", scp, "--resume_model", ckpt, "--batch_size", str(a.batch),
-                "--hip_precision", a.precision, "--load_data_workers", "0", "--hip_bucket", "1", "--hip_max_frames", str(a.max_frames),
+                "--hip_precision", a.precision, "--hip_bucket", "1", "--hip_max_frames", str(a.max_frames),
                 "--print_freq", "100000"]
         audio_s = sum(lengths) * 0.01
         results = {}
-        for name, extra, preload in (("plain", ["--hip_pipelines", "1"], False), ("pipelined", [], False), ("preloaded", [], True)):
+        for name, extra, preload in (("plain", ["--hip_pipelines", "1", "--load_data_workers", "0"], False),
+                                     ("pipelined", ["--load_data_workers", "0"], False),
+                                     ("pipelined_4_loader_workers", ["--load_data_workers", "4"], False), ("preloaded", ["--load_data_workers", "0"], True)):
             res = os.path.join(tmp, f"result_{name}.txt")
             task, args = make_task(base + extra + ["--result_file", res], conf)
             if preload:  # the collated batches as pinned host tensors: what a loader with enough workers hands over
@@ -110,6 +112,7 @@ def main():
                 rec["batches"] = st["batches"]
                 rec["passes_mixing_frame_counts"] = st["merged_ragged"]
                 rec["row_predictions_missed"] = st["missed"]
+                rec["worker_host_seconds"] = {k: round(v, 3) for k, v in st.items() if k.startswith("s_")}
             out[name] = rec
             eng = getattr(task.model, "_engine", None)
             if eng is not None:
@@ -120,7 +123,7 @@ def main():
             del task
         assert len(results["plain"]) == a.utts
         assert results["pipelined"] == results["plain"], "result files differ between the merged-pass decoder and the plain loop"
-        assert results["preloaded"] == results["plain"]
+        assert results["preloaded"] == results["plain"] and results["pipelined_4_loader_workers"] == results["plain"]
         out["result_files_identical"] = True
     out.update(utterances=a.utts, batch_size=a.batch, precision=a.precision, frames_min_max=[min(lengths), max(lengths)],
                mean_frames=round(float(np.mean(lengths)), 1), audio_seconds=round(audio_s, 1),
