@@ -117,9 +117,16 @@ __device__ __forceinline__ void ch_tab4(unsigned addr, const D& dep, f32x4& a, f
                  : "memory");
 }
 
+// wait until at most N of this wave's LDS reads are outstanding; the listed values are (re-)defined here, so arithmetic on
+// them cannot move above the wait
+#define CH_LGKM_WAIT4(N, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
+
 // acc (+ per-channel add from the table) -> LayerNorm over the 256 channels of each row -> bf16 B operands.
 // Row m lives in lanes m and m+32 (128 channels each): statistics need one exchange across the half-waves.
-__device__ __forceinline__ void ch_layernorm_pack(const f32x16 (&acc)[8], unsigned tab_lane, int off_a, int off_b,
+// The per-channel vectors of a 32-channel tile (gain, offset, optionally a bias added to acc afterwards: ADD) are read one
+// tile ahead of their use (round 2 read them tile by tile with a full wait each: sixteen exposed LDS latencies per LayerNorm).
+template <bool ADD>
+__device__ __forceinline__ void ch_layernorm_pack(f32x16 (&acc)[8], unsigned tab_lane, int off_a, int off_b, int off_add,
                                                   float eps, bf16x8 (&bop)[16]) {
     float s = 0.f;
 #pragma unroll
@@ -135,37 +142,61 @@ __device__ __forceinline__ void ch_layernorm_pack(const f32x16 (&acc)[8], unsign
         for (int r = 0; r < 16; ++r) ss = fmaf(acc[nt][r] - mean, acc[nt][r] - mean, ss);
     ss += __shfl_xor(ss, 32);
     const float inv = 1.0f / (sqrtf(ss / (float)(CH_D - 1)) + eps);  // the bf16 rounding below dwarfs x/d vs x*(1/d)
+    f32x4 ga[2][4], be[2][4], ad[2][4];
+    ch_tab4_nowait(tab_lane + off_a * 4, ga[0][0], ga[0][1], ga[0][2], ga[0][3]);
+    ch_tab4_nowait(tab_lane + off_b * 4, be[0][0], be[0][1], be[0][2], be[0][3]);
+    if constexpr (ADD) ch_tab4_nowait(tab_lane + off_add * 4, ad[0][0], ad[0][1], ad[0][2], ad[0][3]);
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-        f32x4 ga[4], be[4];
-        if (nt == 0) {
-            ch_tab4(tab_lane + (off_a + 32 * nt) * 4, inv, ga[0], ga[1], ga[2], ga[3]);
+        const int c = nt & 1, n = c ^ 1;
+        if (nt + 1 < 8) {  // the next tile's vectors go out before this tile's are waited for
+            ch_tab4_nowait(tab_lane + (off_a + 32 * (nt + 1)) * 4, ga[n][0], ga[n][1], ga[n][2], ga[n][3]);
+            ch_tab4_nowait(tab_lane + (off_b + 32 * (nt + 1)) * 4, be[n][0], be[n][1], be[n][2], be[n][3]);
+            if constexpr (ADD) ch_tab4_nowait(tab_lane + (off_add + 32 * (nt + 1)) * 4, ad[n][0], ad[n][1], ad[n][2], ad[n][3]);
+            if constexpr (ADD) {
+                CH_LGKM_WAIT4(12, ga[c][0], ga[c][1], ga[c][2], ga[c][3]);
+                CH_LGKM_WAIT4(12, be[c][0], be[c][1], be[c][2], be[c][3]);
+                CH_LGKM_WAIT4(12, ad[c][0], ad[c][1], ad[c][2], ad[c][3]);
+            } else {
+                CH_LGKM_WAIT4(8, ga[c][0], ga[c][1], ga[c][2], ga[c][3]);
+                CH_LGKM_WAIT4(8, be[c][0], be[c][1], be[c][2], be[c][3]);
+            }
         } else {
-            ch_tab4(tab_lane + (off_a + 32 * nt) * 4, bop[2 * nt - 1], ga[0], ga[1], ga[2], ga[3]);
+            CH_LGKM_WAIT4(0, ga[c][0], ga[c][1], ga[c][2], ga[c][3]);
+            CH_LGKM_WAIT4(0, be[c][0], be[c][1], be[c][2], be[c][3]);
+            if constexpr (ADD) CH_LGKM_WAIT4(0, ad[c][0], ad[c][1], ad[c][2], ad[c][3]);
         }
-        ch_tab4(tab_lane + (off_b + 32 * nt) * 4, ga[3], be[0], be[1], be[2], be[3]);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * g + e;
-                bop[2 * nt + (r >> 3)][r & 7] = (bf16)fmaf(ga[g][e] * (acc[nt][r] - mean), inv, be[g][e]);
+                bop[2 * nt + (r >> 3)][r & 7] = (bf16)fmaf(ga[c][g][e] * (acc[nt][r] - mean), inv, be[c][g][e]);
+                if constexpr (ADD) acc[nt][r] += ad[c][g][e];
             }
         // materialise this tile's operands here: without the pin the compiler defers half of the arithmetic to the
         // operands' first use and spills the table values it still needs (scratch reloads drain the DMA queue)
         asm volatile("" : "+v"(bop[2 * nt]), "+v"(bop[2 * nt + 1]));
+        if constexpr (ADD) asm volatile("" : "+a"(acc[nt]));
     }
 }
 
 __device__ __forceinline__ void ch_add_channel(f32x16 (&acc)[8], unsigned tab_lane, int off) {
+    f32x4 b[2][4];
+    ch_tab4_nowait(tab_lane + off * 4, b[0][0], b[0][1], b[0][2], b[0][3]);
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-        f32x4 b[4];
-        ch_tab4(tab_lane + (off + 32 * nt) * 4, acc[nt == 0 ? 0 : nt - 1][15], b[0], b[1], b[2], b[3]);
+        const int c = nt & 1, n = c ^ 1;
+        if (nt + 1 < 8) {
+            ch_tab4_nowait(tab_lane + (off + 32 * (nt + 1)) * 4, b[n][0], b[n][1], b[n][2], b[n][3]);
+            CH_LGKM_WAIT4(4, b[c][0], b[c][1], b[c][2], b[c][3]);
+        } else {
+            CH_LGKM_WAIT4(0, b[c][0], b[c][1], b[c][2], b[c][3]);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[nt][4 * g + e] += b[g][e];
+            for (int e = 0; e < 4; ++e) acc[nt][4 * g + e] += b[c][g][e];
         asm volatile("" : "+a"(acc[nt]));
     }
 }
@@ -416,7 +447,6 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     // unit 0 (and the table): own quarter landed -> barrier -> first half into Fa
     if (NG > 0) {
         asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
-        CH_READ8(Fa, ra0, 0);
     } else {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -430,11 +460,18 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
 #define CH_S1(k, RA_A, RK_A, RA_B, RK_B, M0OFF, SOFF, SB)                                                     \
         CH_BLK1A(k, acc, Fa, bop, 0, Fb, RA_A, RK_A, CH_PRE_A, "", "", "", "", SB, CH_NODRAIN);                \
         CH_BLK1A(k, acc, Fb, bop, 8, Fa, RA_B, RK_B, CH_PRE_B_##k(M0OFF), CH_DMA0(SOFF), CH_DMA1, CH_DMA2, CH_DMA3, SB, CH_NODRAIN);
+        // Every stage reads the first half of its first unit itself, right in front of its loop, and waits for it: a fragment
+        // set requested by the previous stage's last block would be live (and PENDING, which hipcc cannot see: it spilled such
+        // registers right behind the reads) across the compiler-scheduled LayerNorm code in between
+        CH_READ8(Fa, ra0, 0);
+        CH_WAIT8(Fa);
         asm volatile("s_nop 1" ::: "memory");  // the compiler's copies into the accumulators -> first MFMA
         CH_POSITIONS(CH_S1)
 #undef CH_S1
-        asm volatile(CH_DRAIN : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]),
-                     "+a"(acc[6]), "+a"(acc[7]));
+        // (the last block's fragment reads - the next unit's first half - are pending: they land here, before compiler-scheduled
+        // code may spill or move their registers)
+        asm volatile(CH_DRAIN "s_waitcnt lgkmcnt(0)" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]),
+                     "+a"(acc[6]), "+a"(acc[7]) :: "memory");  // (lgkmcnt: the last block's fragment reads, unused - see above)
         ++gpos;
         ch_add_channel(acc, tab_lane, CT_BO);
     }
@@ -446,8 +483,8 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     // group of 8 units the odd positions are W1 products (tiles 4 g + 1 .. 4 g + 4), the even ones W2 (tiles 4 g - 1 .. 4 g + 2);
     // the first group opens with W1(0), the last one ends with W2(n - 1) in place of a W1.
     if (p.ffn_tiles) {
-        ch_layernorm_pack(acc, tab_lane, CT_LN1A, CT_LN1B, p.eps, bop);
-        ch_add_channel(acc, tab_lane, CT_B2);  // b2 once; the W2 products accumulate on top of x + b2
+        // LayerNorm 1 -> B operands; b2 is added to x in the same sweep (once: the W2 products accumulate on top of x + b2)
+        ch_layernorm_pack<true>(acc, tab_lane, CT_LN1A, CT_LN1B, CT_B2, p.eps, bop);
         CH_STAMP(4)
         const int NTL = p.ffn_tiles;
         f32x16 xh0, xh1;
@@ -455,7 +492,9 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
         bf16x8 pb[2];
         auto tabb = [&](int t) -> unsigned { return tab_lane + (unsigned)((CT_B1 + 32 * (t < NTL ? t : NTL - 1)) * 4); };
         ch_tab4_nowait(tabb(0), b1v[0], b1v[1], b1v[2], b1v[3]);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]) :: "memory");
+        CH_READ8(Fa, ra0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]), "+v"(Fa[0]), "+v"(Fa[1]), "+v"(Fa[2]),
+                     "+v"(Fa[3]), "+v"(Fa[4]), "+v"(Fa[5]), "+v"(Fa[6]), "+v"(Fa[7]) :: "memory");
         // bias + activation + pack of values 2 i, 2 i + 1 of the finished tile XO (ReLU as an integer max on the fp32 bits)
 #define CH_ACT_PIECE(XO, i)                                                                                    \
         {                                                                                                      \
@@ -556,7 +595,8 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
 #undef CH_W2N
 #undef CH_ACT_GAP
 #undef CH_ACT_PIECE
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]) :: "memory");  // the last (unused) bias read
+        // the last (unused) bias read and the last block's (unused) fragment reads
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]) :: "memory");
     }
     CH_STAMP(5)
 
@@ -576,7 +616,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     }
     CH_STAMP(6)
     if (p.has_next) {
-        ch_layernorm_pack(acc, tab_lane, CT_NLNA, CT_NLNB, p.eps, bop);
+        ch_layernorm_pack<false>(acc, tab_lane, CT_NLNA, CT_NLNB, 0, p.eps, bop);
         CH_STAMP(7)
         if (p.ln_out) {
             // y = LNn(x) itself, row-major bf16.  bop[2 nt + s][j] is channel 32 nt + 16 s + 8 (j >> 2) + 4 half + (j & 3)
@@ -613,7 +653,9 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
             const int st_tile = p.out_blk ? 2048 : 64, st_half = p.out_blk ? 1024 : 32;
             const bool st_on = (p.out_blk ? rb < nrb : live) && p.stamps != 2;  // (blocked: whole tiles, rows past M land in the padding)
             ch_tab4_nowait(tabt(0), btv[0], btv[1], btv[2], btv[3]);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(btv[0]), "+v"(btv[1]), "+v"(btv[2]), "+v"(btv[3]) :: "memory");
+            CH_READ8(Fa, ra0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(btv[0]), "+v"(btv[1]), "+v"(btv[2]), "+v"(btv[3]), "+v"(Fa[0]), "+v"(Fa[1]),
+                         "+v"(Fa[2]), "+v"(Fa[3]), "+v"(Fa[4]), "+v"(Fa[5]), "+v"(Fa[6]), "+v"(Fa[7]) :: "memory");
 // (plain stores: with the nt policy the tail ran 40 % longer - 38k against 27k cycles for 24 positions at 63 workgroups, 79k
 // against 51k at 256, `tools/chain_stamps.py`; a tail without its stores takes 21k - and the whole benchmark 2.6 % longer)
 #define CH_TAIL_STORE(v, ptr) *(ptr) = (v)
