@@ -482,9 +482,15 @@ class DecodePipelines:
             return
         group = max(1, int(gather_every or self.coalesce))
         pending = []
+        # every rank's records of a step must have ONE shape whatever pass the step rode in (a record's width follows the frame
+        # count of its pass, which differs between ranks): they are padded to the width of the engines' longest utterance
+        cap = subsampled(self.frames_cap) + 2 + 3
+
+        def widen(r):
+            return r if r.shape[1] >= cap else torch.nn.functional.pad(r, (0, cap - r.shape[1]))
 
         def flush():
-            recs = [r for _, r in pending]
+            recs = [widen(r) for _, r in pending]
             nb, width = recs[0].shape
             everyone = cdist.all_gather_records(torch.cat(recs, 0) if len(recs) > 1 else recs[0]).cpu()  # one collective, one copy
             world = everyone.shape[0] // (len(recs) * nb)
@@ -494,7 +500,7 @@ class DecodePipelines:
             return out
 
         for tag, rec in self.records(batches, args, sos, plan=plan):
-            if pending and tuple(rec.shape) != tuple(pending[0][1].shape):
+            if pending and rec.shape[0] != pending[0][1].shape[0]:
                 for t_, (h_, s_) in flush():
                     yield t_, h_, s_
             pending.append((tag, rec))

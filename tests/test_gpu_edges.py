@@ -623,3 +623,34 @@ def test_bench_size_merged_pass_and_esa_50_in_every_precision(capsys):
         print(f"\n[bench size] merged ten-batch pass: bf16x3 == fp32 on {same}/320 hypotheses, bf16 == fp32 on {same_bf}/320; "
               f"ESA 50: bf16x3 == fp32 on {same_esa}/32")
     assert same >= 316 and same_esa >= 30
+
+
+def test_merged_pass_whose_conv_image_exceeds_4_gib():
+    """13 batches of 32 x 1000 frames in one engine pass: the bordered conv1 image is 416 x 502 x 42 x 512 B = 4.5 GB.  The LDS-DMA
+    convolution used absolute 32-bit lane offsets into it (they wrapped silently past 4 GiB: wrong hypotheses, no fault); they are
+    relative to the tile's first row now.  The last batch - the one whose rows lie past 4 GiB - must decode exactly as it does alone."""
+    from cassnat_asr_public_amd.pipeline import DecodePipelines
+
+    B, T, n = 32, 1000, 13
+    args = synth.make_args("config2")
+    args.hip_max_batch, args.hip_max_frames = B, T
+    state = synth.make_state(args, seed=0, blank_bias=synth.BENCH_BLANK_BIAS)
+    model = build(args, state, capture=False, prec="bf16")
+    first = synth.make_feats(B, T, 80, seed=2100)
+    rng = np.random.default_rng(9)
+    lens = sorted((int(x) for x in rng.integers(500, T + 1, size=B)), reverse=True)
+    lens[0] = T
+    last = synth.make_feats(B, T, 80, lengths=lens, seed=2101)
+    want = _separate(model, args, [first, last])
+    model._engine.close()
+    model._engine = None
+    f0, s0 = torch.from_numpy(first[0]).cuda(), torch.from_numpy(first[1]).cuda()
+    items = [(f0, s0, k) for k in range(n - 1)] + [(torch.from_numpy(last[0]).cuda(), torch.from_numpy(last[1]).cuda(), n - 1)]
+    with DecodePipelines(model, 1, B, T, coalesce=n) as pipes:
+        assert pipes.fits(n * B, T)
+        got = list(pipes.decode(items, args, sos=1, plan=[n]))
+        assert pipes.stats["passes"] == 1
+    assert (n * B) * (T // 2 + 2) * 42 * 512 > 1 << 32
+    for k in (0, n - 2):
+        assert got[k][1] == want[0][0] and list(got[k][2]) == want[0][1], k
+    assert got[n - 1][1] == want[1][0] and list(got[n - 1][2]) == want[1][1]
