@@ -36,6 +36,7 @@ struct AttnParams {
     int stamps;  // investigation aid (CASSNAT_ATTN_STAMPS): the last workgroup's thread 0 records s_memtime at its phase boundaries
     const int* kv_index;  // non-null: ... at entry kv_index[b] (beam search: every hypothesis row names its utterance)
     const int* klen;
+    int o_blk;          // bf16: O in the row-chain kernel's B-operand order (AttnArgs.o_blocked)
     int q_blk, kv_blk;  // bf16: Q / K|V are blocked matrices (cn_blk16_off) of q_n / kv_n columns, head 0 at column q_col / k_col / v_col
     int q_col, k_col, v_col, q_n, kv_n;
     const int* kcap;  // keys the K / V entry's own batch has (merged passes; null: Lk) - later keys get -inf, not the float-min fill
@@ -479,7 +480,16 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                 const uint2 lo_ = __builtin_bit_cast(uint2, o0), hi_ = __builtin_bit_cast(uint2, o1);
                 const auto s0_ = __builtin_amdgcn_permlane32_swap(lo_.x, hi_.x, false, false);
                 const auto s1_ = __builtin_amdgcn_permlane32_swap(lo_.y, hi_.y, false, false);
-                if (q_row < p.Lq) *reinterpret_cast<u32x4*>(orow + 32 * d + 16 * gp) = u32x4{s0_[0], s1_[0], s0_[1], s1_[1]};
+                if (q_row < p.Lq) {
+                    if (p.o_blk) {  // channels h * 64 + 32 d + 16 gp + 8 half .. + 7 = k-step 4 h + 2 d + gp of the chain's B operand
+                        const long long om = (long long)b * p.Lq + q_row;
+                        unsigned char* ob = reinterpret_cast<unsigned char*>(p.O) +
+                                            ((om >> 5) * (p.ldo >> 4) + (4 * h + 2 * d + gp)) * 1024 + ((half << 5) + (int)(om & 31)) * 16;
+                        *reinterpret_cast<u32x4*>(ob) = u32x4{s0_[0], s1_[0], s0_[1], s1_[1]};
+                    } else {
+                        *reinterpret_cast<u32x4*>(orow + 32 * d + 16 * gp) = u32x4{s0_[0], s1_[0], s0_[1], s1_[1]};
+                    }
+                }
             }
         }
         return;
@@ -547,6 +557,7 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     p.klen = a.klen;
     p.kcap = a.kcap;
     p.kcap_stride = a.kcap_stride;
+    p.o_blk = a.o_blocked;
     p.q_blk = a.q_blocked;
     p.kv_blk = a.kv_blocked;
     p.q_col = a.q_col;
@@ -554,7 +565,7 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     p.v_col = a.v_col;
     p.q_n = a.q_n;
     p.kv_n = a.kv_n;
-    if ((a.q_blocked || a.kv_blocked) && (sizeof(T) != 2 || __is_same(T, split_t) || a.rel_pos || (a.q_blocked && a.q_n % 32) ||
+    if ((a.q_blocked || a.kv_blocked || a.o_blocked) && (sizeof(T) != 2 || __is_same(T, split_t) || a.rel_pos || (a.q_blocked && a.q_n % 32) ||
                                           (a.kv_blocked && a.kv_n % 32))) {
         cn_set_error("attention: blocked operands exist for the bf16 kernels without relative positions; column counts % 32 == 0");
         return -1;

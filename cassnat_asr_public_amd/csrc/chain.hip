@@ -68,6 +68,7 @@ struct ChainParams {
     int stamps;
     int x_in_blk, x_out_blk, store_x;
     int out_blk;  // tail projection in the blocked layout (cn_blk16_off): every store instruction writes 1 KiB contiguous
+    int ctx_blk;  // ctx in the attention kernel's blocked output layout: per 32-row block [16 k-steps][64 lanes][16 B]
 };
 
 #define CH_STR2(x) #x
@@ -394,10 +395,14 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
         for (int i = 0; i < 32; ++i)
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&a"(xr[i]) : "v"(xp + step * i) : "memory");
         if (p.ctx) {
-            const bf16* cp = p.ctx + (long long)mc * p.ldctx + 8 * half;
+            // row-major: the lane's row, 16-byte pieces 32 bytes apart; blocked (the attention kernel's o_blocked form): k-step ks of
+            // this wave's row block is 1 KiB contiguous, [lane][16 B] - the lane order of the B operand itself
+            const bf16* cp = p.ctx_blk ? p.ctx + ((long long)(rb < nrb ? rb : nrb - 1) * 16 * 64 + lane) * 8
+                                       : p.ctx + (long long)mc * p.ldctx + 8 * half;
+            const int cstep = p.ctx_blk ? 512 : 16;
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bop[ks]) : "v"(cp + 16 * ks) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bop[ks]) : "v"(cp + cstep * ks) : "memory");
         }
     }
     {
@@ -794,6 +799,11 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
     p.x_out_blk = a.x_out_blocked;
     p.store_x = a.store_x && (a.ctx || a.dff);
     p.out_blk = a.out_blocked && a.tail_n > 0;
+    p.ctx_blk = a.ctx && a.ctx_blocked;
+    if (p.ctx_blk && a.ldctx != CH_D) {
+        cn_set_error("chain: a blocked ctx has 256 columns");
+        return -1;
+    }
     if (p.out_blk && a.ldo % 32 != 0) {
         cn_set_error("chain: a blocked tail output needs ldo % 32 == 0");
         return -1;

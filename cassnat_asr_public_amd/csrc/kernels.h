@@ -116,6 +116,10 @@ struct AttnArgs {
     // first column of head 0 (ldq / ldk / ldv are unused for a blocked operand)
     int q_blocked = 0, kv_blocked = 0;
     int q_col = 0, k_col = 0, v_col = 0, q_n = 0, kv_n = 0;
+    // bf16 only: O is written as the row-chain kernel reads its B operands - per 32-row block [k-step of 16 channels][lane = 32 *
+    // (bit 3 of the channel) + row % 32][8 bf16], i.e. a blocked matrix of 64-byte-wide column tiles: byte offset of the chunk at
+    // (row m, channel c) = ((m >> 5) * (ldo / 16) + (c >> 4)) * 1024 + (((c >> 3) & 1) * 32 + (m & 31)) * 16
+    int o_blocked = 0;
     const int* intervals = nullptr;          // [B][iv_stride][4] (s1,e1,s2,e2) per query row, or null
     int iv_stride = 0;
     int causal = 0;  // key j allowed only if j <= i
@@ -268,6 +272,7 @@ struct ChainArgs {
     float* x = nullptr;          // [M][256] fp32 residual stream, in place
     const void* ctx = nullptr;   // [M][ldctx] bf16 attention context; null = no output projection
     int ldctx = 0;
+    int ctx_blocked = 0;         // ctx comes in the attention kernel's `o_blocked` layout (ldctx == 256): 1-KiB load instructions
     const void* wstream = nullptr;  // pack_chain units
     const float* tab = nullptr;     // pack_chain table (CHAIN_TAB_FLOATS)
     void* out = nullptr;            // [M][ldo] bf16: tail projection of LNn(x), or LNn(x) itself when tail_n == 0

@@ -183,6 +183,7 @@ struct cn_model {
     int kv_cols = 0;          // chain launch's tail (0: each layer projects its own into kvm)
     bool kv_ready = false;    // ... and that launch ran for the current batch
     bool kv_blocked = false;  // ... writing the blocked layout (common.h: cn_blk16_off)
+    bool ctx_blocked = false; // m->ctx holds the attention kernel's o_blocked form (its reader is the row-chain kernel)
     long long call_id = 0;  // counts encoder passes: a captured tensor is only served for the call that wrote it
     int c1_halo_B = -1, c1_halo_T1 = -1;  // shape of the haloed conv1 image the buffer currently holds (-1: none)
     bool ctc_maxlp_valid = false;  // the fused arg-max-only CTC generator does not produce it
@@ -1124,7 +1125,7 @@ void ws_needs(const cn_model* m, const WsDims& v, WsList& out) {
     out.push_back({"x", (M + 32) * d * 4});  // + one 32-row block: the chain kernel's blocked layout rounds up
     out.push_back({"xn", M * d * es});
     out.push_back({"qkv", (M + 32) * 3 * d * es});  // (+ 32 rows: the chain kernel writes whole 32-row blocks of its blocked output)
-    out.push_back({"ctx", M * d * es});
+    out.push_back({"ctx", (M + 32) * d * es});  // (+ 32 rows: whole 32-row blocks of the blocked form)
     out.push_back({"hbuf", M * dff * es});
     out.push_back({"enc_h", M0 * d * es});
     out.push_back({"kvm", M0 * 2 * d * es});
@@ -1363,7 +1364,9 @@ int run_self_attn_core(cn_model* m, int B, int Lseq, const unsigned char* keymas
         a.k_col = d;
         a.v_col = 2 * d;
         a.q_n = a.kv_n = 3 * d;
+        a.o_blocked = 1;  // (blocked in = the row-chain path: its next launch reads ctx as B operands)
     }
+    m->ctx_blocked = a.o_blocked != 0;
     a.O = m->ctx;
     a.ldq = a.ldk = a.ldv = 3 * d;
     a.ldo = d;
@@ -1408,6 +1411,7 @@ int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ld
     a.x = x;
     a.ctx = r.has_wo ? m->ctx : nullptr;
     a.ldctx = d;
+    a.ctx_blocked = m->ctx_blocked ? 1 : 0;  // (as the attention launch before this one wrote it)
     a.wstream = r.w;
     a.tab = r.tab;
     a.out = out;
@@ -1528,6 +1532,7 @@ int run_rel_attn_core(cn_model* m, const Layer& L, int B, int Lseq, const unsign
     a.Q = m->qkv;
     a.K = (const unsigned char*)m->qkv + (size_t)d * es;
     a.V = (const unsigned char*)m->qkv + (size_t)2 * d * es;
+    m->ctx_blocked = false;  // (the relative-position kernel writes row-major)
     a.O = m->ctx;
     a.ldq = a.ldk = a.ldv = 3 * d;
     a.ldo = d;
@@ -1592,6 +1597,7 @@ int run_conformer_layer_chain(cn_model* m, const Layer& L, float* x, int B, int 
         CN_TRY(launch_dwconv(m->prec, m->xn, L.conv.dw_w, L.conv.dw_b, m->cv_f, B, Lseq, d, L.conv.k, s));
         // (the module's output goes to m->ctx: the next chain's output projection is pointwise conv 2)
         CN_TRY(launch_groupnorm_swish(m->prec, m->cv_f, m->gn_stats, L.conv.gn_w, L.conv.gn_b, m->ctx, B, Lseq, d, 1e-5f, s));
+        m->ctx_blocked = false;  // (row-major)
     }
     if (!mixed) return run_chain(m, L.cf_c, x, M, final_out, d, final_out != nullptr, mid_in | x_out, s);
     CN_TRY(run_chain(m, L.cf_c, x, M, m->qd, d, true, mid_in | mid_out, s));
@@ -1626,7 +1632,9 @@ int run_src_attn_core(cn_model* m, const Layer& L, int B, int U, int Tp, const i
         a.q_blocked = 1;
         a.q_col = 0;
         a.q_n = d;
+        a.o_blocked = 1;
     }
+    m->ctx_blocked = a.o_blocked != 0;
     a.O = m->ctx;
     a.ldq = d;
     a.ldo = d;
