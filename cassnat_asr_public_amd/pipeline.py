@@ -160,16 +160,22 @@ class DecodePipelines:
             return 0
         with self._rows_lock:
             r = self._rows["ratio"]
+            hist = self._rows.get("hist", ())
         if r is None:
             return 0
         tp = subsampled(T)
-        return min(tp + 1, int(math.ceil(r * 1.3 * (tp + 1))) + 8)  # (a generous margin: extra decoder rows cost ~0.1 % each, a miss a whole pass)
+        # margin over the largest tokens-per-frame ratio seen: extra decoder rows cost ~0.1 % of a pass each, a miss a whole pass.
+        # It follows the spread of the recent passes' ratios: 8 % when they barely move (a test set of similar speech), up to 40 %
+        spread = (max(hist) - min(hist)) / max(hist) if len(hist) >= 4 and max(hist) > 0 else 0.2
+        margin = min(1.4, max(1.08, 1.05 + 1.5 * spread))
+        return min(tp + 1, int(math.ceil(r * margin * (tp + 1))) + 4)
 
     def _learn(self, ymax, T):
         with self._rows_lock:
             r = ymax / float(subsampled(T) + 1)
             if self._rows["ratio"] is None or r > self._rows["ratio"]:
                 self._rows["ratio"] = r
+            self._rows["hist"] = (tuple(self._rows.get("hist", ())) + (r,))[-32:]
 
     # ------------------------------------------------------------------------------------------ workers
     def _start(self):
