@@ -252,6 +252,19 @@ def main():
                        "decode_pipelines": NS1, "note": "same workload and step count with one batch of 32 per engine pass"}
         pipes2.close()
 
+    # ---- extra (never `value`; N = 1 only): the same pipelines over ten times as many steps - at the driver's 20 steps the timed
+    # region is one engine pass per pipeline (~15 ms: the first launch's wake-up and the last pass's copy home are 10 % of it)
+    steady = None
+    if world == 1 and not dist_on and a.steps < 100 and not a.no_uncoalesced:
+        run_steps(10 * a.steps)  # (once untimed: the passes of a longer list are cut differently)
+        fence()
+        c0 = time.perf_counter()
+        run_steps(10 * a.steps)
+        fence()
+        el_s = time.perf_counter() - c0
+        steady = {"value": round(10 * a.steps * B / el_s, 2), "unit": "utt/s", "steps": 10 * a.steps,
+                  "ms_per_step": round(el_s / (10 * a.steps) * 1e3, 4), "note": "same pipelines, same batch, ten times the steps"}
+
     # ---- extra (never `value`; N = 1 only): what decode_asr meets - a length-sorted list of batches of DIFFERENT frame counts
     # (300..1500, every batch padded to its own longest utterance), merged into engine passes by workspace area
     ragged_leg = None
@@ -455,7 +468,7 @@ def main():
         # algorithmic FLOP/s of the whole path against the chip's peak for this precision's products (bf16x3: three MFMAs each)
         "mfma_frac_end_to_end": round(flops / B * value / (world * peak * 1e12 / (3.0 if a.precision == "bf16x3" else 1.0)), 5),
         "roofline": roofline, "roofline_conv2": roofline_conv2, "cpu_baseline": cpu, "parity_engine": parity_engine,
-        "fp32_engine": fp32_engine, "one_batch_per_pass": uncoalesced, "ragged_set": ragged_leg,
+        "fp32_engine": fp32_engine, "one_batch_per_pass": uncoalesced, "ragged_set": ragged_leg, "steady_state": steady,
         "stage_ms": stage_ms,
         "weight_blob_mb": round(blob_bytes / 1e6, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
     }
