@@ -126,11 +126,14 @@ int launch_ctc_align(const AlignArgs& a, hipStream_t s) {
 // (ylen already includes the EOS row), the score is a sequential double sum of the float32 maxima.
 // sub > 0: the batch is `B / sub` coalesced reference batches of `sub` utterances each; the row limit of an utterance is then
 // the largest ylen of ITS batch (what U would have been had that batch been decoded alone), so its hypothesis is the same.
-__global__ void greedy_pack_kernel(const int* __restrict__ tok, const float* __restrict__ val,
-                                   const int* __restrict__ ylen, int B, int U, int sos, int hyp_stride,
-                                   int* __restrict__ hyp, int* __restrict__ hyp_len, double* __restrict__ score, int sub,
-                                   const UttMeta* __restrict__ utt_meta, const int* __restrict__ ymax_dev) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void greedy_pack_kernel(const int* __restrict__ tok, const float* __restrict__ val,
+                                                         const int* __restrict__ ylen, int B, int U, int sos, int hyp_stride,
+                                                         int* __restrict__ hyp, int* __restrict__ hyp_len, double* __restrict__ score, int sub,
+                                                         const UttMeta* __restrict__ utt_meta, const int* __restrict__ ymax_dev) {
+    // one wave per utterance (round 2: one THREAD per utterance - 16 to 45 us for a merged pass): the lanes share the scan over
+    // the batch's row counts and the token copy; the score stays ONE sequential double sum, in row order, on lane 0 (the
+    // reference accumulates a Python float row by row: any other order differs in the last bits)
+    const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= B) return;
     int ulim = U;
     if (ymax_dev && *ymax_dev < ulim) ulim = *ymax_dev;  // U was a prediction: the reference's row count is the true maximum
@@ -144,28 +147,30 @@ __global__ void greedy_pack_kernel(const int* __restrict__ tok, const float* __r
             b1 = b0 + sub < B ? b0 + sub : B;
         }
         int um = 0;
-        for (int j = b0; j < b1; ++j) um = ylen[j] > um ? ylen[j] : um;
+        for (int j = b0 + lane; j < b1; j += 64) um = ylen[j] > um ? ylen[j] : um;
+        for (int o = 32; o > 0; o >>= 1) {
+            const int v = __shfl_xor(um, o);
+            um = v > um ? v : um;
+        }
         if (um < ulim) ulim = um;
     }
     int n = ylen[b] + 1;
     if (n > ulim) n = ulim;
     if (n > hyp_stride - 1) n = hyp_stride - 1;
     int* h = hyp + (long long)b * hyp_stride;
-    h[0] = sos;
-    double sc = 0.0;
-    for (int i = 0; i < n; ++i) {
-        h[1 + i] = tok[(long long)b * U + i];
-        sc = sc + (double)val[(long long)b * U + i];
+    for (int i = lane; i < hyp_stride; i += 64) h[i] = i == 0 ? sos : (i <= n ? tok[(long long)b * U + i - 1] : 0);
+    if (lane == 0) {
+        double sc = 0.0;
+        for (int i = 0; i < n; ++i) sc = sc + (double)val[(long long)b * U + i];
+        hyp_len[b] = n + 1;
+        score[b] = sc;
     }
-    for (int i = n + 1; i < hyp_stride; ++i) h[i] = 0;
-    hyp_len[b] = n + 1;
-    score[b] = sc;
 }
 
 int launch_greedy_pack(const int* tok, const float* val, const int* ylen, int B, int U, int sos, int hyp_stride,
                        int* hyp, int* hyp_len, double* score, hipStream_t s, int sub, const UttMeta* utt_meta, const int* ymax_dev) {
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(greedy_pack_kernel, dim3(cn_ceil_div(B, 64)), dim3(64), 0, s, tok, val, ylen, B, U, sos,
+    hipLaunchKernelGGL(greedy_pack_kernel, dim3(B), dim3(64), 0, s, tok, val, ylen, B, U, sos,
                        hyp_stride, hyp, hyp_len, score, sub, utt_meta, ymax_dev);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
