@@ -276,7 +276,13 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         }
         k3 = k3n;
     }
-    asm volatile("s_nop 13\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // MFMA results -> vector reads below
+    // MFMA results -> vector reads below.  Both fragment sets are operands: the last block requested fragments nobody uses - dead
+    // values to the compiler, whose registers it handed to the epilogue's address arithmetic while the reads were still on their
+    // way (tools/pending_reg_check.py; harmless only as long as the reads land within the block's remaining MFMAs)
+    asm volatile("s_nop 13\n\ts_waitcnt lgkmcnt(0)"
+                 : "+v"(Ax[0]), "+v"(Ax[1]), "+v"(Ax[2]), "+v"(Ax[3]), "+v"(Wx[0]), "+v"(Wx[1]), "+v"(Wx[2]), "+v"(Wx[3]),
+                   "+v"(Ay[0]), "+v"(Ay[1]), "+v"(Ay[2]), "+v"(Ay[3]), "+v"(Wy[0]), "+v"(Wy[1]), "+v"(Wy[2]), "+v"(Wy[3])
+                 :: "memory");
     if constexpr (LINEAR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant requests of the last steps (they write this workgroup's LDS)
 
     if constexpr (LINEAR) {

@@ -286,6 +286,8 @@ struct ChainArgs {
     int x_in_blocked = 0, x_out_blocked = 0, store_x = 1;
     int out_blocked = 0;  // the tail projection `out` is written as a blocked bf16 matrix of ldo columns (common.h: cn_blk16_off)
     int swish = 0;  // feed-forward activation: x * sigmoid(x) instead of ReLU (conformer)
+    int f8 = 0;     // the stream's feed-forward units are e4m3 (pack_chain with f8_q)
+    const int* f8_q = nullptr;  // device: the four scale bytes pack_chain returned
     float eps = 1e-6f;
 };
 int launch_chain(const ChainArgs& a, hipStream_t s);
@@ -295,8 +297,14 @@ struct ChainWeights {  // host fp32, nn.Linear layout [out][in]; null members = 
                 *b2 = nullptr, *nln_a = nullptr, *nln_b = nullptr, *wt = nullptr, *bt = nullptr;
     int dff = 0, tail_n = 0;
 };
-size_t chain_stream_units(int has_outproj, int dff, int tail_n);
-void pack_chain(const ChainWeights& w, uint16_t* stream, float* tab);
+// F8 form (BASELINE config 5): the two feed-forward products on e4m3 operands - weights at a per-tensor power-of-two scale
+// chosen at pack time, LayerNorm outputs at x16 and ReLU outputs at x8 as in the unfused fp8 path (model.hip); d_ff % 256 == 0.
+// pack_chain with f8_q != null writes such a stream and returns the four E8M0 scale bytes the kernel's products need.
+constexpr float CHAIN_F8_S_LN = 16.f, CHAIN_F8_S_HID = 8.f;
+size_t chain_stream_units(int has_outproj, int dff, int tail_n, int f8 = 0);
+void pack_chain(const ChainWeights& w, uint16_t* stream, float* tab, int* f8_q = nullptr);
+// float -> OCP e4m3fn byte, round to nearest even, saturating at +-448 (host side; the device's v_cvt_pk_fp8_f32 after a clamp)
+unsigned char cn_f32_to_e4m3_host(float f);
 
 // ---- d_model-deep projections of the split-bf16 engine (K = 256): C = A . W^T + bias, split-bf16 or fp32 (+ residual) output   (proj_x3.hip)
 struct ProjX3Args {

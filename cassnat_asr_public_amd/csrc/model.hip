@@ -56,6 +56,7 @@ struct ChainRef {
     float* tab = nullptr;
     int dff = 0, tail_n = 0;
     bool has_wo = false, has_next = false, swish = false;
+    int* f8q = nullptr;  // e4m3 feed-forward units (chain.hip, F8 form): the four scale bytes of its products, in the blob
 };
 struct Layer {
     Norm n[5];
@@ -318,28 +319,7 @@ struct Packer {
         return reinterpret_cast<float*>(at);
     }
     // [sum rows][K] matrix in model precision from several [rows][K] matrices, optional column permutation
-    // float -> OCP e4m3fn byte, round to nearest even, saturating at +-448 (what v_cvt_pk_fp8_f32 produces on gfx950)
-    static unsigned char f32_to_e4m3(float f) {
-        const unsigned char sign = std::signbit(f) ? 0x80 : 0;
-        float a = std::fabs(f);
-        if (a != a) return 0x7f;
-        if (a >= 448.f) return sign | 0x7e;
-        if (a < 0.0009765625f) return sign;  // below half of the smallest subnormal (2^-9): zero (the tie goes to even = 0)
-        int e;
-        (void)std::frexp(a, &e);
-        int E = e - 1;  // a = 1.xxx * 2^E
-        if (E < -6) {   // subnormal: multiples of 2^-9
-            const int r = (int)std::nearbyint(a * 512.f);
-            return sign | (unsigned char)(r >= 8 ? 0x08 : r);
-        }
-        int r = (int)std::nearbyint((a / std::ldexp(1.f, E) - 1.f) * 8.f);
-        if (r == 8) {
-            r = 0;
-            ++E;
-        }
-        const int bits = ((E + 7) << 3) | r;
-        return sign | (unsigned char)(bits > 0x7e ? 0x7e : bits);
-    }
+    static unsigned char f32_to_e4m3(float f) { return cn_f32_to_e4m3_host(f); }
     // fp8 copy of a packed Linear (same row order as `linear` built it from `prefixes`): one power-of-two scale per tensor,
     // the largest that keeps max|w| * scale <= 448
     void quant8(Linear& l, std::initializer_list<std::string> prefixes, int64_t rows_each) {
@@ -547,11 +527,12 @@ struct Packer {
     // `nln` ("" = nothing follows) and the concatenated projections `tails` (each [d][d]) of whatever consumes the
     // stream next.  Seven spare units follow the stream: the kernel's dummy refills past the end read them.
     ChainRef chain(const std::string& wo, const std::string& ln1, const std::string& p, int64_t dff, const std::string& nln,
-                   std::vector<std::string> tails, int64_t d) {
+                   std::vector<std::string> tails, int64_t d, bool f8 = false) {
         ChainRef r;
         const int tail_n = (int)(tails.size() * d);
-        const size_t units = chain_stream_units(!wo.empty(), (int)dff, tail_n);
+        const size_t units = chain_stream_units(!wo.empty(), (int)dff, tail_n, f8);
         const size_t aw = reserve((units + 7) * CHAIN_UNIT_BYTES), at = reserve((size_t)CHAIN_TAB_FLOATS * 4);
+        const size_t aq = f8 ? reserve(16) : 0;
         if (fill) {
             ChainWeights w;
             bool ok = true;
@@ -591,10 +572,12 @@ struct Packer {
             w.bt = tb.data();
             w.dff = (int)dff;
             w.tail_n = tail_n;
-            if (ok) pack_chain(w, reinterpret_cast<uint16_t*>(&host[aw]), reinterpret_cast<float*>(&host[at]));
+            if (ok) pack_chain(w, reinterpret_cast<uint16_t*>(&host[aw]), reinterpret_cast<float*>(&host[at]),
+                               f8 ? reinterpret_cast<int*>(&host[aq]) : nullptr);
         }
         r.w = reinterpret_cast<void*>(aw);
         r.tab = reinterpret_cast<float*>(at);
+        r.f8q = f8 ? reinterpret_cast<int*>(aq) : nullptr;
         r.dff = (int)dff;
         r.tail_n = tail_n;
         r.has_wo = !wo.empty();
@@ -877,13 +860,17 @@ int build_weights(cn_model* m) {
                               n + 1 == c.n_enc ? "encoder.norm" : "");
     m->enc_chain.clear();
     m->kv_cols = 0;
-    if (!c.conf_enc && !m->fp8_enc && pk.chain_ok(d, c.d_encff))  // (the TransformerLM's layers are encoder layers: same chains)
+    // fp8 engine: the same chains with the feed-forward units in e4m3 (chain.hip, F8 form) when d_ff allows, else the unfused
+    // per-product path (run_enc_layer_fp8)
+    static const bool f8_unfused = getenv("CASSNAT_FP8_UNFUSED") != nullptr;
+    const bool f8c = m->fp8_enc && !lm && !f8_unfused && c.d_encff % 256 == 0;
+    if (!c.conf_enc && (!m->fp8_enc || f8c) && pk.chain_ok(d, c.d_encff))  // (the TransformerLM's layers are encoder layers: same chains)
         for (int n = 0; n < c.n_enc; ++n) {
             const std::string p = "encoder.layers." + std::to_string(n), q = "encoder.layers." + std::to_string(n + 1);
             if (n + 1 < c.n_enc)
                 m->enc_chain.push_back(pk.chain(p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff,
                                                 q + ".sublayer.0.norm",
-                                                {q + ".self_attn.linears.0", q + ".self_attn.linears.1", q + ".self_attn.linears.2"}, d));
+                                                {q + ".self_attn.linears.0", q + ".self_attn.linears.1", q + ".self_attn.linears.2"}, d, f8c));
             else {
                 // the last launch also projects enc_h = encoder.norm(x) onto the cross-attention K|V of every decoder-side
                 // layer (extractor, then mixed-attention decoder): three 8000-row GEMM launches per batch become the tail of
@@ -899,7 +886,7 @@ int build_weights(cn_model* m) {
                 }
                 m->kv_cols = (int)kv_tails.size() * (int)d;
                 m->enc_chain.push_back(
-                    pk.chain(p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff, "encoder.norm", kv_tails, d));
+                    pk.chain(p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff, "encoder.norm", kv_tails, d, f8c));
             }
         }
     m->enc_entry = ChainRef();
@@ -1080,6 +1067,7 @@ int build_weights(cn_model* m) {
     auto rebase_chain = [&](ChainRef& r) {
         rebase(r.w, base);
         rebase(r.tab, base);
+        rebase(r.f8q, base);
     };
     for (auto& r : m->enc_chain) rebase_chain(r);
     rebase_chain(m->enc_entry);
@@ -1428,6 +1416,8 @@ int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ld
     a.store_x = (x_mode & CHX_NO_STORE) == 0;
     a.swish = r.swish ? 1 : 0;
     a.out_blocked = out_blocked ? 1 : 0;
+    a.f8 = r.f8q ? 1 : 0;
+    a.f8_q = r.f8q;
     return launch_chain(a, s);
 }
 
@@ -1862,7 +1852,11 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         if (cap) CN_TRY(capture(m, "enc_h", m->enc_h, true, CN_DTYPE_F32, {B, Tp, d}, s));
         return 0;
     }
-    if (m->fp8_enc) {  // BASELINE config 5: the four products of every encoder layer on the fp8 MFMA
+    static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
+    // BASELINE config 5.  With row chains (d_model 256, d_ff % 256 == 0) the feed-forward products - 80 % of a layer's
+    // multiply-adds - run on e4m3 operands inside the chain kernel at twice the bf16 rate (chain.hip, F8 form) and the layer
+    // goes down the bf16 engine's path below; without them, the four products of every layer as separate e4m3 launches
+    if (m->fp8_enc && (m->enc_chain.size() != m->enc.size() || no_chain)) {
         for (size_t n = 0; n < m->enc.size(); ++n) {
             CN_TRY(run_enc_layer_fp8(m, m->enc[n], m->x, B, Tp, s));
             if (cap) CN_TRY(capture(m, ("enc_layer" + std::to_string(n)).c_str(), m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
@@ -1871,7 +1865,6 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         if (cap) CN_TRY(capture(m, "enc_h", m->enc_h, true, CN_DTYPE_F32, {B, Tp, d}, s));
         return 0;
     }
-    static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
     const bool chain = !m->enc.empty() && m->enc_chain.size() == m->enc.size() && !no_chain;
     // the projections a chain launch writes for the attention kernel (Q|K|V, and the decoder side's K|V) go out in the blocked
     // layout: 1-KiB store instructions instead of thirty-two 32-byte row segments (the tail phase was store-bound)
@@ -3324,15 +3317,22 @@ extern "C" int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, con
     w.bt = bt_host;
     w.dff = dff;
     w.tail_n = tail_n;
-    const size_t units = chain_stream_units(ctx_dev != nullptr, dff, tail_n);
-    std::vector<uint16_t> hs(units * (CHAIN_UNIT_BYTES / 2) + 8);
+    const int f8 = (x_mode & 32) != 0;
+    if (f8 && (dff <= 0 || dff % 256 != 0 || (x_mode & 8))) {
+        cn_set_error("cn_op_chain: the e4m3 feed-forward form (x_mode bit 32) needs d_ff % 256 == 0 and the ReLU activation");
+        return -1;
+    }
+    const size_t units = chain_stream_units(ctx_dev != nullptr, dff, tail_n, f8);
+    std::vector<uint16_t> hs((units + 7) * (CHAIN_UNIT_BYTES / 2));  // (seven spare units: the kernel's dummy refills read them)
     std::vector<float> ht(CHAIN_TAB_FLOATS);
-    pack_chain(w, hs.data(), ht.data());
+    int hq[4] = {127, 127, 127, 127};
+    pack_chain(w, hs.data(), ht.data(), f8 ? hq : nullptr);
     void *ds = nullptr, *dt = nullptr;
     CN_HIP_CHECK(hipMalloc(&ds, hs.size() * 2));
-    CN_HIP_CHECK(hipMalloc(&dt, ht.size() * 4));
+    CN_HIP_CHECK(hipMalloc(&dt, ht.size() * 4 + 16));
     CN_HIP_CHECK(hipMemcpy(ds, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
     CN_HIP_CHECK(hipMemcpy(dt, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
+    CN_HIP_CHECK(hipMemcpy((char*)dt + ht.size() * 4, hq, 16, hipMemcpyHostToDevice));
     ChainArgs a;
     a.x = x_dev;
     a.ctx = ctx_dev;
@@ -3352,6 +3352,8 @@ extern "C" int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, con
     a.store_x = (x_mode & 4) == 0;
     a.swish = (x_mode & 8) != 0;
     a.out_blocked = (x_mode & 16) != 0;
+    a.f8 = f8;
+    a.f8_q = f8 ? reinterpret_cast<const int*>((char*)dt + ht.size() * 4) : nullptr;
     int rc = launch_chain(a, (hipStream_t)stream);
     if (const char* rep = getenv("CASSNAT_CHAIN_REPEAT")) {  // timing runs only: x keeps being updated
         // CASSNAT_CHAIN_STREAMS = n: the repeats go round-robin onto n private streams (how do concurrent launches share

@@ -234,7 +234,10 @@ int cn_profile_end(cn_model* m, char* json_out, int64_t cap);
  * written as a blocked bf16 matrix of ldo columns (ceil(M / 32) * 32 rows; 32 x 32 tiles of 2 KiB, each [16-column half][lane =
  * 32 * (bit 3 of the column) + row % 32][8 bf16]: what the attention kernel reads as `blocked` Q / K / V).  Blocked x: 32-row
  * blocks of [32 pieces i][64 lanes][4 floats], lane = row % 32 + 32 h holding channels 32 (i / 4) + 8 (i % 4) + 4 h + (0..3);
- * the buffer then holds ceil(M / 32) * 32 rows. */
+ * the buffer then holds ceil(M / 32) * 32 rows.  32 = the two feed-forward products take e4m3fn operands (BASELINE config 5,
+ * CN_PRECISION_FP8 engines; d_ff % 256 == 0, ReLU only): LN1(x) at x16 and the ReLU output at x8, both saturating at +-448,
+ * W1 and W2 each at the largest power-of-two scale that keeps its largest magnitude <= 448; accumulation, bias, residual and
+ * everything else of the launch as without the bit. */
 int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, const float* wo_host, const float* bo_host,
                 const float* ln1_a_host, const float* ln1_b_host, const float* w1_host, const float* b1_host,
                 const float* w2_host, const float* b2_host, const float* nln_a_host, const float* nln_b_host,

@@ -473,6 +473,66 @@ def test_generator_target_gather_fused_bf16(B, U, ld, V):
         assert torch.isnan(out.cpu()[:, U:]).all()  # nothing written outside the U scored positions
 
 
+def _e4m3(t):
+    """round to OCP e4m3fn, saturating (torch's CPU cast is the emulation, as in test_gemm_fp8_...)"""
+    return t.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize("M,dff,tail_n,with_ctx,x_mode", [(8000, 2048, 768, True, 32), (8000, 2048, 768, True, 32 | 19), (257, 256, 0, False, 32),
+                                                           (33, 512, 256, True, 32 | 16), (4100, 1024, 1536, True, 32 | 3)])
+def test_chain_fp8_feed_forward(M, dff, tail_n, with_ctx, x_mode):
+    """x_mode bit 32 (BASELINE config 5): the two feed-forward products of the chain on e4m3 operands - LayerNorm output at x16,
+    ReLU output at x8 (both saturating), weights at the largest power-of-two scale that keeps them in range - against an emulation
+    with the same roundings; everything else of the launch as in test_chain_bf16."""
+    from oracle.cassnat_oracle import layer_norm
+
+    g = torch.Generator().manual_seed(M + dff + tail_n)
+    d = 256
+    rn = lambda *s: torch.randn(*s, generator=g)
+    x = rn(M, d) * 2 + 0.3
+    ctx = rn(M, d)
+    wo, bo = (rn(d, d) / 16).contiguous(), 0.1 * rn(d)
+    a1, b1n = 1 + 0.1 * rn(d), 0.1 * rn(d)
+    w1, b1 = (rn(dff, d) / 16).contiguous(), 0.1 * rn(dff)
+    w2, b2 = (rn(d, dff) / math.sqrt(dff)).contiguous(), 0.1 * rn(d)
+    na, nb = 1 + 0.1 * rn(d), 0.1 * rn(d)
+    wt, bt = (rn(max(tail_n, 1), d) / 16).contiguous(), 0.1 * rn(max(tail_n, 1))
+    ref = x.clone()
+    if with_ctx:
+        ref = ref + F.linear(rounded(ctx, "bf16"), rounded(wo, "bf16"), bo)
+    pow2 = lambda w: 2.0 ** math.floor(math.log2(448.0 / w.abs().max().item()))
+    s1, s2 = pow2(w1), pow2(w2)
+    xn8 = _e4m3(layer_norm(ref, a1, b1n) * 16.0)
+    pre = F.linear(xn8, _e4m3(w1 * s1)) / (s1 * 16.0) + b1
+    h8 = _e4m3(F.relu(pre) * 8.0)
+    ref = ref + F.linear(h8, _e4m3(w2 * s2)) / (s2 * 8.0) + b2
+    xd = dev(_to_blocked(x) if x_mode & 1 else x)
+    if x_mode & 2 and not x_mode & 1:
+        xd = torch.cat([xd, torch.zeros(32, d, device="cuda")])
+    ctxd = dev(ctx, torch.bfloat16) if with_ctx else None
+    with_next = True
+    ldo = tail_n if tail_n else d
+    rows_out = (M + 31) // 32 * 32 if x_mode & 16 else M
+    out = torch.full((rows_out, ldo), float("nan"), dtype=torch.bfloat16, device="cuda")
+    hip.check(hip.lib().cn_op_chain(p(xd), p(ctxd) if with_ctx else None, d, _hp(wo), _hp(bo), _hp(a1), _hp(b1n), _hp(w1),
+                                    _hp(b1), _hp(w2), _hp(b2), _hp(na), _hp(nb), _hp(wt), _hp(bt), p(out), ldo, M, dff, tail_n, 1e-6,
+                                    x_mode, stream()))
+    torch.cuda.synchronize()
+    nrb = (M + 31) // 32
+    xo = xd.cpu().reshape(-1)[: nrb * 32 * d]
+    xo = _from_blocked(xo.view(nrb, 32, 64, 4), M) if x_mode & 2 else xo.view(-1, d)[:M]
+    # identical operand bytes except where a LayerNorm output or a pre-activation sits on a rounding boundary of e4m3 and the two
+    # summation orders fall on different sides: one step there is 1/16 of the value (bf16: 1/256), in one of 256 / d_ff terms.
+    # Measured 3.2e-3 of the output range at worst over these cases (most: < 1e-3)
+    assert relerr(xo, ref) < 8e-3
+    out = _from_blocked16(out.cpu(), M, ldo) if (x_mode & 16 and tail_n) else out[:M]
+    y = layer_norm(xo, na, nb)
+    if tail_n:
+        assert relerr(out, F.linear(rounded(y, "bf16"), rounded(wt, "bf16"), bt)) < 6e-3
+    else:
+        assert relerr(out, y) < 5e-3
+
+
 # ---------------------------------------------------------------------------- split-bf16 projections (proj_x3.hip)
 def _unsplit(raw, M, N):
     """split-bf16 rows (per 32 columns: 64 bytes of hi halves, 64 bytes of lo halves) -> float64 hi + lo"""

@@ -382,8 +382,10 @@ def test_config5_fp8_encoder_products(capsys):
         print(f"\n[config 5] V={args.vocab_size}, {g['best_paths'].size} frames, against the fp32 reference: "
               + "; ".join(f"{k}: argmax flips {v['flips']:.4f}, max |d log-posterior| {v['err']:.4f}, hypotheses identical "
                           f"{v['hyp']}/{len(g['hyp'])}" for k, v in rows.items()))
-    # 2x the measured values (fp8: 8.8 % flips, 0.081; bf16 on the same weights: 0.67 %, 5.8e-3)
-    assert rows["fp8"]["flips"] < 0.18 and rows["fp8"]["err"] < 0.17
+    # 2x the measured values (fp8, feed-forward products in e4m3 inside the chain kernel, the layer's other products bf16:
+    # 3.3 % flips, 0.032 - round 2's four-launch form with every product in e4m3 had 8.8 %, 0.081; bf16 on the same weights:
+    # 0.67 %, 5.8e-3)
+    assert rows["fp8"]["flips"] < 0.07 and rows["fp8"]["err"] < 0.065
     assert rows["bf16"]["flips"] < 0.015 and rows["bf16"]["err"] < 1.2e-2
 
 

@@ -1,0 +1,181 @@
+// Probe for v_mfma_scale_f32_32x32x64_f8f6f4 on gfx950 (e4m3 operands): operand lane map, scale semantics, issue rate.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_f8_probe tools/probe/mfma_f8_probe.hip && /tmp/mfma_f8_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <cmath>
+#define HC(x) do { if ((x) != hipSuccess) { printf("HIP error line %d\n", __LINE__); exit(1); } } while (0)
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// A: [64 lanes][32 bytes], B: [64 lanes][32 bytes], sa/sb: [64] ints (E8M0 in byte 0); D: [64 lanes][16]
+__global__ void probe_kernel(const v8i* A, const v8i* B, const int* sa, const int* sb, float* D) {
+    const int lane = threadIdx.x;
+    f32x16 c = {};
+    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[lane], B[lane], c, 0, 0, 0, sa[lane], 0, sb[lane]);
+    for (int i = 0; i < 16; ++i) D[lane * 16 + i] = c[i];
+}
+
+// two 16-byte LDS reads from asm composed into one 8-register operand: does the compiler need copies?
+__global__ void compose_kernel(const v8i* B, float* D, int sa, int sb) {
+    __shared__ __attribute__((aligned(16))) unsigned char sm[4096];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 1024; i += 64) reinterpret_cast<int*>(sm)[i] = i * 2654435761u;
+    __syncthreads();
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)sm + lane * 16;
+    v4i lo0, hi0, lo1, hi1;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(lo0), "=&v"(hi0), "=&v"(lo1), "=&v"(hi1) : "v"(addr) : "memory");
+    const v8i a0 = __builtin_shufflevector(lo0, hi0, 0, 1, 2, 3, 4, 5, 6, 7);
+    const v8i a1 = __builtin_shufflevector(lo1, hi1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const v8i b = B[lane];
+    f32x16 c = {};
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %3, %0, %4, %5 op_sel_hi:[0,0,0]\n\t"
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %2, %3, %0, %4, %5 op_sel_hi:[0,0,0]\n\t"
+                 "s_nop 15\n\ts_nop 15"
+                 : "+v"(c) : "v"(a0), "v"(a1), "v"(b), "v"(sa), "v"(sb));
+    for (int i = 0; i < 16; ++i) D[lane * 16 + i] = c[i];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void rate_kernel(long long* out, int iters, int sa, int sb) {
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    v8i a = {(int)threadIdx.x, 1, 2, 3, 4, 5, 6, 7}, b = {7, 6, 5, 4, 3, 2, 1, (int)threadIdx.x};
+    bf16x8 ha, hb;
+    for (int i = 0; i < 8; ++i) { ha[i] = (__bf16)(float)(threadIdx.x + i); hb[i] = (__bf16)(float)i; }
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %5, %1\n\t"
+                         "v_mfma_f32_32x32x16_bf16 %2, %4, %5, %2\n\tv_mfma_f32_32x32x16_bf16 %3, %4, %5, %3"
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(ha), "v"(hb));
+        } else if (MODE == 1) {
+            asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %4, %5, %0, %6, %7 op_sel_hi:[0,0,0]\n\t"
+                         "v_mfma_scale_f32_32x32x64_f8f6f4 %1, %4, %5, %1, %6, %7 op_sel_hi:[0,0,0]\n\t"
+                         "v_mfma_scale_f32_32x32x64_f8f6f4 %2, %4, %5, %2, %6, %7 op_sel_hi:[0,0,0]\n\t"
+                         "v_mfma_scale_f32_32x32x64_f8f6f4 %3, %4, %5, %3, %6, %7 op_sel_hi:[0,0,0]"
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+        } else {
+            asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %4, %5, %0\n\tv_mfma_f32_32x32x64_f8f6f4 %1, %4, %5, %1\n\t"
+                         "v_mfma_f32_32x32x64_f8f6f4 %2, %4, %5, %2\n\tv_mfma_f32_32x32x64_f8f6f4 %3, %4, %5, %3"
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b));
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+    if (c0[0] + c1[0] + c2[0] + c3[0] == 12345.f) out[1] = 1;
+}
+
+static unsigned char e4m3(int v) {  // small exact integers / halves
+    switch (v) { case 0: return 0x00; case 1: return 0x38; case 2: return 0x40; case 3: return 0x44; case -1: return 0xB8; case -2: return 0xC0; case -3: return 0xC4; }
+    return 0;
+}
+
+static void run_probe(const std::vector<unsigned char>& A, const std::vector<unsigned char>& B, const std::vector<int>& sa,
+                      const std::vector<int>& sb, std::vector<float>& D) {
+    static void *dA = nullptr, *dB, *dsa, *dsb;
+    static float* dD;
+    if (!dA) { HC(hipMalloc(&dA, 2048)); HC(hipMalloc(&dB, 2048)); HC(hipMalloc(&dsa, 256)); HC(hipMalloc(&dsb, 256)); HC(hipMalloc(&dD, 4096)); }
+    HC(hipMemcpy(dA, A.data(), 2048, hipMemcpyHostToDevice)); HC(hipMemcpy(dB, B.data(), 2048, hipMemcpyHostToDevice));
+    HC(hipMemcpy(dsa, sa.data(), 256, hipMemcpyHostToDevice)); HC(hipMemcpy(dsb, sb.data(), 256, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, 0, (const v8i*)dA, (const v8i*)dB, (const int*)dsa, (const int*)dsb, dD);
+    D.resize(1024);
+    HC(hipMemcpy(D.data(), dD, 4096, hipMemcpyDeviceToHost));
+}
+// D as [row][col]
+static std::vector<float> to_rc(const std::vector<float>& D) {
+    std::vector<float> M(1024);
+    for (int lane = 0; lane < 64; ++lane)
+        for (int reg = 0; reg < 16; ++reg) M[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = D[lane * 16 + reg];
+    return M;
+}
+
+int main() {
+    std::vector<unsigned char> A(64 * 32), B(64 * 32);
+    std::vector<int> Ai(64 * 32), Bi(64 * 32), sa(64, 127), sb(64, 127);
+    std::vector<float> D;
+    srand(1);
+    for (int i = 0; i < 64 * 32; ++i) {
+        Ai[i] = rand() % 7 - 3; Bi[i] = rand() % 7 - 3;
+        A[i] = e4m3(Ai[i]); B[i] = e4m3(Bi[i]);
+    }
+    // 1. operand pairing with unit scales: D[row][col] = sum over (h, e) of A[lane row + 32 h][e] B[lane col + 32 h][e]
+    run_probe(A, B, sa, sb, D);
+    {
+        std::vector<float> M = to_rc(D);
+        double maxd = 0;
+        for (int row = 0; row < 32; ++row)
+            for (int col = 0; col < 32; ++col) {
+                double s = 0;
+                for (int h = 0; h < 2; ++h)
+                    for (int e = 0; e < 32; ++e) s += (double)Ai[(row + 32 * h) * 32 + e] * Bi[(col + 32 * h) * 32 + e];
+                maxd = fmax(maxd, fabs(s - M[row * 32 + col]));
+            }
+        printf("unit scales (127): pairing hypothesis max |diff| = %g\n", maxd);
+    }
+    // 2. uniform scale bytes
+    for (int v : {126, 128, 130}) {
+        std::vector<int> u(64, v);
+        std::vector<float> D2;
+        run_probe(A, B, u, sb, D2);
+        double r = 0; int n = 0;
+        for (int i = 0; i < 1024; ++i) if (D[i] != 0) { r += D2[i] / D[i]; ++n; }
+        printf("scale_a = %d on every lane: mean ratio to unit-scale result %g\n", v, r / n);
+        run_probe(A, B, sa, u, D2);
+        r = 0; n = 0;
+        for (int i = 0; i < 1024; ++i) if (D[i] != 0) { r += D2[i] / D[i]; ++n; }
+        printf("scale_b = %d on every lane: mean ratio %g\n", v, r / n);
+    }
+    // 3. which lane's scale byte acts on (row, k block): A = B = 1.0; B restricted to lanes of one half; scale_a[l] = 127 + bit j of l
+    std::vector<unsigned char> ones(2048, 0x38);
+    for (int which = 0; which < 2; ++which)       // 0: decode scale_a sources, 1: scale_b sources
+        for (int blk = 0; blk < 2; ++blk) {
+            std::vector<unsigned char> half(2048, 0);
+            for (int l = 32 * blk; l < 32 * blk + 32; ++l) for (int e = 0; e < 32; ++e) half[l * 32 + e] = 0x38;
+            int src[32][32] = {};
+            for (int j = 0; j < 6; ++j) {
+                std::vector<int> sv(64);
+                for (int l = 0; l < 64; ++l) sv[l] = 127 + ((l >> j) & 1);
+                std::vector<float> Dj;
+                if (which == 0) run_probe(ones, half, sv, sb, Dj); else run_probe(half, ones, sa, sv, Dj);
+                std::vector<float> M = to_rc(Dj);
+                for (int row = 0; row < 32; ++row) for (int col = 0; col < 32; ++col) {
+                    const float v = M[row * 32 + col];  // 32 (bit 0) or 64 (bit 1), if exactly one block contributes
+                    if (v == 64.f) src[row][col] |= 1 << j; else if (v != 32.f) src[row][col] |= 1 << 30;
+                }
+            }
+            printf("scale_%c, operand lanes %d..%d hold the non-zero block: source lane of the scale for (row,col) = (0,0) %d (0,5) %d (3,0) %d (3,5) %d (31,31) %d\n",
+                   which ? 'b' : 'a', 32 * blk, 32 * blk + 31, src[0][0], src[0][5], src[3][0], src[3][5], src[31][31]);
+            bool rowdep = true, coldep = true;
+            for (int row = 0; row < 32; ++row) for (int col = 0; col < 32; ++col) {
+                if (src[row][col] != src[row][0]) rowdep = false;
+                if (src[row][col] != src[0][col]) coldep = false;
+            }
+            printf("   depends on row only: %d, on col only: %d; src[i][0], i = 0..7: %d %d %d %d %d %d %d %d; src[0][i]: %d %d %d %d %d %d %d %d\n", rowdep, coldep,
+                   src[0][0], src[1][0], src[2][0], src[3][0], src[4][0], src[5][0], src[6][0], src[7][0],
+                   src[0][0], src[0][1], src[0][2], src[0][3], src[0][4], src[0][5], src[0][6], src[0][7]);
+        }
+    long long* dT;
+    HC(hipMalloc(&dT, 64));
+    const char* names[3] = {"bf16 32x32x16", "scaled f8 32x32x64", "unscaled f8f6f4 32x32x64 (fp8)"};
+    for (int mode = 0; mode < 3; ++mode) {
+        const int iters = 2000;
+        for (int rep = 0; rep < 2; ++rep) {
+            if (mode == 0) hipLaunchKernelGGL(rate_kernel<0>, dim3(256), dim3(256), 0, 0, dT, iters, 127, 127);
+            if (mode == 1) hipLaunchKernelGGL(rate_kernel<1>, dim3(256), dim3(256), 0, 0, dT, iters, 127, 127);
+            if (mode == 2) hipLaunchKernelGGL(rate_kernel<2>, dim3(256), dim3(256), 0, 0, dT, iters, 127, 127);
+            HC(hipDeviceSynchronize());
+        }
+        long long t[2];
+        HC(hipMemcpy(t, dT, 16, hipMemcpyDeviceToHost));
+        printf("%-34s %.1f shader cycles per MFMA, one wave per SIMD, 256 workgroups of 4 waves\n", names[mode], (double)t[0] / (iters * 4.0));
+    }
+    return 0;
+}
