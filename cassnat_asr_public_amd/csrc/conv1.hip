@@ -13,7 +13,7 @@ template <typename T, bool PLANES = false>
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
                                                     const float* __restrict__ bias, T* __restrict__ out, int B, int Tn,
                                                     int F, int T1, int F1, int C, int halo, long long lo_off = 0,
-                                                    const UttMeta* __restrict__ utt_meta = nullptr) {
+                                                    const UttMeta* __restrict__ utt_meta = nullptr, float out_scale = 1.f) {
     // A thread keeps its 8 channels for the whole kernel, so the 72 tap weights + 8 biases live in registers (as pairs: the
     // 72 multiply-adds of an output position are 36 v_pk_fma_f32).  The three input rows of an output row are staged once in
     // LDS with their zero padding (index f + 1, f = -1 .. F), so a position's nine taps are nine unconditional LDS reads - the
@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
             const bool cell_in = row_in && f1 >= 0 && f1 < F1;
             if (!cell_in) {  // border cell (bordered images only), or a row past the utterance's own batch (written as zeros)
                 if (skip_border && !past_own) continue;
-                if constexpr (sizeof(T) == 2) {
+                if constexpr (sizeof(T) == 1) {  // e4m3fn image: 8 channels = 8 bytes
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(0, 0);
+                } else if constexpr (sizeof(T) == 2) {
                     *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
                     if constexpr (PLANES) *reinterpret_cast<uint4*>(dst + lo_off) = make_uint4(0, 0, 0, 0);
                 } else if constexpr (!__is_same(T, split_t)) {
@@ -95,7 +97,15 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
                 o[2 * j] = fmaxf(acc[j][0], 0.f);
                 o[2 * j + 1] = fmaxf(acc[j][1], 0.f);
             }
-            if constexpr (__is_same(T, split_t)) {  // (no bordered image in this precision: halo == 0)
+            if constexpr (sizeof(T) == 1) {  // e4m3fn at `out_scale`, saturating (the values are >= 0 already)
+                unsigned w0 = 0, w1 = 0;
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(o[0] * out_scale, CN_FP8_MAX), fminf(o[1] * out_scale, CN_FP8_MAX), w0, false);
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(o[2] * out_scale, CN_FP8_MAX), fminf(o[3] * out_scale, CN_FP8_MAX), w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(o[4] * out_scale, CN_FP8_MAX), fminf(o[5] * out_scale, CN_FP8_MAX), w1, false);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(o[6] * out_scale, CN_FP8_MAX), fminf(o[7] * out_scale, CN_FP8_MAX), w1, true);
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_nontemporal_store(u32x2{w0, w1}, reinterpret_cast<u32x2*>(dst));
+            } else if constexpr (__is_same(T, split_t)) {  // (no bordered image in this precision: halo == 0)
                 bf16x8 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -174,6 +184,23 @@ int launch_conv1_planes(const float* x, const float* w9c, const float* bias, voi
     const long long plane = (long long)B * (T1 + 2) * (F1 + 2) * C;
     hipLaunchKernelGGL((conv1_kernel<bf16, true>), dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (bf16*)out, B, T, F, T1,
                        F1, C, halo, plane, utt_meta);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// the fp8 engine's image for conv2's e4m3 form (launch_conv2_f8): bordered, one byte per element at `scale` (a power of two)
+int launch_conv1_f8(const float* x, const float* w9c, const float* bias, void* out8, int B, int T, int F, int T1, int F1, int C,
+                    int halo, float scale, hipStream_t s, const UttMeta* utt_meta) {
+    if (C % 8 != 0 || (256 % (C / 8)) != 0 || (halo != 1 && halo != 2)) {
+        cn_set_error("conv1 (e4m3): channel count must be a multiple of 8 with C/8 dividing 256; the image is always bordered");
+        return -1;
+    }
+    long long blocks = (long long)B * (T1 + 2);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    const size_t lds = (size_t)2 * 3 * (F + 2) * sizeof(float);
+    hipLaunchKernelGGL((conv1_kernel<fp8_t>), dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (fp8_t*)out8, B, T, F, T1, F1,
+                       C, halo, 0ll, utt_meta, scale);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -30,6 +30,9 @@ struct Conv2Params {
     // X3 (template; split-bf16 engine): A and W are the planes of the hi halves, these the planes of the lo halves (same layouts)
     const unsigned char* A_lo;
     const unsigned char* W_lo;
+    // F8 (template; the fp8 engine of BASELINE config 5): A and W hold e4m3fn bytes (same layouts, 256 / 9 * 256 bytes per row),
+    // q8 = the two E8M0 scale bytes of the products (device: they travel in the weight blob): 127 - log2(scale of W), 127 - log2(scale of A)
+    const int* q8;
     const float* bias;
     bf16* out;                   // [M][256] (X3: split-bf16 rows, 1 KiB each)
     int M, T1, F1, T2, F2, ntiles;
@@ -94,14 +97,53 @@ constexpr int C2_KSTEPS = 9 * (C2_C / 64);
                    [vo5] "v"(vo[5]), [vo6] "v"(vo[6]), [vo7] "v"(vo[7]), [st] "s"(st_), [sb] "s"(sb_)          \
                  : "memory", "scc")
 
+// F8 form of a block: one 64-wide k sub-step = 16 x v_mfma_scale_f32_32x32x64_f8f6f4 (64 cycles each: the block takes as long as two
+// bf16 blocks and covers four times the contraction).  An operand is the pair of 16-byte fragments the bf16 kernel reads for
+// sub-steps 2 s and 2 s + 1 (same LDS image, same read instructions, same swizzle): lane half h then holds bytes of chunks
+// 4 s + h and 4 s + 2 + h of the 128-byte slab row - for A and W alike, so every channel of the 64 meets its weight.  Sixteen
+// fragment reads of the NEXT sub-step go behind the first eight MFMAs, up to eight DMA pieces behind the last eight.
+#define C2_MF8 "v_mfma_scale_f32_32x32x64_f8f6f4 "
+#define C2_M8(nt, mt) C2_MF8 "%[c" #nt #mt "], %[w" #nt "], %[a" #mt "], %[c" #nt #mt "], %[qa], %[qb] op_sel_hi:[0,0,0]\n\t"
+#define C2_RDA8(i) "ds_read_b128 %[na" #i "], %[an0] offset:" C2_STR(i * 4096) "\n\tds_read_b128 %[nb" #i "], %[an1] offset:" C2_STR(i * 4096) "\n\t"
+#define C2_RDW8(i) "ds_read_b128 %[nw" #i "], %[wn0] offset:" C2_STR(i * 4096) "\n\tds_read_b128 %[nv" #i "], %[wn1] offset:" C2_STR(i * 4096) "\n\t"
+// W slab pieces are 32 weight rows apart: one lane offset, stepped by the block itself (eight more offset registers were
+// eight too many for the e4m3 form: hipcc kept them in scratch and drained the request queue to reload them, every block)
+#define C2_DMA_W8(i) "s_add_u32 m0, %[st], " C2_STR(i * 4096) "\n\tglobal_load_lds_dwordx4 %[tv], %[sb]\n\tv_add_u32 %[tv], %[wstep], %[tv]\n\t"
+#define C2_JOIN(lo, hi) __builtin_shufflevector(__builtin_bit_cast(c2_v4i, lo), __builtin_bit_cast(c2_v4i, hi), 0, 1, 2, 3, 4, 5, 6, 7)
+#define C2_BLOCK8(PRE, A0c, W0c, A1c, W1c, A0n, W0n, A1n, W1n, DMA, vo)                                        \
+    asm volatile(PRE "s_waitcnt lgkmcnt(0)\n\t"                                                                \
+                 C2_M8(0, 0) C2_RDA8(0) C2_M8(0, 1) C2_RDA8(1) C2_M8(0, 2) C2_RDA8(2) C2_M8(0, 3) C2_RDA8(3)   \
+                 C2_M8(1, 0) C2_RDW8(0) C2_M8(1, 1) C2_RDW8(1) C2_M8(1, 2) C2_RDW8(2) C2_M8(1, 3) C2_RDW8(3)   \
+                 C2_M8(2, 0) DMA(0) C2_M8(2, 1) DMA(1) C2_M8(2, 2) DMA(2) C2_M8(2, 3) DMA(3)                   \
+                 C2_M8(3, 0) DMA(4) C2_M8(3, 1) DMA(5) C2_M8(3, 2) DMA(6) C2_M8(3, 3) DMA(7)                   \
+                 : [c00] "+a"(acc[0]), [c01] "+a"(acc[1]), [c02] "+a"(acc[2]), [c03] "+a"(acc[3]), [c10] "+a"(acc[4]), \
+                   [c11] "+a"(acc[5]), [c12] "+a"(acc[6]), [c13] "+a"(acc[7]), [c20] "+a"(acc[8]), [c21] "+a"(acc[9]), \
+                   [c22] "+a"(acc[10]), [c23] "+a"(acc[11]), [c30] "+a"(acc[12]), [c31] "+a"(acc[13]),          \
+                   [c32] "+a"(acc[14]), [c33] "+a"(acc[15]), [na0] "=&v"(A0n[0]), [na1] "=&v"(A0n[1]),          \
+                   [na2] "=&v"(A0n[2]), [na3] "=&v"(A0n[3]), [nb0] "=&v"(A1n[0]), [nb1] "=&v"(A1n[1]),          \
+                   [nb2] "=&v"(A1n[2]), [nb3] "=&v"(A1n[3]), [nw0] "=&v"(W0n[0]), [nw1] "=&v"(W0n[1]),          \
+                   [nw2] "=&v"(W0n[2]), [nw3] "=&v"(W0n[3]), [nv0] "=&v"(W1n[0]), [nv1] "=&v"(W1n[1]),          \
+                   [nv2] "=&v"(W1n[2]), [nv3] "=&v"(W1n[3]), [tv] "+v"(tv_)                                    \
+                 : [a0] "v"(C2_JOIN(A0c[0], A1c[0])), [a1] "v"(C2_JOIN(A0c[1], A1c[1])), [a2] "v"(C2_JOIN(A0c[2], A1c[2])), \
+                   [a3] "v"(C2_JOIN(A0c[3], A1c[3])), [w0] "v"(C2_JOIN(W0c[0], W1c[0])), [w1] "v"(C2_JOIN(W0c[1], W1c[1])), \
+                   [w2] "v"(C2_JOIN(W0c[2], W1c[2])), [w3] "v"(C2_JOIN(W0c[3], W1c[3])), [an0] "v"(an0_), [an1] "v"(an1_), \
+                   [wn0] "v"(wn0_), [wn1] "v"(wn1_), [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), \
+                   [vo4] "v"(vo[4]), [vo5] "v"(vo[5]), [vo6] "v"(vo[6]), [vo7] "v"(vo[7]), [st] "s"(st_), [sb] "s"(sb_), \
+                   [qa] "v"(qa_), [qb] "v"(qb_), [wstep] "s"(wstep_)                                           \
+                 : "memory", "scc")
+typedef int c2_v4i __attribute__((ext_vector_type(4)));
+
 // LINEAR = false: the 3x3 / stride-2 convolution; true: a plain K-major GEMM with N = 256 (same tiles, stream and blocks)
 // X3 (convolution only): the split-bf16 product.  conv1 wrote the image as two bf16 planes (hi, lo) and the weights come as two
 // matrices; every K step of the bf16 loop becomes three - (A_hi, W_lo), (A_lo, W_hi), (A_hi, W_hi): the small terms first, the hi
 // slab of A asked for twice in a row (the second time from L2) - on the same stages, blocks and accumulators: the kernel is the
 // bf16 kernel with 108 K steps and another epilogue (bias + ReLU + hi / lo split, split-bf16 rows).
-template <bool LINEAR, bool X3 = false>
+// F8 (convolution only): e4m3 operands on the K = 64 block-scaled MFMA at twice the bf16 rate (C2_BLOCK8); slabs, stages and
+// requests as in the bf16 kernel, a slab row now being 128 channels: 18 K steps of two blocks each
+template <bool LINEAR, bool X3 = false, bool F8 = false>
 __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
-    static_assert(!(LINEAR && X3), "the split form exists for the convolution only");
+    static_assert(!(LINEAR && X3) && !(F8 && (LINEAR || X3)), "the split and e4m3 forms exist for the convolution only");
+    constexpr int ES = F8 ? 1 : 2;  // bytes per image / weight element
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,7 +170,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         if constexpr (LINEAR) return (long long)mm * p.lda_bytes;
         const int f2 = mm % p.F2, bt = mm / p.F2;
         const int t2 = bt % p.T2, b = bt / p.T2;
-        return (((long long)b * (p.T1 + 2) + 2 * t2) * F1p + 2 * f2) * (C2_C * 2);
+        return (((long long)b * (p.T1 + 2) + 2 * t2) * F1p + 2 * f2) * (C2_C * ES);
     };
     const long long tile_off = a_off(m0);  // (m0 < M: the grid has ceil(M / 256) workgroups)
     unsigned pa[8], pw[8];
@@ -141,12 +183,12 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         if constexpr (LINEAR)
             pw[i] = (unsigned)(row * (p.ksteps * 128)) + sw;
         else
-            pw[i] = (unsigned)(row * (9 * C2_C * 2)) + sw;
+            pw[i] = (unsigned)(row * (9 * C2_C * ES)) + sw;
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const unsigned m0_wave = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
     // source bases / destinations of K step kt (channel block outermost, tap innermost), stage kt & 1
-    const int KSTEPS = LINEAR ? p.ksteps : (X3 ? 3 * C2_KSTEPS : C2_KSTEPS);
+    const int KSTEPS = LINEAR ? p.ksteps : (X3 ? 3 * C2_KSTEPS : (F8 ? C2_KSTEPS / 2 : C2_KSTEPS));
     auto a_base = [&](int kt) -> const unsigned char* {
         if constexpr (LINEAR) return p.A + tile_off + (long long)kt * 128;
         const unsigned char* plane = p.A + tile_off;
@@ -157,7 +199,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         }
         const int cb = kt / 9, tap = kt - 9 * cb;
         const int kh = tap / 3, kw = tap - 3 * kh;
-        return plane + (long long)((kh * F1p + kw) * (C2_C * 2) + cb * 128);
+        return plane + (long long)((kh * F1p + kw) * (C2_C * ES) + cb * 128);
     };
     auto w_base = [&](int kt) -> const unsigned char* {
         if constexpr (LINEAR) return p.W + (long long)kt * 128;
@@ -168,7 +210,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
             kt = k;
         }
         const int cb = kt / 9, tap = kt - 9 * cb;
-        return plane + (long long)((tap * C2_C + cb * 64) * 2);
+        return plane + (long long)(tap * C2_C * ES + cb * 128);
     };
     // K step kt lives in A stage kt % 3 and W stage kt & 1
     auto a_dst = [&](int k3) -> unsigned { return m0_wave + (unsigned)(k3 * C2_SLAB); };
@@ -198,6 +240,79 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
     bf16x8 Ax[4], Wx[4], Ay[4], Wy[4];  // fragment sets X / Y alternate between sub-steps (4 per step: a step starts on X)
 
     const int KL = KSTEPS - 1;
+#ifdef C2_EXP_NO_VMWAIT  // timing experiment: the K loop without its wait for the next slabs (wrong results)
+#define C2_PRE3 "s_waitcnt lgkmcnt(0)\n\ts_barrier\n\t"
+#else
+#define C2_PRE3 "s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier\n\t"
+#endif
+#define C2_PRE3_ALL "s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)\n\ts_barrier\n\t"
+    if constexpr (F8) {
+        // ---- e4m3 loop: two blocks per K step.  Block 0 (sub-step 0 of stage kt; reads sub-step 1) requests the A slab of step
+        // kt + 2; block 1 starts with the step's barrier (own fragments landed; everything but that A slab landed: vmcnt(8)), reads
+        // sub-step 0 of step kt + 1 behind it and requests the W slab of step kt + 2 into the W stage the barrier has just freed.
+        // So an A slab (HBM) has a step and a half to arrive, a W slab (L2) one step - as in the bf16 loop.
+        bf16x8 Az[4], Wz[4], Au[4], Wu[4];
+        const int qa_ = p.q8[0], qb_ = p.q8[1];
+        const unsigned wstep_ = 32u * (9 * C2_C * ES);  // byte distance of consecutive W pieces (32 weight rows)
+        const unsigned pw0 = pw[0];
+        unsigned tv_ = pw0;
+        C2_ISSUE8(a_dst(0), pa, a_base(0))
+        C2_ISSUE8(w_dst(0), pw, w_base(0))
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        C2_ISSUE8(a_dst(1), pa, a_base(min(1, KL)))
+        C2_ISSUE8(w_dst(1), pw, w_base(min(1, KL)))
+        {  // fragments of step 0, sub-step 0 (chunks of the bf16 sub-steps 0 and 1), landed before anything else touches them
+            const unsigned an0_ = a_rd0, an1_ = C2_RD(a_rd0, 1, 0), wn0_ = w_rd0, wn1_ = C2_RD(w_rd0, 1, 0);
+            asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %16 offset:4096\n\tds_read_b128 %2, %16 offset:8192\n\t"
+                         "ds_read_b128 %3, %16 offset:12288\n\tds_read_b128 %4, %17\n\tds_read_b128 %5, %17 offset:4096\n\t"
+                         "ds_read_b128 %6, %17 offset:8192\n\tds_read_b128 %7, %17 offset:12288\n\t"
+                         "ds_read_b128 %8, %18\n\tds_read_b128 %9, %18 offset:4096\n\tds_read_b128 %10, %18 offset:8192\n\t"
+                         "ds_read_b128 %11, %18 offset:12288\n\tds_read_b128 %12, %19\n\tds_read_b128 %13, %19 offset:4096\n\t"
+                         "ds_read_b128 %14, %19 offset:8192\n\tds_read_b128 %15, %19 offset:12288\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(Ax[0]), "=&v"(Ax[1]), "=&v"(Ax[2]), "=&v"(Ax[3]), "=&v"(Wx[0]), "=&v"(Wx[1]), "=&v"(Wx[2]),
+                           "=&v"(Wx[3]), "=&v"(Ay[0]), "=&v"(Ay[1]), "=&v"(Ay[2]), "=&v"(Ay[3]), "=&v"(Wy[0]), "=&v"(Wy[1]),
+                           "=&v"(Wy[2]), "=&v"(Wy[3])
+                         : "v"(an0_), "v"(wn0_), "v"(an1_), "v"(wn1_)
+                         : "memory");
+        }
+        // (fully unrolled - 18 steps of two blocks: with a back edge hipcc gave the 256 accumulator registers another
+        // assignment at the loop's end than at its head and moved half of them through scratch, every iteration)
+        constexpr int KS8 = C2_KSTEPS / 2;
+#pragma unroll
+        for (int kt = 0; kt < KS8; ++kt) {
+            const int k3 = kt % 3;
+            const int k3n = k3 == 2 ? 0 : k3 + 1, k3p = k3 == 0 ? 2 : k3 - 1;
+            const unsigned so_a = (unsigned)(k3 * C2_SLAB), so_w = (unsigned)((kt & 1) * C2_SLAB);
+            const unsigned sn_a = (unsigned)(k3n * C2_SLAB), sn_w = (unsigned)(((kt + 1) & 1) * C2_SLAB);
+            // (branch-free: past the last K step the requests repeat the last slabs into stages nobody reads any more - with the
+            // two forms of a block behind a branch, as in the bf16 loop, hipcc reshuffled all fragment sets through scratch at every
+            // join; the wait after the loop covers the redundant requests)
+            {
+                const unsigned an0_ = C2_RD(a_rd0, 2, so_a), an1_ = C2_RD(a_rd0, 3, so_a);
+                const unsigned wn0_ = C2_RD(w_rd0, 2, so_w), wn1_ = C2_RD(w_rd0, 3, so_w);
+                const unsigned* vo = pa;
+                const unsigned st_ = a_dst(k3p);  // (kt + 2) % 3
+                const unsigned char* sb_ = a_base(min(kt + 2, KL));
+                C2_BLOCK8("", Ax, Wx, Ay, Wy, Az, Wz, Au, Wu, C2_DMA_I, vo);
+            }
+            {
+                const unsigned an0_ = a_rd0 + sn_a, an1_ = C2_RD(a_rd0, 1, sn_a);
+                const unsigned wn0_ = w_rd0 + sn_w, wn1_ = C2_RD(w_rd0, 1, sn_w);
+                const unsigned* vo = pa;  // (not used by this block's requests)
+                const unsigned st_ = w_dst(kt + 2);
+                const unsigned char* sb_ = w_base(min(kt + 2, KL));
+                tv_ = pw0;
+                C2_BLOCK8(C2_PRE3, Az, Wz, Au, Wu, Ax, Wx, Ay, Wy, C2_DMA_W8, vo);
+            }
+        }
+        // a 16-pass MFMA's result is readable 19 wait states later; the last block's (unused) fragments land here
+        asm volatile("s_nop 15\n\ts_nop 4\n\ts_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)"
+                     : "+v"(Ax[0]), "+v"(Ax[1]), "+v"(Ax[2]), "+v"(Ax[3]), "+v"(Wx[0]), "+v"(Wx[1]), "+v"(Wx[2]), "+v"(Wx[3]),
+                       "+v"(Ay[0]), "+v"(Ay[1]), "+v"(Ay[2]), "+v"(Ay[3]), "+v"(Wy[0]), "+v"(Wy[1]), "+v"(Wy[2]), "+v"(Wy[3])
+                     :: "memory");
+        asm volatile("" : "+v"(Az[0]), "+v"(Az[1]), "+v"(Az[2]), "+v"(Az[3]), "+v"(Wz[0]), "+v"(Wz[1]), "+v"(Wz[2]), "+v"(Wz[3]),
+                     "+v"(Au[0]), "+v"(Au[1]), "+v"(Au[2]), "+v"(Au[3]), "+v"(Wu[0]), "+v"(Wu[1]), "+v"(Wu[2]), "+v"(Wu[3]) :: "memory");
+    } else {
     C2_ISSUE8(a_dst(0), pa, a_base(0))
     C2_ISSUE8(w_dst(0), pw, w_base(0))
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -217,12 +332,6 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
     // (lgkmcnt) and for its share of step kt + 1 with vmcnt(8), i.e. everything but the A slab just requested, then the barrier
     // publishes step kt + 1.  The A slab comes from HBM: with two stages it had one K step (2048 cycles of MFMA) to arrive and
     // the loop waited for it (without the wait: -10 %); now it has a step and a half.  W comes from L2.
-#ifdef C2_EXP_NO_VMWAIT  // timing experiment: the K loop without its wait for the next slabs (wrong results)
-#define C2_PRE3 "s_waitcnt lgkmcnt(0)\n\ts_barrier\n\t"
-#else
-#define C2_PRE3 "s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier\n\t"
-#endif
-#define C2_PRE3_ALL "s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)\n\ts_barrier\n\t"
     // (LINEAR: branch-free, past the last K step the requests repeat the last slabs into stages nobody reads any more; the
     // convolution branches instead - in the branch-free form hipcc spills the request offsets to scratch inside the loop)
     int k3 = 0;  // kt % 3
@@ -283,6 +392,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
                  : "+v"(Ax[0]), "+v"(Ax[1]), "+v"(Ax[2]), "+v"(Ax[3]), "+v"(Wx[0]), "+v"(Wx[1]), "+v"(Wx[2]), "+v"(Wx[3]),
                    "+v"(Ay[0]), "+v"(Ay[1]), "+v"(Ay[2]), "+v"(Ay[3]), "+v"(Wy[0]), "+v"(Wy[1]), "+v"(Wy[2]), "+v"(Wy[3])
                  :: "memory");
+    }
     if constexpr (LINEAR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant requests of the last steps (they write this workgroup's LDS)
 
     if constexpr (LINEAR) {
@@ -424,6 +534,37 @@ int launch_conv2_dma(const void* in, const void* w, const float* bias, void* out
     if (p.M <= 0) return 0;
     if (conv2_tile_span_too_large(T1, F1, F2)) return -1;
     hipLaunchKernelGGL(conv2_kernel<false>, dim3(p.ntiles), dim3(256), C2_LDS, s, p);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// the fp8 engine's convolution (BASELINE config 5): `in8` = conv1's e4m3fn image WITH the zero halo ([B][T1 + 2][F1 + 2][256] bytes),
+// `w8` = [256][9 * 256] e4m3fn (k = (kh * 3 + kw) * 256 + ci), `q8_dev` = {127 - log2(weight scale), 127 - log2(image scale)}; out bf16
+bool conv2_f8_applies(int C, int N) { return C == C2_C && N == C2_N && !getenv("CASSNAT_NO_CONV2_F8"); }
+
+int launch_conv2_f8(const void* in8, const void* w8, const int* q8_dev, const float* bias, void* out, int B, int T1, int F1, int T2,
+                    int F2, hipStream_t s) {
+    static CnAttrOnce attr_once;
+    int attr_dev;
+    if (attr_once.need(&attr_dev)) {
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)conv2_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS));
+        attr_once.mark(attr_dev);
+    }
+    if (conv2_tile_span_too_large(T1, F1, F2)) return -1;
+    Conv2Params p = {};
+    p.A = (const unsigned char*)in8;
+    p.W = (const unsigned char*)w8;
+    p.q8 = q8_dev;
+    p.bias = bias;
+    p.out = (bf16*)out;
+    p.M = B * T2 * F2;
+    p.T1 = T1;
+    p.F1 = F1;
+    p.T2 = T2;
+    p.F2 = F2;
+    p.ntiles = cn_ceil_div(p.M, C2_BM);
+    if (p.M <= 0) return 0;
+    hipLaunchKernelGGL((conv2_kernel<false, false, true>), dim3(p.ntiles), dim3(256), C2_LDS, s, p);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -57,6 +57,9 @@ int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, 
 // split-bf16 engine: the image as two bordered bf16 planes (hi, then lo), for launch_conv2_x3; halo 1 / 2 as above
 int launch_conv1_planes(const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1, int F1,
                         int C, int halo, hipStream_t s, const UttMeta* utt_meta = nullptr);
+// fp8 engine (BASELINE config 5): the bordered image as e4m3fn bytes at `scale`, for launch_conv2_f8
+int launch_conv1_f8(const float* x, const float* w9c, const float* bias, void* out8, int B, int T, int F, int T1, int F1, int C,
+                    int halo, float scale, hipStream_t s, const UttMeta* utt_meta = nullptr);
 // the UttMeta records of a merged pass from its (rows, frames) list: n_sub <= CN_MAX_SUB batches, given by value
 constexpr int CN_MAX_SUB = 64;
 struct SubList {
@@ -255,6 +258,9 @@ int launch_fbank(const FbankOpts& o, const float* wave, const int* num_samples, 
 // ---- conv2 as an LDS-DMA implicit GEMM, bf16 / 256 -> 256 channels (conv2.hip); launch_gemm dispatches to it
 bool conv2_dma_applies(int prec, int C, int N);
 // split-bf16 form of the same kernel: image and weights as hi / lo bf16 planes, three K steps per K step of the bf16 loop
+bool conv2_f8_applies(int C, int N);
+int launch_conv2_f8(const void* in8, const void* w8, const int* q8_dev, const float* bias, void* out, int B, int T1, int F1, int T2,
+                    int F2, hipStream_t s);
 bool conv2_x3_applies(int prec, int C, int N);
 int launch_conv2_x3(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias, void* out, int B,
                     int T1, int F1, int T2, int F2, hipStream_t s);

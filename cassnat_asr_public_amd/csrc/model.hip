@@ -51,6 +51,9 @@ struct ConvMod {
     float *gn_w = nullptr, *gn_b = nullptr;  // GroupNorm(1, d) affine
     int k = 0;
 };
+// fp8 engine: scale of the e4m3 image conv1 writes for conv2's e4m3 form (ReLU outputs: x8, saturating at 56 - as the hidden
+// activations of the feed-forward products)
+constexpr float FP8_S_IMG = 8.f;
 struct ChainRef {
     void* w = nullptr;
     float* tab = nullptr;
@@ -144,6 +147,8 @@ struct cn_model {
     float* conv1_w = nullptr;  // [9][C]
     float* conv1_b = nullptr;
     Linear conv2;       // [C][9C] (kh,kw,cin)
+    void* conv2_f8w = nullptr;  // fp8 engine, 256 channels: the same matrix as e4m3fn bytes at a per-tensor power-of-two scale, and
+    int* conv2_f8q = nullptr;   // the two E8M0 scale bytes of conv2.hip's e4m3 form {127 - log2(weight scale), 127 - log2(image scale)}
     void* conv2_x3w = nullptr;  // split-bf16 engine, 256 channels: the same matrix as two bf16 planes (hi, then lo) for conv2.hip's X3 form
     Linear linear_out;  // [d][F2*C] (f,c)
     std::vector<Layer> enc, extra, sad, mad;
@@ -765,6 +770,26 @@ int build_weights(cn_model* m) {
             }
             m->conv2_x3w = reinterpret_cast<void*>(pat);
         }
+        if (m->fp8_enc && conv2_f8_applies((int)C, (int)C)) {  // config 5: the second convolution on e4m3 operands (conv2.hip, F8)
+            const size_t fat = pk.reserve((size_t)C * 9 * C), qat = pk.reserve(16);
+            if (pk.fill) {
+                const HostTensor* t = pk.find("src_embed.conv.2.weight", {C, C, 3, 3});
+                if (t) {
+                    float mx = 0.f;
+                    for (float v : t->data) mx = std::max(mx, std::fabs(v));
+                    const int lg = mx > 0.f ? (int)std::floor(std::log2(448.f / mx)) : 0;
+                    const float scale = std::ldexp(1.f, lg);
+                    for (int64_t co = 0; co < C; ++co)
+                        for (int64_t ci = 0; ci < C; ++ci)
+                            for (int tap = 0; tap < 9; ++tap)
+                                pk.host[fat + (size_t)(co * 9 * C + tap * C + ci)] = cn_f32_to_e4m3_host(t->data[(co * C + ci) * 9 + tap] * scale);
+                    const int q[4] = {127 - lg, 127 - (int)std::lround(std::log2(FP8_S_IMG)), 0, 0};
+                    std::memcpy(&pk.host[qat], q, 16);
+                }
+            }
+            m->conv2_f8w = reinterpret_cast<void*>(fat);
+            m->conv2_f8q = reinterpret_cast<int*>(qat);
+        }
         m->conv2.b = pk.vec({"src_embed.conv.2.bias"}, C);
     }
     // linear_out: column c*F2+f of the reference (embedding.py:118) -> column f*C+c (the conv2 GEMM's natural output)
@@ -1029,6 +1054,8 @@ int build_weights(cn_model* m) {
     rebase(m->conv1_b, base);
     rebase_linear(m->conv2, base);
     rebase(m->conv2_x3w, base);
+    rebase(m->conv2_f8w, base);
+    rebase(m->conv2_f8q, base);
     rebase_linear(m->linear_out, base);
     auto rebase_layers = [&](std::vector<Layer>& v) {
         for (auto& L : v) {
@@ -1427,7 +1454,7 @@ int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ld
 // ReLU hidden activations x8 (saturating at 56).  Accumulation, bias, residual and LayerNorm stay fp32; attention runs
 // on the bf16 Q|K|V the first product writes.  LayerNorm and the first FFN product write their fp8 outputs directly; only
 // the attention context needs a quantisation pass.
-constexpr float FP8_S_LN = 16.f, FP8_S_CTX = 16.f, FP8_S_HID = 8.f;
+constexpr float FP8_S_LN = 16.f, FP8_S_CTX = 16.f, FP8_S_HID = 8.f;  // (FP8_S_IMG, the conv1 image's: at the top of the file)
 int run_linear_fp8(cn_model* m, const char* tag, const Linear& l, const void* a8, float a_scale, void* C, int ldc, int c_f32,
                    int c_fp8, float c_scale, int M, int epi, const float* resid, int ldr, hipStream_t s) {
     ProfScope ps(m, tag, 2.0 * M * l.N * l.K, (double)M * l.K + (double)l.N * l.K + (double)M * l.N * (c_f32 ? 4 : (c_fp8 ? 1 : 2)), s);
@@ -1763,7 +1790,10 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     // conv1 writes its image with a zero halo when the LDS-DMA conv2 kernel consumes it (captures want the plain image)
     // (the split-bf16 engine: two bordered bf16 planes, hi and lo, for the same kernel's X3 form)
     const bool x3_planes = !cap && m->conv2_x3w && conv2_x3_applies(m->prec, d, d);
-    const int halo = ((!cap && conv2_dma_applies(m->prec, d, d)) || x3_planes) ? 1 : 0;
+    // (the fp8 engine: an e4m3 image for the same kernel's F8 form - config 5's "fp8 MFMA encoder GEMMs" include the largest one)
+    // (also under capture - the accuracy of the mode is measured on captures; the e4m3 image itself is then not captured)
+    const bool f8_img = m->fp8_enc && m->conv2_f8w && conv2_f8_applies(d, d);
+    const int halo = ((!cap && conv2_dma_applies(m->prec, d, d)) || x3_planes || f8_img) ? 1 : 0;
     {
         // the halo cells of the image buffer are zero already when the previous haloed image had this very shape (and nothing
         // else wrote the buffer since): conv1 then writes the interior only (halo mode 2)
@@ -1772,12 +1802,14 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         const UttMeta* um = m->ragged ? m->utt_meta : nullptr;
         if (x3_planes)
             CN_TRY(launch_conv1_planes(feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : 1, s, um));
+        else if (f8_img)
+            CN_TRY(launch_conv1_f8(feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : 1, FP8_S_IMG, s, um));
         else
             CN_TRY(launch_conv1(m->prec, feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : halo, s, um));
         m->c1_halo_B = halo ? B : -1;
         m->c1_halo_T1 = halo ? T1 : -1;
     }
-    if (cap) CN_TRY(capture(m, "conv1", m->c1, true, CN_DTYPE_F32, {B, T1, F1, d}, s));
+    if (cap && !f8_img) CN_TRY(capture(m, "conv1", m->c1, true, CN_DTYPE_F32, {B, T1, F1, d}, s));
     {
         GemmArgs g;
         g.A = m->c1;
@@ -1803,6 +1835,8 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
             const size_t img = (size_t)B * (T1 + 2) * (F1 + 2) * d * 2, wpl = (size_t)d * 9 * d * 2;
             CN_TRY(launch_conv2_x3(m->c1, (const unsigned char*)m->c1 + img, m->conv2_x3w, (const unsigned char*)m->conv2_x3w + wpl,
                                    m->conv2.b, m->c2, B, T1, F1, Tp, F2, s));
+        } else if (f8_img) {
+            CN_TRY(launch_conv2_f8(m->c1, m->conv2_f8w, m->conv2_f8q, m->conv2.b, m->c2, B, T1, F1, Tp, F2, s));
         } else {
             CN_TRY(launch_gemm(m->prec, g, s));
         }
@@ -2957,6 +2991,48 @@ extern "C" int cn_op_convert(int32_t precision, const void* src, void* dst, int6
 extern "C" int cn_op_conv1(int32_t precision, const float* x, const float* w9c, const float* bias, void* out, int32_t B,
                            int32_t T, int32_t F, int32_t C, void* stream) {
     return launch_conv1(precision, x, w9c, bias, out, B, T, F, (T - 1) / 2 + 1, (F - 1) / 2 + 1, C, 0, (hipStream_t)stream);
+}
+
+// conv front-end of the fp8 engine through the ABI (config 5): conv1 -> e4m3fn image at `img_scale` (bordered) -> conv2 on e4m3
+// operands; w2_host fp32 [C][3][3][C] (k = (kh * 3 + kw) * C + ci) is quantised here at the largest power-of-two scale that keeps it
+// in range.  img8_out_dev (optional): the bordered image [B][T1 + 2][F1 + 2][C] bytes.  out: bf16 [B * T2 * F2][C]
+extern "C" int cn_op_conv_frontend_fp8(const float* x_dev, const float* w1_9c_dev, const float* b1_dev, const float* w2_host,
+                                       const float* b2_dev, void* out_dev, void* img8_out_dev, int32_t B, int32_t T, int32_t F,
+                                       int32_t C, float img_scale, float* w_scale_out, void* stream) {
+    if (!conv2_f8_applies(C, C)) {
+        cn_set_error("cn_op_conv_frontend_fp8: 256 channels only");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int T1 = (T - 1) / 2 + 1, F1 = (F - 1) / 2 + 1, T2 = (T1 - 1) / 2 + 1, F2 = (F1 - 1) / 2 + 1;
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)C * 9 * C; ++i) mx = std::max(mx, std::fabs(w2_host[i]));
+    const int lg = mx > 0.f ? (int)std::floor(std::log2(448.f / mx)) : 0;
+    const float ws = std::ldexp(1.f, lg);
+    if (w_scale_out) *w_scale_out = ws;
+    std::vector<unsigned char> w8((size_t)C * 9 * C);
+    for (size_t i = 0; i < w8.size(); ++i) w8[i] = cn_f32_to_e4m3_host(w2_host[i] * ws);
+    const int q[4] = {127 - lg, 127 - (int)std::lround(std::log2(img_scale)), 0, 0};
+    const size_t img_bytes = (size_t)B * (T1 + 2) * (F1 + 2) * C;
+    void *dw = nullptr, *dq = nullptr, *img = nullptr;
+    CN_HIP_CHECK(hipMalloc(&dw, w8.size()));
+    CN_HIP_CHECK(hipMalloc(&dq, 16));
+    CN_HIP_CHECK(hipMalloc(&img, img_bytes));
+    CN_HIP_CHECK(hipMemcpy(dw, w8.data(), w8.size(), hipMemcpyHostToDevice));
+    CN_HIP_CHECK(hipMemcpy(dq, q, 16, hipMemcpyHostToDevice));
+    CN_HIP_CHECK(hipMemsetAsync(img, 0xff, img_bytes, s));  // (NaN bytes: the kernel must write every cell, border included)
+    int rc = launch_conv1_f8(x_dev, w1_9c_dev, b1_dev, img, B, T, F, T1, F1, C, 1, img_scale, s);
+    if (rc == 0) rc = launch_conv2_f8(img, dw, (const int*)dq, b2_dev, out_dev, B, T1, F1, T2, F2, s);
+    if (rc == 0 && img8_out_dev) CN_HIP_CHECK(hipMemcpyAsync(img8_out_dev, img, img_bytes, hipMemcpyDeviceToDevice, s));
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    (void)hipFree(dq);
+    (void)hipFree(img);
+    if (rc == 0 && e != hipSuccess) {
+        cn_set_error(std::string("cn_op_conv_frontend_fp8: ") + hipGetErrorString(e));
+        rc = -2;
+    }
+    return rc;
 }
 
 extern "C" int cn_op_conv2(int32_t precision, const void* conv1_out, const void* w_khwc, const float* bias, void* out,

@@ -274,6 +274,13 @@ int cn_op_gemm(int32_t precision, const void* A, int32_t lda, const void* W, con
                const float* pe, int32_t pe_period, float scale, void* stream);
 int cn_op_conv1(int32_t precision, const float* x, const float* w9c, const float* bias, void* out, int32_t B, int32_t T,
                 int32_t F, int32_t C, void* stream);
+/* fp8 engine's conv front-end (BASELINE config 5, src/models/modules/embedding.py:102-108 on e4m3fn operands): conv1 + ReLU written as
+ * an e4m3fn image at img_scale (a power of two; saturating), conv2 + ReLU from it with w2 (HOST fp32, [C][3][3][C]: k = (kh*3+kw)*C + ci)
+ * quantised at the largest power-of-two scale that keeps max|w| <= 448 (returned in *w_scale_out); out bf16 [B*T2*F2][C].  C == 256.
+ * img8_out_dev (optional): the image as the second kernel reads it, [B][T1+2][F1+2][C] bytes with its border of zeros. */
+int cn_op_conv_frontend_fp8(const float* x_dev, const float* w1_9c_dev, const float* b1_dev, const float* w2_host,
+                            const float* b2_dev, void* out_dev, void* img8_out_dev, int32_t B, int32_t T, int32_t F, int32_t C,
+                            float img_scale, float* w_scale_out, void* stream);
 int cn_op_conv2(int32_t precision, const void* conv1_out, const void* w_khwc, const float* bias, void* out, int32_t B,
                 int32_t T1, int32_t F1, int32_t C, void* stream);
 int cn_op_layernorm(int32_t precision, const float* x, const float* a2, const float* b2, void* y, int32_t M, int32_t d,

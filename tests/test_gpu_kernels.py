@@ -201,6 +201,45 @@ def test_conv1_conv2(prec, B, T, Fd, Cc):
     assert relerr(out2.float().permute(0, 3, 1, 2), ref2) < RTOL[prec]
 
 
+@pytest.mark.parametrize("B,T,Fd", [(2, 67, 80), (3, 200, 80), (1, 9, 16), (5, 1000, 80)])
+def test_conv_frontend_fp8(B, T, Fd):
+    """BASELINE config 5's conv front-end: conv1 + ReLU as an e4m3fn image at x8 (bordered, as conv2's LDS-DMA kernel reads it), conv2 +
+    ReLU on e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4, conv2.hip F8 form).  The image against torch's conv + e4m3 cast (a
+    code may differ by one step where the two fp32 summation orders fall on different sides of a rounding boundary); the second
+    convolution on the kernel's own image bytes and identically quantised weights."""
+    Cc = 256
+    g = torch.Generator().manual_seed(B * T)
+    x = torch.randn(B, T, Fd, generator=g)
+    w1 = torch.randn(Cc, 1, 3, 3, generator=g) / 3
+    b1 = torch.randn(Cc, generator=g) * 0.1
+    w2 = torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc)
+    b2 = torch.randn(Cc, generator=g) * 0.1
+    ref1 = F.relu(F.conv2d(x.unsqueeze(1), w1, b1, stride=2, padding=1))  # (B,C,T1,F1)
+    T1, F1 = ref1.shape[2], ref1.shape[3]
+    T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+    img = torch.empty(B, T1 + 2, F1 + 2, Cc, dtype=torch.uint8, device="cuda")
+    out = torch.full((B, T2, F2, Cc), float("nan"), dtype=torch.bfloat16, device="cuda")
+    w9c, xd, b1d, b2d = dev(w1.reshape(Cc, 9).t()), dev(x), dev(b1), dev(b2)
+    w2k = w2.permute(0, 2, 3, 1).reshape(Cc, 9 * Cc).contiguous()
+    ws = C.c_float(0)
+    hip.check(hip.lib().cn_op_conv_frontend_fp8(p(xd), p(w9c), p(b1d), _hp(w2k), p(b2d), p(out), p(img), B, T, Fd, Cc, 8.0, C.byref(ws),
+                                                stream()))
+    torch.cuda.synchronize()
+    imgc = img.cpu()
+    # border of zeros
+    assert int(imgc[:, 0].max()) == 0 and int(imgc[:, -1].max()) == 0 and int(imgc[:, :, 0].max()) == 0 and int(imgc[:, :, -1].max()) == 0
+    got8 = imgc[:, 1:-1, 1:-1]  # (B,T1,F1,C) bytes
+    want8 = (ref1 * 8.0).clamp(max=448).to(torch.float8_e4m3fn).view(torch.uint8).permute(0, 2, 3, 1)
+    diff = (got8.int() - want8.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 2e-3
+    # second convolution on the kernel's own image
+    c1 = got8.contiguous().view(torch.float8_e4m3fn).float().permute(0, 3, 1, 2) / 8.0
+    wq = (w2 * ws.value).clamp(-448, 448).to(torch.float8_e4m3fn).float() / ws.value
+    ref2 = F.relu(F.conv2d(c1, wq, b2, stride=2, padding=1))
+    assert ws.value == 2.0 ** math.floor(math.log2(448.0 / w2.abs().max().item()))
+    assert relerr(out.float().cpu().permute(0, 3, 1, 2), ref2) < 6e-3  # (bf16 output rounding: 2^-9 of the value)
+
+
 # ----------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("M,d", [(1, 128), (1001, 256), (37, 512), (5, 1024)])
