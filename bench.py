@@ -448,6 +448,16 @@ def main():
                                  "[bf16x3-*]: 0 arg-max flips, 1e-5 logit error, hypotheses token-exact); `hyp_agreement` = whole "
                                  "hypotheses of the benchmark batch equal to the fp32 CPU oracle's")
 
+    # BASELINE configs[4]'s arithmetic on this workload: the fp8 engine (e4m3 feed-forward products inside the chain kernel and an
+    # e4m3 conv front-end on the block-scaled K = 64 MFMA) through the same pipelines - a throughput form without a parity
+    # claim (its agreement with the fp32 reference is measured by tests/test_gpu_pipeline.py::test_config5_fp8_encoder_products)
+    fp8_engine = None
+    if world == 1 and not a.no_parity_engine and a.precision == "bf16":
+        fp8_engine = time_engine("fp8")
+        fp8_engine["note"] = ("e4m3fn operands for the encoder's feed-forward products and both subsampling convolutions (v_mfma_scale_f32_32x32x64_"
+                              "f8f6f4), everything else as the bf16 engine; `hyp_agreement` as for the other engines")
+        fp8_engine["speedup_over_value"] = round(fp8_engine["value"] / value, 3)
+
     out = {
         "metric": "utterances_per_sec", "value": round(value, 2), "unit": "utt/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
@@ -468,7 +478,7 @@ def main():
         # algorithmic FLOP/s of the whole path against the chip's peak for this precision's products (bf16x3: three MFMAs each)
         "mfma_frac_end_to_end": round(flops / B * value / (world * peak * 1e12 / (3.0 if a.precision == "bf16x3" else 1.0)), 5),
         "roofline": roofline, "roofline_conv2": roofline_conv2, "cpu_baseline": cpu, "parity_engine": parity_engine,
-        "fp32_engine": fp32_engine, "one_batch_per_pass": uncoalesced, "ragged_set": ragged_leg, "steady_state": steady,
+        "fp32_engine": fp32_engine, "fp8_engine": fp8_engine, "one_batch_per_pass": uncoalesced, "ragged_set": ragged_leg, "steady_state": steady,
         "stage_ms": stage_ms,
         "weight_blob_mb": round(blob_bytes / 1e6, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
     }

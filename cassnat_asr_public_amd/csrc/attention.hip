@@ -83,8 +83,11 @@ __device__ long long attn_stamps[8];
 // (the LAST workgroup of the grid: with more workgroups than CUs it runs among others in every phase, not in the launch's first burst)
 #define AT_STAMP(i) if (p.stamps && blockIdx.x == 0 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1 && threadIdx.x == 0) attn_stamps[i] = (long long)__builtin_amdgcn_s_memtime();
 
+// (second launch bound = waves per SIMD the register budget must allow: the resident 8-wave form runs two workgroups per CU - one
+// loading while the other computes - which needs <= 128 VGPRs; the allocator otherwise lets the seldom-taken full mask path
+// push it to 132 and halves the occupancy: -2 % on the whole benchmark)
 template <typename T, int NW, bool RES, bool REL = false>
-__global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
+__global__ __launch_bounds__(64 * NW, (RES && NW == 8) ? 4 : 1) void attention_kernel(AttnParams p) {
     typedef AttnCfg<T> Cfg;
     typedef typename Frag<T>::type frag_t;
     constexpr bool SPLIT = __is_same(T, split_t);
@@ -99,7 +102,9 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char Ks_all[NRES * KT_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char Vs_all[NRES * VT_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned int Ms_all[NRES * 16];  // mask bytes: 0 masked, 1 allowed, 2 tile padding
-    __shared__ unsigned int Mplain[NRES];  // 1: every key of the tile is allowed -> mask-free fast path
+    // per key tile: 1 = every key is allowed (mask-free fast path); | 2 = some keys lie past the entry's own batch (code 2: a
+    // suffix, key >= kcap - the "cut" path: one compare + select per score); | 4 = some keys are masked (code 0: full mask logic)
+    __shared__ unsigned int Mplain[NRES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -182,7 +187,6 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
         iv_e2 = r.w;
     }
     const int klen = p.klen ? p.klen[b] : p.Lk;
-    const int nkt = (p.Lk + 63) / 64;
     unsigned char* Ks = Ks_all;
     unsigned char* Vs = Vs_all;
     unsigned int* Ms = Ms_all;
@@ -191,6 +195,10 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
     uint4 k_reg[ST_IT], v_reg[ST_IT];
     const int bk = p.kv_index ? p.kv_index[b] : (p.kv_mod > 0 ? b % p.kv_mod : b);
     const int kcap = p.kcap ? p.kcap[(long long)bk * p.kcap_stride] : p.Lk;
+    // key tiles that hold at least one key of the entry's own batch: a later tile's keys all carry probability exactly 0 (code
+    // 2, -inf) - in a merged pass of ragged batches most tiles of a short utterance (round 3 still loaded and multiplied them)
+    const int kvalid = kcap < p.Lk ? kcap : p.Lk;
+    const int nkt = kvalid > 0 ? (kvalid + 63) / 64 : 1;
     const unsigned char* kbase = p.K + (long long)bk * p.Lk * p.ldk_b + (long long)h * KROW;
     const unsigned char* vbase = p.V + (long long)bk * p.Lk * p.ldv_b + (long long)h * KROW;
     auto load_tile = [&](int kt) {
@@ -234,8 +242,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                 code = ok ? 1 : 0;
             }
             reinterpret_cast<unsigned char*>(Ms)[tid] = code;
-            const unsigned long long bad = __ballot(code != 1);
-            if (tid == 0) Mplain[0] = bad == 0ull ? 1u : 0u;
+            const unsigned long long bad0 = __ballot(code == 0), bad2 = __ballot(code == 2);
+            if (tid == 0) Mplain[0] = 1u | (bad2 != 0ull ? 2u : 0u) | (bad0 != 0ull ? 4u : 0u);
         }
     };
 
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                 code = ok ? 1 : 0;
             }
             reinterpret_cast<unsigned char*>(Ms_all)[i] = code;
-            if (code != 1) atomicAnd(&Mplain[i >> 6], 0u);
+            if (code != 1) atomicOr(&Mplain[i >> 6], code == 2 ? 2u : 4u);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -299,9 +307,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
         // The 64-key tile is consumed as two 32-key sub-tiles, each with its own online-softmax step: 16 score registers live
         // instead of 32, which is what lets the bf16 kernel run at 128 VGPRs - two 8-wave workgroups per CU, one loading
         // while the other computes.
-        const bool plain = !REL && Mplain[RES ? kt : 0] != 0 && !p.iv && !p.causal;
+        const unsigned tile_class = Mplain[RES ? kt : 0];
+        const bool simple = !REL && !p.iv && !p.causal && (tile_class & 4u) == 0;  // no masked key, no per-row limits
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
+            if (simple && kt * 64 + sub * 32 >= kcap) continue;  // (wave-uniform) nothing but keys of probability 0
             // ---- S^T[key][q] of the sub-tile
             f32x16 sc;
 #pragma unroll
@@ -326,10 +336,23 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
             // ---- scale + mask + online softmax.  Fast path (wave-uniform): no key of this tile is masked and there are no
             // per-row intervals / causal limit -> one FMA + exp2 per score instead of ~15 VALU ops of mask logic.
             float psum = 0.f, alpha;
-            if (plain) {
-                float tmax = sc[0];
+            // (wave-uniform) the sub-tile's 32 keys all belong to the entry's own batch
+            const bool plain = simple && kt * 64 + sub * 32 + 32 <= kcap;
+            if (simple) {
+                float tmax;
+                if (plain) {
+                    tmax = sc[0];
 #pragma unroll
-                for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
+                    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
+                } else {  // cut: keys >= kcap get -inf (probability exactly 0), the others are allowed
+                    const int k0 = kt * 64 + sub * 32 + 4 * half;
+                    tmax = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        sc[r] = k0 + 8 * (r >> 2) + (r & 3) < kcap ? sc[r] : -INFINITY;
+                        tmax = fmaxf(tmax, sc[r]);
+                    }
+                }
                 tmax = xhalf_max(tmax) * p.scale;
                 const float m_new = fmaxf(m_run, tmax);
                 alpha = __expf(m_run - m_new);
@@ -342,6 +365,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                     psum += pv;
                 }
             } else {
+                // Full mask logic.  An allowed key's probability is computed exactly as on the fast paths (one FMA on the raw
+                // score + exp2), so that WHICH path a tile takes never shows in the result - a batch decoded alone and in a merged
+                // pass classifies the keys past its own row count differently (absent / masked) and must still agree bit for bit.
+                // sc[r] keeps the raw score of an allowed key; a masked key is marked by the fill value, a key past the entry's
+                // batch by -inf
                 float tmax = -INFINITY;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -360,20 +388,24 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnParams p) {
                             rd = rd < -p.rel_R ? -p.rel_R : (rd > p.rel_R ? p.rel_R : rd);
                             v += rel_bias[wave][l31][rd + p.rel_R];
                         }
-                        v *= p.scale;
                         v = ok ? v : CN_NEG_FILL;
                         v = code == 2u ? -INFINITY : v;
                         sc[r] = v;
-                        tmax = fmaxf(tmax, v);
+                        tmax = fmaxf(tmax, ok ? v * p.scale : v);
                     }
                 }
                 tmax = xhalf_max(tmax);
                 const float m_new = fmaxf(m_run, tmax);
                 alpha = __expf(m_run - m_new);
                 m_run = m_new;
+                const float c2 = p.scale * 1.44269504088896340736f, mb = m_new * 1.44269504088896340736f;
+                const float p_fill = __expf(CN_NEG_FILL - m_new);  // 1 while every key of the row so far is masked, else 0
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = __expf(sc[r] - m_new);
+                    const float v = sc[r];
+                    float pv = __builtin_amdgcn_exp2f(fmaf(v, c2, -mb));
+                    pv = v == CN_NEG_FILL ? p_fill : pv;
+                    pv = v == -INFINITY ? 0.f : pv;
                     sc[r] = pv;
                     psum += pv;
                 }
