@@ -1,5 +1,5 @@
 // Probe for v_mfma_scale_f32_32x32x64_f8f6f4 on gfx950 (e4m3 operands): operand lane map, scale semantics, issue rate.
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_f8_probe tools/probe/mfma_f8_probe.hip && /tmp/mfma_f8_probe
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_f8_probe tools/probes/mfma_f8_probe.hip && /tmp/mfma_f8_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
