@@ -3269,6 +3269,15 @@ extern "C" int cn_op_gemm_fp8(const void* a_bf16_dev, int32_t lda, const float* 
     return rc;
 }
 
+extern "C" int cn_op_cmvn(float* feats_dev, const int32_t* len_dev, const double* mean_dev, const double* std_dev, int32_t B, int32_t T,
+                          int32_t F, void* stream) {
+    if (!feats_dev || !len_dev || !mean_dev || !std_dev) {
+        cn_set_error("cn_op_cmvn: null argument");
+        return -1;
+    }
+    return launch_cmvn(feats_dev, len_dev, mean_dev, std_dev, B, T, F, (hipStream_t)stream);
+}
+
 extern "C" int cn_op_quantize_fp8(const void* src_bf16_dev, int32_t ld, void* dst_dev, int32_t M, int32_t K, float scale,
                                   void* stream) {
     return launch_quantize_fp8(src_bf16_dev, ld, dst_dev, M, K, scale, (hipStream_t)stream);

@@ -605,3 +605,27 @@ int launch_gather_logp(const float* logp, int V, const int* tgt, int ld, float* 
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// Global CMVN of a padded batch on the device: x[b][t][f] <- float((double(x) - mean[f]) / std[f]) for the frames t < len[b] of
+// utterance b, later frames (collate's padding) untouched.  The reference does this per utterance on the host, in numpy's
+// float64 with float64 statistics, and rounds to float32 when it collates (src/data/speech_loader.py:109-115, 147-149, 340): the
+// same two IEEE operations and the same single rounding here, so the values are the reference's bit for bit - at HBM speed
+// instead of the test-set loader's (which it was 3/4 of).
+__global__ void cmvn_kernel(float* __restrict__ x, const int* __restrict__ len, const double* __restrict__ mean,
+                            const double* __restrict__ sd, int T, int F) {
+    const int b = blockIdx.y;
+    const long long n = (long long)len[b] * F;
+    float* xb = x + (long long)b * T * F;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % F);
+        xb[i] = (float)(((double)xb[i] - mean[f]) / sd[f]);
+    }
+}
+
+int launch_cmvn(float* x, const int* len, const double* mean, const double* sd, int B, int T, int F, hipStream_t s) {
+    if (B <= 0 || T <= 0 || F <= 0) return 0;
+    const int per = cn_ceil_div(T * F, 256);
+    hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)(per < 64 ? per : 64), (unsigned)B), dim3(256), 0, s, x, len, mean, sd, T, F);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}

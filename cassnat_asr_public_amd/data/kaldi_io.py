@@ -4,7 +4,9 @@ The reference delegates this to the third-party `kaldiio` package (src/data/spee
 requirements_original.txt), which is not available offline; only the uncompressed binary matrix format that
 `copy-feats` / `compute-cmvn-stats` write by default is implemented here.
 """
+import mmap
 import struct
+import threading
 
 import numpy as np
 
@@ -45,6 +47,47 @@ def load_mat(rxspecifier):
                 while f.read(1) not in (b" ", b""):
                     pass
         return _read_matrix(f)
+
+
+_maps = {}
+_maps_lock = threading.Lock()
+
+
+def _mapped(path):
+    """A read-only memory map of an archive, kept for the life of the process (a test-set decode reads every matrix of a
+    handful of archives once: one map per file instead of one open + seven small reads + a copy per utterance)."""
+    mm = _maps.get(path)
+    if mm is None:
+        with _maps_lock:
+            mm = _maps.get(path)
+            if mm is None:
+                with open(path, "rb") as f:
+                    mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+                _maps[path] = mm
+    return mm
+
+
+def load_mat_view(rxspecifier):
+    """"path:offset" (an .scp entry) -> a READ-ONLY numpy view of the matrix inside a memory map of the archive (no copy;
+    valid as long as the process lives).  Anything else falls back to load_mat."""
+    path, _, off = rxspecifier.rpartition(":")
+    if not path or not off.isdigit():
+        return load_mat(rxspecifier)
+    mm = _mapped(path)
+    o = int(off)
+    head = mm[o : o + 15]
+    if head[:2] != b"\0B":
+        raise ValueError("not a binary Kaldi object")
+    tag = head[2:5]
+    if tag not in _DTYPES:
+        raise ValueError("unsupported Kaldi matrix type %r (compressed matrices are not supported)" % tag)
+    if head[5:6] != b"\x04" or head[10:11] != b"\x04":
+        raise ValueError("corrupt Kaldi matrix header")
+    rows, cols = struct.unpack("<i", head[6:10])[0], struct.unpack("<i", head[11:15])[0]
+    dt = np.dtype(_DTYPES[tag]).newbyteorder("<")
+    if o + 15 + rows * cols * dt.itemsize > len(mm):
+        raise ValueError("truncated Kaldi matrix")
+    return np.frombuffer(mm, dtype=dt, count=rows * cols, offset=o + 15).reshape(rows, cols)
 
 
 def mat_rows(rxspecifier):

@@ -3,6 +3,8 @@ skip -> zero-padded batch + length ratios.  Only what CassNATTask("test") uses i
 SpeechDataLoader); the training-only DynamicDataset / SSL loaders are out of scope.
 """
 import functools
+import os
+import threading
 
 import numpy as np
 import torch
@@ -39,6 +41,9 @@ class SpeechDataset(Dataset):
         self.left_context, self.right_context = args.left_ctx, args.right_ctx
         self.skip_frame = args.skip_frame
         self.use_cmvn = False
+        # set (by the pipelined decoder, for the length of a decode) when the consumer applies the global CMVN itself, on the
+        # device (pipeline.DecodePipelines(cmvn=...)): the fast path below then hands the features over as they are in the archive
+        self.device_cmvn = False
         self.data_streams = [SingleSet(vocab, p, getattr(args, "rank", 0)) for p in data_paths]
         self._items = [it for s in self.data_streams for it in s.items]
 
@@ -56,6 +61,19 @@ class SpeechDataset(Dataset):
 
     def __getitem__(self, idx):
         utt, spec, text = self._items[idx]
+        if self.left_context == 0 and self.right_context == 0 and self.skip_frame <= 1:
+            # The shipped configuration (no splicing, no frame skipping).  Same values as the general path below - the CMVN in
+            # float64, rounded to float32 once (where the reference's collate converts: speech_loader.py:340) - without its
+            # temporaries: the matrix is read in place from a memory map of the archive, the float64 intermediate lives in a
+            # per-thread scratch buffer, and what is handed on is float32 (half the bytes for collate to move).
+            feat = kaldi_io.load_mat_view(spec)
+            if not self.use_cmvn or self.device_cmvn:
+                return utt, feat, text
+            assert feat.shape[1] == self.mean.shape[0]
+            tmp = _scratch64(feat.shape)
+            np.subtract(feat, self.mean, out=tmp)
+            np.divide(tmp, self.std, out=tmp)
+            return utt, tmp.astype(np.float32), text
         feat = kaldi_io.load_mat(spec)
         if self.use_cmvn:
             assert feat.shape[1] == self.mean.shape[0]
@@ -66,19 +84,41 @@ class SpeechDataset(Dataset):
         feat = skip_feat(context_feat(feat, self.left_context, self.right_context), self.skip_frame)
         return utt, feat, text
 
+    def can_defer_cmvn(self):
+        """The global CMVN commutes with everything this dataset does afterwards (no splicing, no frame skipping)."""
+        return self.left_context == 0 and self.right_context == 0 and self.skip_frame <= 1
+
+
+_tls = threading.local()
+
+
+def _scratch64(shape):
+    """float64 scratch of at least `shape` for the calling thread (grown by doubling, reused across utterances)"""
+    n = int(shape[0]) * int(shape[1])
+    buf = getattr(_tls, "buf", None)
+    if buf is None or buf.size < n:
+        buf = np.empty(max(n, 2 * (buf.size if buf is not None else 0)), dtype=np.float64)
+        _tls.buf = buf
+    return buf[:n].reshape(shape)
+
 
 def collate(batch, padding_idx=0):
     """list of (utt, feat (T,F), text) -> (utts, feats (B,Tmax,F) f32, texts (B,L) i64, feat ratios (B,) f32,
-    text sizes (B,) i64), padded with `padding_idx` exactly as the reference's SuperviseLoader.collate_fn."""
+    text sizes (B,) i64), padded with `padding_idx` exactly as the reference's SuperviseLoader.collate_fn.
+    (Measured on the GPU box, 6000 ragged utterances: copying the rows on a small thread pool, or assembling the batch in page-locked
+    memory, both made the recogniser slower than this plain loop - profiles/r04c_*.)"""
     t_max = max(x[1].shape[0] for x in batch)
     l_max = max(len(x[2]) for x in batch)
-    feats = torch.full((len(batch), t_max, batch[0][1].shape[1]), float(padding_idx))
+    feats = torch.empty((len(batch), t_max, batch[0][1].shape[1]))  # (every element is written below: rows, then padding tails)
+    fv = feats.numpy()
     texts = torch.full((len(batch), l_max), int(padding_idx), dtype=torch.long)
     ratios = torch.zeros(len(batch))
     sizes = torch.zeros(len(batch), dtype=torch.long)
     utts = []
     for b, (utt, feat, text) in enumerate(batch):
-        feats[b, : feat.shape[0]] = torch.as_tensor(np.asarray(feat), dtype=torch.float32)
+        fv[b, : feat.shape[0]] = feat  # (numpy: a float64 matrix is rounded to float32 here, as torch.Tensor(feat) does; a read-only map is fine)
+        if feat.shape[0] < t_max:
+            fv[b, feat.shape[0] :] = float(padding_idx)
         texts[b, : len(text)] = torch.as_tensor(text, dtype=torch.long)
         ratios[b] = feat.shape[0] / t_max
         sizes[b] = len(text) - 2

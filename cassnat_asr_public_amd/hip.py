@@ -93,6 +93,7 @@ def lib():
     L.cn_op_topk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_op_gemm_fp8.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                  C.c_int32, C.POINTER(C.c_float), C.c_void_p]
+    L.cn_op_cmvn.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]
     L.cn_op_quantize_fp8.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     L.cn_op_logsoftmax_topk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_model_create.argtypes = [C.POINTER(CnConfig), C.POINTER(C.c_void_p)]
@@ -170,6 +171,16 @@ def current_stream():
     import torch
 
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def cmvn_(feats, lens, mean, std):
+    """In-place global CMVN of a padded (B, T, F) float32 CUDA batch on the current stream: frames t < lens[b] become
+    float((double(x) - mean) / std) - SpeechDataset's arithmetic bit for bit (cn_op_cmvn); lens int32, mean / std float64, all
+    on the batch's device."""
+    B, T, F = feats.shape
+    assert feats.is_contiguous() and feats.dtype.is_floating_point and feats.element_size() == 4 and lens.numel() >= B
+    check(lib().cn_op_cmvn(_ptr(feats), _ptr(lens), _ptr(mean), _ptr(std), B, T, F, current_stream()), "cn_op_cmvn")
+    return feats
 
 
 class Engine:

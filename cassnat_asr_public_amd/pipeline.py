@@ -26,6 +26,7 @@ import queue
 import threading
 import time
 
+import numpy as np
 import torch
 
 from . import dist as cdist
@@ -88,7 +89,7 @@ class _Pass:
 
 class DecodePipelines:
     def __init__(self, model, n_pipelines, batch, frames, with_weights=True, after_engine=None, coalesce=1, share_from=None,
-                 ragged=0.75, predict_rows=True, area_frames=None):
+                 ragged=0.75, predict_rows=True, area_frames=None, cmvn=None):
         """``model``: a CassNAT holding the parameters; ``batch`` x ``frames``: the largest single batch a pipeline must take.
         The pipelines of one GPU share ONE device copy of the packed weights (``cn_model_create_shared``): the first engine
         packs them - or, with ``with_weights=False`` + ``after_engine(engine)`` (multi-GPU start-up), receives them by RCCL
@@ -103,8 +104,13 @@ class DecodePipelines:
         negative number -c, "by area only").  ``predict_rows``: launch the decoder side on a predicted row count instead of
         waiting for the true one in the middle of the pass (verified afterwards; a miss is decoded again).
         Transformer blocks only (a conformer's GroupNorm sees the padded rows of a merged pass): conformer models run one batch
-        per pass.  ``share_from``: an engine of the same model whose device copy of the weights ALL pipelines of this object use."""
+        per pass.  ``share_from``: an engine of the same model whose device copy of the weights ALL pipelines of this object use.
+        ``cmvn`` = (mean, std) float64 arrays: the batches arrive RAW (a SpeechDataset with ``device_cmvn``) and the global CMVN is
+        applied on the device right behind the host-to-device copy (``hip.cmvn_``: the reference's float64 arithmetic bit for bit)
+        - the loader's float64 passes over the features were three quarters of its time."""
         self.model = model
+        self.cmvn = None if cmvn is None else (np.ascontiguousarray(cmvn[0], dtype=np.float64), np.ascontiguousarray(cmvn[1], dtype=np.float64))
+        self._cmvn_dev = {}
         self.n = max(1, int(n_pipelines))
         conformer = bool(getattr(model, "_conf_dec", False) or getattr(model, "_hyper", {}).get("conf_enc"))
         self.by_area = int(coalesce) < 0
@@ -298,6 +304,20 @@ class DecodePipelines:
                 feats[o:o + nb, :t].copy_(src, non_blocking=True)
                 o += nb
         torch.cat([x[1].to(dev_, non_blocking=True) if on_gpu else x[1] for x in items], 0, out=ratio)
+        if self.cmvn is not None:
+            # an utterance's frame count from collate's float32 ratio len / t (exact after rounding: t is a few thousand at most)
+            lens = torch.cat([(x[1].double().cpu() * int(x[0].shape[1])).round().to(torch.int32) for x in items])
+            if on_gpu:
+                stats = self._cmvn_dev.get(device)
+                if stats is None:
+                    stats = self._cmvn_dev[device] = (torch.from_numpy(self.cmvn[0]).to(dev_), torch.from_numpy(self.cmvn[1]).to(dev_))
+                from . import hip
+
+                hip.cmvn_(feats, lens.pin_memory().to(dev_, non_blocking=True), stats[0], stats[1])
+            else:  # CPU rehearsal of the host logic: the same arithmetic in numpy
+                fv = feats.numpy()
+                for b, n in enumerate(lens.tolist()):
+                    fv[b, :n] = ((fv[b, :n].astype(np.float64) - self.cmvn[0]) / self.cmvn[1]).astype(np.float32)
         return feats, ratio
 
     def _launch(self, k, st, job, p, exact=False):
@@ -373,7 +393,7 @@ class DecodePipelines:
                 p.frames = [int(x[0].shape[1]) for x in p.items]
                 p.ticket = None
                 t_ = time.perf_counter()
-                if len(p.items) == 1:
+                if len(p.items) == 1 and self.cmvn is None:  # (raw batches are normalised in the staging buffer, alone or not)
                     p.feats, p.ratio = p.items[0][0], p.items[0][1]
                 else:
                     cs = self._copy_streams[k]

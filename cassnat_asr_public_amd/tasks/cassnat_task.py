@@ -194,18 +194,35 @@ class CassNATTask(BaseTask):
 
         self.model._check_args(args, self.lm_model)
         sos = self.vocab.word2index["sos"]
+        # global CMVN on the device, behind the host-to-device copy (the reference's float64 arithmetic bit for bit: hip.cmvn_), when
+        # nothing else sits between the archive and the batch: the loader then moves raw float32 rows and nothing more
+        ds = getattr(self.test_loader, "dataset", None)
+        dev_cmvn = bool(ds is not None and getattr(ds, "use_cmvn", False) and hasattr(ds, "can_defer_cmvn") and ds.can_defer_cmvn()
+                        and getattr(self.test_loader, "num_workers", 0) == 0 and int(getattr(args, "hip_device_cmvn", 1)))
+        if dev_cmvn:
+            ds.device_cmvn = True
+        try:
+            return self._decode_pipelined_run(args, n_pipes, results, batch_time, progress, sos, (ds.mean, ds.std) if dev_cmvn else None)
+        finally:
+            if dev_cmvn:
+                ds.device_cmvn = False
+
+    def _decode_pipelined_run(self, args, n_pipes, results, batch_time, progress, sos, cmvn):
+        from ..pipeline import DecodePipelines
+
         first = next(iter(self.test_loader))
         max_frames = max(getattr(args, "hip_max_frames", 4096), first[1].shape[1])
         # consecutive batches share an engine pass while they fit the workspace area (hip_coalesce batches of batch_size x 1024
         # frames) and their frame counts are within hip_ragged of each other; passes are filled by area, not by a batch count
-        key = (n_pipes, args.batch_size, max_frames, int(getattr(args, "hip_coalesce", 10)), float(getattr(args, "hip_ragged", 0.75)))
+        key = (n_pipes, args.batch_size, max_frames, int(getattr(args, "hip_coalesce", 10)), float(getattr(args, "hip_ragged", 0.75)),
+               cmvn is not None)
         pipes = getattr(self, "_pipes", None)
         if pipes is None or self._pipes_key != key:  # (kept for further decode() calls on this task: engines, threads, streams)
             if pipes is not None:
                 pipes.close()
             pipes = DecodePipelines(self.model, n_pipes, args.batch_size, max_frames, with_weights=(self.rank == 0),
                                     after_engine=(lambda e: cdist.broadcast_weights(e, src=0)) if self.world > 1 else None,
-                                    coalesce=-max(1, key[3]), ragged=key[4])
+                                    coalesce=-max(1, key[3]), ragged=key[4], cmvn=cmvn)
             self._pipes, self._pipes_key = pipes, key
         stats0 = dict(pipes.stats)
         meta, frames, i, end = {}, 0, -1, time.time()

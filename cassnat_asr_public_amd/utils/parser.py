@@ -37,6 +37,10 @@ class DecodeParser(object):
                        help="1: form the batches from the utterance list sorted by length (frame counts from <scp dir>/utt2num_frames "
                             "or the ark headers) instead of file order - less padding per batch, neighbours that merge well; the "
                             "result file stays in file order.  0 (default): the reference's batches")
+        p.add_argument("--hip_device_cmvn", default=1, type=int,
+                       help="1 (default): the pipelined decoder applies the global CMVN on the device, behind the host-to-device copy "
+                            "(float64 arithmetic, bit-identical to the dataset's), when the dataset neither splices nor skips frames "
+                            "and runs without loader workers; 0: always in the dataset, as the reference does")
         p.add_argument("--hip_dist_backend", default="nccl", choices=["nccl", "gloo"],
                        help="torch.distributed backend under torch.distributed.run (nccl = RCCL over xGMI; gloo: rehearsal of the "
                             "N-rank path, also with several ranks on one GPU)")

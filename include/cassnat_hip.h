@@ -346,6 +346,11 @@ int cn_op_topk(const float* logp, int32_t M, int32_t V, int32_t k, int32_t* idx,
 int cn_op_gemm_fp8(const void* a_bf16_dev, int32_t lda, const float* w_host, const float* bias_dev, float* c_dev, int32_t M,
                    int32_t N, int32_t K, float a_scale, int32_t relu, float* w_scale_out, void* stream);
 /* bf16 [M][ld] -> e4m3fn bytes [M][K] at `scale` (round to nearest even, saturating at +-448): the activation quantiser */
+/* Global CMVN of a padded (B, T, F) float32 batch in place: frames t < len[b] become float((double(x) - mean[f]) / std[f]) - the
+ * reference's SpeechDataset arithmetic (src/data/speech_loader.py:109-115, 147-149: numpy float64 with float64 statistics, rounded to
+ * float32 at collate) bit for bit; later frames (padding) are left alone.  mean / std: F doubles on the device. */
+int cn_op_cmvn(float* feats_dev, const int32_t* len_dev, const double* mean_dev, const double* std_dev, int32_t B, int32_t T, int32_t F,
+               void* stream);
 int cn_op_quantize_fp8(const void* src_bf16_dev, int32_t ld, void* dst_dev, int32_t M, int32_t K, float scale, void* stream);
 /* generator tail of the autoregressive step (src/models/transformer.py:48-51, 199-200): log_softmax(logits / T) and its per-row
  * top-k (sorted descending, ties: lower index) in one pass; the logits [M][V] are left untouched */

@@ -68,6 +68,27 @@ def test_gemm_bias(prec, M, N, K):
         assert relerr(out, ref) < RTOL[prec] * (1 if c_f32 or prec == "fp32" else 1.5)
 
 
+@pytest.mark.parametrize("B,T,Fd", [(5, 77, 80), (1, 1, 3), (32, 1500, 80)])
+def test_cmvn_on_the_device_equals_numpy_float64(B, T, Fd):
+    """cn_op_cmvn (the pipelined decoder's global CMVN, behind the host-to-device copy): float((double(x) - mean) / std) on the frames
+    of each utterance - SpeechDataset's numpy arithmetic (src/data/speech_loader.py:109-115, 147-149, 340) BIT FOR BIT, padding
+    frames untouched."""
+    rng = np.random.default_rng(B + T)
+    x = (rng.standard_normal((B, T, Fd)) * 7 + 2).astype(np.float32)
+    lens = rng.integers(0, T + 1, size=B).astype(np.int32)
+    lens[0] = T
+    for b in range(B):
+        x[b, lens[b]:] = 0.0
+    mean, std = rng.standard_normal(Fd) * 3, np.abs(rng.standard_normal(Fd)) * 2 + 0.1
+    want = x.copy()
+    for b in range(B):
+        want[b, : lens[b]] = ((x[b, : lens[b]] - mean) / std).astype(np.float32)  # float32 - float64 -> float64, as in the dataset
+    xd = torch.from_numpy(x).cuda()
+    hip.cmvn_(xd, torch.from_numpy(lens).cuda(), torch.from_numpy(mean).cuda(), torch.from_numpy(std).cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(xd.cpu().numpy(), want)
+
+
 def test_quantize_fp8_matches_torch_e4m3fn():
     g = torch.Generator().manual_seed(2)
     x = torch.cat([torch.randn(4096, generator=g) * s for s in (1e-4, 1e-3, 1e-2, 0.1, 1.0, 10.0, 40.0)]).view(-1, 256)

@@ -290,6 +290,54 @@ def test_decode_asr_cli_end_to_end(tmp_path, batch_size):
     assert open(result).read().splitlines() == expect
 
 
+def test_decode_asr_cli_with_global_cmvn_on_the_device(tmp_path):
+    """decode_asr with `use_cmvn`: the pipelined decoder takes raw rows from the archive and normalises them on the device
+    (hip.cmvn_) - the result file equals the one with the CMVN in the dataset (--hip_device_cmvn 0), line for line, and the
+    oracle's on the normalised features."""
+    import yaml
+
+    from cassnat_asr_public_amd.bin import decode_asr
+    from cassnat_asr_public_amd.data import kaldi_io
+    from oracle import cassnat_oracle as orc
+
+    args, state, feats, sizes = tiny_case()
+    lengths = [61, 50, 37, 61, 12]
+    rng = np.random.default_rng(1)
+    raw = [(rng.standard_normal((n, feats.shape[2])) * 2.5 + 0.7).astype(np.float32) for n in lengths]
+    mats = [(f"spk-utt{b}", m) for b, m in enumerate(raw)]
+    scp = str(tmp_path / "feats.scp")
+    kaldi_io.write_ark_scp(str(tmp_path / "feats.ark"), scp, mats)
+    allf = np.vstack(raw).astype(np.float64)
+    stats = np.zeros((2, feats.shape[2] + 1))
+    stats[0, :-1], stats[0, -1], stats[1, :-1] = allf.sum(0), len(allf), (allf ** 2).sum(0)
+    kaldi_io.write_ark_scp(str(tmp_path / "cmvn.ark"), str(tmp_path / "cmvn.scp"), [("global", stats)])
+    cmvn_spec = kaldi_io.read_scp(str(tmp_path / "cmvn.scp"))[0][1]
+    vocab_file = tmp_path / "vocab.txt"
+    vocab_file.write_text("".join(f"w{i}\n" for i in range(args.vocab_size - 4)))
+    ckpt = str(tmp_path / "model.mdl")
+    torch.save({"model_state": {"module." + k: torch.from_numpy(v) for k, v in state.items()}}, ckpt)
+    conf = {k: getattr(args, k) for k in ("input_size", "d_model", "n_head", "d_encff", "d_decff", "d_ff", "N_enc", "N_extra",
+                                          "N_self_dec", "N_mix_dec", "model_type", "n_features", "left_ctx", "right_ctx",
+                                          "skip_frame", "padding_idx", "beam_width", "length_penalty", "use_trigger")}
+    conf.update(vocab_file=str(vocab_file), use_gpu=True, use_cmvn=True, global_cmvn=cmvn_spec)
+    cfg = tmp_path / "decode.yaml"
+    cfg.write_text(yaml.safe_dump(conf))
+    out = {}
+    for dev in (1, 0):
+        result = str(tmp_path / f"token_results_{dev}.txt")
+        rc = decode_asr.main(["--task", "cassnat", "--test_config", str(cfg), "--data_path", scp, "--resume_model", ckpt,
+                              "--result_file", result, "--batch_size", "1", "--hip_precision", "fp32", "--load_data_workers", "0",
+                              "--hip_device_cmvn", str(dev)])
+        assert rc == 0
+        out[dev] = open(result).read().splitlines()
+    assert out[1] == out[0]
+    mean = stats[0, :-1] / stats[0, -1]  # (as SpeechDataset._load_cmvn derives them from the Kaldi stats matrix)
+    std = np.sqrt(stats[1, :-1] / stats[0, -1] - mean ** 2)
+    index2word = {i + 4: f"w{i}" for i in range(args.vocab_size - 4)}
+    hyps = [orc.decode_nast(state, ((m - mean) / std).astype(np.float32)[None], np.ones(1, np.float32), args)["hyps"][0] for m in raw]
+    assert out[1] == [f"spk-utt{b} " + " ".join(orc.hyp_to_text(h, index2word)) for b, h in enumerate(hyps)]
+
+
 def test_bf16_production_path_against_golden(capsys):
     """The path bench.py times (bf16, fused FFN sublayer, fused generator arg-max, no capture) on the benchmark workload:
     CTC arg-max agreement with the reference and hypothesis agreement on utterances whose alignment did not flip."""

@@ -134,6 +134,53 @@ def test_kaldi_roundtrip_cmvn_and_collate(tmp_path):
     assert ((feats[:, :, 0] != 0).sum(1)).tolist() == [5, 3, 4]
 
 
+def test_fast_feature_path_equals_the_general_one_bit_for_bit(tmp_path):
+    """No splicing / no skipping (the shipped configuration): the dataset reads the matrix in place from a memory map, does the
+    CMVN into a float64 scratch and hands on float32 - the same values as the reference's order of operations (float64 all the
+    way, rounded to float32 where collate converts).  With `device_cmvn` it hands on the raw rows (the consumer normalises)."""
+    rng = np.random.default_rng(3)
+    mats = [(f"utt{b:02d}", (rng.standard_normal((n, 6)) * 3 + 1).astype(np.float32)) for b, n in enumerate([9, 5, 70, 33, 4, 1])]
+    scp = str(tmp_path / "feats.scp")
+    kaldi_io.write_ark_scp(str(tmp_path / "feats.ark"), scp, mats)
+    allf = np.vstack([m for _, m in mats]).astype(np.float64)
+    stats = np.zeros((2, 7))
+    stats[0, :6], stats[0, 6], stats[1, :6] = allf.sum(0), len(allf), (allf ** 2).sum(0)
+    kaldi_io.write_ark_scp(str(tmp_path / "cmvn.ark"), str(tmp_path / "cmvn.scp"), [("global", stats)])
+    (tmp_path / "v").mkdir()
+    _, _, vocab_file, _ = _write_dataset(tmp_path / "v", [3])
+    args = synth.make_args("tiny", left_ctx=0, right_ctx=0, skip_frame=1)
+    ds = SpeechDataset(Vocab(vocab_file, 1), [{"name": "test", "scp_path": scp}], args)
+    ds._load_cmvn(kaldi_io.read_scp(str(tmp_path / "cmvn.scp"))[0][1])
+    assert ds.can_defer_cmvn()
+    utts, feats, _, ratios, _ = next(iter(SpeechDataLoader(ds, 6, padding_idx=0)))
+    for b, (_, m) in enumerate(mats):
+        want = torch.Tensor((m - ds.mean) / ds.std)  # the reference: float64 arithmetic, float32 at collate (speech_loader.py:340)
+        assert torch.equal(feats[b, : len(m)], want) and (feats[b, len(m):] == 0).all()
+        np.testing.assert_array_equal(kaldi_io.load_mat_view(kaldi_io.read_scp(scp)[b][1]), m)
+    ds.device_cmvn = True
+    _, raw, _, ratios2, _ = next(iter(SpeechDataLoader(ds, 6, padding_idx=0)))
+    assert torch.equal(ratios, ratios2)
+    for b, (_, m) in enumerate(mats):
+        assert torch.equal(raw[b, : len(m)], torch.from_numpy(m))
+    # what the pipelines do with raw batches on a CPU-only host (on the GPU: hip.cmvn_, tests/test_gpu_kernels.py)
+    lens = (ratios.double() * raw.shape[1]).round().to(torch.int32).tolist()
+    assert lens == [len(m) for _, m in mats]
+
+
+def test_loader_workers_read_the_same_batches(tmp_path):
+    """Main-process loader and forked loader workers (memory maps of the archives are inherited) hand over identical batches."""
+    rng = np.random.default_rng(5)
+    mats = [(f"utt{b:03d}", rng.standard_normal((int(rng.integers(20, 60)), 6)).astype(np.float32)) for b in range(40)]
+    scp = str(tmp_path / "feats.scp")
+    kaldi_io.write_ark_scp(str(tmp_path / "feats.ark"), scp, mats)
+    (tmp_path / "v").mkdir()
+    _, _, vocab_file, _ = _write_dataset(tmp_path / "v", [3])
+    ds = SpeechDataset(Vocab(vocab_file, 1), [{"name": "test", "scp_path": scp}], synth.make_args("tiny", left_ctx=0, right_ctx=0, skip_frame=1))
+    a = [b[1].clone() for b in SpeechDataLoader(ds, 8, padding_idx=0)]
+    b = [x[1].clone() for x in SpeechDataLoader(ds, 8, padding_idx=0, num_workers=2)]
+    assert len(a) == 5 and all(torch.equal(x, y) for x, y in zip(a, b))
+
+
 def test_collate_ratio_is_float32_of_python_division():
     batch = [("a", np.ones((1000, 2)), [1, 2]), ("b", np.ones((333, 2)), [1, 2])]
     _, _, _, ratios, _ = collate(batch)

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--min-frames", type=int, default=300)
     ap.add_argument("--max-frames", type=int, default=1500)
+    ap.add_argument("--cmvn", type=int, default=1, help="1: the test config has use_cmvn + a global CMVN stats file (as the recipes do)")
     a = ap.parse_args()
     torch.set_num_threads(1)
     margs = synth.make_args("config2")
@@ -78,6 +79,12 @@ def main():
                 "padding_idx", "beam_width", "length_penalty", "d_encff", "d_decff", "N_extra", "N_self_dec", "N_mix_dec", "use_trigger")
         conf = {k: getattr(margs, k) for k in keys}
         conf.update(vocab_file=vocab_file, use_gpu=True, test_paths=[{"name": "test", "scp_path": scp}])
+        if a.cmvn:  # Kaldi global CMVN stats (sums, sums of squares, count) of N(0.2, 1.5^2) features
+            n = float(sum(lengths))
+            stats = np.zeros((2, margs.input_size + 1))
+            stats[0, :-1], stats[0, -1], stats[1, :-1] = 0.2 * n, n, (1.5 ** 2 + 0.2 ** 2) * n
+            kaldi_io.write_ark_scp(os.path.join(tmp, "cmvn.ark"), os.path.join(tmp, "cmvn.scp"), [("global", stats)])
+            conf.update(use_cmvn=True, global_cmvn=kaldi_io.read_scp(os.path.join(tmp, "cmvn.scp"))[0][1])
         cfg = os.path.join(tmp, "decode.yaml")
         with open(cfg, "w") as f:
             yaml.safe_dump({k: v for k, v in conf.items() if k != "test_paths"}, f)
@@ -89,7 +96,10 @@ def main():
         results = {}
         for name, extra, preload in (("plain", ["--hip_pipelines", "1", "--load_data_workers", "0"], False),
                                      ("pipelined", ["--load_data_workers", "0"], False),
+                                     ("pipelined_cmvn_in_dataset", ["--load_data_workers", "0", "--hip_device_cmvn", "0"], False),
+                                     ("pipelined_again", ["--load_data_workers", "0"], False),
                                      ("pipelined_4_loader_workers", ["--load_data_workers", "4"], False), ("preloaded", ["--load_data_workers", "0"], True)):
+            print(f"[ragged_cli_bench] {name} ...", file=sys.stderr, flush=True)
             res = os.path.join(tmp, f"result_{name}.txt")
             task, args = make_task(base + extra + ["--result_file", res], conf)
             if preload:  # the collated batches as pinned host tensors: what a loader with enough workers hands over
@@ -124,8 +134,9 @@ def main():
         assert len(results["plain"]) == a.utts
         assert results["pipelined"] == results["plain"], "result files differ between the merged-pass decoder and the plain loop"
         assert results["preloaded"] == results["plain"] and results["pipelined_4_loader_workers"] == results["plain"]
+        assert results["pipelined_cmvn_in_dataset"] == results["plain"]
         out["result_files_identical"] = True
-    out.update(utterances=a.utts, batch_size=a.batch, precision=a.precision, frames_min_max=[min(lengths), max(lengths)],
+    out.update(global_cmvn=bool(a.cmvn), utterances=a.utts, batch_size=a.batch, precision=a.precision, frames_min_max=[min(lengths), max(lengths)],
                mean_frames=round(float(np.mean(lengths)), 1), audio_seconds=round(audio_s, 1),
                note="plain / pipelined include reading and collating the ark on the host (single process, no loader workers); "
                     "preloaded = the decode loop alone; bench.py's rtfx is audio seconds per second on resident features")
