@@ -30,7 +30,7 @@ def per_kernel(path, counter):
 def mfma_summary(sdir, out):
     names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "GRBM_GUI_ACTIVE"]
     acc = {n: per_kernel(sdir, n) for n in names}
-    kernels = {"chain_kernel": "chain_kernel", "conv2_kernel<false, false>": "conv2_kernel (conv2)", "conv2_kernel<true, false>": "conv2_kernel<LINEAR> (linear_out)",
+    kernels = {"chain_kernel": "chain_kernel", "conv2_kernel<false, false, false>": "conv2_kernel (conv2)", "conv2_kernel<true, false, false>": "conv2_kernel<LINEAR> (linear_out)",
                "attention_kernel": "attention_kernel", "genmax_kernel": "genmax_kernel", "conv1_kernel": "conv1_kernel"}
     c = int(sys.argv[5]) if len(sys.argv) > 5 else 10
     rec = {"source": "rocprofv3 --pmc " + " ".join(names) + f" (its own pass, --kernel-trace only), bench.py --steps {2 * c} --warmup {c} --streams 1 --coalesce {c} "
@@ -78,8 +78,8 @@ def main():
     c = int(sys.argv[5]) if len(sys.argv) > 5 else 10  # batches of 32 x 1000 frames per engine pass in the profiled runs
     rows_per_batch = int(sys.argv[6]) if len(sys.argv) > 6 else 8000
     targets = {"row_chain": ("chain_kernel", 128, f"chain_kernel (21 launches per engine pass: 12 encoder launches at {rows_per_batch * c} rows, 9 decoder-side)"),
-               "conv2": ("conv2_kernel<false, false>", 256, f"conv2_kernel<false, false> (LDS-DMA implicit GEMM, {c} batches of 32 x 1000 frames per launch)"),
-               "linear_out": ("conv2_kernel<true, false>", 256, f"conv2_kernel<true, false> (linear_out on the LDS-DMA tile kernel, {rows_per_batch * c} x 5120 -> 256)")}
+               "conv2": ("conv2_kernel<false, false, false>", 256, f"conv2_kernel<false, false, false> (LDS-DMA implicit GEMM, {c} batches of 32 x 1000 frames per launch)"),
+               "linear_out": ("conv2_kernel<true, false, false>", 256, f"conv2_kernel<true, false, false> (linear_out on the LDS-DMA tile kernel, {rows_per_batch * c} x 5120 -> 256)")}
     for tag, (needle, wg_rows, label) in targets.items():
         fg, wg = by_grid(fdir, "FETCH_SIZE", needle), by_grid(wdir, "WRITE_SIZE", needle)
         if not fg or not wg:
