@@ -3,6 +3,8 @@
 // the kernel is shaped by its store: each lane produces 8 consecutive channels of one (b,t1,f1) position
 // and writes them with one 16-byte (bf16) / two 16-byte (f32) stores into the channels-last image
 // (B,T1,F1,C) that the implicit-GEMM second convolution reads; a wave covers two full 512-B/1-KiB rows.
+#include <cstdlib>
+
 #include "kernels.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -188,12 +190,130 @@ int launch_conv1_planes(const float* x, const float* w9c, const float* bias, voi
     return 0;
 }
 
+// ---- e4m3 image on the matrix cores -------------------------------------------------------------------------------
+// The VALU kernel above is shaped by its store; with one byte per element the store halves and what is left is its arithmetic
+// (36 packed FMAs, 8 maxima, conversions per 8 channels: 0.70 ms per ten-batch pass - more than the bf16 image's 0.64, which is
+// HBM-bound).  Here a position's 256 channels are one column of eight 32x32x16 bf16 MFMAs: out^T[channel][position] =
+// W[channel][k] . X[k][position] with k = nine taps, then a constant 1 that carries the bias (the remaining six k are zero);
+// the image scale is folded into W and the bias (a power of two: exact).  A wave takes 32 consecutive cells of an utterance's
+// bordered image; its rows of channels are permuted so that a lane ends up with 16 consecutive channels per tile (one
+// 16-byte piece), the tile goes through a wave-private LDS pad and leaves as 1-KiB contiguous stores (4 cells x 256 B).
+// Inputs and weights go in as split bf16 (hi + lo halves, three MFMAs per tile: lo.hi + hi.lo + hi.hi - the matrix pipe has the
+// time) so that the sums carry 16 significant bits in front of the e4m3 rounding: with plain bf16 operands some 6 % of the
+// cells would land one code away from the fp32 convolution's (tests/test_gpu_kernels.py::test_conv_frontend_fp8 allows 0.2 %).
+constexpr int C1M_ROWB = 272;                      // bytes of one cell's row in the pad (256 + 16: bank spread)
+constexpr int C1M_PAD = 32 * C1M_ROWB;             // per wave
+constexpr int C1M_MAXROWS = 12;                    // input rows a block of 128 cells can need (F1 + 2 >= 32: five image rows)
+
+__global__ __launch_bounds__(256) void conv1_f8_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
+                                                            const float* __restrict__ bias, unsigned char* __restrict__ out,
+                                                            int B, int Tn, int F, int T1, int F1, float scale,
+                                                            const UttMeta* __restrict__ utt_meta) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char c1m_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int FW = F + 2, T1p = T1 + 2, F1p = F1 + 2, P = T1p * F1p;
+    float* xs = reinterpret_cast<float*>(c1m_smem);                       // [C1M_MAXROWS][FW]
+    unsigned char* pad = c1m_smem + ((C1M_MAXROWS * FW * 4 + 15) & ~15) + wave * C1M_PAD;
+    // weight fragments (A operands), kept for the whole kernel: tile nt, row r -> channel 32 nt + 16 ((r >> 2) & 1) + 4 (r >> 3) + (r & 3)
+    bf16x8 wf[8], wl[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        const int ch = 32 * nt + 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * half + j;
+            const float v = (k < 9 ? w9c[k * 256 + ch] : (k == 9 ? bias[ch] : 0.f)) * scale;
+            wf[nt][j] = (bf16)v;
+            wl[nt][j] = (bf16)(v - (float)wf[nt][j]);
+        }
+    }
+    // this lane's tap offsets inside the staged rows: tap = 8 half + j -> (tap / 3) rows down, tap % 3 to the right; -1 = none
+    int toff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int tap = 8 * half + j;
+        toff[j] = tap < 9 ? (tap / 3) * FW + tap % 3 : -1;
+    }
+    const int nblk = (P + 127) / 128;
+    for (int blk = blockIdx.x; blk < B * nblk; blk += gridDim.x) {
+        const int b = blk / nblk, p0 = (blk - b * nblk) * 128;
+        const int plast = p0 + 127 < P ? p0 + 127 : P - 1;
+        const int r_lo = p0 / F1p, r_hi = plast / F1p;      // bordered image rows of the block
+        const int t_base = 2 * (r_lo - 1) - 1;               // first input row that can be needed
+        const int nrows = 2 * (r_hi - r_lo) + 3;
+        const int tl = utt_meta ? utt_meta[b].frames : Tn;   // merged pass: the utterance's own batch is `tl` frames long
+        const int t1_own = utt_meta ? (tl - 1) / 2 + 1 : T1;
+        __syncthreads();  // the previous block's readers are done with xs
+        for (int i = tid; i < nrows * FW; i += 256) {
+            const int lr = i / FW, f = i - lr * FW - 1, t = t_base + lr;
+            xs[i] = (t >= 0 && t < tl && f >= 0 && f < F) ? x[((long long)b * Tn + t) * F + f] : 0.f;
+        }
+        __syncthreads();
+        // ---- this wave's 32 cells
+        const int p = p0 + 32 * wave + l31;
+        const int r = p / F1p, t1 = r - 1, f1 = p - r * F1p - 1;
+        const bool cell_in = p < P && t1 >= 0 && t1 < t1_own && f1 >= 0 && f1 < F1;
+        const int base = (2 * t1 - 1 - t_base) * FW + 2 * f1;  // input row 2 t1 - 1 + kh at staged row .. + kh, column f = 2 f1 - 1 + kw at index f + 1
+        bf16x8 xf, xl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = 0.f;
+            if (cell_in && toff[j] >= 0) v = xs[base + toff[j]];
+            if (half == 1 && j == 1) v = cell_in ? 1.f : 0.f;  // k = 9: the bias rides on a constant one (a border cell stays 0)
+            xf[j] = (bf16)v;
+            xl[j] = (bf16)(v - (float)xf[j]);
+        }
+        if (32 * wave < 128 && p0 + 32 * wave < P) {  // (wave-uniform: the wave has at least one cell)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[nt], xf, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf, acc, 0, 0, 0);
+                // registers 0..15 of lane half h = channels 32 nt + 16 h + (0..15) of cell l31: ReLU + saturation, e4m3, one 16-byte piece
+                unsigned w[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float v0 = __builtin_amdgcn_fmed3f(acc[4 * g + 0], 0.f, CN_FP8_MAX), v1 = __builtin_amdgcn_fmed3f(acc[4 * g + 1], 0.f, CN_FP8_MAX);
+                    const float v2 = __builtin_amdgcn_fmed3f(acc[4 * g + 2], 0.f, CN_FP8_MAX), v3 = __builtin_amdgcn_fmed3f(acc[4 * g + 3], 0.f, CN_FP8_MAX);
+                    unsigned d = 0;
+                    d = __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, d, false);
+                    w[g] = __builtin_amdgcn_cvt_pk_fp8_f32(v2, v3, d, true);
+                }
+                *reinterpret_cast<uint4*>(pad + l31 * C1M_ROWB + 32 * nt + 16 * half) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            // (LDS operations of one wave complete in order: the reads below see the writes above)
+            unsigned char* ob = out + ((long long)b * P + p0 + 32 * wave) * 256;
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx) {
+                const int cell = 4 * sidx + (lane >> 4), chunk = lane & 15;
+                typedef unsigned c1m_u32x4 __attribute__((ext_vector_type(4)));
+                const c1m_u32x4 v = *reinterpret_cast<const c1m_u32x4*>(pad + cell * C1M_ROWB + 16 * chunk);
+                if (p0 + 32 * wave + cell < P)
+                    __builtin_nontemporal_store(v, reinterpret_cast<c1m_u32x4*>(ob + cell * 256 + 16 * chunk));
+            }
+        }
+    }
+}
+
 // the fp8 engine's image for conv2's e4m3 form (launch_conv2_f8): bordered, one byte per element at `scale` (a power of two)
 int launch_conv1_f8(const float* x, const float* w9c, const float* bias, void* out8, int B, int T, int F, int T1, int F1, int C,
                     int halo, float scale, hipStream_t s, const UttMeta* utt_meta) {
     if (C % 8 != 0 || (256 % (C / 8)) != 0 || (halo != 1 && halo != 2)) {
         cn_set_error("conv1 (e4m3): channel count must be a multiple of 8 with C/8 dividing 256; the image is always bordered");
         return -1;
+    }
+    static const bool no_mfma = getenv("CASSNAT_CONV1_F8_VALU") != nullptr;
+    if (C == 256 && F1 + 2 >= 32 && !no_mfma) {  // (F1 + 2 >= 32: a block of 128 cells spans at most 5 image rows = 11 input rows)  // the matrix-core form (its weight fragments and pad rows are laid out for 256 channels)
+        const long long nb = (long long)B * (((long long)(T1 + 2) * (F1 + 2) + 127) / 128);
+        const unsigned grid = (unsigned)(nb < 256 * 4 ? (nb < 1 ? 1 : nb) : 256 * 4);  // 4 workgroups per CU (38 KiB of LDS each), grid-stride
+        const size_t lds = (((size_t)C1M_MAXROWS * (F + 2) * 4 + 15) & ~(size_t)15) + 4 * (size_t)C1M_PAD;
+        hipLaunchKernelGGL(conv1_f8_mfma_kernel, dim3(grid), dim3(256), lds, s, x, w9c, bias, (unsigned char*)out8, B, T, F, T1, F1, scale,
+                           utt_meta);
+        CN_HIP_CHECK(hipGetLastError());
+        return 0;
     }
     long long blocks = (long long)B * (T1 + 2);
     if (blocks > 256 * 8) blocks = 256 * 8;
