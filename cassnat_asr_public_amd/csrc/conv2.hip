@@ -33,6 +33,9 @@ struct Conv2Params {
     // F8 (template; the fp8 engine of BASELINE config 5): A and W hold e4m3fn bytes (same layouts, 256 / 9 * 256 bytes per row),
     // q8 = the two E8M0 scale bytes of the products (device: they travel in the weight blob): 127 - log2(scale of W), 127 - log2(scale of A)
     const int* q8;
+    // F8 convolution: out8_scale > 0 = the output rows are e4m3fn bytes at that scale ([M][256] bytes: the A operand of linear_out's
+    // e4m3 form) instead of bf16
+    float out8_scale;
     const float* bias;
     bf16* out;                   // [M][256] (X3: split-bf16 rows, 1 KiB each)
     int M, T1, F1, T2, F2, ntiles;
@@ -54,6 +57,7 @@ constexpr int C2_LDS = 5 * C2_SLAB;
 static_assert(C2_BM * C2_OSTRIDE <= C2_LDS && C2_BM == C2_N, "epilogue image fits; A and W slabs are the same size");
 static_assert(C2_LDS <= 160 * 1024, "LDS budget");
 constexpr int C2_KSTEPS = 9 * (C2_C / 64);
+constexpr int C2_LIN8_KSTEPS = 40;  // K steps (of 128 bytes) of the e4m3 linear_out form, unrolled: K = 5120
 
 #define C2_STR2(x) #x
 #define C2_STR(x) C2_STR2(x)
@@ -142,7 +146,7 @@ typedef int c2_v4i __attribute__((ext_vector_type(4)));
 // requests as in the bf16 kernel, a slab row now being 128 channels: 18 K steps of two blocks each
 template <bool LINEAR, bool X3 = false, bool F8 = false>
 __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
-    static_assert(!(LINEAR && X3) && !(F8 && (LINEAR || X3)), "the split and e4m3 forms exist for the convolution only");
+    static_assert(!(LINEAR && X3) && !(F8 && X3), "the split form exists for the convolution only; e4m3: convolution and linear_out");
     constexpr int ES = F8 ? 1 : 2;  // bytes per image / weight element
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         // So an A slab (HBM) has a step and a half to arrive, a W slab (L2) one step - as in the bf16 loop.
         bf16x8 Az[4], Wz[4], Au[4], Wu[4];
         const int qa_ = p.q8[0], qb_ = p.q8[1];
-        const unsigned wstep_ = 32u * (9 * C2_C * ES);  // byte distance of consecutive W pieces (32 weight rows)
+        const unsigned wstep_ = LINEAR ? 32u * (unsigned)(p.ksteps * 128) : 32u * (9 * C2_C * ES);  // byte distance of consecutive W pieces (32 weight rows)
         const unsigned pw0 = pw[0];
         unsigned tv_ = pw0;
         C2_ISSUE8(a_dst(0), pa, a_base(0))
@@ -277,7 +281,8 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         }
         // (fully unrolled - 18 steps of two blocks: with a back edge hipcc gave the 256 accumulator registers another
         // assignment at the loop's end than at its head and moved half of them through scratch, every iteration)
-        constexpr int KS8 = C2_KSTEPS / 2;
+        // (LINEAR: linear_out of the 20 x 256 = 5120-wide embedding input: 40 steps - the launcher checks)
+        constexpr int KS8 = LINEAR ? C2_LIN8_KSTEPS : C2_KSTEPS / 2;
 #pragma unroll
         for (int kt = 0; kt < KS8; ++kt) {
             const int k3 = kt % 3;
@@ -465,6 +470,44 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         }
         return;
     }
+    if constexpr (F8) {
+        if (p.out8_scale > 0.f) {
+            // ---- e4m3 epilogue: + bias, ReLU (and saturation) in one v_med3, x scale, four channels = one dword into the row image
+            // (272-byte rows), out as contiguous 256-byte rows
+            constexpr int OST8 = 256 + 16;
+            __syncthreads();
+            unsigned char* orow = smem + (wm * 128 + l31) * OST8 + (wnn * 128 + 4 * half);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4 bv[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(p.bias + wnn * 128 + 32 * nt + 8 * g + 4 * half);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = __builtin_amdgcn_fmed3f((acc[4 * nt + mt][4 * g + e] + bv[g][e]) * p.out8_scale, 0.f, CN_FP8_MAX);
+                        unsigned d = 0;
+                        d = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], d, false);
+                        d = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], d, true);
+                        *reinterpret_cast<unsigned*>(orow + mt * 32 * OST8 + 32 * nt + 8 * g) = d;
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = 16 * it + (tid >> 4), ch = tid & 15;
+                const int m = m0 + row;
+                if (m < p.M)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + (long long)m * 256 + ch * 16) =
+                        *reinterpret_cast<const uint4*>(smem + row * OST8 + ch * 16);
+            }
+            return;
+        }
+    }
     // ---- epilogue: + bias, ReLU, bf16, through LDS (row image of the tile), out as contiguous 512-byte rows
     __syncthreads();
     {
@@ -543,7 +586,7 @@ int launch_conv2_dma(const void* in, const void* w, const float* bias, void* out
 bool conv2_f8_applies(int C, int N) { return C == C2_C && N == C2_N && !getenv("CASSNAT_NO_CONV2_F8"); }
 
 int launch_conv2_f8(const void* in8, const void* w8, const int* q8_dev, const float* bias, void* out, int B, int T1, int F1, int T2,
-                    int F2, hipStream_t s) {
+                    int F2, hipStream_t s, float out8_scale) {
     static CnAttrOnce attr_once;
     int attr_dev;
     if (attr_once.need(&attr_dev)) {
@@ -555,6 +598,7 @@ int launch_conv2_f8(const void* in8, const void* w8, const int* q8_dev, const fl
     p.A = (const unsigned char*)in8;
     p.W = (const unsigned char*)w8;
     p.q8 = q8_dev;
+    p.out8_scale = out8_scale;
     p.bias = bias;
     p.out = (bf16*)out;
     p.M = B * T2 * F2;
@@ -565,6 +609,42 @@ int launch_conv2_f8(const void* in8, const void* w8, const int* q8_dev, const fl
     p.ntiles = cn_ceil_div(p.M, C2_BM);
     if (p.M <= 0) return 0;
     hipLaunchKernelGGL((conv2_kernel<false, false, true>), dim3(p.ntiles), dim3(256), C2_LDS, s, p);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// linear_out of the fp8 engine on the same tile kernel: A [M][5120] e4m3fn (conv2's e4m3 output rows viewed per frame), W [256][5120]
+// e4m3fn, q8_dev = {127 - log2(weight scale), 127 - log2(activation scale)}; epilogue as the bf16 form: (acc + bias) * scale + PE, fp32
+bool linear256_f8_applies(int N, int K) { return N == C2_N && K == C2_LIN8_KSTEPS * 128 && !getenv("CASSNAT_NO_LINEAR_F8"); }
+
+int launch_linear256_f8(const void* A8, const void* W8, const int* q8_dev, const float* bias, float* out, int M, int K, float scale,
+                        const float* pe, int pe_period, hipStream_t s) {
+    static CnAttrOnce attr_once;
+    int attr_dev;
+    if (attr_once.need(&attr_dev)) {
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)conv2_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS));
+        attr_once.mark(attr_dev);
+    }
+    if (M <= 0) return 0;
+    if (!linear256_f8_applies(C2_N, K)) {
+        cn_set_error("linear256 (e4m3): K must be 5120");
+        return -1;
+    }
+    Conv2Params p = {};
+    p.A = (const unsigned char*)A8;
+    p.W = (const unsigned char*)W8;
+    p.q8 = q8_dev;
+    p.bias = bias;
+    p.M = M;
+    p.T1 = p.F1 = p.T2 = p.F2 = 1;
+    p.ntiles = cn_ceil_div(M, C2_BM);
+    p.lda_bytes = (long long)K;
+    p.ksteps = K / 128;
+    p.out_f32 = out;
+    p.pe = pe;
+    p.pe_period = pe_period > 0 ? pe_period : 1;
+    p.scale = scale;
+    hipLaunchKernelGGL((conv2_kernel<true, false, true>), dim3(p.ntiles), dim3(256), C2_LDS, s, p);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -260,8 +260,12 @@ int launch_fbank(const FbankOpts& o, const float* wave, const int* num_samples, 
 bool conv2_dma_applies(int prec, int C, int N);
 // split-bf16 form of the same kernel: image and weights as hi / lo bf16 planes, three K steps per K step of the bf16 loop
 bool conv2_f8_applies(int C, int N);
+// out8_scale > 0: the output rows are e4m3fn bytes at that scale ([M][256] bytes) instead of bf16 - the input of launch_linear256_f8
 int launch_conv2_f8(const void* in8, const void* w8, const int* q8_dev, const float* bias, void* out, int B, int T1, int F1, int T2,
-                    int F2, hipStream_t s);
+                    int F2, hipStream_t s, float out8_scale = 0.f);
+bool linear256_f8_applies(int N, int K);
+int launch_linear256_f8(const void* A8, const void* W8, const int* q8_dev, const float* bias, float* out, int M, int K, float scale,
+                        const float* pe, int pe_period, hipStream_t s);
 bool conv2_x3_applies(int prec, int C, int N);
 int launch_conv2_x3(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias, void* out, int B,
                     int T1, int F1, int T2, int F2, hipStream_t s);

@@ -149,6 +149,8 @@ struct cn_model {
     Linear conv2;       // [C][9C] (kh,kw,cin)
     void* conv2_f8w = nullptr;  // fp8 engine, 256 channels: the same matrix as e4m3fn bytes at a per-tensor power-of-two scale, and
     int* conv2_f8q = nullptr;   // the two E8M0 scale bytes of conv2.hip's e4m3 form {127 - log2(weight scale), 127 - log2(image scale)}
+    void* linear_f8w = nullptr;  // fp8 engine: linear_out's (column-permuted) matrix as e4m3fn bytes, and its two scale bytes
+    int* linear_f8q = nullptr;   // {127 - log2(weight scale), 127 - log2(scale of conv2's e4m3 output)}
     void* conv2_x3w = nullptr;  // split-bf16 engine, 256 channels: the same matrix as two bf16 planes (hi, then lo) for conv2.hip's X3 form
     Linear linear_out;  // [d][F2*C] (f,c)
     std::vector<Layer> enc, extra, sad, mad;
@@ -798,6 +800,25 @@ int build_weights(cn_model* m) {
         for (int64_t f = 0; f < F2; ++f)
             for (int64_t ch = 0; ch < C; ++ch) perm[(size_t)(f * C + ch)] = (int)(ch * F2 + f);
         m->linear_out = pk.linear({"src_embed.linear_out"}, d, C * F2, &perm);
+        if (m->fp8_enc && m->conv2_f8w && linear256_f8_applies((int)d, (int)(C * F2))) {  // config 5: linear_out on e4m3 operands as well
+            const size_t fat = pk.reserve((size_t)d * C * F2), qat = pk.reserve(16);
+            if (pk.fill) {
+                const HostTensor* t = pk.find("src_embed.linear_out.weight", {d, C * F2});
+                if (t) {
+                    float mx = 0.f;
+                    for (float v : t->data) mx = std::max(mx, std::fabs(v));
+                    const int lg = mx > 0.f ? (int)std::floor(std::log2(448.f / mx)) : 0;
+                    const float scale = std::ldexp(1.f, lg);
+                    for (int64_t r = 0; r < d; ++r)
+                        for (int64_t cc = 0; cc < C * F2; ++cc)
+                            pk.host[fat + (size_t)(r * C * F2 + cc)] = cn_f32_to_e4m3_host(t->data[r * C * F2 + perm[(size_t)cc]] * scale);
+                    const int q[4] = {127 - lg, 127 - (int)std::lround(std::log2(FP8_S_IMG)), 0, 0};
+                    std::memcpy(&pk.host[qat], q, 16);
+                }
+            }
+            m->linear_f8w = reinterpret_cast<void*>(fat);
+            m->linear_f8q = reinterpret_cast<int*>(qat);
+        }
     }
     auto self_layer = [&](const std::string& p, const std::string& att, int64_t dff, int nnorm) {
         Layer L;
@@ -1056,6 +1077,8 @@ int build_weights(cn_model* m) {
     rebase(m->conv2_x3w, base);
     rebase(m->conv2_f8w, base);
     rebase(m->conv2_f8q, base);
+    rebase(m->linear_f8w, base);
+    rebase(m->linear_f8q, base);
     rebase_linear(m->linear_out, base);
     auto rebase_layers = [&](std::vector<Layer>& v) {
         for (auto& L : v) {
@@ -1793,6 +1816,7 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     // (the fp8 engine: an e4m3 image for the same kernel's F8 form - config 5's "fp8 MFMA encoder GEMMs" include the largest one)
     // (also under capture - the accuracy of the mode is measured on captures; the e4m3 image itself is then not captured)
     const bool f8_img = m->fp8_enc && m->conv2_f8w && conv2_f8_applies(d, d);
+    const bool f8_lin = f8_img && m->linear_f8w && linear256_f8_applies(d, F2 * d);  // conv2 then hands its rows on as e4m3 too
     const int halo = ((!cap && conv2_dma_applies(m->prec, d, d)) || x3_planes || f8_img) ? 1 : 0;
     {
         // the halo cells of the image buffer are zero already when the previous haloed image had this very shape (and nothing
@@ -1836,13 +1860,17 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
             CN_TRY(launch_conv2_x3(m->c1, (const unsigned char*)m->c1 + img, m->conv2_x3w, (const unsigned char*)m->conv2_x3w + wpl,
                                    m->conv2.b, m->c2, B, T1, F1, Tp, F2, s));
         } else if (f8_img) {
-            CN_TRY(launch_conv2_f8(m->c1, m->conv2_f8w, m->conv2_f8q, m->conv2.b, m->c2, B, T1, F1, Tp, F2, s));
+            CN_TRY(launch_conv2_f8(m->c1, m->conv2_f8w, m->conv2_f8q, m->conv2.b, m->c2, B, T1, F1, Tp, F2, s, f8_lin ? FP8_S_IMG : 0.f));
         } else {
             CN_TRY(launch_gemm(m->prec, g, s));
         }
     }
-    if (cap) CN_TRY(capture(m, "conv2", m->c2, true, CN_DTYPE_F32, {B, Tp, F2, d}, s));
-    {
+    if (cap && !f8_lin) CN_TRY(capture(m, "conv2", m->c2, true, CN_DTYPE_F32, {B, Tp, F2, d}, s));
+    if (f8_lin) {
+        ProfScope ps(m, "linear_out_embed", 2.0 * M * d * (double)F2 * d, (double)M * F2 * d + (double)d * F2 * d + (double)M * d * 4, s);
+        CN_TRY(launch_linear256_f8(m->c2, m->linear_f8w, m->linear_f8q, m->linear_out.b, m->x, M, F2 * d, sqrtf((float)d),
+                                   c.conf_enc ? nullptr : m->pe, Tp, s));
+    } else {
         GemmArgs g;
         g.A = m->c2;
         g.lda = F2 * d;
@@ -2995,10 +3023,11 @@ extern "C" int cn_op_conv1(int32_t precision, const float* x, const float* w9c, 
 
 // conv front-end of the fp8 engine through the ABI (config 5): conv1 -> e4m3fn image at `img_scale` (bordered) -> conv2 on e4m3
 // operands; w2_host fp32 [C][3][3][C] (k = (kh * 3 + kw) * C + ci) is quantised here at the largest power-of-two scale that keeps it
-// in range.  img8_out_dev (optional): the bordered image [B][T1 + 2][F1 + 2][C] bytes.  out: bf16 [B * T2 * F2][C]
+// in range.  img8_out_dev (optional): the bordered image [B][T1 + 2][F1 + 2][C] bytes.  out: bf16 [B * T2 * F2][C], or with
+// out8_scale > 0 e4m3fn bytes at that scale (what linear_out's e4m3 form reads)
 extern "C" int cn_op_conv_frontend_fp8(const float* x_dev, const float* w1_9c_dev, const float* b1_dev, const float* w2_host,
                                        const float* b2_dev, void* out_dev, void* img8_out_dev, int32_t B, int32_t T, int32_t F,
-                                       int32_t C, float img_scale, float* w_scale_out, void* stream) {
+                                       int32_t C, float img_scale, float out8_scale, float* w_scale_out, void* stream) {
     if (!conv2_f8_applies(C, C)) {
         cn_set_error("cn_op_conv_frontend_fp8: 256 channels only");
         return -1;
@@ -3022,7 +3051,7 @@ extern "C" int cn_op_conv_frontend_fp8(const float* x_dev, const float* w1_9c_de
     CN_HIP_CHECK(hipMemcpy(dq, q, 16, hipMemcpyHostToDevice));
     CN_HIP_CHECK(hipMemsetAsync(img, 0xff, img_bytes, s));  // (NaN bytes: the kernel must write every cell, border included)
     int rc = launch_conv1_f8(x_dev, w1_9c_dev, b1_dev, img, B, T, F, T1, F1, C, 1, img_scale, s);
-    if (rc == 0) rc = launch_conv2_f8(img, dw, (const int*)dq, b2_dev, out_dev, B, T1, F1, T2, F2, s);
+    if (rc == 0) rc = launch_conv2_f8(img, dw, (const int*)dq, b2_dev, out_dev, B, T1, F1, T2, F2, s, out8_scale);
     if (rc == 0 && img8_out_dev) CN_HIP_CHECK(hipMemcpyAsync(img8_out_dev, img, img_bytes, hipMemcpyDeviceToDevice, s));
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(dw);
@@ -3030,6 +3059,40 @@ extern "C" int cn_op_conv_frontend_fp8(const float* x_dev, const float* w1_9c_de
     (void)hipFree(img);
     if (rc == 0 && e != hipSuccess) {
         cn_set_error(std::string("cn_op_conv_frontend_fp8: ") + hipGetErrorString(e));
+        rc = -2;
+    }
+    return rc;
+}
+
+// linear_out of the fp8 engine through the ABI: a8_dev [M][K] e4m3fn at a_scale (K = 5120), w_host fp32 [256][K] quantised here at
+// the largest power-of-two scale in range; out fp32 [M][256] = (a . w^T / (a_scale w_scale) + bias) * out_scale + pe[m % pe_period]
+extern "C" int cn_op_linear256_fp8(const void* a8_dev, const float* w_host, const float* bias_dev, float* out_dev, int32_t M, int32_t K,
+                                   float a_scale, float out_scale, const float* pe_dev, int32_t pe_period, float* w_scale_out,
+                                   void* stream) {
+    if (!linear256_f8_applies(256, K)) {
+        cn_set_error("cn_op_linear256_fp8: K must be 5120");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)256 * K; ++i) mx = std::max(mx, std::fabs(w_host[i]));
+    const int lg = mx > 0.f ? (int)std::floor(std::log2(448.f / mx)) : 0;
+    const float ws = std::ldexp(1.f, lg);
+    if (w_scale_out) *w_scale_out = ws;
+    std::vector<unsigned char> w8((size_t)256 * K);
+    for (size_t i = 0; i < w8.size(); ++i) w8[i] = cn_f32_to_e4m3_host(w_host[i] * ws);
+    const int q[4] = {127 - lg, 127 - (int)std::lround(std::log2(a_scale)), 0, 0};
+    void *dw = nullptr, *dq = nullptr;
+    CN_HIP_CHECK(hipMalloc(&dw, w8.size()));
+    CN_HIP_CHECK(hipMalloc(&dq, 16));
+    CN_HIP_CHECK(hipMemcpy(dw, w8.data(), w8.size(), hipMemcpyHostToDevice));
+    CN_HIP_CHECK(hipMemcpy(dq, q, 16, hipMemcpyHostToDevice));
+    int rc = launch_linear256_f8(a8_dev, dw, (const int*)dq, bias_dev, out_dev, M, K, out_scale, pe_dev, pe_period, s);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    (void)hipFree(dq);
+    if (rc == 0 && e != hipSuccess) {
+        cn_set_error(std::string("cn_op_linear256_fp8: ") + hipGetErrorString(e));
         rc = -2;
     }
     return rc;

@@ -280,7 +280,13 @@ int cn_op_conv1(int32_t precision, const float* x, const float* w9c, const float
  * img8_out_dev (optional): the image as the second kernel reads it, [B][T1+2][F1+2][C] bytes with its border of zeros. */
 int cn_op_conv_frontend_fp8(const float* x_dev, const float* w1_9c_dev, const float* b1_dev, const float* w2_host,
                             const float* b2_dev, void* out_dev, void* img8_out_dev, int32_t B, int32_t T, int32_t F, int32_t C,
-                            float img_scale, float* w_scale_out, void* stream);
+                            float img_scale, float out8_scale, float* w_scale_out, void* stream);
+/* (out8_scale > 0: out_dev receives e4m3fn bytes [B*T2*F2][C] at that scale instead of bf16 - the input of the next entry)
+ * linear_out (src/models/modules/embedding.py:118-119) of the fp8 engine: a8_dev [M][K] e4m3fn at a_scale, K = 5120; w_host fp32
+ * [256][K] quantised at the largest power-of-two scale in range (*w_scale_out); out fp32 [M][256] =
+ * (a . w^T + bias) * out_scale + pe[m % pe_period] (pe_dev may be NULL). */
+int cn_op_linear256_fp8(const void* a8_dev, const float* w_host, const float* bias_dev, float* out_dev, int32_t M, int32_t K,
+                        float a_scale, float out_scale, const float* pe_dev, int32_t pe_period, float* w_scale_out, void* stream);
 int cn_op_conv2(int32_t precision, const void* conv1_out, const void* w_khwc, const float* bias, void* out, int32_t B,
                 int32_t T1, int32_t F1, int32_t C, void* stream);
 int cn_op_layernorm(int32_t precision, const float* x, const float* a2, const float* b2, void* y, int32_t M, int32_t d,

@@ -243,7 +243,7 @@ def test_conv_frontend_fp8(B, T, Fd):
     w9c, xd, b1d, b2d = dev(w1.reshape(Cc, 9).t()), dev(x), dev(b1), dev(b2)
     w2k = w2.permute(0, 2, 3, 1).reshape(Cc, 9 * Cc).contiguous()
     ws = C.c_float(0)
-    hip.check(hip.lib().cn_op_conv_frontend_fp8(p(xd), p(w9c), p(b1d), _hp(w2k), p(b2d), p(out), p(img), B, T, Fd, Cc, 8.0, C.byref(ws),
+    hip.check(hip.lib().cn_op_conv_frontend_fp8(p(xd), p(w9c), p(b1d), _hp(w2k), p(b2d), p(out), p(img), B, T, Fd, Cc, 8.0, 0.0, C.byref(ws),
                                                 stream()))
     torch.cuda.synchronize()
     imgc = img.cpu()
@@ -259,6 +259,34 @@ def test_conv_frontend_fp8(B, T, Fd):
     ref2 = F.relu(F.conv2d(c1, wq, b2, stride=2, padding=1))
     assert ws.value == 2.0 ** math.floor(math.log2(448.0 / w2.abs().max().item()))
     assert relerr(out.float().cpu().permute(0, 3, 1, 2), ref2) < 6e-3  # (bf16 output rounding: 2^-9 of the value)
+    # the same with e4m3 output rows (x8): what linear_out's e4m3 form reads
+    out8 = torch.zeros((B, T2, F2, Cc), dtype=torch.uint8, device="cuda")
+    hip.check(hip.lib().cn_op_conv_frontend_fp8(p(xd), p(w9c), p(b1d), _hp(w2k), p(b2d), p(out8), None, B, T, Fd, Cc, 8.0, 8.0, C.byref(ws),
+                                                stream()))
+    torch.cuda.synchronize()
+    want8 = (ref2 * 8.0).clamp(max=448).to(torch.float8_e4m3fn).view(torch.uint8).permute(0, 2, 3, 1)
+    d8 = (out8.cpu().int() - want8.int()).abs()
+    assert int(d8.max()) <= 1 and float((d8 != 0).float().mean()) < 5e-3  # (a code apart where the summation orders straddle a boundary)
+
+
+@pytest.mark.parametrize("M", [8000, 257, 33])
+def test_linear_out_fp8(M):
+    """linear_out + sqrt(d) scale + positional rows on e4m3 operands (K = 5120; conv2_kernel<LINEAR, F8>) against an emulation on
+    identically quantised operands."""
+    K, N, Tp = 5120, 256, 250
+    g = torch.Generator().manual_seed(M)
+    a = torch.rand(M, K, generator=g) * 6  # (ReLU outputs)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).contiguous()
+    bias, pe = 0.1 * torch.randn(N, generator=g), torch.randn(Tp, N, generator=g)
+    a8 = (a * 8.0).clamp(max=448).to(torch.float8_e4m3fn)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    ws = C.c_float(0)
+    ad, bd, ped = a8.view(torch.uint8).cuda(), dev(bias), dev(pe)  # (named: a temporary would be freed before the call runs)
+    hip.check(hip.lib().cn_op_linear256_fp8(p(ad), _hp(w), p(bd), p(out), M, K, 8.0, 16.0, p(ped), Tp, C.byref(ws), stream()))
+    torch.cuda.synchronize()
+    wq = (w * ws.value).clamp(-448, 448).to(torch.float8_e4m3fn).float() / ws.value
+    ref = (F.linear(a8.float() / 8.0, wq) + bias) * 16.0 + pe[torch.arange(M) % Tp]
+    assert relerr(out, ref) < 2e-5
 
 
 # ----------------------------------------------------------------------------------------------- LayerNorm
