@@ -441,10 +441,12 @@ def test_fp8_engine_without_row_chains_keeps_the_unfused_layer():
     """d_ff not a multiple of 256: the e4m3 feed-forward form of the chain kernel does not apply and the fp8 engine runs round 2's
     layer - four e4m3 products per encoder layer as separate launches (run_enc_layer_fp8) - behind the same e4m3 conv front-end.
     Held against the bf16 engine on the same weights, loosely (the path must stay alive and of the fp8 order)."""
-    args = synth.make_args("config2", d_encff=384, N_enc=3)
+    # 40-dim features as well: conv1's VALU form of the e4m3 image (F1 + 2 < 32), conv2's e4m3 form with bf16 output rows, bf16
+    # linear_out (K = 10 x 256, not the 5120 its e4m3 form is unrolled for)
+    args = synth.make_args("config2", d_encff=384, N_enc=3, input_size=40, n_features=40)
     state = synth.make_state(args, seed=11, blank_bias=0.35)
     lens = synth.ragged_lengths(3, 400, 200, seed=2)
-    feats, sizes = synth.make_feats(3, 400, 80, lengths=lens, seed=5)
+    feats, sizes = synth.make_feats(3, 400, 40, lengths=lens, seed=5)
     got = {}
     for prec in ("bf16", "fp8"):
         model = build(args, state, prec, capture=True)
