@@ -30,8 +30,11 @@ def main():
     ap.add_argument("--same-seed", action="store_true", help="the same random draws in every repetition")
     ap.add_argument("--rank", default="lm", choices=["lm", "at_baseline"],
                     help="ranker: the TransformerLM (lm_small) or the autoregressive baseline (config 4 model, teacher-forced)")
+    ap.add_argument("--group", type=int, default=0, help="args.hip_esa_group: samples per decoder-side pass (0: the package's default)")
     a = ap.parse_args()
     args = synth.make_args("config2", sample_num=a.samples, rank_model=a.rank, threshold=0.9)
+    if a.group > 0:
+        args.hip_esa_group = a.group
     args.hip_precision = a.precision
     args.hip_max_batch, args.hip_max_frames = a.batch, a.frames
     if a.rank == "lm":
@@ -66,7 +69,7 @@ def main():
         times.append(time.perf_counter() - t0)
     best = min(times[1:])
     print(json.dumps({"workload": f"ESA: config 2 model, sample_num {a.samples}, " + ("TransformerLM lm_small" if a.rank == "lm" else "autoregressive-baseline (config 4 model)") + " ranking",
-                      "batch": a.batch, "frames": a.frames, "precision": a.precision, "sec_per_batch": round(best, 4),
+                      "batch": a.batch, "frames": a.frames, "precision": a.precision, "esa_group": a.group or None, "sec_per_batch": round(best, 4),
                       "utt_per_sec": round(a.batch / best, 2), "rtf": round(best / (a.batch * a.frames * 0.01), 6),
                       "tokens_max": max(len(o[0]["hyp"]) for o in out) - 1, "all_runs_sec": [round(t, 4) for t in times]}))
 
