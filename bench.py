@@ -347,6 +347,10 @@ def main():
              "launches_timed": pr["count"], "isolated_achieved": iso_tf,
              "isolated_frac": None if iso_tf is None else round(iso_tf / peak, 4),
              "isolated_at_width_achieved": isow_tf, "isolated_at_width_frac": None if isow_tf is None else round(isow_tf / peak, 4)}
+        if a.precision == "bf16":
+            # context for `peak` (not a replacement): what a bare register-resident v_mfma_f32_32x32x16_bf16 loop on random operands
+            # sustains on this pool - the chip holds ~1.63 GHz under that load (tools/probes/mfma_shape_probe.hip)
+            r["bare_mfma_loop_sustained"] = {"value": 1712.0, "unit": "TFLOP/s", "source": "profiles/r04n_mfma_shape_probe.txt"}
         r.update(extra)
         return r
 
