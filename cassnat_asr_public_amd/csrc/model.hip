@@ -123,6 +123,7 @@ inline uint16_t f32_to_bf16_host(float f) {
 struct cn_model {
     cn_config cfg;
     int prec = 0;
+    int fp8_scope = 0;     // CN_FP8_* bits in force (cn_config.fp8_scope, 0 resolved to all)
     bool fp8_enc = false;  // CN_PRECISION_FP8: bf16 engine whose encoder-layer products run on the fp8 MFMA (BASELINE config 5)
     size_t es = 4;
     std::map<std::string, HostTensor> host;
@@ -772,7 +773,7 @@ int build_weights(cn_model* m) {
             }
             m->conv2_x3w = reinterpret_cast<void*>(pat);
         }
-        if (m->fp8_enc && conv2_f8_applies((int)C, (int)C)) {  // config 5: the second convolution on e4m3 operands (conv2.hip, F8)
+        if (m->fp8_enc && (m->fp8_scope & CN_FP8_CONV2) && conv2_f8_applies((int)C, (int)C)) {  // config 5: the second convolution on e4m3 operands (conv2.hip, F8)
             const size_t fat = pk.reserve((size_t)C * 9 * C), qat = pk.reserve(16);
             if (pk.fill) {
                 const HostTensor* t = pk.find("src_embed.conv.2.weight", {C, C, 3, 3});
@@ -800,7 +801,7 @@ int build_weights(cn_model* m) {
         for (int64_t f = 0; f < F2; ++f)
             for (int64_t ch = 0; ch < C; ++ch) perm[(size_t)(f * C + ch)] = (int)(ch * F2 + f);
         m->linear_out = pk.linear({"src_embed.linear_out"}, d, C * F2, &perm);
-        if (m->fp8_enc && m->conv2_f8w && linear256_f8_applies((int)d, (int)(C * F2))) {  // config 5: linear_out on e4m3 operands as well
+        if (m->fp8_enc && (m->fp8_scope & CN_FP8_LINEAR) && m->conv2_f8w && linear256_f8_applies((int)d, (int)(C * F2))) {  // config 5: linear_out on e4m3 operands as well
             const size_t fat = pk.reserve((size_t)d * C * F2), qat = pk.reserve(16);
             if (pk.fill) {
                 const HostTensor* t = pk.find("src_embed.linear_out.weight", {d, C * F2});
@@ -910,13 +911,18 @@ int build_weights(cn_model* m) {
     // per-product path (run_enc_layer_fp8)
     static const bool f8_unfused = getenv("CASSNAT_FP8_UNFUSED") != nullptr;
     const bool f8c = m->fp8_enc && !lm && !f8_unfused && c.d_encff % 256 == 0;
+    // CASSNAT_FP8_LAYERS: bit n set = layer n's feed-forward products in e4m3 (accuracy experiments: tools/fp8_accuracy.py)
+    static const unsigned f8_layers = getenv("CASSNAT_FP8_LAYERS") ? (unsigned)strtoul(getenv("CASSNAT_FP8_LAYERS"), nullptr, 0) : ~0u;
+    auto f8_at = [&](int n) {
+        return f8c && (m->fp8_scope & CN_FP8_FFN) && n >= c.fp8_ffn_first_layer && ((f8_layers >> (n & 31)) & 1u);
+    };
     if (!c.conf_enc && (!m->fp8_enc || f8c) && pk.chain_ok(d, c.d_encff))  // (the TransformerLM's layers are encoder layers: same chains)
         for (int n = 0; n < c.n_enc; ++n) {
             const std::string p = "encoder.layers." + std::to_string(n), q = "encoder.layers." + std::to_string(n + 1);
             if (n + 1 < c.n_enc)
                 m->enc_chain.push_back(pk.chain(p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff,
                                                 q + ".sublayer.0.norm",
-                                                {q + ".self_attn.linears.0", q + ".self_attn.linears.1", q + ".self_attn.linears.2"}, d, f8c));
+                                                {q + ".self_attn.linears.0", q + ".self_attn.linears.1", q + ".self_attn.linears.2"}, d, f8_at(n)));
             else {
                 // the last launch also projects enc_h = encoder.norm(x) onto the cross-attention K|V of every decoder-side
                 // layer (extractor, then mixed-attention decoder): three 8000-row GEMM launches per batch become the tail of
@@ -932,7 +938,7 @@ int build_weights(cn_model* m) {
                 }
                 m->kv_cols = (int)kv_tails.size() * (int)d;
                 m->enc_chain.push_back(
-                    pk.chain(p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff, "encoder.norm", kv_tails, d, f8c));
+                    pk.chain(p + ".self_attn.linears.3", p + ".sublayer.1.norm", p, c.d_encff, "encoder.norm", kv_tails, d, f8_at(n)));
             }
         }
     m->enc_entry = ChainRef();
@@ -2203,6 +2209,10 @@ extern "C" int cn_model_create(const cn_config* cfg, cn_model** out) {
         cn_set_error("cn_model_create: the fp8 encoder mode covers the transformer-block NAT model with d_model, d_encff % 128 == 0");
         return -1;
     }
+    if (c.fp8_scope < 0 || c.fp8_scope > 7 || ((c.fp8_scope & CN_FP8_LINEAR) && !(c.fp8_scope & CN_FP8_CONV2)) || c.fp8_ffn_first_layer < 0) {
+        cn_set_error("cn_model_create: fp8_scope is a mask of CN_FP8_CONV2 | CN_FP8_LINEAR | CN_FP8_FFN (LINEAR needs CONV2), fp8_ffn_first_layer >= 0");
+        return -1;
+    }
     if (c.input_size < 4 || c.vocab_size < 4 || c.max_batch < 1 || c.max_frames < 4 || c.n_enc < 0 || c.n_extra < 0 ||
         c.n_self_dec < 0 || c.n_mix_dec < 0) {
         cn_set_error("cn_model_create: bad dimensions");
@@ -2213,6 +2223,7 @@ extern "C" int cn_model_create(const cn_config* cfg, cn_model** out) {
     m->cfg = c;
     // fp8: a bf16 engine (storage, decoder side, conv front-end) whose encoder-layer products take e4m3fn operands
     m->fp8_enc = c.precision == CN_PRECISION_FP8;
+    m->fp8_scope = c.fp8_scope ? c.fp8_scope : (CN_FP8_CONV2 | CN_FP8_LINEAR | CN_FP8_FFN);
     m->prec = m->fp8_enc ? CN_PREC_BF16 : (c.precision == CN_PRECISION_BF16X3 ? CN_PREC_X3 : c.precision);
     m->es = cn_elem_size(m->prec);
     m->maxB = c.max_batch;

@@ -15,13 +15,36 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cassnat_hip.h")
 
 PRECISION = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp8": 2, "bf16x3": 3}
 DTYPES = {0: np.float32, 1: np.int32, 2: np.uint8, 3: np.float64}
+FP8_SCOPE_BITS = {"conv2": 1, "linear": 2, "ffn": 4}
+
+
+def parse_fp8_scope(text):
+    """``--hip_fp8_scope``: which encoder-side products of the fp8 engine take e4m3 operands - "all" or a "+"-joined list
+    of ``conv2``, ``linear`` (needs conv2) and ``ffn`` / ``ffn:N`` (the feed-forward products of the encoder layers >= N).
+    Returns (cn_config.fp8_scope, cn_config.fp8_ffn_first_layer)."""
+    text = (text or "all").strip().lower()
+    if text == "all":
+        return 0, 0
+    scope, first = 0, 0
+    for part in text.split("+"):
+        name, _, arg = part.strip().partition(":")
+        if name not in FP8_SCOPE_BITS or (arg and name != "ffn"):
+            raise ValueError(f"hip_fp8_scope: unknown part {part!r} (all, or conv2 / linear / ffn[:first layer] joined by +)")
+        scope |= FP8_SCOPE_BITS[name]
+        if arg:
+            first = int(arg)
+            if first < 0:
+                raise ValueError("hip_fp8_scope: ffn:N needs N >= 0")
+    if scope & 2 and not scope & 1:
+        raise ValueError("hip_fp8_scope: linear needs conv2 (conv2 hands its rows to linear_out in e4m3)")
+    return scope, first
 
 
 class CnConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "input_size", "d_model", "n_head", "d_encff", "d_decff", "n_enc", "n_extra", "n_self_dec", "n_mix_dec",
         "vocab_size", "precision", "max_batch", "max_frames", "device", "ast", "conf_enc", "conf_dec", "enc_max_rel", "dec_max_rel",
-        "enc_kernel", "dec_kernel", "d_ff", "esa_group")]
+        "enc_kernel", "dec_kernel", "d_ff", "esa_group", "fp8_scope", "fp8_ffn_first_layer")]
 
 
 class CnDecodeOpts(C.Structure):
@@ -200,7 +223,8 @@ class Engine:
             conf_enc=int(getattr(args, "conf_enc", 0)), conf_dec=int(getattr(args, "conf_dec", 0)),
             enc_max_rel=int(getattr(args, "enc_max_rel", 0)), dec_max_rel=int(getattr(args, "dec_max_rel", 0)),
             enc_kernel=int(getattr(args, "enc_kernel", 0)), dec_kernel=int(getattr(args, "dec_kernel", 0)),
-            d_ff=int(getattr(args, "d_ff", 0)), esa_group=int(esa_group))
+            d_ff=int(getattr(args, "d_ff", 0)), esa_group=int(esa_group),
+            fp8_scope=int(getattr(args, "fp8_scope", 0)), fp8_ffn_first_layer=int(getattr(args, "fp8_ffn_first_layer", 0)))
         self.precision = precision
         self.handle = C.c_void_p()
         if share_with is not None:

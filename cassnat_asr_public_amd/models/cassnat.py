@@ -258,6 +258,7 @@ class CassNAT(nn.Module):
                            d_ff=getattr(args, "d_ff", 0) if conf_dec else 0)
         self._conf_dec = conf_dec
         self.hip_precision = getattr(args, "hip_precision", "bf16")
+        self._hyper["fp8_scope"], self._hyper["fp8_ffn_first_layer"] = hip.parse_fp8_scope(getattr(args, "hip_fp8_scope", "all"))
         self.hip_max_batch = getattr(args, "hip_max_batch", 32)
         self.hip_max_frames = getattr(args, "hip_max_frames", 2048)
         self._engine = None

@@ -23,6 +23,9 @@ class DecodeParser(object):
         # engine switches (not in the reference)
         p.add_argument("--hip_precision", default="bf16", choices=["bf16", "fp32", "fp8", "bf16x3"],
                        help="bf16 MFMA (throughput) or exact-f32 MFMA (parity with the reference CPU path)")
+        p.add_argument("--hip_fp8_scope", default="all",
+                       help="--hip_precision fp8: which encoder-side products take e4m3 operands - all, or conv2 / linear / "
+                            "ffn[:first layer] joined by + (e.g. conv2+ffn:8); fewer products = fewer arg-max flips, less speed-up")
         p.add_argument("--hip_max_frames", default=4096, type=int, help="workspace size in input frames")
         p.add_argument("--hip_pipelines", default=2, type=int,
                        help="decode pipelines per GPU for greedy decoding of a test set (1 = batch after batch, the reference's loop)")

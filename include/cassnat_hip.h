@@ -51,7 +51,17 @@ typedef struct cn_config {
     int32_t d_ff;                     /* args.d_ff: width of the conformer extractor's FFN */
     int32_t esa_group;                /* ESA: sampled alignments per utterance one cn_esa_sample pass may take (0/1: one);
                                          sizes the decoder-side workspace (max_batch x esa_group query sets) */
+    /* CN_PRECISION_FP8 only: which encoder-side products take e4m3 operands (every e4m3 product adds ~5 % of relative
+     * noise to its output; the throughput each one buys differs - DESIGN.md 5d has the measured table).  Bits:
+     * CN_FP8_CONV2 the second convolution (conv1 then writes its image in e4m3), CN_FP8_LINEAR linear_out (needs CONV2:
+     * conv2 hands its rows on in e4m3), CN_FP8_FFN the two feed-forward products of the encoder layers
+     * n >= fp8_ffn_first_layer.  0 = all three, every layer. */
+    int32_t fp8_scope;
+    int32_t fp8_ffn_first_layer;
 } cn_config;
+#define CN_FP8_CONV2 1
+#define CN_FP8_LINEAR 2
+#define CN_FP8_FFN 4
 
 /* Decode-time switches read by beam_decode from `args` (src/models/cassnat.py:435-636). */
 typedef struct cn_decode_opts {
