@@ -203,12 +203,17 @@ int launch_conv1_planes(const float* x, const float* w9c, const float* bias, voi
 // cells would land one code away from the fp32 convolution's (tests/test_gpu_kernels.py::test_conv_frontend_fp8 allows 0.2 %).
 constexpr int C1M_ROWB = 272;                      // bytes of one cell's row in the pad (256 + 16: bank spread)
 constexpr int C1M_PAD = 32 * C1M_ROWB;             // per wave
+constexpr int C1M_PRE = 6;                         // staged floats per thread: 256 x 6 >= C1M_MAXROWS x (F + 2), i.e. F <= 126
 constexpr int C1M_MAXROWS = 12;                    // input rows a block of 128 cells can need (F1 + 2 >= 32: five image rows)
 
-__global__ __launch_bounds__(256) void conv1_f8_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
-                                                            const float* __restrict__ bias, unsigned char* __restrict__ out,
-                                                            int B, int Tn, int F, int T1, int F1, float scale,
-                                                            const UttMeta* __restrict__ utt_meta) {
+// OUT8 = false: the same kernel writing the bf16 engine's bordered image (512 bytes per cell, scale 1): a cell's row crosses the pad
+// in two halves of four tiles (128 channels = 256 bytes each), so the pad and the store pattern are the e4m3 form's.
+template <bool OUT8>
+__global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
+                                                         const float* __restrict__ bias, unsigned char* __restrict__ out,
+                                                         int B, int Tn, int F, int T1, int F1, float scale,
+                                                         const UttMeta* __restrict__ utt_meta) {
+    constexpr int CELLB = OUT8 ? 256 : 512;  // bytes of a cell's 256 channels in the image
     extern __shared__ __attribute__((aligned(16))) unsigned char c1m_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int FW = F + 2, T1p = T1 + 2, F1p = F1 + 2, P = T1p * F1p;
@@ -235,6 +240,23 @@ __global__ __launch_bounds__(256) void conv1_f8_mfma_kernel(const float* __restr
         toff[j] = tap < 9 ? (tap / 3) * FW + tap % 3 : -1;
     }
     const int nblk = (P + 127) / 128;
+    // a block's input rows travel in registers while the block before it is computed (the workgroup is resident twice per CU: with
+    // the rows requested at the top of a block, the round trip to L2 / HBM was most of the block's time)
+    float pre[C1M_PRE];
+    auto request_rows = [&](int blk) {
+        const int b = blk / nblk, p0 = (blk - b * nblk) * 128;
+        const int plast = p0 + 127 < P ? p0 + 127 : P - 1;
+        const int r_lo = p0 / F1p, r_hi = plast / F1p;
+        const int t_base = 2 * (r_lo - 1) - 1, nrows = 2 * (r_hi - r_lo) + 3;
+        const int tl = utt_meta ? utt_meta[b].frames : Tn;
+#pragma unroll
+        for (int q = 0; q < C1M_PRE; ++q) {
+            const int i = tid + 256 * q;
+            const int lr = i / FW, f = i - lr * FW - 1, t = t_base + lr;
+            pre[q] = (i < nrows * FW && t >= 0 && t < tl && f >= 0 && f < F) ? x[((long long)b * Tn + t) * F + f] : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < B * nblk) request_rows(blockIdx.x);
     for (int blk = blockIdx.x; blk < B * nblk; blk += gridDim.x) {
         const int b = blk / nblk, p0 = (blk - b * nblk) * 128;
         const int plast = p0 + 127 < P ? p0 + 127 : P - 1;
@@ -244,11 +266,11 @@ __global__ __launch_bounds__(256) void conv1_f8_mfma_kernel(const float* __restr
         const int tl = utt_meta ? utt_meta[b].frames : Tn;   // merged pass: the utterance's own batch is `tl` frames long
         const int t1_own = utt_meta ? (tl - 1) / 2 + 1 : T1;
         __syncthreads();  // the previous block's readers are done with xs
-        for (int i = tid; i < nrows * FW; i += 256) {
-            const int lr = i / FW, f = i - lr * FW - 1, t = t_base + lr;
-            xs[i] = (t >= 0 && t < tl && f >= 0 && f < F) ? x[((long long)b * Tn + t) * F + f] : 0.f;
-        }
+#pragma unroll
+        for (int q = 0; q < C1M_PRE; ++q)
+            if (tid + 256 * q < nrows * FW) xs[tid + 256 * q] = pre[q];
         __syncthreads();
+        if (blk + (int)gridDim.x < B * nblk) request_rows(blk + gridDim.x);
         // ---- this wave's 32 cells
         const int p = p0 + 32 * wave + l31;
         const int r = p / F1p, t1 = r - 1, f1 = p - r * F1p - 1;
@@ -272,30 +294,77 @@ __global__ __launch_bounds__(256) void conv1_f8_mfma_kernel(const float* __restr
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[nt], xf, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xl, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf, acc, 0, 0, 0);
-                // registers 0..15 of lane half h = channels 32 nt + 16 h + (0..15) of cell l31: ReLU + saturation, e4m3, one 16-byte piece
-                unsigned w[4];
+                // registers 0..15 of lane half h = channels 32 nt + 16 h + (0..15) of cell l31
+                if constexpr (OUT8) {  // ReLU + saturation, e4m3, one 16-byte piece
+                    unsigned w[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float v0 = __builtin_amdgcn_fmed3f(acc[4 * g + 0], 0.f, CN_FP8_MAX), v1 = __builtin_amdgcn_fmed3f(acc[4 * g + 1], 0.f, CN_FP8_MAX);
-                    const float v2 = __builtin_amdgcn_fmed3f(acc[4 * g + 2], 0.f, CN_FP8_MAX), v3 = __builtin_amdgcn_fmed3f(acc[4 * g + 3], 0.f, CN_FP8_MAX);
-                    unsigned d = 0;
-                    d = __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, d, false);
-                    w[g] = __builtin_amdgcn_cvt_pk_fp8_f32(v2, v3, d, true);
+                    for (int g = 0; g < 4; ++g) {
+                        const float v0 = __builtin_amdgcn_fmed3f(acc[4 * g + 0], 0.f, CN_FP8_MAX), v1 = __builtin_amdgcn_fmed3f(acc[4 * g + 1], 0.f, CN_FP8_MAX);
+                        const float v2 = __builtin_amdgcn_fmed3f(acc[4 * g + 2], 0.f, CN_FP8_MAX), v3 = __builtin_amdgcn_fmed3f(acc[4 * g + 3], 0.f, CN_FP8_MAX);
+                        unsigned d = 0;
+                        d = __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, d, false);
+                        w[g] = __builtin_amdgcn_cvt_pk_fp8_f32(v2, v3, d, true);
+                    }
+                    *reinterpret_cast<uint4*>(pad + l31 * C1M_ROWB + 32 * nt + 16 * half) = make_uint4(w[0], w[1], w[2], w[3]);
+                } else {  // ReLU, bf16: two 16-byte pieces at 64 (nt & 3) + 32 half of the pad row
+                    bf16x8 o0, o1;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        o0[q] = (bf16)fmaxf(acc[q], 0.f);
+                        o1[q] = (bf16)fmaxf(acc[8 + q], 0.f);
+                    }
+                    unsigned char* pr = pad + l31 * C1M_ROWB + 64 * (nt & 3) + 32 * half;
+                    *reinterpret_cast<bf16x8*>(pr) = o0;
+                    *reinterpret_cast<bf16x8*>(pr + 16) = o1;
                 }
-                *reinterpret_cast<uint4*>(pad + l31 * C1M_ROWB + 32 * nt + 16 * half) = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            // (LDS operations of one wave complete in order: the reads below see the writes above)
-            unsigned char* ob = out + ((long long)b * P + p0 + 32 * wave) * 256;
+                // (LDS operations of one wave complete in order: the reads below see the writes above, the next writes come after them)
+                if (OUT8 ? nt == 7 : (nt & 3) == 3) {
+                    unsigned char* ob = out + ((long long)b * P + p0 + 32 * wave) * CELLB + (OUT8 ? 0 : 256 * (nt >> 2));
 #pragma unroll
-            for (int sidx = 0; sidx < 8; ++sidx) {
-                const int cell = 4 * sidx + (lane >> 4), chunk = lane & 15;
-                typedef unsigned c1m_u32x4 __attribute__((ext_vector_type(4)));
-                const c1m_u32x4 v = *reinterpret_cast<const c1m_u32x4*>(pad + cell * C1M_ROWB + 16 * chunk);
-                if (p0 + 32 * wave + cell < P)
-                    __builtin_nontemporal_store(v, reinterpret_cast<c1m_u32x4*>(ob + cell * 256 + 16 * chunk));
+                    for (int sidx = 0; sidx < 8; ++sidx) {
+                        const int cell = 4 * sidx + (lane >> 4), chunk = lane & 15;
+                        typedef unsigned c1m_u32x4 __attribute__((ext_vector_type(4)));
+                        const c1m_u32x4 v = *reinterpret_cast<const c1m_u32x4*>(pad + cell * C1M_ROWB + 16 * chunk);
+                        if (p0 + 32 * wave + cell < P)
+                            __builtin_nontemporal_store(v, reinterpret_cast<c1m_u32x4*>(ob + cell * CELLB + 16 * chunk));
+                    }
+                }
             }
         }
     }
+}
+
+static inline bool conv1_mfma_applies(int C, int F1) {  // (F1 + 2 >= 32: a block of 128 cells spans at most 5 image rows = 11 input rows)
+    return C == 256 && F1 + 2 >= 32 && F1 <= 63;        // (weight fragments and pad rows are laid out for 256 channels; F <= 126: C1M_PRE)
+}
+static inline int launch_conv1_mfma(bool out8, const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1,
+                                    int F1, float scale, hipStream_t s, const UttMeta* utt_meta) {
+    const long long nb = (long long)B * (((long long)(T1 + 2) * (F1 + 2) + 127) / 128);
+    const unsigned grid = (unsigned)(nb < 256 * 4 ? (nb < 1 ? 1 : nb) : 256 * 4);  // 4 workgroups per CU (38 KiB of LDS each), grid-stride
+    const size_t lds = (((size_t)C1M_MAXROWS * (F + 2) * 4 + 15) & ~(size_t)15) + 4 * (size_t)C1M_PAD;
+    if (out8)
+        hipLaunchKernelGGL(conv1_mfma_kernel<true>, dim3(grid), dim3(256), lds, s, x, w9c, bias, (unsigned char*)out, B, T, F, T1, F1, scale, utt_meta);
+    else
+        hipLaunchKernelGGL(conv1_mfma_kernel<false>, dim3(grid), dim3(256), lds, s, x, w9c, bias, (unsigned char*)out, B, T, F, T1, F1, 1.f, utt_meta);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// the bf16 engine's bordered image on the matrix cores (conv2's LDS-DMA kernel reads it): every cell of the border is written
+int launch_conv1_bordered_bf16(const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1, int F1, int C,
+                               hipStream_t s, const UttMeta* utt_meta) {
+    if (!conv1_mfma_applies(C, F1)) {
+        cn_set_error("conv1 (matrix-core form): 256 channels and at least 30 feature columns after the stride");
+        return -1;
+    }
+    return launch_conv1_mfma(false, x, w9c, bias, out, B, T, F, T1, F1, 1.f, s, utt_meta);
+}
+// (A/B on the benchmark, `profiles/r05g_conv1_mfma_ab.txt`: the bf16 image is bound by its 3.4 GB of writes either way - 0.077 ms per
+// batch against the VALU kernel's 0.080, end to end a tie - so the engine keeps the VALU kernel, whose sums are the fp32 FMA chain's;
+// CASSNAT_CONV1_MFMA=1 selects this form)
+bool conv1_bordered_bf16_applies(int C, int F1) {
+    static const bool on = getenv("CASSNAT_CONV1_MFMA") != nullptr;
+    return on && conv1_mfma_applies(C, F1);
 }
 
 // the fp8 engine's image for conv2's e4m3 form (launch_conv2_f8): bordered, one byte per element at `scale` (a power of two)
@@ -306,15 +375,7 @@ int launch_conv1_f8(const float* x, const float* w9c, const float* bias, void* o
         return -1;
     }
     static const bool no_mfma = getenv("CASSNAT_CONV1_F8_VALU") != nullptr;
-    if (C == 256 && F1 + 2 >= 32 && !no_mfma) {  // (F1 + 2 >= 32: a block of 128 cells spans at most 5 image rows = 11 input rows)  // the matrix-core form (its weight fragments and pad rows are laid out for 256 channels)
-        const long long nb = (long long)B * (((long long)(T1 + 2) * (F1 + 2) + 127) / 128);
-        const unsigned grid = (unsigned)(nb < 256 * 4 ? (nb < 1 ? 1 : nb) : 256 * 4);  // 4 workgroups per CU (38 KiB of LDS each), grid-stride
-        const size_t lds = (((size_t)C1M_MAXROWS * (F + 2) * 4 + 15) & ~(size_t)15) + 4 * (size_t)C1M_PAD;
-        hipLaunchKernelGGL(conv1_f8_mfma_kernel, dim3(grid), dim3(256), lds, s, x, w9c, bias, (unsigned char*)out8, B, T, F, T1, F1, scale,
-                           utt_meta);
-        CN_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
+    if (conv1_mfma_applies(C, F1) && !no_mfma) return launch_conv1_mfma(true, x, w9c, bias, out8, B, T, F, T1, F1, scale, s, utt_meta);
     long long blocks = (long long)B * (T1 + 2);
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;

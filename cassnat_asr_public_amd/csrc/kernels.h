@@ -60,6 +60,10 @@ int launch_conv1_planes(const float* x, const float* w9c, const float* bias, voi
 // fp8 engine (BASELINE config 5): the bordered image as e4m3fn bytes at `scale`, for launch_conv2_f8
 int launch_conv1_f8(const float* x, const float* w9c, const float* bias, void* out8, int B, int T, int F, int T1, int F1, int C,
                     int halo, float scale, hipStream_t s, const UttMeta* utt_meta = nullptr);
+// bf16 engine: the bordered bf16 image on the matrix cores (the e4m3 form's kernel with 512-byte cells); C == 256, F1 + 2 >= 32
+bool conv1_bordered_bf16_applies(int C, int F1);
+int launch_conv1_bordered_bf16(const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1, int F1,
+                               int C, hipStream_t s, const UttMeta* utt_meta = nullptr);
 // the UttMeta records of a merged pass from its (rows, frames) list: n_sub <= CN_MAX_SUB batches, given by value
 constexpr int CN_MAX_SUB = 64;
 struct SubList {

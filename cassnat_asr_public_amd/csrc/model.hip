@@ -1834,6 +1834,8 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
             CN_TRY(launch_conv1_planes(feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : 1, s, um));
         else if (f8_img)
             CN_TRY(launch_conv1_f8(feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : 1, FP8_S_IMG, s, um));
+        else if (halo && m->prec == CN_PREC_BF16 && conv1_bordered_bf16_applies(d, F1))
+            CN_TRY(launch_conv1_bordered_bf16(feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, s, um));
         else
             CN_TRY(launch_conv1(m->prec, feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : halo, s, um));
         m->c1_halo_B = halo ? B : -1;
@@ -3030,6 +3032,13 @@ extern "C" int cn_op_convert(int32_t precision, const void* src, void* dst, int6
 extern "C" int cn_op_conv1(int32_t precision, const float* x, const float* w9c, const float* bias, void* out, int32_t B,
                            int32_t T, int32_t F, int32_t C, void* stream) {
     return launch_conv1(precision, x, w9c, bias, out, B, T, F, (T - 1) / 2 + 1, (F - 1) / 2 + 1, C, 0, (hipStream_t)stream);
+}
+
+// the bf16 engine's bordered image ([B][T1 + 2][F1 + 2][C] bf16, zero border) as conv2's LDS-DMA kernel reads it, from the
+// matrix-core kernel (C == 256, (F - 1) / 2 + 3 >= 32)
+extern "C" int cn_op_conv1_bordered(const float* x, const float* w9c, const float* bias, void* out, int32_t B, int32_t T, int32_t F,
+                                    int32_t C, void* stream) {
+    return launch_conv1_bordered_bf16(x, w9c, bias, out, B, T, F, (T - 1) / 2 + 1, (F - 1) / 2 + 1, C, (hipStream_t)stream);
 }
 
 // conv front-end of the fp8 engine through the ABI (config 5): conv1 -> e4m3fn image at `img_scale` (bordered) -> conv2 on e4m3

@@ -284,6 +284,11 @@ int cn_op_gemm(int32_t precision, const void* A, int32_t lda, const void* W, con
                const float* pe, int32_t pe_period, float scale, void* stream);
 int cn_op_conv1(int32_t precision, const float* x, const float* w9c, const float* bias, void* out, int32_t B, int32_t T,
                 int32_t F, int32_t C, void* stream);
+/* the bf16 engine's form of the same layer (src/models/modules/embedding.py:102-104): conv1 + ReLU written as the bordered bf16
+ * image [B][T1+2][F1+2][C] (zero border) that the second convolution's tile kernel reads; computed on the matrix cores from
+ * split-bf16 operands (16 significant bits in front of the bf16 rounding).  C == 256, (F-1)/2 + 3 >= 32. */
+int cn_op_conv1_bordered(const float* x, const float* w9c, const float* bias, void* out, int32_t B, int32_t T, int32_t F,
+                         int32_t C, void* stream);
 /* fp8 engine's conv front-end (BASELINE config 5, src/models/modules/embedding.py:102-108 on e4m3fn operands): conv1 + ReLU written as
  * an e4m3fn image at img_scale (a power of two; saturating), conv2 + ReLU from it with w2 (HOST fp32, [C][3][3][C]: k = (kh*3+kw)*C + ci)
  * quantised at the largest power-of-two scale that keeps max|w| <= 448 (returned in *w_scale_out); out bf16 [B*T2*F2][C].  C == 256.

@@ -222,6 +222,38 @@ def test_conv1_conv2(prec, B, T, Fd, Cc):
     assert relerr(out2.float().permute(0, 3, 1, 2), ref2) < RTOL[prec]
 
 
+@pytest.mark.parametrize("B,T,Fd", [(2, 67, 80), (3, 200, 80), (1, 9, 59), (5, 1000, 80), (1, 4, 83)])
+def test_conv1_bordered_bf16_image_from_the_matrix_cores(B, T, Fd):
+    """The bf16 engine's conv1 (embedding.py:102-104) as conv2's tile kernel reads it: [B][T1+2][F1+2][256] bf16 with a border of
+    zeros.  Split-bf16 operands carry 16 significant bits in front of the bf16 rounding: the image equals bf16(relu(fp32
+    convolution)) except where the fp32 value sits within 2^-16 of a rounding boundary (one code apart, a fraction of a percent)."""
+    Cc = 256
+    g = torch.Generator().manual_seed(B * T + Fd)
+    x = torch.randn(B, T, Fd, generator=g) * 3
+    w1 = torch.randn(Cc, 1, 3, 3, generator=g) / 3
+    b1 = torch.randn(Cc, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x.unsqueeze(1), w1, b1, stride=2, padding=1)).permute(0, 2, 3, 1)  # (B,T1,F1,C)
+    T1, F1 = ref.shape[1], ref.shape[2]
+    want = torch.zeros(B, T1 + 2, F1 + 2, Cc)
+    want[:, 1:-1, 1:-1] = ref
+    want16 = want.to(torch.bfloat16)
+    L = hip.lib()
+    img = torch.full((B, T1 + 2, F1 + 2, Cc), 7.0, dtype=torch.bfloat16, device="cuda")
+    w9c, xd, b1d = dev(w1.reshape(Cc, 9).t()), dev(x), dev(b1)
+    hip.check(L.cn_op_conv1_bordered(p(xd), p(w9c), p(b1d), p(img), B, T, Fd, Cc, stream()))
+    torch.cuda.synchronize()
+    got = img.cpu()
+    border = torch.ones(T1 + 2, F1 + 2, dtype=torch.bool)
+    border[1:-1, 1:-1] = False
+    assert (got[:, border] == 0).all()
+    differ = got.view(torch.int16) != want16.view(torch.int16)
+    assert differ.float().mean() < 5e-3
+    # where they differ they are neighbours (one bf16 code apart), or a sum that cancels to almost nothing (the operands' 16 bits
+    # are relative to the terms, not to the sum)
+    assert bool(((got.float() - want16.float()).abs() <= want.abs() * 2.0 ** -7 + 2e-4).all())
+    assert relerr(got.float(), want) < 5e-3
+
+
 @pytest.mark.parametrize("B,T,Fd", [(2, 67, 80), (3, 200, 80), (1, 9, 16), (5, 1000, 80)])
 def test_conv_frontend_fp8(B, T, Fd):
     """BASELINE config 5's conv front-end: conv1 + ReLU as an e4m3fn image at x8 (bordered, as conv2's LDS-DMA kernel reads it), conv2 +
