@@ -9,6 +9,9 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcassnat_hip.so")
 SOURCES = ["gemm.hip", "fbank.hip", "conv2.hip", "conv1.hip", "rowops.hip", "attention.hip", "ctc_align.hip", "ctc_beam.hip", "fused.hip", "fused_x3.hip", "genmax.hip", "proj_x3.hip", "conformer.hip", "chain.hip", "ast.hip", "model.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# conv1.hip: its matrix-core kernel converts every accumulator right behind the MFMAs - with the results in VGPRs (not AGPRs) the
+# 128 v_accvgpr_read per block of 128 cells go (the kernel is bound by its VALU instruction count)
+FILE_FLAGS = {"conv1.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():
@@ -33,7 +36,7 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir=None):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         path = os.path.join(CSRC, src)
         if force or _stale(obj, [path] + headers):
-            cmd = [_hipcc()] + FLAGS + list(extra_flags) + ["-c", path, "-o", obj]
+            cmd = [_hipcc()] + FLAGS + FILE_FLAGS.get(src, []) + list(extra_flags) + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             r = subprocess.run(cmd, capture_output=True, text=True)

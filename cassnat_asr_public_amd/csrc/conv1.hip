@@ -257,6 +257,25 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict
         }
     };
     if ((int)blockIdx.x < B * nblk) request_rows(blockIdx.x);
+    // the wave's 32 cells waiting in the pad: where they go and how many of them exist (0: nothing waits)
+    long long pend_off = 0;
+    int pend_cells = 0;
+    auto flush = [&](int grp) {  // (LDS operations of one wave complete in order: these reads see the writes before them, later writes come after)
+        if (pend_cells > 0) {
+            typedef unsigned c1m_u32x4 __attribute__((ext_vector_type(4)));
+            unsigned char* ob = out + pend_off + 256 * grp;
+            c1m_u32x4 v[8];  // all eight pieces first, then the stores (a read, its wait and its store in turn: eight LDS round trips)
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx)
+                v[sidx] = *reinterpret_cast<const c1m_u32x4*>(pad + (4 * sidx + (lane >> 4)) * C1M_ROWB + 16 * (lane & 15));
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx) {
+                const int cell = 4 * sidx + (lane >> 4), chunk = lane & 15;
+                if (cell < pend_cells)
+                    __builtin_nontemporal_store(v[sidx], reinterpret_cast<c1m_u32x4*>(ob + cell * CELLB + 16 * chunk));
+            }
+        }
+    };
     for (int blk = blockIdx.x; blk < B * nblk; blk += gridDim.x) {
         const int b = blk / nblk, p0 = (blk - b * nblk) * 128;
         const int plast = p0 + 127 < P ? p0 + 127 : P - 1;
@@ -285,7 +304,14 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict
             xf[j] = (bf16)v;
             xl[j] = (bf16)(v - (float)xf[j]);
         }
-        if (32 * wave < 128 && p0 + 32 * wave < P) {  // (wave-uniform: the wave has at least one cell)
+        // The pad's content leaves one phase late: the last group of block k is stored at the top of block k + 1, in front of its
+        // MFMAs.  hipcc waits for a block's row requests with vmcnt(0) (loads and stores share the counter), i.e. for every store
+        // issued before that point as well; issued here the stores have a block's arithmetic to land before that wait.
+        // (Measured alone on the bf16 image of ten batches, 3.45 GB: 0.63-0.71 ms by box; without its stores 0.38, without its row
+        // requests 0.72, a plain fill of the buffer 0.50 - arithmetic and stores overlap only in part; `tools/conv1_time.py`.)
+        flush(OUT8 ? 0 : 1);
+        const bool have = p0 + 32 * wave < P;  // (wave-uniform: the wave has at least one cell)
+        if (have) {
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
                 f32x16 acc;
@@ -316,22 +342,18 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict
                     unsigned char* pr = pad + l31 * C1M_ROWB + 64 * (nt & 3) + 32 * half;
                     *reinterpret_cast<bf16x8*>(pr) = o0;
                     *reinterpret_cast<bf16x8*>(pr + 16) = o1;
-                }
-                // (LDS operations of one wave complete in order: the reads below see the writes above, the next writes come after them)
-                if (OUT8 ? nt == 7 : (nt & 3) == 3) {
-                    unsigned char* ob = out + ((long long)b * P + p0 + 32 * wave) * CELLB + (OUT8 ? 0 : 256 * (nt >> 2));
-#pragma unroll
-                    for (int sidx = 0; sidx < 8; ++sidx) {
-                        const int cell = 4 * sidx + (lane >> 4), chunk = lane & 15;
-                        typedef unsigned c1m_u32x4 __attribute__((ext_vector_type(4)));
-                        const c1m_u32x4 v = *reinterpret_cast<const c1m_u32x4*>(pad + cell * C1M_ROWB + 16 * chunk);
-                        if (p0 + 32 * wave + cell < P)
-                            __builtin_nontemporal_store(v, reinterpret_cast<c1m_u32x4*>(ob + cell * CELLB + 16 * chunk));
+                    if (nt == 3) {  // the first half of the cells' rows leaves in the middle of the block
+                        pend_off = ((long long)b * P + p0 + 32 * wave) * CELLB;
+                        pend_cells = P - (p0 + 32 * wave);
+                        flush(0);
                     }
                 }
             }
         }
+        pend_off = ((long long)b * P + p0 + 32 * wave) * CELLB;
+        pend_cells = have ? P - (p0 + 32 * wave) : 0;
     }
+    flush(OUT8 ? 0 : 1);
 }
 
 static inline bool conv1_mfma_applies(int C, int F1) {  // (F1 + 2 >= 32: a block of 128 cells spans at most 5 image rows = 11 input rows)
