@@ -70,6 +70,7 @@ struct ChainParams {
     int M, ffn_tiles, tail_tiles, has_next;
     float eps;
     int stamps;
+    int stamp_block;  // which workgroup writes the stamps (CASSNAT_CHAIN_STAMP_BLOCK: a later round's phases are not the first round's)
     int x_in_blk, x_out_blk, store_x;
     int out_blk;  // tail projection in the blocked layout (cn_blk16_off): every store instruction writes 1 KiB contiguous
     int ctx_blk;  // ctx in the attention kernel's blocked output layout: per 32-row block [16 k-steps][64 lanes][16 B]
@@ -591,9 +592,9 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     const int mc = m < p.M ? m : p.M - 1;
     const bool live = m < p.M;
 #define CH_STAMP(i)                                                                              \
-    if (p.stamps && blockIdx.x == 0 && tid == 0) ch_stamps[i] = (long long)__builtin_amdgcn_s_memtime();
+    if (p.stamps && (int)blockIdx.x == p.stamp_block && tid == 0) ch_stamps[i] = (long long)__builtin_amdgcn_s_memtime();
     CH_STAMP(0)
-    if (p.stamps && blockIdx.x == 0 && tid == 0) ch_stamps[10] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (p.stamps && (int)blockIdx.x == p.stamp_block && tid == 0) ch_stamps[10] = (long long)__builtin_amdgcn_s_memrealtime();
     // groups of 8 units in consumption order: [output projection] [FFN: ffn_tiles / 4 groups, walked in a rotation of
     // its own by every workgroup - the sum over tiles is order-free, and the workgroups of a launch then do not pull the
     // same L2 lines at the same moment] [tail projection: tail_tiles / 8 groups]
@@ -1114,7 +1115,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     // the dummy refills of the last units may still be writing this workgroup's LDS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     CH_STAMP(9)
-    if (p.stamps && blockIdx.x == 0 && tid == 0) ch_stamps[11] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (p.stamps && (int)blockIdx.x == p.stamp_block && tid == 0) ch_stamps[11] = (long long)__builtin_amdgcn_s_memrealtime();
 }
 
 int chain_print_stamps() {
@@ -1159,6 +1160,8 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
     p.eps = a.eps;
     static const int stamps = getenv("CASSNAT_CHAIN_STAMPS") ? atoi(getenv("CASSNAT_CHAIN_STAMPS")) : 0;  // (thread-safe init)
     p.stamps = stamps;
+    static const int stamp_block = getenv("CASSNAT_CHAIN_STAMP_BLOCK") ? atoi(getenv("CASSNAT_CHAIN_STAMP_BLOCK")) : 0;
+    p.stamp_block = stamp_block;
     p.x_in_blk = a.x_in_blocked;
     p.x_out_blk = a.x_out_blocked;
     p.store_x = a.store_x && (a.ctx || a.dff);
