@@ -642,8 +642,13 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainParams p) {
     {
         // piece i = 4 nt + g holds channels 32 nt + 8 g + 4 half + (0..3): row-major it sits at float 8 i of the row,
         // blocked at float 256 i + 4 lane of the row block
+#ifdef CH_EXP_HOT_X  // timing experiment: every workgroup reads row block (wave) of x - L2-hot after the first round (wrong results):
+                     // what a launch costs when its x rows do not have to come from HBM at the start of a workgroup
+        const float* xp = p.x + (long long)wave * 8192 + 4 * lane;
+#else
         const float* xp = p.x_in_blk ? p.x + (long long)(rb < nrb ? rb : nrb - 1) * 8192 + 4 * lane
                                      : p.x + (long long)mc * CH_D + 4 * half;
+#endif
         const int step = p.x_in_blk ? 256 : 8;
         const float* xb[8];
 #pragma unroll

@@ -21,7 +21,7 @@ def main():
     if extra:
         lib = B.build(extra_flags=extra, lib=os.path.join(out, "libcassnat_hip_chain%s.so" % tag), objdir=os.path.join(out, "cn_chain_obj" + tag))
     else:
-        lib = B.LIB  # the product build (CASSNAT_CHAIN_STAMP_BLOCK chooses the workgroup that writes the stamps)
+        lib = os.environ.get("CASSNAT_HIP_LIB") or B.LIB  # the product build (CASSNAT_CHAIN_STAMP_BLOCK chooses the workgroup that writes the stamps)
     L = C.CDLL(lib)
     L.cn_op_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 12 + [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                                                        C.c_float, C.c_int32, C.c_void_p]
