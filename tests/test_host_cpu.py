@@ -39,6 +39,20 @@ def test_create_rejects_unsupported_geometry_without_touching_the_gpu():
     assert b"d_model" in L.cn_last_error()
     cfg.d_model, cfg.precision = 256, 7
     assert L.cn_model_create(C.byref(cfg), C.byref(h)) != 0 and b"precision" in L.cn_last_error()
+    cfg.precision, cfg.fp8_scope = 2, 2  # linear_out in e4m3 without the convolution that feeds it
+    assert L.cn_model_create(C.byref(cfg), C.byref(h)) != 0 and b"fp8_scope" in L.cn_last_error()
+
+
+def test_fp8_scope_strings():
+    """--hip_fp8_scope -> (cn_config.fp8_scope, fp8_ffn_first_layer)"""
+    assert hip.parse_fp8_scope("all") == (0, 0) and hip.parse_fp8_scope(None) == (0, 0)
+    assert hip.parse_fp8_scope("conv2") == (1, 0) and hip.parse_fp8_scope("conv2+linear+ffn") == (7, 0)
+    assert hip.parse_fp8_scope("conv2 + ffn:8") == (5, 8) and hip.parse_fp8_scope("ffn") == (4, 0)
+    for bad in ("linear", "ffn+linear", "conv", "conv2:3", "ffn:-1"):
+        with pytest.raises(ValueError):
+            hip.parse_fp8_scope(bad)
+    a = DecodeParser().get_args(["--test_config", "c.yaml", "--data_path", "f.scp", "--hip_precision", "fp8", "--hip_fp8_scope", "conv2+ffn:8"])
+    assert hip.parse_fp8_scope(a.hip_fp8_scope) == (5, 8)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
