@@ -25,6 +25,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+PEAK_FP8_DENSE_TFLOPS = 5000.0  # MI355X_MICROARCH.md: ~5 PF dense fp8 (e4m3) MFMA
 PEAK_HBM_GBS = 8000.0
 
 
@@ -371,6 +372,15 @@ def main():
                           if a.precision in ("bf16", "fp8") else "gemm_kernel<implicit-conv> (conv2)", {})
     if roofline is None:
         roofline = roofline_conv2
+    if roofline_conv2 is not None and a.precision == "fp8" and (hip.parse_fp8_scope(a.fp8_scope)[0] in (0, 1, 3, 5, 7)):
+        # the e4m3 form of conv2 runs on v_mfma_scale_f32_32x32x64_f8f6f4: priced against the dense fp8 peak, not the bf16 one
+        r_ = roofline_conv2
+        r_["peak"] = PEAK_FP8_DENSE_TFLOPS
+        r_["frac"] = round(r_["achieved"] / r_["peak"], 4)
+        for k_ in ("isolated", "isolated_at_width"):
+            if r_.get(k_ + "_achieved") is not None:
+                r_[k_ + "_frac"] = round(r_[k_ + "_achieved"] / r_["peak"], 4)
+        r_["kernel"] = "conv2_kernel<false, false, true> (e4m3 operands, K = 64 block-scaled MFMA; 188.7 GFLOP per batch)"
     if roofline is not None and a.precision == "bf16x3":  # three MFMAs per product: algorithmic FLOPs against peak / 3
         for r_ in (roofline, roofline_conv2):
             if r_:
