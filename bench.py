@@ -182,7 +182,8 @@ def main():
     U = int(engines[0].fetch("ymax")[0])
     eng = engines[0]
     fence()
-    ROOF_TAGS = ["row_chain", "conv2"]  # the dominant kernel (by time) and the largest single product
+    # the dominant kernel (by time; its encoder-side and decoder-side launches are timed apart) and the largest single product
+    ROOF_TAGS = ["row_chain", "row_chain_dec", "conv2"]
     # HIP-event pairs on the launch stream around these kernels only, on ONE of the pipelines (22 pairs per step: on all
     # of them the event traffic itself costs a few percent of throughput)
     for e in engines[:1]:
@@ -318,8 +319,23 @@ def main():
     # (the non-scaled fp8 MFMA of gfx950 runs at the bf16 rate: same peak)
     peak = PEAK_BF16_DENSE_TFLOPS if a.precision in ("bf16", "fp8", "bf16x3") else 157.3
 
+    def merged(table, tags):  # one row for several profile tags (the chain kernel's encoder-side + decoder-side launches)
+        rows = [table[t] for t in tags if table.get(t) and table[t].get("count")]
+        if not rows:
+            return None
+        return {k: sum(r_.get(k, 0.0) for r_ in rows) for k in ("count", "ms", "flops", "bytes")}
+
+    def side(pr):  # a launch class of the chain kernel on its own
+        if not pr or not pr.get("count"):
+            return None
+        avg_s = pr["ms"] / pr["count"] * 1e-3
+        ach = pr["flops"] / pr["count"] / avg_s / 1e12
+        return {"launches_timed": pr["count"], "flops_per_launch": round(pr["flops"] / pr["count"]), "avg_launch_us": round(avg_s * 1e6, 2),
+                "achieved": round(ach, 2), "frac": round(ach / peak, 4)}
+
     def roof(tag, kernel, extra):
-        pr = prof.get(tag)
+        tags = ["row_chain", "row_chain_dec"] if tag == "row_chain" else [tag]
+        pr = merged(prof, tags)
         if not pr or not pr["count"]:
             return None
         avg_s = pr["ms"] / pr["count"] * 1e-3
@@ -335,9 +351,9 @@ def main():
             except Exception:
                 pmc = None
         alg_bytes = pr["bytes"] / pr["count"] if pr.get("bytes") else None
-        iso = stages.get(tag)
+        iso = merged(stages, tags)
         iso_tf = round(iso["flops"] / (iso["ms"] * 1e-3) / 1e12, 2) if iso and iso["ms"] > 0 else None
-        isow = stages_wide.get(tag)
+        isow = merged(stages_wide, tags)
         isow_tf = round(isow["flops"] / (isow["ms"] * 1e-3) / 1e12, 2) if isow and isow["ms"] > 0 else None
         r = {"kernel": kernel,
              "note": f"timed with HIP events inside the timed region while {NS} decode pipelines share the GPU; "
@@ -354,6 +370,14 @@ def main():
             # context for `peak` (not a replacement): what a bare register-resident v_mfma_f32_32x32x16_bf16 loop on random operands
             # sustains on this pool - the chip holds ~1.63 GHz under that load (tools/probes/mfma_shape_probe.hip)
             r["bare_mfma_loop_sustained"] = {"value": 1712.0, "unit": "TFLOP/s", "source": "profiles/r04n_mfma_shape_probe.txt"}
+        if tag == "row_chain":
+            # the same kernel at two launch widths: 12 encoder-side launches of every row of the pass (93 % of the kernel's FLOPs)
+            # and 9 decoder-side ones of a tenth of the rows on a quarter of the CUs; the fields above are all 21 together
+            r["encoder_launches"] = side(prof.get("row_chain"))
+            r["decoder_side_launches"] = side(prof.get("row_chain_dec"))
+            ew = stages_wide.get("row_chain")
+            if r["encoder_launches"] and ew and ew.get("ms"):
+                r["encoder_launches"]["isolated_at_width_frac"] = round(ew["flops"] / (ew["ms"] * 1e-3) / 1e12 / peak, 4)
         r.update(extra)
         return r
 

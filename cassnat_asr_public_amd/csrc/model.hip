@@ -1445,12 +1445,14 @@ int run_self_attn(cn_model* m, const Layer& L, const Norm* pre, float* x, int B,
 // `with_next` false drops the norm/projection part of a stream that has one (use_unimask cuts the carry SAD -> MAD).
 // x_mode: CHX_* bits - the fp32 stream is read / written row-major or in the kernel's blocked tile layout, or not written
 enum { CHX_IN_BLK = 1, CHX_OUT_BLK = 2, CHX_NO_STORE = 4 };
+// tag: the profile row of the launch ("row_chain": encoder-side, full-width launches; "row_chain_dec": the decoder side's - a
+// tenth of the rows, a quarter of the CUs: bench.py prices the two apart)
 int run_chain(cn_model* m, const ChainRef& r, float* x, int M, void* out, int ldo, bool with_next, int x_mode,
-              hipStream_t s, void* ln_out = nullptr, int ld_ln = 0, bool out_blocked = false) {
+              hipStream_t s, void* ln_out = nullptr, int ld_ln = 0, bool out_blocked = false, const char* tag = "row_chain") {
     const int d = m->cfg.d_model;
     const int tail_n = with_next ? r.tail_n : 0;
     const double macs = (r.has_wo ? (double)d * d : 0.0) + 2.0 * d * r.dff + (double)d * tail_n;
-    ProfScope ps(m, "row_chain", 2.0 * M * macs, (double)M * d * (8 + 2) + (double)M * ldo * 2 + 2.0 * macs, s);
+    ProfScope ps(m, tag, 2.0 * M * macs, (double)M * d * (8 + 2) + (double)M * ldo * 2 + 2.0 * macs, s);
     ChainArgs a;
     a.x = x;
     a.ctx = r.has_wo ? m->ctx : nullptr;
@@ -2096,7 +2098,7 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
                 void* out;
                 int ldo;
                 proj_out(st, out, ldo);
-                CN_TRY(run_chain(m, st.entry, xdec, MU, out, ldo, true, CHX_NO_STORE, s, nullptr, 0, blkd));  // reads row-major x, writes none
+                CN_TRY(run_chain(m, st.entry, xdec, MU, out, ldo, true, CHX_NO_STORE, s, nullptr, 0, blkd, "row_chain_dec"));  // reads row-major x, writes none
             }
             if (st.self)
                 CN_TRY(run_self_attn_core(m, B, U, nullptr, m->ylen, (st.stack == 2 && uni) ? 1 : 0, s, blkd));
@@ -2115,7 +2117,7 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
             const bool in_rm = k == 0 || (first_mad && uni);
             const bool out_rm = !final && !carry;
             const int xm = cap ? 0 : ((in_rm ? 0 : CHX_IN_BLK) | (final ? CHX_NO_STORE : (out_rm ? 0 : CHX_OUT_BLK)));
-            CN_TRY(run_chain(m, st.chain, xdec, MU, out, ldo, carry, xm, s, nullptr, 0, blkd && !final));
+            CN_TRY(run_chain(m, st.chain, xdec, MU, out, ldo, carry, xm, s, nullptr, 0, blkd && !final, "row_chain_dec"));
             if (cap && st.stack == 0 && (k + 1 == n || m->dec_steps[k + 1].stack != 0))
                 CN_TRY(capture(m, "ac_embed", m->xd, false, CN_DTYPE_F32, {B, U, d}, s));
         }
