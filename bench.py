@@ -282,7 +282,8 @@ def main():
             fh, sh = synth.make_feats(B, lk[0], F, lengths=lk, seed=7000 + k)
             rb.append((torch.from_numpy(fh).cuda(), torch.from_numpy(sh).cuda(), k))
         audio_r = float(lens.sum()) * 0.01
-        pipes3 = DecodePipelines(model, NS, B, 1500, coalesce=-CO, share_from=engines[0], predict_rows=not a.no_predict)
+        pipes3 = DecodePipelines(model, NS, B, 1500, coalesce=-CO, share_from=engines[0], predict_rows=not a.no_predict,
+                                 ragged=float(os.environ.get("CASSNAT_BENCH_RAGGED", "0.75")))  # (--hip_ragged of the CLI; its default)
 
         # the list four times over (6144 utterances, 0.15 s): at 48 batches the leg is seven engine passes, i.e. mostly the first
         # and the last pass of either pipeline
