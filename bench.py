@@ -222,8 +222,9 @@ def main():
     stage_ms = {k: round(v["ms"] / 3, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])}
     # ... and the roofline kernels once more with the GPU to themselves at the WIDTH of the timed run (CO batches per pass)
     stages_wide = {}
-    if CO > 1:
-        fw, sw = torch.cat([feats] * CO, 0), torch.cat([sizes] * CO, 0)
+    COW = min(CO, int(eng.cfg.max_batch) // B)  # (the workspace is sized by area: at --frames > 1024 it holds fewer batches than CO)
+    if COW > 1:
+        fw, sw = torch.cat([feats] * COW, 0), torch.cat([sizes] * COW, 0)
         model.decode_device(fw, sw, args, 1, engine=eng, sub_batch=B)
         eng.profile_begin(ROOF_TAGS)
         for _ in range(2):
@@ -274,7 +275,7 @@ def main():
     ragged_leg = None
     if not a.no_ragged_leg and world == 1 and not dist_on and a.precision in ("bf16", "bf16x3"):
         rng = np.random.default_rng(99)
-        n_b = 48
+        n_b = 192  # 6144 utterances: the size of a test set (dev-clean + dev-other); neighbouring batches of the sorted list differ by ~6 frames
         lens = np.sort(rng.integers(300, 1501, size=n_b * B))[::-1]
         rb = []
         for k in range(n_b):
@@ -285,13 +286,8 @@ def main():
         pipes3 = DecodePipelines(model, NS, B, 1500, coalesce=-CO, share_from=engines[0], predict_rows=not a.no_predict,
                                  ragged=float(os.environ.get("CASSNAT_BENCH_RAGGED", "0.75")))  # (--hip_ragged of the CLI; its default)
 
-        # the list four times over (6144 utterances, 0.15 s): at 48 batches the leg is seven engine passes, i.e. mostly the first
-        # and the last pass of either pipeline
-        REP3 = 4
-        rb_long = [(f_, s_, i_) for i_, (f_, s_, _k) in enumerate(rb * REP3)]
-
         def run3():
-            for _ in pipes3.decode(rb_long, args, sos=1, as_lists=False):
+            for _ in pipes3.decode(rb, args, sos=1, as_lists=False):
                 pass
 
         run3()
@@ -301,17 +297,17 @@ def main():
         run3()
         fence()
         el3 = time.perf_counter() - c0
-        ragged_leg = {"value": round(REP3 * n_b * B / el3, 2), "unit": "utt/s", "audio_seconds_per_second": round(REP3 * audio_r / el3, 1),
-                      "batches": REP3 * n_b, "frames_min_max": [int(lens.min()), int(lens.max())], "mean_frames": round(float(lens.mean()), 1),
+        ragged_leg = {"value": round(n_b * B / el3, 2), "unit": "utt/s", "audio_seconds_per_second": round(audio_r / el3, 1),
+                      "batches": n_b, "frames_min_max": [int(lens.min()), int(lens.max())], "mean_frames": round(float(lens.mean()), 1),
                       "engine_passes": pipes3.stats["passes"] - st3["passes"],
                       "passes_mixing_frame_counts": pipes3.stats["merged_ragged"] - st3["merged_ragged"],
                       "row_predictions_missed": pipes3.stats["missed"] - st3["missed"],
-                      "note": "length-sorted list of 48 batches of 32 utterances of 300..1500 frames, decoded four times over as one list of 192; "
+                      "note": "length-sorted list of 192 batches of 32 utterances of 300..1500 frames (6144 utterances), "
                               "each batch padded to its own longest utterance; consecutive batches share an engine pass while they fit the workspace area "
                               "(cn_decode_nast_merged: per-batch results identical to separate passes); compare "
                               "audio_seconds_per_second with rtfx"}
         pipes3.close()
-        del rb, rb_long
+        del rb
 
     if rank != 0:
         if dist_on:
@@ -364,7 +360,7 @@ def main():
         r = {"kernel": kernel,
              "note": f"timed with HIP events inside the timed region while {NS} decode pipelines share the GPU; "
                      "'isolated_achieved' is the same kernel with the GPU to itself (one pipeline, one batch per pass, outside the "
-                     f"timed region), 'isolated_at_width_achieved' likewise at the timed run's {CO} batches per pass",
+                     f"timed region), 'isolated_at_width_achieved' likewise at {COW} batches per pass (the timed run's width where the workspace holds it)",
              "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
              "traffic": pmc, "algorithmic_bytes_per_launch": None if alg_bytes is None else round(alg_bytes),
              "traffic_over_algorithmic": None if (pmc is None or not alg_bytes) else round(pmc / alg_bytes, 3),
