@@ -510,10 +510,11 @@ def test_merged_pass_of_different_frame_counts_equals_separate_passes(prec):
         assert hyps == wh and list(scores) == ws, tag
 
 
-@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3", "fp8"])
 def test_merged_ragged_pass_config2_size(prec):
     """The same equality on the config-2 model at sizes where the fast kernels run (row chain, LDS-DMA convolution, fused
-    generator; 128-/256-row tiles cut across batches of 100-, 91- and 78-row utterances)."""
+    generator; 128-/256-row tiles cut across batches of 100-, 91- and 78-row utterances).  fp8: the e4m3 forms of the front end
+    (conv1 on the matrix cores with per-utterance frame counts, conv2, linear_out) and of the chain's feed-forward products."""
     from cassnat_asr_public_amd.pipeline import DecodePipelines
 
     args = synth.make_args("config2")
