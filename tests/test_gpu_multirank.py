@@ -112,6 +112,35 @@ def test_broadcast_receiver_never_repacks_its_unloaded_parameters():
         dst.build_engine(3, 64)
 
 
+@pytest.mark.parametrize("prec,scope", [("bf16", "all"), ("bf16x3", "all"), ("fp8", "all"), ("fp8", "conv2+ffn:1")])
+def test_blob_carries_everything_a_receiving_rank_needs(prec, scope):
+    """The rank-0 -> rank-n hand-off is ONE buffer (cn_model_weight_blob): every packed form an engine reads - bf16 / split-bf16
+    matrices, the chain kernels' weight streams and tables, the fp8 engine's e4m3 copies with their scale words - has to live
+    in it, at the same offsets on a rank that packed nothing.  An engine built without weights that receives the blob (a device
+    copy here, RCCL's broadcast in a job) decodes exactly what the sender decodes."""
+    from conftest import config2_b8_case
+    from cassnat_asr_public_amd import dist as cdist
+
+    args, state, feats, sizes = config2_b8_case()
+    args.hip_precision, args.hip_fp8_scope = prec, scope
+    src = make_model(80, args).cuda()
+    with torch.no_grad():
+        for k, p in src.named_parameters():
+            p.copy_(torch.from_numpy(state[k]))
+    B, T, _ = feats.shape
+    f, s = torch.from_numpy(feats).cuda(), torch.from_numpy(sizes).cuda()
+    want = src.decode_device(f, s, args)
+    dst = make_model(80, args).cuda()  # never loaded: xavier-initialised parameters
+    eng = dst.build_engine(B, T, with_weights=False)
+    (pa, na), (pb, nb) = src._engine.weight_blob(), eng.weight_blob()
+    assert na == nb, (na, nb)
+    torch.as_tensor(cdist._CudaBlob(pb, nb), device="cuda").copy_(torch.as_tensor(cdist._CudaBlob(pa, na), device="cuda"))
+    torch.cuda.synchronize()
+    got = dst.decode_device(f, s, args)
+    for w, g in zip(want, got):
+        assert torch.equal(w, g)
+
+
 # ------------------------------------------------------------------------------------------- two ranks through the CLI
 def _write_case(tmp, args, state, feats, lengths, extra_conf=None, ast=False):
     from cassnat_asr_public_amd.data import kaldi_io
