@@ -31,6 +31,8 @@ class TransformerLM(nn.Module):
         self._hyper = dict(input_size=80, d_model=d, n_head=args.n_head, d_encff=args.d_ff, d_decff=args.d_ff, N_enc=args.N,
                            N_extra=0, N_self_dec=0, N_mix_dec=0, vocab_size=args.vocab_size, ast=2)
         self.hip_precision = getattr(args, "hip_precision", "bf16")
+        if self.hip_precision == "fp8":  # the e4m3 products are the NAT recogniser's encoder (BASELINE config 5): this model runs bf16 beside it
+            self.hip_precision = "bf16"
         self._engine = None
         self._engine_key = None
 

@@ -41,6 +41,8 @@ class Transformer(nn.Module):
         self._hyper = dict(input_size=input_size, d_model=d, n_head=args.n_head, d_encff=args.d_ff, d_decff=args.d_ff,
                            N_enc=args.N_enc, N_extra=0, N_self_dec=0, N_mix_dec=args.N_dec, vocab_size=args.vocab_size, ast=1)
         self.hip_precision = getattr(args, "hip_precision", "bf16")
+        if self.hip_precision == "fp8":  # the e4m3 products are the NAT recogniser's encoder (BASELINE config 5): this model runs bf16 beside it
+            self.hip_precision = "bf16"
         self.hip_max_batch = getattr(args, "hip_max_batch", 32)
         self.hip_max_frames = getattr(args, "hip_max_frames", 2048)
         self._engine = None

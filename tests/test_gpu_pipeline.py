@@ -369,6 +369,7 @@ def test_bf16_production_path_against_golden(capsys):
 # ------------------------------------------------------------------------------------------- ESA + LM ranking (8f rank 3)
 @pytest.mark.parametrize("which,prec", [("esa_tiny", "fp32"), ("esa_config2", "fp32"), ("esa_config2", "bf16"),
                                         ("esa_tiny", "bf16x3"), ("esa_config2", "bf16x3"),  # the split-bf16 engine: gated like fp32
+                                        ("esa_config2", "fp8"),  # (the ranking LM of an fp8 recogniser runs bf16)
                                         ("esa_conf_tiny", "fp32")])  # (conformer blocks under ESA: the shipped YAML's combination)
 def test_esa_sampling_with_lm_ranking(which, prec, capsys):
     """sample_num = 4 alignments per utterance (random draws = the fixture's, i.e. the reference's torch.randint stream),
@@ -399,6 +400,9 @@ def test_esa_sampling_with_lm_ranking(which, prec, capsys):
     if prec in ("fp32", "bf16x3"):
         assert same == len(out)
         np.testing.assert_allclose([s[0]["score"] for s in out], g["score"], rtol=1e-5, atol=2e-3)
+    elif prec == "fp8":  # e4m3 encoder products: the path runs with its LM beside it, the ranking score stays of the reference's order
+        assert lm.hip_precision == "bf16"
+        np.testing.assert_allclose([s[0]["score"] for s in out], g["score"], rtol=0.2, atol=2.0)
     else:  # bf16: another of the sampled alignments may win the ranking; its score stays within a few percent (measured: 1.6 %)
         np.testing.assert_allclose([s[0]["score"] for s in out], g["score"], rtol=0.05, atol=0.5)
     if which in ("esa_tiny", "esa_conf_tiny"):  # the samples go through the decoder side in groups: any group size gives the same answer
