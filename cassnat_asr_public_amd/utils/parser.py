@@ -22,7 +22,9 @@ class DecodeParser(object):
         p.add_argument("--seed", default=1, type=int)
         # engine switches (not in the reference)
         p.add_argument("--hip_precision", default="bf16", choices=["bf16", "fp32", "fp8", "bf16x3"],
-                       help="bf16 MFMA (throughput) or exact-f32 MFMA (parity with the reference CPU path)")
+                       help="bf16 MFMA (throughput), bf16x3 (split-bf16: the reference's tolerance at MFMA speed), fp32 (exact-f32 MFMA), "
+                            "fp8 (e4m3 encoder products of the NAT recogniser, BASELINE config 5; a ranking LM / AT model or the "
+                            "autoregressive recogniser of --task art run bf16 under it)")
         p.add_argument("--hip_fp8_scope", default="all",
                        help="--hip_precision fp8: which encoder-side products take e4m3 operands - all, or conv2 / linear / "
                             "ffn[:first layer] joined by + (e.g. conv2+ffn:8); fewer products = fewer arg-max flips, less speed-up")
