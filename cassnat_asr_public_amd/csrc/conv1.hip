@@ -383,7 +383,9 @@ int launch_conv1_bordered_bf16(const float* x, const float* w9c, const float* bi
 }
 // (A/B on the benchmark, `profiles/r05g_conv1_mfma_ab.txt`: the bf16 image is bound by its 3.4 GB of writes either way - 0.077 ms per
 // batch against the VALU kernel's 0.080, end to end a tie - so the engine keeps the VALU kernel, whose sums are the fp32 FMA chain's;
-// CASSNAT_CONV1_MFMA=1 selects this form)
+// CASSNAT_CONV1_MFMA=1 selects this form - an experiment switch: the capture path keeps the VALU image, so with it the tests that hold
+// the product path against captures to the last bit, and the bf16 beam-search report gate tuned on the VALU image's near-ties, fail:
+// 3 of 359)
 bool conv1_bordered_bf16_applies(int C, int F1) {
     static const bool on = getenv("CASSNAT_CONV1_MFMA") != nullptr;
     return on && conv1_mfma_applies(C, F1);
