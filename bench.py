@@ -78,6 +78,8 @@ def main():
                     help="skip the extra measurement on a length-sorted list of batches of DIFFERENT frame counts (300..1500), "
                          "merged by workspace area as decode_asr does (reported beside `value`)")
     ap.add_argument("--no-predict", action="store_true", help="decode every pass with the mid-pass host sync on the row count (round 2's form)")
+    ap.add_argument("--ragged", type=float, default=0.75, help="--hip_ragged of the CLI for the ragged leg (its default)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on the host threads of the cpu_baseline leg")
     ap.add_argument("--plan", default="", help="explicit pass sizes of the timed run, e.g. 8,8,4 (default: equal shares)")
     a = ap.parse_args()
 
@@ -219,6 +221,7 @@ def main():
     for _ in range(3):  # one pipeline, the GPU to itself
         cdist.unpack_records(cdist.pack_records(*model.decode_device(feats, sizes, args, engine=eng)))
     stages = eng.profile_end()
+    best_gpu = eng.fetch("best_paths")[:B]  # the timed engine's CTC arg-max per frame on the benchmark batch (for cpu_baseline)
     stage_ms = {k: round(v["ms"] / 3, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])}
     # ... and the roofline kernels once more with the GPU to themselves at the WIDTH of the timed run (CO batches per pass)
     stages_wide = {}
@@ -284,7 +287,7 @@ def main():
             rb.append((torch.from_numpy(fh).cuda(), torch.from_numpy(sh).cuda(), k))
         audio_r = float(lens.sum()) * 0.01
         pipes3 = DecodePipelines(model, NS, B, 1500, coalesce=-CO, share_from=engines[0], predict_rows=not a.no_predict,
-                                 ragged=float(os.environ.get("CASSNAT_BENCH_RAGGED", "0.75")))  # (--hip_ragged of the CLI; its default)
+                                 ragged=a.ragged)
 
         def run3():
             for _ in pipes3.decode(rb, args, sos=1, as_lists=False):
@@ -416,6 +419,14 @@ def main():
                     if r_.get(k_ + "_achieved") is not None:
                         r_[k_ + "_frac"] = round(r_[k_ + "_achieved"] / r_["peak"], 4)
 
+    def margin_fields(best, ref_):
+        from cassnat_asr_public_amd.utils.agreement import flips_by_margin
+
+        m = flips_by_margin(best, ref_["best_paths"], ref_["ctc_margin"])
+        return {"frames": m["frames"], "flips": m["flips"], "max_flip_margin": round(m["max_flip_margin"], 5),
+                "flip_rate_margin_ge_0.05": round(m["flip_rate_margin_ge_0.05"], 5), "frames_margin_ge_0.05": m["frames_margin_ge_0.05"],
+                "flip_rate_margin_ge_0.2": round(m["flip_rate_margin_ge_0.2"], 5), "frames_margin_ge_0.2": m["frames_margin_ge_0.2"]}
+
     cpu, ref = None, None
     if not a.no_cpu_baseline and world == 1:
         from oracle import cassnat_oracle as orc
@@ -425,7 +436,7 @@ def main():
             ncores = len(os.sched_getaffinity(0))
         except AttributeError:
             ncores = os.cpu_count() or 1
-        ncores = max(1, min(ncores, int(os.environ.get("CASSNAT_CPU_THREADS", "16"))))
+        ncores = max(1, min(ncores, a.cpu_threads))
         torch.set_num_threads(ncores)
         st = orc.to_torch_state(state)
         orc.decode_nast(st, feats_h, sizes_h, args)  # warm-up
@@ -439,7 +450,11 @@ def main():
                "sample": f"{a.cpu_batches} batches of {B} x {T} frames (same workload), median of per-batch wall time "
                          f"{med:.2f} s after 1 warm-up; RTF {med / (B * T * 0.01):.5f}",
                "hyp_agreement_with_gpu": round(float(np.mean([h == r for h, r in zip(hyps[:B], ref["hyps"])])), 3),
-               "note": "hyp_agreement_with_gpu: whole hypotheses of the timed engine (`dtype`) equal to this fp32 CPU run's"}
+               "note": "hyp_agreement_with_gpu: whole hypotheses of the timed engine (`dtype`) equal to this fp32 CPU run's; "
+                       "ctc_argmax_vs_gpu: the timed engine's CTC arg-max per frame against this run's, by this run's top-2 margin "
+                       "(a random-weight model's posteriors are near-flat; the flips of a reduced-precision engine sit on "
+                       "low-margin frames: tests/test_gpu_pipeline.py gates that)"}
+        cpu["ctc_argmax_vs_gpu"] = margin_fields(best_gpu, ref)
         torch.set_num_threads(1)  # (back to single-threaded host ops for the GPU legs below)
 
     # ---- the engines that meet north_star's tolerance (1e-3 on the CTC log-posteriors, token-exact alignment: tests/
@@ -472,6 +487,9 @@ def main():
         r = {"dtype": prec, "value": round(a.steps * B / el, 2), "unit": "utt/s", "ms_per_step": round(el / a.steps * 1e3, 4),
              "steps": a.steps, "decode_pipelines": nsx, "batches_per_engine_pass": 1 if prec == "fp32" else CO,
              "hyp_agreement": None if ref is None else round(float(np.mean([h == list(q) for h, q in zip(hx, ref["hyps"])])), 3)}
+        if ref is not None:  # CTC arg-max agreement by the reference's top-2 margin (one more pass of the benchmark batch alone)
+            mx.decode_device(feats, sizes, ax, engine=px.engines[0])
+            r["ctc_argmax_vs_cpu"] = margin_fields(px.engines[0].fetch("best_paths")[:B], ref)
         px.close()
         return r
 

@@ -54,5 +54,18 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir=None):
     return lib
 
 
+def experiments_lib(extra_flags=(), tag="exp"):
+    """The -DCASSNAT_EXPERIMENTS build of the library (csrc/common.h: cn_exp_env) for the measurement tools: reads the CASSNAT_*
+    experiment switches from the environment, which the product library does not.  Built into ab/ (git-ignored; travels to the
+    GPU box with the snapshot, so build it BEFORE gpurun - the box has hipcc too, this just saves its minutes)."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ab")
+    os.makedirs(root, exist_ok=True)
+    return build(extra_flags=["-DCASSNAT_EXPERIMENTS"] + list(extra_flags), lib=os.path.join(root, "libcassnat_hip_%s.so" % tag),
+                 objdir=os.path.join(root, "obj_" + tag))
+
+
 if __name__ == "__main__":
+    if "--experiments" in sys.argv:
+        print(experiments_lib())
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

@@ -583,7 +583,7 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     p.Lk = a.Lk;
     p.keymask = a.keymask;
     p.kv_mod = a.kv_mod;
-    static const int stamps = getenv("CASSNAT_ATTN_STAMPS") ? 1 : 0;
+    static const int stamps = cn_exp_env("CASSNAT_ATTN_STAMPS") ? 1 : 0;
     p.stamps = stamps;
     p.kv_index = a.kv_index;
     p.klen = a.klen;
@@ -624,11 +624,11 @@ template <typename T> static int run_attention(const AttnArgs& a, hipStream_t s)
     }
     const long long big_grid = (long long)cn_ceil_div(a.Lq, 128) * a.H * a.B;
     if constexpr (sizeof(T) == 2) {
-        static const int no_res = getenv("CASSNAT_ATTN_NO_RES") ? 1 : 0;
+        static const int no_res = cn_exp_env("CASSNAT_ATTN_NO_RES") ? 1 : 0;
         if (a.Lk <= 256 && !no_res) {  // all keys/values of a (batch, head) resident in 64 KB of LDS
             // Query rows per workgroup: every workgroup loads the whole K/V of its (batch, head), so fewer, larger
             // workgroups mean less CU time per launch (what counts when several decode pipelines share the GPU).
-            static const int nw = getenv("CASSNAT_ATTN_NW") ? atoi(getenv("CASSNAT_ATTN_NW")) : 0;
+            static const int nw = cn_exp_env("CASSNAT_ATTN_NW") ? atoi(cn_exp_env("CASSNAT_ATTN_NW")) : 0;
             const int use = nw ? nw : (a.Lq > 128 ? 8 : (a.Lq > 64 ? 4 : 2));
             if (use >= 8)
                 hipLaunchKernelGGL((attention_kernel<T, 8, true>), dim3(cn_ceil_div(a.Lq, 256), a.H, a.B), dim3(512), 0, s, p);

@@ -1163,9 +1163,9 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
     p.tail_tiles = a.tail_n / 32;
     p.has_next = a.has_next;
     p.eps = a.eps;
-    static const int stamps = getenv("CASSNAT_CHAIN_STAMPS") ? atoi(getenv("CASSNAT_CHAIN_STAMPS")) : 0;  // (thread-safe init)
+    static const int stamps = cn_exp_env("CASSNAT_CHAIN_STAMPS") ? atoi(cn_exp_env("CASSNAT_CHAIN_STAMPS")) : 0;  // (thread-safe init)
     p.stamps = stamps;
-    static const int stamp_block = getenv("CASSNAT_CHAIN_STAMP_BLOCK") ? atoi(getenv("CASSNAT_CHAIN_STAMP_BLOCK")) : 0;
+    static const int stamp_block = cn_exp_env("CASSNAT_CHAIN_STAMP_BLOCK") ? atoi(cn_exp_env("CASSNAT_CHAIN_STAMP_BLOCK")) : 0;
     p.stamp_block = stamp_block;
     p.x_in_blk = a.x_in_blocked;
     p.x_out_blk = a.x_out_blocked;

@@ -2,6 +2,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+// Experiment switches.  The product library reads NO environment variable: every kernel-selection / stamp / repeat switch the
+// measurement tools use (tools/*.py, tools/scripts/ab_bench.sh) exists only in a -DCASSNAT_EXPERIMENTS build of the library
+// (cassnat_asr_public_amd.build.build(extra_flags=["-DCASSNAT_EXPERIMENTS"], lib=...), loaded through CASSNAT_HIP_LIB - the one
+// loader-level variable, read by hip.py).  In the product build the helper is a constant and the switched-off paths fold away.
+#ifdef CASSNAT_EXPERIMENTS
+static inline const char* cn_exp_env(const char* name) { return getenv(name); }
+#else
+static inline const char* cn_exp_env(const char*) { return nullptr; }
+#endif
 
 typedef __bf16 bf16;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));

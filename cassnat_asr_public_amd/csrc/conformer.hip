@@ -139,7 +139,7 @@ static void launch_dwconv_tiled(const void* x, const float* w, const float* bias
 
 int launch_dwconv(int prec, const void* x, const float* w, const float* bias, float* y, int B, int L, int d, int k, hipStream_t s) {
     if (B * L <= 0) return 0;
-    static const bool naive = getenv("CASSNAT_DWCONV_NAIVE") != nullptr;
+    static const bool naive = cn_exp_env("CASSNAT_DWCONV_NAIVE") != nullptr;
 #define DW_CASE(KK)                                                                                   \
     case KK:                                                                                          \
         if (prec == CN_PREC_F32) launch_dwconv_tiled<float, KK>(x, w, bias, y, B, L, d, s);           \

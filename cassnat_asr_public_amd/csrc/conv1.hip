@@ -387,7 +387,7 @@ int launch_conv1_bordered_bf16(const float* x, const float* w9c, const float* bi
 // the product path against captures to the last bit, and the bf16 beam-search report gate tuned on the VALU image's near-ties, fail:
 // 3 of 359)
 bool conv1_bordered_bf16_applies(int C, int F1) {
-    static const bool on = getenv("CASSNAT_CONV1_MFMA") != nullptr;
+    static const bool on = cn_exp_env("CASSNAT_CONV1_MFMA") != nullptr;
     return on && conv1_mfma_applies(C, F1);
 }
 
@@ -398,7 +398,7 @@ int launch_conv1_f8(const float* x, const float* w9c, const float* bias, void* o
         cn_set_error("conv1 (e4m3): channel count must be a multiple of 8 with C/8 dividing 256; the image is always bordered");
         return -1;
     }
-    static const bool no_mfma = getenv("CASSNAT_CONV1_F8_VALU") != nullptr;
+    static const bool no_mfma = cn_exp_env("CASSNAT_CONV1_F8_VALU") != nullptr;
     if (conv1_mfma_applies(C, F1) && !no_mfma) return launch_conv1_mfma(true, x, w9c, bias, out8, B, T, F, T1, F1, scale, s, utt_meta);
     long long blocks = (long long)B * (T1 + 2);
     if (blocks > 256 * 8) blocks = 256 * 8;

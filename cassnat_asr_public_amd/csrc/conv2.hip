@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
 }
 
 // bf16, 256 -> 256 channels only; everything else stays on the generic implicit GEMM (gemm.hip)
-bool conv2_dma_applies(int prec, int C, int N) { return prec == CN_PREC_BF16 && C == C2_C && N == C2_N && !getenv("CASSNAT_NO_CONV2_DMA"); }
+bool conv2_dma_applies(int prec, int C, int N) { return prec == CN_PREC_BF16 && C == C2_C && N == C2_N && !cn_exp_env("CASSNAT_NO_CONV2_DMA"); }
 
 // The lane offsets of a tile are relative to its first row: what has to fit 32 bits is the span of 256 consecutive output
 // positions in the image - (256 / F2 + 2) output rows of two image rows each, plus a batch boundary's two halo rows
@@ -583,7 +583,7 @@ int launch_conv2_dma(const void* in, const void* w, const float* bias, void* out
 
 // the fp8 engine's convolution (BASELINE config 5): `in8` = conv1's e4m3fn image WITH the zero halo ([B][T1 + 2][F1 + 2][256] bytes),
 // `w8` = [256][9 * 256] e4m3fn (k = (kh * 3 + kw) * 256 + ci), `q8_dev` = {127 - log2(weight scale), 127 - log2(image scale)}; out bf16
-bool conv2_f8_applies(int C, int N) { return C == C2_C && N == C2_N && !getenv("CASSNAT_NO_CONV2_F8"); }
+bool conv2_f8_applies(int C, int N) { return C == C2_C && N == C2_N && !cn_exp_env("CASSNAT_NO_CONV2_F8"); }
 
 int launch_conv2_f8(const void* in8, const void* w8, const int* q8_dev, const float* bias, void* out, int B, int T1, int F1, int T2,
                     int F2, hipStream_t s, float out8_scale) {
@@ -615,7 +615,7 @@ int launch_conv2_f8(const void* in8, const void* w8, const int* q8_dev, const fl
 
 // linear_out of the fp8 engine on the same tile kernel: A [M][5120] e4m3fn (conv2's e4m3 output rows viewed per frame), W [256][5120]
 // e4m3fn, q8_dev = {127 - log2(weight scale), 127 - log2(activation scale)}; epilogue as the bf16 form: (acc + bias) * scale + PE, fp32
-bool linear256_f8_applies(int N, int K) { return N == C2_N && K == C2_LIN8_KSTEPS * 128 && !getenv("CASSNAT_NO_LINEAR_F8"); }
+bool linear256_f8_applies(int N, int K) { return N == C2_N && K == C2_LIN8_KSTEPS * 128 && !cn_exp_env("CASSNAT_NO_LINEAR_F8"); }
 
 int launch_linear256_f8(const void* A8, const void* W8, const int* q8_dev, const float* bias, float* out, int M, int K, float scale,
                         const float* pe, int pe_period, hipStream_t s) {
@@ -651,7 +651,7 @@ int launch_linear256_f8(const void* A8, const void* W8, const int* q8_dev, const
 
 // the split-bf16 engine's convolution on the same kernel: `in_hi` / `in_lo` are the haloed bf16 planes conv1 wrote
 // ([B][T1 + 2][F1 + 2][256] each), `w_hi` / `w_lo` the [256][9 * 256] matrices of the weights' halves; out: split-bf16 rows
-bool conv2_x3_applies(int prec, int C, int N) { return prec == CN_PREC_X3 && C == C2_C && N == C2_N && !getenv("CASSNAT_NO_CONV2_X3"); }
+bool conv2_x3_applies(int prec, int C, int N) { return prec == CN_PREC_X3 && C == C2_C && N == C2_N && !cn_exp_env("CASSNAT_NO_CONV2_X3"); }
 
 int launch_conv2_x3(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias, void* out, int B,
                     int T1, int F1, int T2, int F2, hipStream_t s) {
@@ -684,7 +684,7 @@ int launch_conv2_x3(const void* in_hi, const void* in_lo, const void* w_hi, cons
 // linear_out (+ sqrt(d) scale + positional rows) on the same tile kernel: A [M][K] bf16 (row stride lda elements), W [256][K]
 // bf16, K % 64 == 0, A and W below 4 GiB.  A launch occupies ceil(M / 256) CUs (32 for the encoder input of config 2) for about
 // as long as the generic GEMM occupies all of them.
-bool linear256_dma_applies(int prec, int N, int K) { return prec == CN_PREC_BF16 && N == C2_N && K % 64 == 0 && K >= 128 && !getenv("CASSNAT_NO_LINEAR_DMA"); }
+bool linear256_dma_applies(int prec, int N, int K) { return prec == CN_PREC_BF16 && N == C2_N && K % 64 == 0 && K >= 128 && !cn_exp_env("CASSNAT_NO_LINEAR_DMA"); }
 
 int launch_linear256_dma(const void* A, int lda, const void* W, const float* bias, float* out, int M, int K, float scale,
                          const float* pe, int pe_period, hipStream_t s) {

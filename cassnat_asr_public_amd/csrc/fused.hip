@@ -399,8 +399,8 @@ int launch_ffn_fused(const FfnFusedArgs& a, hipStream_t s) {
         cn_set_error("ffn_fused: a d_ff split needs d_ff % (128 * slices) == 0 and a partial-sum buffer");
         return -1;
     }
-    static const int dbg = getenv("CASSNAT_FFN_DEBUG") ? atoi(getenv("CASSNAT_FFN_DEBUG")) : 0;  // (magic statics: thread-safe)
-    static const int force_mt = getenv("CASSNAT_FFN_MT") ? atoi(getenv("CASSNAT_FFN_MT")) : 0;
+    static const int dbg = cn_exp_env("CASSNAT_FFN_DEBUG") ? atoi(cn_exp_env("CASSNAT_FFN_DEBUG")) : 0;  // (magic statics: thread-safe)
+    static const int force_mt = cn_exp_env("CASSNAT_FFN_MT") ? atoi(cn_exp_env("CASSNAT_FFN_MT")) : 0;
     const int mt = force_mt ? force_mt : (a.M > 32 ? 2 : 1);
     if (mt == 2) {
         if (dbg == 3) return launch_ffn_variant<2, 3>(p, s);

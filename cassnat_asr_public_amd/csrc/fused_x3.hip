@@ -414,7 +414,7 @@ extern "C" int cn_debug_ffn_x3_stamps(unsigned long long* out, int n_wg) {
 }
 #endif
 
-bool ffn_x3_applies(int d, int dff) { return d == FX_D && dff % 128 == 0 && dff >= 128 && dff <= 2048 && !getenv("CASSNAT_NO_FFN_X3"); }
+bool ffn_x3_applies(int d, int dff) { return d == FX_D && dff % 128 == 0 && dff >= 128 && dff <= 2048 && !cn_exp_env("CASSNAT_NO_FFN_X3"); }
 
 int launch_ffn_x3(const FfnX3Args& a, hipStream_t s) {
     if (!ffn_x3_applies(a.d, a.dff)) {
@@ -436,7 +436,7 @@ int launch_ffn_x3(const FfnX3Args& a, hipStream_t s) {
     p.dff = a.dff;
     p.eps = a.eps;
     // (off by default: the rotation made a row's accumulation order depend on its workgroup and measured no gain)
-    static const int rotate = getenv("CASSNAT_FFN_X3_ROTATE") ? atoi(getenv("CASSNAT_FFN_X3_ROTATE")) : 0;
+    static const int rotate = cn_exp_env("CASSNAT_FFN_X3_ROTATE") ? atoi(cn_exp_env("CASSNAT_FFN_X3_ROTATE")) : 0;
     p.rotate = rotate;
 #ifdef FX_STAMPS
     static unsigned long long* stamps_dev = nullptr;

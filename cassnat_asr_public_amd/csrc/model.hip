@@ -177,6 +177,7 @@ struct cn_model {
     // known; the count lands in one of four page-locked words (a ticket names its word) for cn_decode_ticket
     int* ymax_ring = nullptr;  // [4], page-locked
     int ticket_U[4] = {0, 0, 0, 0};
+    int ticket_id[4] = {-1, -1, -1, -1};  // the ticket (sequence number) whose pass owns the word now: an older ticket has expired
     long long ticket_seq = 0;
     unsigned char* keymask = nullptr;
     void *c1 = nullptr, *c2 = nullptr;
@@ -909,10 +910,10 @@ int build_weights(cn_model* m) {
     m->kv_cols = 0;
     // fp8 engine: the same chains with the feed-forward units in e4m3 (chain.hip, F8 form) when d_ff allows, else the unfused
     // per-product path (run_enc_layer_fp8)
-    static const bool f8_unfused = getenv("CASSNAT_FP8_UNFUSED") != nullptr;
+    static const bool f8_unfused = cn_exp_env("CASSNAT_FP8_UNFUSED") != nullptr;
     const bool f8c = m->fp8_enc && !lm && !f8_unfused && c.d_encff % 256 == 0;
     // CASSNAT_FP8_LAYERS: bit n set = layer n's feed-forward products in e4m3 (accuracy experiments: tools/fp8_accuracy.py)
-    static const unsigned f8_layers = getenv("CASSNAT_FP8_LAYERS") ? (unsigned)strtoul(getenv("CASSNAT_FP8_LAYERS"), nullptr, 0) : ~0u;
+    static const unsigned f8_layers = cn_exp_env("CASSNAT_FP8_LAYERS") ? (unsigned)strtoul(cn_exp_env("CASSNAT_FP8_LAYERS"), nullptr, 0) : ~0u;
     auto f8_at = [&](int n) {
         return f8c && (m->fp8_scope & CN_FP8_FFN) && n >= c.fp8_ffn_first_layer && ((f8_layers >> (n & 31)) & 1u);
     };
@@ -1300,7 +1301,7 @@ int run_linear(cn_model* m, const char* tag, const Linear& l, const void* A, int
                int epi, const float* resid, int ldr, hipStream_t s) {
     ProfScope ps(m, tag, 2.0 * M * l.N * l.K,
                  (double)M * l.K * m->es + (double)l.N * l.K * m->es + (double)M * l.N * (c_f32 ? 4 : m->es), s);
-    static const bool no_proj_x3 = getenv("CASSNAT_NO_PROJ_X3") != nullptr;
+    static const bool no_proj_x3 = cn_exp_env("CASSNAT_NO_PROJ_X3") != nullptr;
     if (l.px3 && m->prec == CN_PREC_X3 && !no_proj_x3 && (epi == 0 || epi == CN_EPI_RESID) && (epi == 0 || c_f32) && lda % 32 == 0 &&
         (c_f32 || ldc % 32 == 0) && (long long)M * std::max(ldc, ldr) * 4 < (1ll << 31)) {
         ProjX3Args a;
@@ -1901,7 +1902,7 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         CN_TRY(launch_gemm(m->prec, g, s));
     }
     if (cap) CN_TRY(capture(m, "x_embed", m->x, false, CN_DTYPE_F32, {B, Tp, d}, s));
-    static const bool no_chain_c = getenv("CASSNAT_NO_CHAIN") != nullptr;
+    static const bool no_chain_c = cn_exp_env("CASSNAT_NO_CHAIN") != nullptr;
     if (c.conf_enc && !m->enc.empty() && m->enc[0].cf_a.w && !no_chain_c) {
         // conformer encoder on the row-chain kernel: per layer A -> relative-position attention -> B -> GLU / depthwise
         // conv / GroupNorm + Swish -> C (see build_weights); the residual stream stays in the blocked layout in between
@@ -1924,7 +1925,7 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         if (cap) CN_TRY(capture(m, "enc_h", m->enc_h, true, CN_DTYPE_F32, {B, Tp, d}, s));
         return 0;
     }
-    static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
+    static const bool no_chain = cn_exp_env("CASSNAT_NO_CHAIN") != nullptr;
     // BASELINE config 5.  With row chains (d_model 256, d_ff % 256 == 0) the feed-forward products - 80 % of a layer's
     // multiply-adds - run on e4m3 operands inside the chain kernel at twice the bf16 rate (chain.hip, F8 form) and the layer
     // goes down the bf16 engine's path below; without them, the four products of every layer as separate e4m3 launches
@@ -1940,7 +1941,7 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     const bool chain = !m->enc.empty() && m->enc_chain.size() == m->enc.size() && !no_chain;
     // the projections a chain launch writes for the attention kernel (Q|K|V, and the decoder side's K|V) go out in the blocked
     // layout: 1-KiB store instructions instead of thirty-two 32-byte row segments (the tail phase was store-bound)
-    static const bool blk = getenv("CASSNAT_NO_BLOCKED_QKV") == nullptr;
+    static const bool blk = cn_exp_env("CASSNAT_NO_BLOCKED_QKV") == nullptr;
     m->kv_blocked = false;
     if (chain) {  // bf16 / d_model 256: LN + QKV of layer 0 (an entry chain launch: no FFN, x left alone), then per layer
                   // attention -> row-chain kernel
@@ -2040,7 +2041,7 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
             CN_TRY(run_ffn_swish(m, L.w1, L.w2, L.n[0], x, MU, 1.0f, s));
         }
         if (cap) CN_TRY(capture(m, "ac_embed", x, false, CN_DTYPE_F32, {B, U, d}, s));
-        static const bool no_chain_d = getenv("CASSNAT_NO_CHAIN") != nullptr;
+        static const bool no_chain_d = cn_exp_env("CASSNAT_NO_CHAIN") != nullptr;
         const bool dchain = !no_chain_d && ((!m->sad.empty() && m->sad[0].cf_a.w) || (!m->mad.empty() && m->mad[0].cf_a.w));
         if (dchain) {
             // the self- and mixed-attention conformer layers on the row-chain kernel (the extractor above stays generic);
@@ -2072,7 +2073,7 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
         CN_TRY(run_ln(m, m->dec_norm, x, m->dec_h, MU, s));
         return stage_decode_tail(m, U, o, hyp, hyp_stride, hyp_len, score, s);
     }
-    static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
+    static const bool no_chain = cn_exp_env("CASSNAT_NO_CHAIN") != nullptr;
     if (!m->dec_steps.empty() && !no_chain) {
         // bf16 / d_model 256: every sublayer is [attention] + one row-chain launch that also produces the next
         // sublayer's input projection (src Q -> m->qd, self Q|K|V -> m->qkv) or, after the last one, dec_h
@@ -2093,7 +2094,7 @@ int stage_decode(cn_model* m, int U, const cn_decode_opts* o, int32_t* hyp, int 
                     xdec = m->xd2;
                 }
             }
-            static const bool blkd = getenv("CASSNAT_NO_BLOCKED_QKV") == nullptr;
+            static const bool blkd = cn_exp_env("CASSNAT_NO_BLOCKED_QKV") == nullptr;
             if (k == 0 || (first_mad && uni)) {
                 void* out;
                 int ldo;
@@ -2410,7 +2411,10 @@ int decode_nast_impl(cn_model* m, const float* feats_dev, const float* size_rati
         m->ticket_U[slot] = ymax;
         CN_TRY(stage_decode(m, ymax, opts, hyp_out_dev, hyp_stride, hyp_len_dev, score_dev, s));
     }
-    if (ticket_out) *ticket_out = slot;
+    // a ticket is the call's sequence number (its word is seq & 3): cn_decode_ticket can tell a word that a later call on this
+    // handle - cn_decode_nast included - has taken over, instead of handing out another pass's counts
+    m->ticket_id[slot] = (int)(m->ticket_seq & 0x3fffffff);
+    if (ticket_out) *ticket_out = m->ticket_id[slot];
     ++m->ticket_seq;
     return 0;
 }
@@ -2455,12 +2459,18 @@ extern "C" int cn_decode_nast_merged(cn_model* m, const float* feats_dev, const 
 }
 
 extern "C" int cn_decode_ticket(cn_model* m, int32_t ticket, int32_t* ymax_host, int32_t* rows_used_host) {
-    if (!m || !m->ymax_ring || ticket < 0 || ticket > 3) {
+    if (!m || !m->ymax_ring || ticket < 0) {
         cn_set_error("cn_decode_ticket: bad ticket");
         return -1;
     }
-    if (ymax_host) *ymax_host = m->ymax_ring[ticket];
-    if (rows_used_host) *rows_used_host = m->ticket_U[ticket];
+    const int slot = ticket & 3;
+    if (m->ticket_id[slot] != ticket) {
+        cn_set_error("cn_decode_ticket: ticket " + std::to_string(ticket) + " has expired - more than three decode calls were started on "
+                     "this handle since it was issued (at most four passes may be outstanding per handle)");
+        return -1;
+    }
+    if (ymax_host) *ymax_host = m->ymax_ring[slot];
+    if (rows_used_host) *rows_used_host = m->ticket_U[slot];
     return 0;
 }
 
@@ -2724,7 +2734,7 @@ extern "C" int cn_lm_score(cn_model* m, const int32_t* tok_dev, const int32_t* t
     const int d = m->cfg.d_model, V = m->cfg.vocab_size, M = B * U;
     float* x = m->x;
     CN_TRY(launch_lm_embed(tok_dev, ld, m->tgt_lut, m->pe, x, B, U, d, sqrtf((float)d), s));
-    static const bool no_chain = getenv("CASSNAT_NO_CHAIN") != nullptr;
+    static const bool no_chain = cn_exp_env("CASSNAT_NO_CHAIN") != nullptr;
     if (!m->enc.empty() && m->enc_chain.size() == m->enc.size() && !no_chain) {
         // bf16 / d_model 256: per layer [causal + length-masked attention] + one row-chain launch, as in stage_encode
         if (m->enc_entry.w) {
@@ -2747,7 +2757,7 @@ extern "C" int cn_lm_score(cn_model* m, const int32_t* tok_dev, const int32_t* t
         }
         CN_TRY(run_ln(m, m->enc_norm, x, m->enc_h, M, s));
     }
-    static const bool no_fused = getenv("CASSNAT_LM_NO_FUSED_TAIL") != nullptr;
+    static const bool no_fused = cn_exp_env("CASSNAT_LM_NO_FUSED_TAIL") != nullptr;
     if (m->att_gen.gm_w && !no_fused) {  // bf16 / d_model 256: generator + log-softmax + gather in one kernel, no (M, V) tensor
         const bool x3 = m->prec == CN_PREC_X3;
         ProfScope ps(m, "generator_gather_fused", (x3 ? 6.0 : 2.0) * M * V * d, ((double)M * d + (double)V * d) * (x3 ? 4 : 2), s);
@@ -3192,7 +3202,7 @@ extern "C" int cn_op_attention(int32_t precision, const void* Q, int32_t ldq, co
     a.causal = causal;
     a.scale = scale;
     int rc = launch_attention(precision, a, (hipStream_t)stream);
-    if (rc == 0 && getenv("CASSNAT_ATTN_STAMPS")) {
+    if (rc == 0 && cn_exp_env("CASSNAT_ATTN_STAMPS")) {
         (void)hipStreamSynchronize((hipStream_t)stream);
         (void)attention_print_stamps();
     }
@@ -3525,10 +3535,10 @@ extern "C" int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, con
     a.f8 = f8;
     a.f8_q = f8 ? reinterpret_cast<const int*>((char*)dt + ht.size() * 4) : nullptr;
     int rc = launch_chain(a, (hipStream_t)stream);
-    if (const char* rep = getenv("CASSNAT_CHAIN_REPEAT")) {  // timing runs only: x keeps being updated
+    if (const char* rep = cn_exp_env("CASSNAT_CHAIN_REPEAT")) {  // timing runs only: x keeps being updated
         // CASSNAT_CHAIN_STREAMS = n: the repeats go round-robin onto n private streams (how do concurrent launches share
         // the chip?); they race on x, which a timing run does not look at
-        const int ns = getenv("CASSNAT_CHAIN_STREAMS") ? atoi(getenv("CASSNAT_CHAIN_STREAMS")) : 0;
+        const int ns = cn_exp_env("CASSNAT_CHAIN_STREAMS") ? atoi(cn_exp_env("CASSNAT_CHAIN_STREAMS")) : 0;
         std::vector<hipStream_t> ss(ns > 0 ? ns : 0);
         for (auto& q : ss) (void)hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
         (void)hipStreamSynchronize((hipStream_t)stream);
@@ -3539,7 +3549,7 @@ extern "C" int cn_op_chain(float* x_dev, const void* ctx_dev, int32_t ldctx, con
         }
     }
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
-    if (getenv("CASSNAT_CHAIN_STAMPS")) (void)chain_print_stamps();
+    if (cn_exp_env("CASSNAT_CHAIN_STAMPS")) (void)chain_print_stamps();
     (void)hipFree(ds);
     (void)hipFree(dt);
     if (rc == 0 && e != hipSuccess) {
@@ -3579,7 +3589,7 @@ static int op_genmax_impl(const void* h_dev, const float* w_host, const float* b
     a.tgt_U = U;
     a.tgt_ld = ld;
     int rc = launch_genmax(a, (hipStream_t)stream);
-    if (const char* rep = getenv("CASSNAT_GENMAX_REPEAT"))  // timing runs only
+    if (const char* rep = cn_exp_env("CASSNAT_GENMAX_REPEAT"))  // timing runs only
         for (int i = 1, n = atoi(rep); rc == 0 && i < n; ++i) rc = launch_genmax(a, (hipStream_t)stream);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(dw);
@@ -3647,7 +3657,7 @@ extern "C" int cn_op_genmax_x3(const float* h_host, const float* w_host, const f
     a.tgt_U = U;
     a.tgt_ld = ld;
     int rc = launch_genmax(a, (hipStream_t)stream);
-    if (const char* rep = getenv("CASSNAT_GENMAX_REPEAT"))  // timing runs only
+    if (const char* rep = cn_exp_env("CASSNAT_GENMAX_REPEAT"))  // timing runs only
         for (int i = 1, n = atoi(rep); rc == 0 && i < n; ++i) rc = launch_genmax(a, (hipStream_t)stream);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(dw);
@@ -3802,7 +3812,7 @@ int ast_step_run(cn_model* m, int n, int pos, const int32_t* tok_dev, const int3
     // ceil(n / 64) workgroups that each stream the whole 2 MB of W1|W2.  Its d_ff split spreads the hidden units over 8
     // workgroups per row tile; the reduce kernel that adds the slices also writes the LayerNorm the next sublayer starts
     // with (the next layer's self-attention pre-norm, or decoder.norm after the last layer).
-    static const bool no_split = getenv("CASSNAT_AST_NO_FFN_SPLIT") != nullptr;
+    static const bool no_split = cn_exp_env("CASSNAT_AST_NO_FFN_SPLIT") != nullptr;
     const int ffn_slices = (m->mad.empty() || !m->mad[0].w1p || no_split) ? 1 : (c.d_decff % (128 * 8) == 0 ? 8 : (c.d_decff % (128 * 4) == 0 ? 4 : 1));
     bool have_ln = false;  // m->xn already holds LN(x) for the sublayer about to start
     // (only while the rows are few, and the slices fit the hidden-activation buffer they borrow)
@@ -3854,7 +3864,7 @@ int ast_step_run(cn_model* m, int n, int pos, const int32_t* tok_dev, const int3
         b.utt = utt_dev;
         b.keymask = m->keymask;
         b.scale = scale;
-        static const bool no_fast_src = getenv("CASSNAT_AST_GATHER_SRC") != nullptr;
+        static const bool no_fast_src = cn_exp_env("CASSNAT_AST_GATHER_SRC") != nullptr;
         if (m->prec == CN_PREC_BF16 && m->Tp <= 256 && !no_fast_src) {
             // every hypothesis row is a batch entry of one query whose keys / values are its utterance's: the LDS-resident
             // attention kernel (K|V of a (row, head) by LDS-DMA, MFMA products) instead of the scalar gather kernel

@@ -614,7 +614,8 @@ int launch_gather_logp(const float* logp, int V, const int* tgt, int ld, float* 
 __global__ void cmvn_kernel(float* __restrict__ x, const int* __restrict__ len, const double* __restrict__ mean,
                             const double* __restrict__ sd, int T, int F) {
     const int b = blockIdx.y;
-    const long long n = (long long)len[b] * F;
+    const int lb = len[b];  // (clamped to the batch's frames: a bad length must not write past the utterance's rows)
+    const long long n = (long long)(lb < 0 ? 0 : lb > T ? T : lb) * F;
     float* xb = x + (long long)b * T * F;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int f = (int)(i % F);

@@ -5,6 +5,7 @@ requirements_original.txt), which is not available offline; only the uncompresse
 `copy-feats` / `compute-cmvn-stats` write by default is implemented here.
 """
 import mmap
+import os
 import struct
 import threading
 
@@ -54,17 +55,34 @@ _maps_lock = threading.Lock()
 
 
 def _mapped(path):
-    """A read-only memory map of an archive, kept for the life of the process (a test-set decode reads every matrix of a
-    handful of archives once: one map per file instead of one open + seven small reads + a copy per utterance)."""
-    mm = _maps.get(path)
-    if mm is None:
+    """A read-only memory map of an archive, kept while the file stays the same (a test-set decode reads every matrix of a
+    handful of archives once: one map per file instead of one open + seven small reads + a copy per utterance).  The map is
+    keyed on the file's identity - inode, size, modification time: an archive rewritten or truncated at the same path gets a new
+    map (the stale one stays alive only as long as views into it do)."""
+    st = os.stat(path)
+    ident = (st.st_ino, st.st_size, st.st_mtime_ns)
+    hit = _maps.get(path)
+    if hit is None or hit[0] != ident:
         with _maps_lock:
-            mm = _maps.get(path)
-            if mm is None:
+            hit = _maps.get(path)
+            if hit is None or hit[0] != ident:
                 with open(path, "rb") as f:
-                    mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
-                _maps[path] = mm
-    return mm
+                    hit = (ident, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ))
+                _maps[path] = hit  # (a replaced map is not closed: numpy views handed out earlier keep it alive)
+    return hit[1]
+
+
+def mat_dtype(rxspecifier):
+    """Element type (numpy dtype) of an .scp entry's matrix, from its header."""
+    path, _, off = rxspecifier.rpartition(":")
+    if not path or not off.isdigit():
+        return load_mat(rxspecifier).dtype
+    with open(path, "rb") as f:
+        f.seek(int(off))
+        head = f.read(5)
+    if head[:2] != b"\0B" or head[2:5] not in _DTYPES:
+        raise ValueError("not a binary Kaldi matrix at %s" % rxspecifier)
+    return np.dtype(_DTYPES[head[2:5]])
 
 
 def load_mat_view(rxspecifier):

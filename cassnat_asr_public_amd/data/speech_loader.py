@@ -85,8 +85,19 @@ class SpeechDataset(Dataset):
         return utt, feat, text
 
     def can_defer_cmvn(self):
-        """The global CMVN commutes with everything this dataset does afterwards (no splicing, no frame skipping)."""
-        return self.left_context == 0 and self.right_context == 0 and self.skip_frame <= 1
+        """The global CMVN commutes with everything this dataset does afterwards (no splicing, no frame skipping) AND the archive
+        holds float32 matrices: the device form computes float((double)x - mean) / std) on the float32 rows collate hands over,
+        which is the reference's arithmetic bit for bit only when those rows are the archive's own values.  A float64 (`DM`)
+        archive is normalised in float64 and rounded once (here, on the host, as the reference does)."""
+        if not (self.left_context == 0 and self.right_context == 0 and self.skip_frame <= 1):
+            return False
+        if getattr(self, "_defer_ok", None) is None:
+            # one header per archive file (all matrices of a copy-feats archive share a type)
+            firsts = {}
+            for _, spec, _ in self._items:
+                firsts.setdefault(spec.rpartition(":")[0] or spec, spec)
+            self._defer_ok = all(kaldi_io.mat_dtype(spec) == np.float32 for spec in firsts.values())
+        return self._defer_ok
 
 
 _tls = threading.local()

@@ -263,6 +263,7 @@ class CassNAT(nn.Module):
         self.hip_max_frames = getattr(args, "hip_max_frames", 2048)
         self._engine = None
         self._engine_key = None
+        self._invalidations = 0  # bumped by invalidate_engine / load_state_dict: holders of further engine handles key on it
 
     # the reference moves the module with .cuda(); parameters stay where they are - the engine owns HBM copies
     def cuda(self, device=None):
@@ -330,6 +331,12 @@ class CassNAT(nn.Module):
     def invalidate_engine(self):
         """Call after changing parameters through ``.data`` (which does not bump tensor versions)."""
         self._engine_key = None
+        self._invalidations += 1
+
+    def weights_key(self):
+        """What an engine handle's packed weights depend on: parameter versions, explicit invalidations, precision and the fp8
+        scope.  Holders of handles of their own (a task's cached decode pipelines) rebuild when it changes."""
+        return (self._weights_version(), self._invalidations, self.hip_precision, self._hyper["fp8_scope"], self._hyper["fp8_ffn_first_layer"])
 
     def _params_unloaded(self):
         """True while the local nn.Parameters are still the untouched initial values of a rank whose engine weights came by

@@ -61,9 +61,7 @@ class _Job:
         # per pass: 3 3 2 2 2 2 2 2 2, not 3 3 3 3 3 2 1 1 1 - so that the pipelines finish together without one-batch passes
         c = max(1, coalesce)
         self.passes_left = None if total is None else n * max(1, -(-total // (n * c)))
-        # experiment hook (tools/scripts/r02_plan.sh): CASSNAT_PASS_PLAN="10,4,6" = explicit pass sizes, in the order they are taken
-        env = os.environ.get("CASSNAT_PASS_PLAN")
-        self.plan = [int(x) for x in env.split(",")] if env else plan
+        self.plan = plan  # explicit pass sizes, in the order they are taken (records(plan=...); bench.py --plan)
         self.lock = threading.Lock()
         self.cv = threading.Condition()
         self.slots = {}          # index -> queue of one (tag, records, event)
@@ -144,9 +142,15 @@ class DecodePipelines:
         self._stage = [{} for _ in range(self.n)]  # per pipeline: merged-batch input buffers (two: two passes in flight), by kind
         self._rows = {"ratio": None}  # row-count predictor shared by the pipelines: largest tokens-per-frame ratio seen
         self._rows_lock = threading.Lock()
+        self._stats_lock = threading.Lock()
         self.stats = {"passes": 0, "batches": 0, "predicted": 0, "missed": 0, "merged_ragged": 0,
                       # host seconds of the worker threads, by what they were doing (summed over the pipelines)
                       "s_take": 0.0, "s_stage": 0.0, "s_launch": 0.0, "s_retire_wait": 0.0}
+
+    def _bump(self, key, v):
+        """The counters are shared by the worker threads: a read-modify-write on the dict is not atomic across them."""
+        with self._stats_lock:
+            self.stats[key] += v
 
     # ------------------------------------------------------------------------------------------ capacity
     def fits(self, rows, T):
@@ -348,15 +352,15 @@ class DecodePipelines:
         if p.ev is not None:
             t_ = time.perf_counter()
             p.ev.synchronize()
-            self.stats["s_retire_wait"] += time.perf_counter() - t_
+            self._bump("s_retire_wait", time.perf_counter() - t_)
         if p.ticket is not None and p.ticket >= 0:
             ymax, used = self.engines[k].ticket(p.ticket)
-            self.stats["passes"] += 1
-            self.stats["batches"] += len(p.items)
+            self._bump("passes", 1)
+            self._bump("batches", len(p.items))
             if p.u_hint:
-                self.stats["predicted"] += 1
+                self._bump("predicted", 1)
             if used < ymax:  # the prediction fell short: this pass again, exactly (its inputs are still in their staging slot)
-                self.stats["missed"] += 1
+                self._bump("missed", 1)
                 self._learn(ymax, max(p.frames))
                 self._launch(k, st, job, p, exact=True)
                 if p.ev is not None:
@@ -384,7 +388,7 @@ class DecodePipelines:
                     if state["done"] or state["err"] is not None:
                         break
                     got = self._take(job)
-                self.stats["s_take"] += time.perf_counter() - t_
+                self._bump("s_take", time.perf_counter() - t_)
                 if got is None:
                     break
                 p = _Pass()
@@ -409,12 +413,12 @@ class DecodePipelines:
                     else:
                         p.feats, p.ratio = self._stage_inputs(k, n_pass & 1, p.items, pad)
                     if len(set(p.frames)) > 1:
-                        self.stats["merged_ragged"] += 1
+                        self._bump("merged_ragged", 1)
                 n_pass += 1
                 t1_ = time.perf_counter()
-                self.stats["s_stage"] += t1_ - t_
+                self._bump("s_stage", t1_ - t_)
                 self._launch(k, st, job, p)
-                self.stats["s_launch"] += time.perf_counter() - t1_
+                self._bump("s_launch", time.perf_counter() - t1_)
                 inflight.append(p)
                 if len(inflight) >= 2:  # two passes in flight: this one's launches are queued behind the older one's kernels
                     self._retire(k, st, job, inflight.pop(0))
@@ -423,11 +427,11 @@ class DecodePipelines:
         finally:
             st.synchronize()
 
-    def close(self):
+    def close(self, join_timeout=None):
         for q in self._inbox:
             q.put(None)
         for t in self._threads:
-            t.join()
+            t.join(join_timeout)
         self._threads, self._inbox = [], []
         for e in self.engines:
             e.close()

@@ -214,8 +214,13 @@ class CassNATTask(BaseTask):
         max_frames = max(getattr(args, "hip_max_frames", 4096), first[1].shape[1])
         # consecutive batches share an engine pass while they fit the workspace area (hip_coalesce batches of batch_size x 1024
         # frames) and their frame counts are within hip_ragged of each other; passes are filled by area, not by a batch count
+        # ... and the pipelines' engines hold their own packed weights and CMVN statistics: a changed parameter (load_state_dict,
+        # an in-place edit, invalidate_engine), precision or statistics vector rebuilds them, as the plain path's engine is rebuilt
+        import hashlib
+
+        cmvn_id = None if cmvn is None else hashlib.sha1(np.ascontiguousarray(cmvn[0]).tobytes() + np.ascontiguousarray(cmvn[1]).tobytes()).hexdigest()
         key = (n_pipes, args.batch_size, max_frames, int(getattr(args, "hip_coalesce", 10)), float(getattr(args, "hip_ragged", 0.75)),
-               cmvn is not None)
+               cmvn_id, self.model.weights_key())
         pipes = getattr(self, "_pipes", None)
         if pipes is None or self._pipes_key != key:  # (kept for further decode() calls on this task: engines, threads, streams)
             if pipes is not None:
@@ -246,16 +251,21 @@ class CassNATTask(BaseTask):
         self.pipeline_stats = {k: pipes.stats[k] - stats0[k] for k in stats0}
         return frames, i
 
-    def close(self):
+    def close(self, join_timeout=None):
         """Release the decode pipelines (engine workspaces, worker threads) a pipelined decode() left in place."""
         pipes = getattr(self, "_pipes", None)
         if pipes is not None:
-            pipes.close()
             self._pipes = None
+            pipes.close(join_timeout)
 
     def __del__(self):
+        # at interpreter shutdown the daemon workers may already be gone or frozen: joining them there can hang the exit.
+        # decode_asr closes its task explicitly; a task dropped without close() gives its threads two seconds
+        import sys
+
         try:
-            self.close()
+            if not sys.is_finalizing():
+                self.close(join_timeout=2.0)
         except Exception:
             pass
 

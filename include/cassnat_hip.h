@@ -128,7 +128,9 @@ int cn_decode_nast(cn_model* m, const float* feats_dev, const float* size_ratio_
  * reference's `.item()` sync, src/models/cassnat.py:387): nothing in the call blocks the host.  Results equal the exact call's
  * whenever u_hint >= the true count; *ticket_out names the page-locked word that receives the true count - once the stream has
  * drained, cn_decode_ticket(ticket) returns it beside the rows used, and on rows_used < ymax the caller decodes the pass again
- * (u_hint 0 = exact: the call synchronises the stream once, as cn_decode_nast). */
+ * (u_hint 0 = exact: the call synchronises the stream once, as cn_decode_nast).  A ticket is the call's sequence number on this
+ * handle; its counts live in one of FOUR words, so it stays valid until four further decode calls (cn_decode_nast included) have
+ * been started on the handle - after that cn_decode_ticket fails ("expired") instead of returning another pass's counts. */
 int cn_decode_nast_merged(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,
                           const cn_decode_opts* opts, int32_t n_sub, const int32_t* sub_rows_host, const int32_t* sub_frames_host,
                           int32_t u_hint, int32_t* hyp_out_dev, int32_t hyp_stride, int32_t* hyp_len_dev, double* score_dev,

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from cassnat_asr_public_amd import synth
+from cassnat_asr_public_amd import hip, synth
 from cassnat_asr_public_amd.models.cassnat import make_model
 from oracle.cassnat_oracle import decode_nast
 
@@ -655,3 +655,30 @@ def test_merged_pass_whose_conv_image_exceeds_4_gib():
     for k in (0, n - 2):
         assert got[k][1] == want[0][0] and list(got[k][2]) == want[0][1], k
     assert got[n - 1][1] == want[1][0] and list(got[n - 1][2]) == want[1][1]
+
+
+def test_a_ticket_expires_instead_of_returning_another_passes_counts():
+    """A ticket names the pass by its sequence number on the handle; its counts live in one of four page-locked words.  After four
+    further decode calls on the handle (plain cn_decode_nast calls included) the word belongs to another pass: cn_decode_ticket
+    fails loudly instead of handing out that pass's row counts (a caller with more than three outstanding passes
+    could accept a short prediction as covered and return truncated hypotheses)."""
+    args = synth.make_args("tiny")
+    args.hip_max_batch, args.hip_max_frames = 4, 96
+    state = synth.make_state(args, seed=0, gain=2.0)
+    model = build(args, state, capture=False, prec="fp32")
+    f, s = synth.make_feats(3, 61, 80, lengths=[61, 50, 37], seed=11)
+    feats, ratio = torch.from_numpy(f).cuda(), torch.from_numpy(s).cuda()
+    eng = model.engine(3, 61)
+    tickets = []
+    for _ in range(4):
+        *_, t = model.decode_device(feats, ratio, args, 1, engine=eng, u_hint=40, want_ticket=True)
+        tickets.append(t)
+    torch.cuda.synchronize()
+    assert tickets == list(range(tickets[0], tickets[0] + 4))
+    counts = [eng.ticket(t) for t in tickets]  # four outstanding passes: all still valid, all the same counts
+    assert len(set(counts)) == 1 and counts[0][1] == 40 and 1 <= counts[0][0] <= 40
+    model.decode_device(feats, ratio, args, 1, engine=eng)  # a plain call takes the oldest ticket's word over
+    torch.cuda.synchronize()
+    with pytest.raises(hip.HipError, match="expired"):
+        eng.ticket(tickets[0])
+    assert eng.ticket(tickets[1]) == counts[1]

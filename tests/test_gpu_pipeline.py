@@ -14,9 +14,15 @@ import torch
 from conftest import config1_case, config2_b8_case, config2_b32_case, config5_shape_case, load_golden, tiny_case
 from cassnat_asr_public_amd import hip, synth
 from cassnat_asr_public_amd.models.cassnat import make_model
+from cassnat_asr_public_amd.utils.agreement import assert_flips_explained, flips_by_margin
 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-3  # north_star: "within 1e-3 on encoder logits"
+# A frame's arg-max can only change when the error on its two best log-posteriors exceeds the reference's margin between them:
+# margin < 2 max|d log-posterior| over ALL logits.  The fixtures hold a strided sample of the logits (every st-th frame, every
+# sv-th label), whose maximum error is a little below the full maximum; FLIP_K x the sampled error is the gate (the tests print
+# the measured ratio beside the flip counts).
+FLIP_K = 3.0
 
 
 class Vocab:
@@ -105,6 +111,7 @@ def check_against_golden(model, args, feats, sizes, g, st, sv, dt, fp32):
     flips = best != g["best_paths"]
     ctc_err = maxerr(eng.fetch("ctc_out")[:, ::st, ::sv], g["ctc_sample"])
     report = dict(frames=int(flips.size), flips=int(flips.sum()), ctc_logit_err=ctc_err)
+    report["margins"] = flips_by_margin(best, g["best_paths"], margin)
     if fp32:
         assert (margin[flips] < 1e-4).all(), f"argmax differs on a clear-margin frame: {report}"
         assert ctc_err < LOGIT_TOL, report
@@ -191,6 +198,11 @@ def test_bf16_agreement_report(case, name, strides, capsys):
     # rounding (an accumulation moved to bf16, a dropped fp32 residual) shows here; SURVEY 7 predicts 0.65-2.8 % for bf16 alone
     assert rep["flips"] / rep["frames"] < 0.015
     assert rep["ctc_logit_err"] < 1.2e-2
+    # the statement that transfers to a trained model's peaked posteriors (src/models/cassnat.py:378-389 is an arg-max per frame):
+    # every flip sits on a frame whose fp32 margin is within FLIP_K x the measured logit error, none on a clear-margin frame
+    m = rep["margins"]
+    assert_flips_explained(m, rep["ctc_logit_err"], FLIP_K, f"bf16 {name}")
+    assert m["flips_margin_ge_0.05"] == 0 and m["flips_margin_ge_0.2"] == 0, m
 
 
 def test_full_size_properties_bf16():
@@ -433,12 +445,16 @@ def test_config5_fp8_encoder_products(capsys):
         assert np.isfinite(ctc).all() and all(np.isfinite(s[0]["score"]) for s in out)
         rows[prec if prec == "bf16" else f"fp8[{scope}]"] = dict(
             flips=float((best != g["best_paths"]).mean()), err=maxerr(ctc[:, ::st, ::sv], g["ctc_sample"]),
-            hyp=sum(s[0]["hyp"] == g["hyp"][b, : g["hyp_len"][b]].tolist() for b, s in enumerate(out)))
+            hyp=sum(s[0]["hyp"] == g["hyp"][b, : g["hyp_len"][b]].tolist() for b, s in enumerate(out)),
+            margins=flips_by_margin(best, g["best_paths"], g["margin"]))
     args.hip_fp8_scope = "all"
     with capsys.disabled():
         print(f"\n[config 5] V={args.vocab_size}, {g['best_paths'].size} frames, against the fp32 reference: "
               + "; ".join(f"{k}: argmax flips {v['flips']:.4f}, max |d log-posterior| {v['err']:.4f}, hypotheses identical "
-                          f"{v['hyp']}/{len(g['hyp'])}" for k, v in rows.items()))
+                          f"{v['hyp']}/{len(g['hyp'])}, largest flip margin {v['margins']['max_flip_margin']:.4f} "
+                          f"(= {v['margins']['max_flip_margin'] / max(v['err'], 1e-9):.2f} x err), flips at margin >= 0.05: "
+                          f"{v['margins']['flips_margin_ge_0.05']}/{v['margins']['frames_margin_ge_0.05']}, >= 0.2: "
+                          f"{v['margins']['flips_margin_ge_0.2']}/{v['margins']['frames_margin_ge_0.2']}" for k, v in rows.items()))
     # gates at about 2x the measured values
     assert rows["fp8[all]"]["flips"] < 0.07 and rows["fp8[all]"]["err"] < 0.065
     assert rows["fp8[conv2]"]["flips"] < 0.04 and rows["fp8[conv2]"]["err"] < 0.04
@@ -446,6 +462,12 @@ def test_config5_fp8_encoder_products(capsys):
     for k, v in rows.items():  # no scope is worse than all of them together (beyond the 600-frame fixture's resolution)
         if k.startswith("fp8["):
             assert v["flips"] <= rows["fp8[all]"]["flips"] + 0.012, (k, v)
+    # margin-conditioned: whatever the rate on this near-flat fixture, no engine flips a frame whose fp32 margin exceeds
+    # FLIP_K x its own measured logit error, and none flips a frame of margin >= 0.2 (a trained model's typical frame)
+    for k, v in rows.items():
+        assert_flips_explained(v["margins"], v["err"], FLIP_K, k)
+        assert v["margins"]["flips_margin_ge_0.2"] == 0, (k, v["margins"])
+    assert rows["bf16"]["margins"]["flips_margin_ge_0.05"] == 0
 
 
 def test_fp8_scope_strings():
@@ -521,3 +543,102 @@ def test_esa_group_rows_beyond_one_alignment_per_utterance():
         assert max(len(h) for h in got[prec][0]) * 16 > T // 4 + 1  # the group's rows do exceed one alignment's capacity
     assert got["fp32"][0] == got["bf16x3"][0]
     np.testing.assert_allclose(got["fp32"][1], got["bf16x3"][1], rtol=1e-4, atol=5e-3)
+
+
+def _task_on_synthetic_table(tmp_path, args, state, mats, batch_size, **conf_over):
+    """A CassNATTask over a synthetic Kaldi table, built the way decode_asr.main builds it."""
+    import yaml
+
+    from cassnat_asr_public_amd.data import kaldi_io
+    from cassnat_asr_public_amd.tasks import CassNATTask
+    from cassnat_asr_public_amd.utils.parser import DecodeParser
+
+    scp = str(tmp_path / "feats.scp")
+    kaldi_io.write_ark_scp(str(tmp_path / "feats.ark"), scp, mats)
+    vocab_file = tmp_path / "vocab.txt"
+    vocab_file.write_text("".join(f"w{i}\n" for i in range(args.vocab_size - 4)))
+    ckpt = str(tmp_path / "model.mdl")
+    torch.save({"model_state": {"module." + k: torch.from_numpy(v) for k, v in state.items()}}, ckpt)
+    conf = {k: getattr(args, k) for k in ("input_size", "d_model", "n_head", "d_encff", "d_decff", "d_ff", "N_enc", "N_extra",
+                                          "N_self_dec", "N_mix_dec", "model_type", "n_features", "left_ctx", "right_ctx",
+                                          "skip_frame", "padding_idx", "beam_width", "length_penalty", "use_trigger")}
+    conf.update(vocab_file=str(vocab_file), use_gpu=True, **conf_over)
+    cfg = tmp_path / "decode.yaml"
+    cfg.write_text(yaml.safe_dump(conf))
+    a = DecodeParser().get_args(["--task", "cassnat", "--test_config", str(cfg), "--data_path", scp, "--resume_model", ckpt,
+                                 "--result_file", str(tmp_path / "res.txt"), "--batch_size", str(batch_size), "--hip_precision", "fp32",
+                                 "--load_data_workers", "0"])
+    for k, v in conf.items():
+        setattr(a, k, v)
+    a.test_paths = [{"name": "test", "scp_path": scp}]
+    a.rank = 0
+    return CassNATTask("test", a), a
+
+
+def test_cached_pipelines_follow_the_models_weights(tmp_path):
+    """A task keeps its decode pipelines (engines with their own packed weights) across decode() calls.  After the parameters
+    change - in place, through .data + invalidate_engine, or by load_state_dict - the next decode() must not run on the old
+    weights: its result file equals the plain loop's on the new ones (the cache key ignored the weights)."""
+    args, state, feats, sizes = tiny_case()
+    lengths = [61, 50, 37, 44]
+    mats = [(f"spk-utt{b}", feats[b % 3, :n]) for b, n in enumerate(lengths)]
+    task, a = _task_on_synthetic_table(tmp_path, args, state, mats, batch_size=1)
+
+    def run(pipelines, name):
+        a.hip_pipelines, a.result_file = pipelines, str(tmp_path / name)
+        task.decode(a)
+        return open(a.result_file).read().splitlines()
+
+    first = run(2, "p0.txt")
+    assert first == run(1, "l0.txt")
+    pipes0 = task._pipes
+    assert run(2, "p0b.txt") == first and task._pipes is pipes0  # unchanged weights: the pipelines are kept
+    rng = np.random.default_rng(5)
+    w = task.model.att_generator.proj.weight
+    with torch.no_grad():  # 1. an in-place edit (bumps the tensor version)
+        w.copy_(torch.from_numpy(rng.standard_normal(tuple(w.shape)).astype(np.float32)))
+    second = run(2, "p1.txt")
+    assert task._pipes is not pipes0
+    assert second == run(1, "l1.txt") and second != first
+    pipes1 = task._pipes
+    w.data = torch.from_numpy(rng.standard_normal(tuple(w.shape)).astype(np.float32))  # 2. through .data: invisible to versions
+    task.model.invalidate_engine()
+    third = run(2, "p2.txt")
+    assert task._pipes is not pipes1
+    assert third == run(1, "l2.txt") and third != second
+    sd = {k: torch.from_numpy(v) for k, v in state.items()}  # 3. load_state_dict: back to the checkpoint
+    task.model.load_state_dict(sd)
+    assert run(2, "p3.txt") == first
+    task.close()
+
+
+def test_decode_asr_cli_cmvn_on_a_float64_archive(tmp_path):
+    """A `DM` (float64) archive: the reference normalises the float64 values and rounds once.  The device form would round the
+    features to float32 BEFORE normalising, so it must not be chosen: the dataset keeps the CMVN on the host, and the result
+    equals the oracle's on features normalised in float64."""
+    from cassnat_asr_public_amd.data import kaldi_io
+    from oracle import cassnat_oracle as orc
+
+    args, state, feats, sizes = tiny_case()
+    lengths = [61, 50, 37, 12]
+    rng = np.random.default_rng(2)
+    raw = [rng.standard_normal((n, feats.shape[2])) * 2.5 + 0.7 for n in lengths]  # float64 matrices
+    allf = np.vstack(raw)
+    stats = np.zeros((2, feats.shape[2] + 1))
+    stats[0, :-1], stats[0, -1], stats[1, :-1] = allf.sum(0), len(allf), (allf ** 2).sum(0)
+    kaldi_io.write_ark_scp(str(tmp_path / "cmvn.ark"), str(tmp_path / "cmvn.scp"), [("global", stats)])
+    cmvn_spec = kaldi_io.read_scp(str(tmp_path / "cmvn.scp"))[0][1]
+    task, a = _task_on_synthetic_table(tmp_path, args, state, [(f"spk-utt{b}", m) for b, m in enumerate(raw)], batch_size=1,
+                                       use_cmvn=True, global_cmvn=cmvn_spec)
+    assert kaldi_io.mat_dtype(kaldi_io.read_scp(str(tmp_path / "feats.scp"))[0][1]) == np.float64
+    assert not task.test_loader.dataset.can_defer_cmvn()
+    a.hip_pipelines = 2
+    task.decode(a)
+    assert task._pipes.cmvn is None  # the pipelines received normalised batches
+    got = open(a.result_file).read().splitlines()
+    task.close()
+    mean = stats[0, :-1] / stats[0, -1]
+    std = np.sqrt(stats[1, :-1] / stats[0, -1] - mean ** 2)
+    index2word = {i + 4: f"w{i}" for i in range(args.vocab_size - 4)}
+    hyps = [orc.decode_nast(state, ((m - mean) / std).astype(np.float32)[None], np.ones(1, np.float32), args)["hyps"][0] for m in raw]
+    assert got == [f"spk-utt{b} " + " ".join(orc.hyp_to_text(h, index2word)) for b, h in enumerate(hyps)]

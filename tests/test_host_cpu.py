@@ -30,6 +30,25 @@ def test_library_exports_every_declared_symbol():
     assert L.cn_version().startswith(b"cassnat_hip")
 
 
+def test_product_library_reads_no_environment_variable():
+    """Kernel-selection / stamp / repeat switches exist only in -DCASSNAT_EXPERIMENTS builds (csrc/common.h: cn_exp_env): the
+    shipped library neither imports getenv nor carries the name of a switch; the package's only environment variable is the
+    loader-level CASSNAT_HIP_LIB (which library file to load)."""
+    import re
+
+    out = subprocess.run(["nm", "-D", "--undefined-only", hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert not re.search(r"\bgetenv\b", out)
+    blob = open(hip.LIB_PATH, "rb").read()
+    assert b"CASSNAT_" not in blob
+    pkg = os.path.join(REPO, "cassnat_asr_public_amd")
+    used = set()
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                used |= set(re.findall(r"environ[^\n]*?[\"'](CASSNAT_\w+)[\"']", open(os.path.join(root, f)).read()))
+    assert used == {"CASSNAT_HIP_LIB"}, used
+
+
 def test_create_rejects_unsupported_geometry_without_touching_the_gpu():
     L = hip.lib()
     h = C.c_void_p()
@@ -536,3 +555,22 @@ def test_batched_hypothesis_to_words_equals_the_per_utterance_rule():
     lens = rng.integers(0, 26, size=64)
     got = hyps_to_words_batch(toks, lens, V, 0)
     assert got == [hyp_to_words(toks[b, : lens[b]].tolist(), V, 0) for b in range(64)]
+
+
+def test_flips_by_margin_counts_and_gate():
+    """The margin-conditioned agreement report (utils/agreement.py) that the bf16 / fp8 GPU gates and bench.py use."""
+    from cassnat_asr_public_amd.utils.agreement import assert_flips_explained, flips_by_margin
+
+    ref = np.array([[1, 2, 3, 4, 5, 6]])
+    got = np.array([[1, 9, 3, 9, 5, 9]])
+    margin = np.array([[0.5, 0.003, 0.3, 0.06, 0.0, 0.25]], np.float32)
+    own = np.array([[1, 1, 1, 1, 1, 0]], bool)  # the last frame is padding: its flip does not count
+    r = flips_by_margin(got, ref, margin, own)
+    assert (r["frames"], r["flips"]) == (5, 2) and abs(r["max_flip_margin"] - 0.06) < 1e-7
+    assert (r["flips_margin_ge_0.05"], r["frames_margin_ge_0.05"]) == (1, 3)
+    assert (r["flips_margin_ge_0.2"], r["frames_margin_ge_0.2"]) == (0, 2)
+    assert sum(f for f, _ in r["flips_frames_by_margin"].values()) == 2 and sum(n for _, n in r["flips_frames_by_margin"].values()) == 5
+    assert_flips_explained(r, 0.03, 2.0)  # 0.06 <= 2 x 0.03
+    with pytest.raises(AssertionError, match="clear-margin frame flipped"):
+        assert_flips_explained(r, 0.02, 2.0)
+    assert flips_by_margin(ref, ref, margin)["max_flip_margin"] == 0.0

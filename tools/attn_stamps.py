@@ -8,7 +8,11 @@ os.environ.setdefault("CASSNAT_ATTN_STAMPS", "1")
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cassnat_asr_public_amd import hip
+from cassnat_asr_public_amd import build as _B  # noqa: E402
+
+# (an experiment switch: only the -DCASSNAT_EXPERIMENTS build of the library reads it)
+os.environ.setdefault("CASSNAT_HIP_LIB", _B.experiments_lib())
+from cassnat_asr_public_amd import hip  # noqa: E402
 
 
 def main():

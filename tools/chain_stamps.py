@@ -18,10 +18,9 @@ def main():
     extra = sys.argv[2:]
     out = os.environ.get("TMPDIR", "/tmp")
     tag = "".join(c for c in "".join(extra) if c.isalnum())
-    if extra:
-        lib = B.build(extra_flags=extra, lib=os.path.join(out, "libcassnat_hip_chain%s.so" % tag), objdir=os.path.join(out, "cn_chain_obj" + tag))
-    else:
-        lib = os.environ.get("CASSNAT_HIP_LIB") or B.LIB  # the product build (CASSNAT_CHAIN_STAMP_BLOCK chooses the workgroup that writes the stamps)
+    # the stamps are an experiment switch (csrc/common.h: cn_exp_env): an experiments build of the library, with the extra flags if
+    # any (CASSNAT_CHAIN_STAMP_BLOCK chooses the workgroup that writes the stamps)
+    lib = os.environ.get("CASSNAT_HIP_LIB") or B.experiments_lib(extra, tag="chain" + tag)
     L = C.CDLL(lib)
     L.cn_op_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 12 + [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                                                        C.c_float, C.c_int32, C.c_void_p]

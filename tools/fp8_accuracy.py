@@ -2,8 +2,10 @@
 
 The config-5 fixture holds 600 frames (one flip = 0.17 %); this tool decodes B ragged utterances of up to T frames with the
 fp32 engine (the parity engine: within 2e-6 of the reference, tests/test_gpu_pipeline.py) and with each engine named on the
-command line, and prints the share of frames whose CTC arg-max differs and the largest log-posterior difference.  Build
-switches (CASSNAT_NO_CONV2_F8, CASSNAT_NO_LINEAR_F8, CASSNAT_FP8_LAYERS, ...) are read from the environment by the library.
+command line, and prints the share of frames whose CTC arg-max differs, the largest log-posterior difference and WHERE the flips
+sit by the fp32 engine's top-2 margin (utils/agreement.py).  The experiment switches (CASSNAT_NO_CONV2_F8, CASSNAT_NO_LINEAR_F8,
+CASSNAT_FP8_LAYERS, ...) are read only by a -DCASSNAT_EXPERIMENTS build of the library (CASSNAT_HIP_LIB=ab/libcassnat_hip_exp.so,
+`python -m cassnat_asr_public_amd.build --experiments`); `--hip_fp8_scope` is the product's setting for the same question.
 
     python tools/fp8_accuracy.py --engines "bf16,fp8,fp8[conv2+ffn:8],fp8[conv2]" --batch 48 --frames 1000
 """
@@ -17,6 +19,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cassnat_asr_public_amd import synth  # noqa: E402
 from cassnat_asr_public_amd.models.cassnat import make_model  # noqa: E402
+from cassnat_asr_public_amd.utils.agreement import flips_by_margin  # noqa: E402
 
 
 class Vocab:
@@ -57,6 +60,8 @@ def main():
     own = np.zeros(ref_best.shape, bool)
     for b, n in enumerate(lens):
         own[b, : min(tp, ((n - 1) // 2 - 1) // 2)] = True
+    top2 = np.sort(np.partition(ref_ctc, -2, axis=-1)[..., -2:], axis=-1)
+    margin = top2[..., 1] - top2[..., 0]  # the fp32 engine's top-2 margin per frame
     tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("CASSNAT_"))
     for prec in a.engines.split(","):
         best, ctc, hyp = run(args, state, feats, sizes, prec)
@@ -64,8 +69,12 @@ def main():
         err = float(np.abs(ctc.astype(np.float64) - ref_ctc.astype(np.float64))[own].max())
         rms = float(np.sqrt(np.mean((ctc.astype(np.float64) - ref_ctc.astype(np.float64))[own] ** 2)))
         same = sum(h == r for h, r in zip(hyp, ref_hyp))
+        mg = flips_by_margin(best, ref_best, margin, own)
         print(f"{prec:18s} [{tag}] frames {int(own.sum())}: argmax flips {flips:.4f}, max |d log-posterior| {err:.4f}, rms {rms:.5f}, "
-              f"hypotheses identical {same}/{len(hyp)}", flush=True)
+              f"hypotheses identical {same}/{len(hyp)}; largest flip margin {mg['max_flip_margin']:.4f} = "
+              f"{mg['max_flip_margin'] / max(err, 1e-12):.2f} x max err (bound: 2); flips at margin >= 0.05: "
+              f"{mg['flips_margin_ge_0.05']}/{mg['frames_margin_ge_0.05']}, >= 0.2: {mg['flips_margin_ge_0.2']}/{mg['frames_margin_ge_0.2']}; "
+              f"[flips, frames] by margin {mg['flips_frames_by_margin']}", flush=True)
 
 
 if __name__ == "__main__":

@@ -8,10 +8,13 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from cassnat_asr_public_amd import build as _B  # noqa: E402
+
+os.environ.setdefault("CASSNAT_GENMAX_REPEAT", "12")  # (an experiment switch: only the -DCASSNAT_EXPERIMENTS build reads it)
+os.environ.setdefault("CASSNAT_HIP_LIB", _B.experiments_lib())
 from cassnat_asr_public_amd import hip  # noqa: E402
 
 M, V = int(os.environ.get("GM_M", 7968)), 5000
-os.environ.setdefault("CASSNAT_GENMAX_REPEAT", "12")
 g = torch.Generator().manual_seed(1)
 h = torch.randn(M, 256, generator=g).contiguous()
 w = (torch.randn(V, 256, generator=g) / 16).contiguous()
