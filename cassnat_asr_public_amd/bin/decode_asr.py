@@ -40,10 +40,11 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        if args.hip_dist_backend == "gloo":  # rehearsal: the ranks may share a GPU
-            local = min(local, torch.cuda.device_count() - 1)
-            os.environ["LOCAL_RANK"] = str(local)
-            torch.cuda.set_device(local)
+        if args.hip_dist_backend == "gloo":  # rehearsal: the ranks may share a GPU (or, in the host-logic tests, have none)
+            if torch.cuda.device_count() > 0:
+                local = min(local, torch.cuda.device_count() - 1)
+                os.environ["LOCAL_RANK"] = str(local)
+                torch.cuda.set_device(local)
             torch.distributed.init_process_group("gloo")
         else:
             torch.cuda.set_device(local)

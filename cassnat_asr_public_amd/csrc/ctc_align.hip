@@ -73,19 +73,22 @@ __global__ __launch_bounds__(256) void ctc_align_kernel(AlignArgs a) {
     const int ssz = (int)(long long)(a.size_ratio[bs] * (float)Tp);
     if (tid == 0) {
         a.src_size[b] = ssz;
-        a.ylen[b] = ylen0 + 1;
-        atomicMax(a.ymax, ylen0 + 1);
+        a.ylen[b] = ylen0 + (a.no_trigger ? 0 : 1);
+        atomicMax(a.ymax, ylen0 + (a.no_trigger ? 0 : 1));
     }
     for (int u = tid; u <= Tw; u += 256) {
         int s1 = s_lo[u], e1 = s_hi[u], s2 = 0, e2 = 0;
-        if (s1 == 0x7fffffff) {
+        if (a.no_trigger) {  // trigger_mask = src_mask (cassnat.py:470): all frames of the utterance's own batch, & keymask downstream
+            s1 = 0;
+            e1 = Tp;
+        } else if (s1 == 0x7fffffff) {
             s1 = 0;
             e1 = 0;
         } else {
             if (a.left > 0) s1 = s1 > 0 ? s1 - 1 : 0;
             if (a.right > 0) e1 = e1 < Tp ? e1 + 1 : Tp;
         }
-        if (u == ylen0) {  // trigger_mask[b, ylens[b], src_size[b]-1] = 1, python negative index wraps
+        if (u == ylen0 && !a.no_trigger) {  // trigger_mask[b, ylens[b], src_size[b]-1] = 1, python negative index wraps
             int f = ssz - 1;
             if (f < 0) f += Tp;
             if (f >= 0 && f < Tp) {
@@ -118,6 +121,48 @@ int launch_ctc_align(const AlignArgs& a, hipStream_t s) {
         attr_once.mark(attr_dev);
     }
     hipLaunchKernelGGL(ctc_align_kernel, dim3(a.B), dim3(256), lds, s, a);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// CTC greedy hypothesis as a decoder input (Transformer.fast_decode_with_ctc, src/models/transformer.py:256-270): arg-max path
+// zeroed on masked frames, repeats of the previous frame's label zeroed, the non-zero labels compacted behind sos; the row is
+// padded with `pad`.  One wave per utterance; tgt [B][ld] (ld >= Tp + 1), len [B] (labels, without sos), maxlen [1].
+__global__ __launch_bounds__(64) void ctc_collapse_kernel(const int* __restrict__ best, const unsigned char* __restrict__ km, int B, int Tp,
+                                                          int sos, int pad, int ld, int* __restrict__ tgt, int* __restrict__ len,
+                                                          int* __restrict__ keylen, int* __restrict__ maxlen) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= B) return;
+    const int* p = best + (long long)b * Tp;
+    const unsigned char* k = km + (long long)b * Tp;
+    int* row = tgt + (long long)b * ld;
+    int count = 0;
+    for (int base = 0; base < Tp; base += 64) {
+        const int t = base + lane;
+        int tok = 0;
+        if (t < Tp) {
+            const int cur = k[t] ? p[t] : 0;
+            const int prev = t >= 1 ? (k[t - 1] ? p[t - 1] : 0) : 0;
+            tok = cur == prev ? 0 : cur;
+        }
+        const unsigned long long m = __ballot(tok != 0);
+        if (tok != 0) row[1 + count + __popcll(m & ((1ull << lane) - 1ull))] = tok;
+        count += __popcll(m);
+    }
+    for (int i = count + 1 + lane; i < ld; i += 64) row[i] = pad;
+    if (lane == 0) {
+        row[0] = sos;
+        len[b] = count;
+        keylen[b] = count + 1;  // keys the causal + padding mask allows: sos and the labels (tgt_input != padding_idx)
+        atomicMax(maxlen, count);
+    }
+}
+
+int launch_ctc_collapse(const int* best, const unsigned char* km, int B, int Tp, int sos, int pad, int ld, int* tgt, int* len, int* keylen,
+                        int* maxlen, hipStream_t s) {
+    if (B <= 0 || Tp <= 0 || ld < Tp + 1) return -1;
+    CN_HIP_CHECK(hipMemsetAsync(maxlen, 0, sizeof(int), s));
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(64), 0, s, best, km, B, Tp, sos, pad, ld, tgt, len, keylen, maxlen);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

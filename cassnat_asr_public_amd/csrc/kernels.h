@@ -167,8 +167,15 @@ struct AlignArgs {
     // merged pass (null otherwise): utterance b's own batch has utt_meta[b].tp <= Tp frames - the width of its ctc_out in the
     // reference: the shift drops a token that starts on ITS last frame, src_size = (ratio * tp).long(), rows wrap at tp
     const UttMeta* utt_meta = nullptr;
+    // args.use_trigger == False (src/models/cassnat.py:469-473): trigger_mask = src_mask - every row's interval is the utterance's
+    // whole frame range (the attention kernel ANDs it with the key mask) - and ylen / ymax are best_path_align's own counts: no
+    // EOS row is added (align_to_mask, which adds it, does not run)
+    int no_trigger = 0;
 };
 int launch_ctc_align(const AlignArgs& a, hipStream_t s);
+// CTC greedy hypothesis compacted behind sos (Transformer.fast_decode_with_ctc's decoder input)
+int launch_ctc_collapse(const int* best, const unsigned char* km, int B, int Tp, int sos, int pad, int ld, int* tgt, int* len, int* keylen,
+                        int* maxlen, hipStream_t s);
 
 // ---- CTC prefix beam search + forced alignment (decode_type ctc_only / ctc_att)              (ctc_beam.hip)
 struct CtcBeamArgs {

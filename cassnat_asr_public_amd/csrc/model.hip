@@ -1793,6 +1793,7 @@ int stage_encode_align(cn_model* m, const float* feats, const float* ratio, int 
     al.ymax = m->ymax;
     al.intervals = m->intervals;
     al.utt_meta = m->ragged ? m->utt_meta : nullptr;
+    al.no_trigger = o->no_trigger != 0;
     {
         ProfScope ps(m, "ctc_align", 0, (double)B * Tp * 9 + (double)B * (Tp + 1) * 16, s);
         CN_TRY(launch_ctc_align(al, s));
@@ -2504,9 +2505,10 @@ extern "C" int cn_ctc_beam(cn_model* m, const float* feats_dev, const float* siz
                            int32_t hyp_cap, int32_t* hyp_len_dev, double* score_dev, double* p_blk_dev, double* p_nblk_dev,
                            int32_t* nbeam_dev, void* stream) {
     CN_TRY(check_call(m, B, T, F));
-    if (!opts || m->cfg.ast || beam < 1 || beam > 32 || pruning < 0 || pruning > 32 || !hyp_out_dev || !hyp_len_dev || !score_dev ||
-        !p_blk_dev || !p_nblk_dev || !nbeam_dev) {
-        cn_set_error("cn_ctc_beam: needs a NAT model, 1 <= ctc_beam <= 32, 0 <= ctc_pruning <= 32 and all output buffers");
+    // (a NAT model, or the autoregressive model with its CTC head: ArtTask decode_type 'ctc_only', src/tasks/art_task.py:252-253)
+    if (!opts || m->cfg.ast == 2 || !m->ctc_gen.W || beam < 1 || beam > 32 || pruning < 0 || pruning > 32 || !hyp_out_dev || !hyp_len_dev ||
+        !score_dev || !p_blk_dev || !p_nblk_dev || !nbeam_dev) {
+        cn_set_error("cn_ctc_beam: needs a model with a CTC head, 1 <= ctc_beam <= 32, 0 <= ctc_pruning <= 32 and all output buffers");
         return -1;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -2654,9 +2656,12 @@ extern "C" int cn_esa_begin(cn_model* m, const float* feats_dev, int32_t B, int3
 extern "C" int cn_esa_sample(cn_model* m, const uint8_t* select_dev, int32_t n_samples, float threshold,
                              const float* size_ratio_dev, const cn_decode_opts* opts, int32_t* tok_out_dev, float* val_out_dev,
                              int32_t out_stride, int32_t* ylen_out_dev, int32_t* ymax_host, int32_t force_U, void* stream) {
-    if (!m || !opts || !ymax_host || m->B < 1 || opts->beam_width != 1 ||
-        (force_U >= 0 && (!tok_out_dev || !val_out_dev || !ylen_out_dev))) {
-        cn_set_error("cn_esa_sample: call cn_esa_begin first; beam_width must be 1");
+    // beam_width > 1: the pass of the SELECTED alignments (src/models/cassnat.py:556-561 gathers them, :574-637 finishes with
+    // top-k per row): the per-row top-k stays in the engine (cn_fetch "topk_idx" / "topk_val" / "ylen"), no token rows are copied
+    const bool topk_pass = opts && opts->beam_width > 1;
+    if (!m || !opts || !ymax_host || m->B < 1 || opts->beam_width < 1 || opts->beam_width > 16 ||
+        (force_U >= 0 && !topk_pass && (!tok_out_dev || !val_out_dev || !ylen_out_dev))) {
+        cn_set_error("cn_esa_sample: call cn_esa_begin first; 1 <= beam_width <= 16; beam_width 1 needs the output buffers");
         return -1;
     }
     if (n_samples < 1 || n_samples > std::max(1, m->cfg.esa_group) || (n_samples > 1 && !select_dev)) {
@@ -2700,7 +2705,7 @@ extern "C" int cn_esa_sample(cn_model* m, const uint8_t* select_dev, int32_t n_s
         }
         U = force_U;
     }
-    if (U < 1 || U > Tp + 1 || U > out_stride) {
+    if (U < 1 || U > Tp + 1 || (!topk_pass && U > out_stride)) {
         cn_set_error("cn_esa_sample: token count outside the output stride");
         return -3;
     }
@@ -2708,6 +2713,8 @@ extern "C" int cn_esa_sample(cn_model* m, const uint8_t* select_dev, int32_t n_s
     const int rc = stage_decode(m, U, opts, nullptr, 0, nullptr, nullptr, s);
     m->dec_group = 1;
     if (rc) return rc;
+    *ymax_host = U;
+    if (topk_pass) return 0;
     CN_TRY(launch_copy_rows(tok_out_dev, out_stride, m->tok, U, U, BG, s));
     CN_TRY(launch_copy_rows(val_out_dev, out_stride, m->val, U, U, BG, s));
     CN_TRY(launch_copy_rows(ylen_out_dev, BG, m->ylen, BG, BG, 1, s));
@@ -2825,6 +2832,56 @@ extern "C" int cn_ast_teacher_score(cn_model* m, const float* feats_dev, int32_t
         CN_TRY(launch_gather_logp(m->logits, V, tgt_dev + (size_t)e0 * ld, ld, score_dev + (size_t)e0 * ld, ne, U, s));
     }
     m->dec_group = 1;
+    return 0;
+}
+
+// ArtTask decode_type 'ctc_correct' (Transformer.fast_decode_with_ctc, src/models/transformer.py:243-342): the CTC greedy hypothesis
+// of every utterance, behind sos, is the decoder's teacher-forced input under the causal + padding mask; the finish loop then reads
+// the k best labels of row i while i <= length[b].  Device part: encoder, CTC arg-max + collapse, decoder, generator + log-softmax +
+// top-k.  Outputs: len_out_dev [B] (CTC labels per utterance), tok_out_dev / val_out_dev [B][U][k] (U = longest + 1 rows, returned
+// in *rows_host; the buffers hold B * (T' + 1) * k entries).  One host sync on the longest hypothesis (the reference's max(length)).
+extern "C" int cn_ast_ctc_correct(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts,
+                                  int32_t k, int32_t* tok_out_dev, float* val_out_dev, int32_t* len_out_dev, int32_t* rows_host,
+                                  void* stream) {
+    CN_TRY(check_call(m, B, T, F));
+    if (!opts || m->cfg.ast != 1 || !m->tgt_lut || !m->ctc_gen.W || k < 1 || k > 16 || !tok_out_dev || !val_out_dev || !len_out_dev ||
+        !rows_host) {
+        cn_set_error("cn_ast_ctc_correct: needs an autoregressive model (cfg.ast = 1) with a CTC head, 1 <= k <= 16 and all output buffers");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+    CN_TRY(stage_encode_ctc_rows(m, feats_dev, B, T, F, opts, s));
+    const int d = m->cfg.d_model, V = m->cfg.vocab_size, Tp = m->Tp, ld = Tp + 1;
+    if (ld > m->pe_rows) {
+        cn_set_error("cn_ast_ctc_correct: more subsampled frames than rows of the positional table");
+        return -1;
+    }
+    void *tgt = nullptr, *keylen = nullptr;
+    CN_TRY(scratch_buf(m, "cc_tgt", (size_t)B * ld * 4, &tgt));
+    CN_TRY(scratch_buf(m, "cc_keylen", (size_t)B * 4, &keylen));
+    CN_TRY(launch_ctc_collapse(m->best, m->keymask, B, Tp, opts->sos, opts->padding_idx, ld, (int*)tgt, len_out_dev, (int*)keylen, m->ymax, s));
+    CN_HIP_CHECK(hipMemcpyAsync(m->ymax_pinned, m->ymax, sizeof(int), hipMemcpyDeviceToHost, s));
+    CN_HIP_CHECK(hipStreamSynchronize(s));  // the decoder's row count is data dependent (max_length + 1, transformer.py:266)
+    const int U = *m->ymax_pinned + 1, M = B * U;
+    if (U < 1 || U > ld) {
+        cn_set_error("cn_ast_ctc_correct: impossible CTC hypothesis length");
+        return -3;
+    }
+    m->dec_group = 1;
+    float* x = m->xd;
+    CN_TRY(launch_lm_embed((const int*)tgt, ld, m->tgt_lut, m->pe, x, B, U, d, sqrtf((float)d), s));
+    for (size_t i = 0; i < m->mad.size(); ++i) {  // DecoderLayer: self attention (causal + padding mask), source attention, feed-forward
+        const Layer& L = m->mad[i];
+        CN_TRY(run_self_attn(m, L, &L.n[0], x, B, U, nullptr, (const int*)keylen, 1, s));
+        CN_TRY(run_src_attn(m, L, &L.n[1], x, B, U, Tp, nullptr, s));
+        CN_TRY(run_ffn(m, L, L.n[2], x, M, nullptr, nullptr, s));
+    }
+    CN_TRY(run_ln(m, m->dec_norm, x, m->dec_h, M, s));
+    CN_TRY(run_linear(m, "generator_proj", m->att_gen, m->dec_h, d, m->logits, V, 1, M, 0, nullptr, 0, s));
+    CN_TRY(launch_logsoftmax_argmax(m->logits, M, V, V, m->tok, m->val, 1, s));
+    CN_TRY(launch_topk(m->logits, M, V, V, k, tok_out_dev, val_out_dev, s));
+    *rows_host = U;
     return 0;
 }
 

@@ -33,10 +33,11 @@ def broadcast_weights(engine, src=0, group=None):
     """RCCL broadcast of the packed weight blob from `src` into every other rank's (layout-identical) blob."""
     ptr, nbytes = engine.weight_blob()
     t = torch.as_tensor(_CudaBlob(ptr, nbytes), device="cuda")
-    sizes = [None] * dist.get_world_size(group)
-    dist.all_gather_object(sizes, nbytes, group=group)
-    if len(set(sizes)) != 1:
-        raise RuntimeError(f"weight blob layout differs across ranks: {sizes}")
+    # every rank's blob must have the sender's layout: one 16-byte all-reduce (max of n and of -n), no pickled objects
+    chk = torch.tensor([nbytes, -nbytes], dtype=torch.int64, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(chk, op=dist.ReduceOp.MAX, group=group)
+    if int(chk[0]) != nbytes or int(chk[1]) != -nbytes:
+        raise RuntimeError(f"weight blob layout differs across ranks: {nbytes} bytes here, {-int(chk[1])}..{int(chk[0])} over the ranks")
     dist.broadcast(t, src=src, group=group)
     torch.cuda.synchronize()
     return nbytes

@@ -50,7 +50,7 @@ class CnConfig(C.Structure):
 class CnDecodeOpts(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "padding_idx", "sos", "left_trigger", "right_trigger", "src_trigger", "use_unimask", "beam_width",
-        "capture", "sub_batch")] + [("reserved", C.c_int32 * 7)]
+        "capture", "sub_batch", "no_trigger")] + [("reserved", C.c_int32 * 6)]
 
 
 class CnAstOpts(C.Structure):
@@ -175,6 +175,8 @@ def lib():
                                         C.c_void_p]
     L.cn_ast_teacher_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts), C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.cn_ast_ctc_correct.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CnDecodeOpts), C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
     L.cn_profile_begin.argtypes = [C.c_void_p, C.c_char_p]
     L.cn_profile_end.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     _lib = L
@@ -272,10 +274,11 @@ class Engine:
 
     @staticmethod
     def make_opts(args, capture=False):
-        return CnDecodeOpts(padding_idx=int(args.padding_idx), sos=1, left_trigger=int(args.left_trigger),
-                            right_trigger=int(args.right_trigger), src_trigger=int(bool(args.src_trigger)),
-                            use_unimask=int(bool(args.use_unimask)), beam_width=int(args.beam_width),
-                            capture=int(bool(capture)))
+        # (an autoregressive model's args carry no trigger options: ctc_beam_decode runs on either kind of model)
+        return CnDecodeOpts(padding_idx=int(args.padding_idx), sos=1, left_trigger=int(getattr(args, "left_trigger", 0)),
+                            right_trigger=int(getattr(args, "right_trigger", 0)), src_trigger=int(bool(getattr(args, "src_trigger", False))),
+                            use_unimask=int(bool(getattr(args, "use_unimask", False))), beam_width=int(args.beam_width),
+                            capture=int(bool(capture)), no_trigger=int(not getattr(args, "use_trigger", True)))
 
     def decode(self, feats, size_ratio, opts, hyp, hyp_len, score):
         """feats (B,T,F) f32 cuda, size_ratio (B,) f32 cuda; outputs are caller-owned cuda tensors."""
@@ -338,7 +341,7 @@ class Engine:
         ymax = C.c_int32()
         n = select.shape[0]
         assert select.is_contiguous()
-        if force_U >= 0:
+        if force_U >= 0 and opts.beam_width == 1:  # (beam_width > 1: the per-row top-k stays in the engine, nothing is copied out)
             assert tok.shape[0] == n and tok.is_contiguous() and val.is_contiguous() and ylen.is_contiguous()
         check(self.L.cn_esa_sample(self.handle, _ptr(select), n, float(threshold), _ptr(size_ratio), C.byref(opts), _ptr(tok),
                                    _ptr(val), tok.shape[2] if tok is not None else 0, _ptr(ylen), C.byref(ymax), int(force_U),
@@ -384,6 +387,19 @@ class Engine:
         B, T, F = feats.shape
         check(self.L.cn_ast_teacher_score(self.handle, _ptr(feats), B, T, F, C.byref(opts), _ptr(tok), _ptr(tgt), _ptr(length),
                                           int(n_per_utt), int(U), tok.shape[1], _ptr(score), current_stream()), "cn_ast_teacher_score")
+
+    def ast_ctc_correct(self, feats, opts, k):
+        """Transformer.fast_decode_with_ctc's device half: -> (length (B,) int32 cuda, tok (B, U, k) int32 cuda, val (B, U, k) f32 cuda)."""
+        B, T, F = feats.shape
+        Tp = ((T - 1) // 2 + 1 - 1) // 2 + 1
+        tok = torch.empty(B * (Tp + 1) * k, dtype=torch.int32, device=feats.device)
+        val = torch.empty(B * (Tp + 1) * k, dtype=torch.float32, device=feats.device)
+        length = torch.empty(B, dtype=torch.int32, device=feats.device)
+        rows = C.c_int32()
+        check(self.L.cn_ast_ctc_correct(self.handle, _ptr(feats), B, T, F, C.byref(opts), int(k), _ptr(tok), _ptr(val), _ptr(length),
+                                        C.byref(rows), current_stream()), "cn_ast_ctc_correct")
+        U = rows.value
+        return length, tok[: B * U * k].view(B, U, k), val[: B * U * k].view(B, U, k)
 
     def profile_begin(self, tags=None):
         """Start HIP-event timing of the tagged kernels (None = all) on the launch stream."""

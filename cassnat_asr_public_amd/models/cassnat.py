@@ -358,9 +358,10 @@ class CassNAT(nn.Module):
 
     # ------------------------------------------------------------------------------------------ decode
     def _check_args(self, args, lm_model):
-        if not getattr(args, "use_trigger", True):
-            raise NotImplementedError("use_trigger=False is not on the accelerated path")
         dtype = getattr(args, "decode_type", "att_only")
+        if not getattr(args, "use_trigger", True) and (dtype != "att_only" or getattr(args, "sample_num", 0) > 1):
+            # (the reference reads decode_type / sample_num only inside `if args.use_trigger:`, src/models/cassnat.py:435-468)
+            raise NotImplementedError("use_trigger=False goes with decode_type att_only and sample_num <= 1")
         if dtype not in ("att_only", "ctc_att"):
             raise NotImplementedError("decode_type '%s' is outside the accelerated path (att_only, ctc_att; ctc_only goes through "
                                       "utils.beam_decode.ctc_beam_decode)" % dtype)
@@ -377,8 +378,8 @@ class CassNAT(nn.Module):
             if not ok:
                 raise NotImplementedError("ESA ranking needs rank_model 'lm' (models.lm.TransformerLM), 'at_baseline' "
                                           "(models.transformer.Transformer) or 'n-gram' (an object with kenlm's score(str))")
-            if args.beam_width != 1:
-                raise NotImplementedError("ESA is implemented for beam_width == 1")
+            if not 1 <= int(args.beam_width) <= 16:
+                raise NotImplementedError("ESA: beam_width must be in [1, 16]")
         if getattr(args, "test_hitrate", False):
             raise NotImplementedError("test_hitrate needs the training-time viterbi aligner")
         if self._conf_dec and getattr(args, "use_unimask", False):
@@ -484,6 +485,8 @@ class CassNAT(nn.Module):
         eng = self.engine(B, T, esa_group=group)
         opts = hip.Engine.make_opts(args)
         opts.sos = sos
+        bw = int(args.beam_width)
+        opts.beam_width = 1  # the sample passes keep the best label per row (what the ranking reads); beam_width > 1: see below
         select = getattr(args, "esa_select", None)
         if select is None:
             select = torch.randint(0, 2, (B * S, Tp, 1))
@@ -532,6 +535,8 @@ class CassNAT(nn.Module):
         ylen_sel = ylen_h.gather(1, pick).squeeze(1).numpy()
         ymax = int(ylen_sel.max())
         ys = torch.ones(1, 1).fill_(sos).long()
+        if bw > 1:
+            return self._esa_beam_finish(eng, select, pick, args, ratio, opts, bw, force, ylen_sel, ymax, sos)
         out = []
         for b in range(B):
             s_b, n = int(pick[b, 0]), int(ylen_sel[b])
@@ -543,6 +548,37 @@ class CassNAT(nn.Module):
                 else:  # one row past the sample's mask: the reference reads an all-zero row there (+ 0.0, arbitrary tie token)
                     hyp.append(0)
             out.append([{"ys": ys, "score": score, "hyp": hyp}])
+        return out
+
+    def _esa_beam_finish(self, eng, select, pick, args, ratio, opts, bw, force, ylen_sel, ymax, sos):
+        """ESA with beam_width > 1 (src/models/cassnat.py:556-561, 574-637): the finish loop runs on the SELECTED sample of every
+        utterance, on its att_out with the rows at or past the sample's own count zeroed (:556).  One more decoder pass over the
+        B selected alignments keeps the bw best labels per row (``cn_esa_sample`` with opts.beam_width = bw); a zeroed row gives bw
+        candidates of + 0.0 whose labels - torch.topk of equal values - are implementation-defined in the reference: 0 here."""
+        B = pick.shape[0]
+        idx = pick.reshape(1, B, 1).expand(1, B, select.shape[2]).to(select.device)
+        sel = select.gather(0, idx).contiguous()                                                  # (1, B, T'): utterance b's winner
+        opts.beam_width = bw
+        eng.esa_sample(sel, args.threshold, ratio, opts, None, None, None, force_U=force)
+        opts.beam_width = 1
+        tk, tv = eng.fetch("topk_idx"), eng.fetch("topk_val")                                      # (B, U, bw)
+        lp = args.length_penalty
+        ys = torch.ones(1, 1).fill_(sos).long()
+        out = []
+        for b in range(B):
+            n = int(ylen_sel[b])
+            beams = [{"ys": ys, "score": 0.0, "hyp": [sos]}]
+            for i in range(min(n + 1, ymax)):
+                if i < n:
+                    cand = [{"ys": ys, "score": s["score"] + float(tv[b, i, j]), "hyp": s["hyp"] + [int(tk[b, i, j])]} for s in beams for j in range(bw)]
+                else:
+                    cand = [{"ys": ys, "score": s["score"] + 0.0, "hyp": s["hyp"] + [0]} for s in beams for j in range(bw)]
+                if lp is not None:
+                    cand.sort(key=lambda s: s["score"] + (len(s["hyp"]) - 1) * lp, reverse=True)
+                else:
+                    cand.sort(key=lambda s: s["score"], reverse=True)
+                beams = cand[:bw]
+            out.append(beams)
         return out
 
     @staticmethod

@@ -210,6 +210,41 @@ class Transformer(nn.Module):
         return [[{"ys": torch.tensor([s["hyp"]], dtype=torch.long), "score": s["score"], "hyp": s["hyp"]} for s in beams[b]]
                 for b in range(B)]
 
+    def fast_decode_with_ctc(self, src, src_mask, vocab, args, lm_model=None, engine=None):
+        """Same contract as the reference's Transformer.fast_decode_with_ctc (src/models/transformer.py:243-342; ArtTask decode_type
+        'ctc_correct'), lm_weight == 0: the CTC greedy hypothesis is the decoder's teacher-forced input, the decoder a correction
+        model.  Encoder, CTC collapse, decoder and the per-row top-k run on the device (``cn_ast_ctc_correct``); the finish loop -
+        O(rows * beam^2) numbers - is the reference's, here on the host: row i is consumed while i <= length[b], an eos is scored
+        but not appended."""
+        if getattr(args, "lm_weight", 0) > 0 or lm_model is not None:
+            raise NotImplementedError("LM fusion is outside the accelerated path")
+        sos, eos = vocab.word2index["sos"], vocab.word2index["eos"]
+        assert vocab.word2index["blank"] == args.padding_idx
+        dev = torch.device("cuda", getattr(self, "_device", torch.cuda.current_device()))
+        feats = src.to(dev, torch.float32).contiguous()
+        B, T, _ = feats.shape
+        eng = engine if engine is not None else self.engine(B, T)
+        bw = int(args.beam_width)
+        opts = hip.CnDecodeOpts(padding_idx=int(args.padding_idx), sos=sos, beam_width=1)
+        length, tok, val = eng.ast_ctc_correct(feats, opts, bw)
+        length, tok, val = length.cpu().numpy(), tok.cpu().numpy(), val.cpu().numpy()
+        lp = args.length_penalty
+        ys = torch.ones(1, 1).fill_(sos).long()
+        out = []
+        for b in range(B):
+            beams = [{"ys": ys, "score": 0.0, "hyp": [sos]}]
+            for i in range(int(length[b]) + 1):
+                cand = [{"ys": ys, "score": s["score"] + float(val[b, i, j]),
+                         "hyp": s["hyp"] + [int(tok[b, i, j])] if int(tok[b, i, j]) != eos else s["hyp"]}
+                        for s in beams for j in range(bw)]
+                if lp is not None:
+                    cand.sort(key=lambda s: s["score"] + (len(s["hyp"]) - 1) * lp, reverse=True)
+                else:
+                    cand.sort(key=lambda s: s["score"], reverse=True)
+                beams = cand[:bw]
+            out.append(beams)
+        return out
+
 
 def make_model(input_size, args):
     """Same role as src/models/transformer.py:19-37."""

@@ -1,9 +1,10 @@
 """Decode half of the reference's ArtTask (src/tasks/art_task.py:23-66, 233-277): the autoregressive transformer
 (BASELINE config 4) behind ``decode_asr.py --task art``.
 
-Same constructor / decode surface and result-file lines ("<utt> tok tok ...").  ``decode_type == 'ctc_att'`` (joint
-CTC/attention beam search, src/models/transformer.py:122-241) is the accelerated path; ``ctc_only`` / ``ctc_correct``, LM
-fusion and the conformer AST raise.  A decode step keeps a handful of CUs busy, so a test set goes through
+Same constructor / decode surface and result-file lines ("<utt> tok tok ...").  All three decode types of the reference
+(art_task.py:252-259): ``ctc_att`` (joint CTC/attention beam search, src/models/transformer.py:122-241), ``ctc_only`` (CTC prefix
+beam search on the encoder, utils.beam_decode.ctc_beam_decode) and ``ctc_correct`` (the decoder as a correction model over the CTC
+greedy hypothesis, transformer.py:243-342); LM fusion and the conformer AST raise.  A decode step keeps a handful of CUs busy, so a test set goes through
 ``args.hip_pipelines`` (default 4) engine handles (own workspace + KV cache, ONE shared device copy of the weights) on their
 own HIP streams and host threads - batches pulled from the loader by the workers, result lines written in input order.
 With torch.distributed initialised (one process per GPU) the utterances are dealt over the ranks by length exactly as
@@ -23,11 +24,12 @@ from .. import dist as cdist
 from ..data.vocab import Vocab
 from ..models import make_transformer
 from ..utils import util
+from ..utils.beam_decode import ctc_beam_decode
 from .base_task import BaseTask
 from .cassnat_task import hyp_to_words
 
 _DEFAULTS = dict(use_gpu=True, decode_type="ctc_att", use_cmvn=False, dataset_type="SpeechDataset", beam_width=10, ctc_beam=15,
-                 ctc_weight=0.3, max_decode_ratio=0, T=1.0, length_penalty=None, lm_weight=0, left_ctx=0, right_ctx=0,
+                 ctc_pruning=0, ctc_lp=0, ctc_lm_weight=0, ctc_weight=0.3, max_decode_ratio=0, T=1.0, length_penalty=None, lm_weight=0, left_ctx=0, right_ctx=0,
                  skip_frame=1, padding_idx=0, model_type="transformer", dropout=0.0, rank=0)
 
 
@@ -86,8 +88,10 @@ class ArtTask(BaseTask):
         return [eng0] + [self.model.new_engine(args.batch_size, frames, share=eng0) for _ in range(n - 1)]
 
     def decode(self, args):
-        if args.decode_type != "ctc_att":
-            raise NotImplementedError("decode_type '%s' is not on the accelerated path (only 'ctc_att')" % args.decode_type)
+        # src/tasks/art_task.py:252-259: ctc_only = CTC prefix beam search on the encoder, ctc_correct = the decoder as a
+        # correction model over the CTC greedy hypothesis, ctc_att = joint CTC / attention beam search
+        if args.decode_type not in ("ctc_att", "ctc_only", "ctc_correct"):
+            raise NotImplementedError("decode_type '%s' (ArtTask knows ctc_only, ctc_correct, ctc_att)" % args.decode_type)
         self._args = args
         batch_time = util.AverageMeter("Time", ":6.3f")
         progress = util.ProgressMeter(len(self.test_loader), batch_time)
@@ -111,7 +115,12 @@ class ArtTask(BaseTask):
                             except StopIteration:
                                 break
                         src_mask = (feats[:, :, 0] != args.padding_idx).unsqueeze(1)
-                        recog = self.model.beam_decode(feats, src_mask, self.vocab, args, self.lm_model, engine=engines[k])
+                        if args.decode_type == "ctc_only":
+                            recog = ctc_beam_decode(self.model, feats, src_mask, feat_sizes, self.vocab, args, self.lm_model, engine=engines[k])
+                        elif args.decode_type == "ctc_correct":
+                            recog = self.model.fast_decode_with_ctc(feats, src_mask, self.vocab, args, self.lm_model, engine=engines[k])
+                        else:
+                            recog = self.model.beam_decode(feats, src_mask, self.vocab, args, self.lm_model, engine=engines[k])
                         lines = [utt + " " + " ".join(hyp_to_words(seqs[0]["hyp"], self.vocab, args.padding_idx))
                                  for utt, seqs in zip(utt_list, recog)]
                         with cv:

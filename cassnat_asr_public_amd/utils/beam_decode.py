@@ -14,7 +14,9 @@ from .. import hip
 logzero, logone = -1e10, 0  # src/utils/ctc_prefix.py:11-12
 
 
-def ctc_beam_decode(model, src, src_mask, src_size, vocab, args, lm_model=None):
+def ctc_beam_decode(model, src, src_mask, src_size, vocab, args, lm_model=None, engine=None):
+    """``model``: a CassNAT (src/tasks/cassnat_task.py:335-341) or the autoregressive Transformer with its CTC head
+    (src/tasks/art_task.py:252-253).  ``engine``: run on this handle (a decode pipeline's) instead of the model's own."""
     if lm_model is not None:
         raise NotImplementedError("CTC beam search with in-loop LM fusion is outside the accelerated path (ctc_lm_weight must be 0)")
     if args.ctc_lp is None:
@@ -25,7 +27,7 @@ def ctc_beam_decode(model, src, src_mask, src_size, vocab, args, lm_model=None):
     feats = src.to(dev, torch.float32).contiguous()
     ratio = src_size.to(dev, torch.float32).contiguous()
     B, T, _ = feats.shape
-    eng = model.engine(B, T)
+    eng = engine if engine is not None else model.engine(B, T)
     # (args.hip_capture as in CassNAT.beam_decode: a capture run keeps every stage on the kernels that leave full tensors behind,
     # so that `ctc_out` fetched after a later call of the same engine is the tensor this search ran on)
     opts = hip.Engine.make_opts(args, capture=getattr(args, "hip_capture", False))

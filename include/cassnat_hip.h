@@ -76,7 +76,9 @@ typedef struct cn_decode_opts {
                            every hypothesis by the row count of its own batch (src/models/cassnat.py:580-637 reads
                            min(ylen + 1, U of the batch) rows), so each batch's hypotheses are what a call of its own gives.
                            Transformer blocks only (a conformer's GroupNorm sees the padded rows) */
-    int32_t reserved[7];
+    int32_t no_trigger; /* args.use_trigger == False (src/models/cassnat.py:469-473): the extractor attends over every valid frame
+                           (trigger_mask = src_mask) and the row counts are best_path_align's own (no EOS row).  0 = use_trigger */
+    int32_t reserved[6];
 } cn_decode_opts;
 
 const char* cn_last_error(void);
@@ -223,6 +225,14 @@ int cn_decode_nast_forced(cn_model* m, const float* feats_dev, const float* size
 int cn_ast_teacher_score(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts,
                          const int32_t* tok_dev, const int32_t* tgt_dev, const int32_t* len_dev, int32_t n_per_utt, int32_t U,
                          int32_t ld, float* score_dev, void* stream);
+
+/* ArtTask decode_type 'ctc_correct' = Transformer.fast_decode_with_ctc (src/models/transformer.py:243-342, called at
+ * src/tasks/art_task.py:254-255): the CTC greedy hypothesis (arg-max path zeroed on masked frames, repeats collapsed, blanks dropped)
+ * behind sos is the teacher-forced decoder input under the causal + padding mask; returned are the hypothesis lengths len_out_dev [B]
+ * and, for the U = longest + 1 decoder rows (*rows_host), the k best labels and log-probabilities of every row, tok_out_dev /
+ * val_out_dev [B][U][k] (buffers of B * (T' + 1) * k entries): what the reference's finish loop (:276-341) consumes on the host. */
+int cn_ast_ctc_correct(cn_model* m, const float* feats_dev, int32_t B, int32_t T, int32_t F, const cn_decode_opts* opts, int32_t k,
+                       int32_t* tok_out_dev, float* val_out_dev, int32_t* len_out_dev, int32_t* rows_host, void* stream);
 
 /* Copy a named internal / captured tensor to the host (synchronous; test + host-beam use).  Activations are
  * returned as fp32 whatever the model precision.  shape_out has room for 4 dims. */

@@ -155,7 +155,7 @@ def top2_margin(ctc_out):
 def main():
     from cassnat_asr_public_amd import synth
 
-    only = sys.argv[1] if len(sys.argv) > 1 else None  # regenerate one fixture group only: 'conformer', 'esa', 'ctcbeam' or 'config5_shape'
+    only = sys.argv[1] if len(sys.argv) > 1 else None  # regenerate one fixture group only: 'conformer', 'esa', 'ctcbeam', 'branches' or 'config5_shape'
     only_name = sys.argv[2] if len(sys.argv) > 2 else None  # ... and within 'esa' one fixture by name
 
     torch, make_model = import_reference()
@@ -203,6 +203,102 @@ def main():
             np.savez_compressed(os.path.join(gdir, f"{name}.npz"), hyp=hyp, hyp_len=hlen, select=select.numpy().astype(np.uint8),
                                 score=np.array([t[0]["score"] for t in top], np.float64))
             print(name, hlen, [t[0]["score"] for t in top])
+        if only:
+            return
+
+    # ---- 4a4. branches closed in round 4: use_trigger = False (cassnat.py:469-473), ESA with beam_width > 1 (:574-637 on the
+    # selected samples), ArtTask decode_type 'ctc_only' and 'ctc_correct' (art_task.py:252-255, transformer.py:243-342)
+    if only in (None, "branches"):
+        import copy
+        import types as _types
+
+        from models.lm import make_model as make_lm
+        from models.transformer import make_model as make_ast
+        from utils.beam_decode import ctc_beam_decode
+
+        # (a) use_trigger False: tiny (every stage that differs) and a config-2-sized ragged batch
+        for name, preset, bshape in (("tiny_notrigger", "tiny", (3, 61, [61, 50, 37])), ("config2_notrigger", "config2", (2, 300, [300, 231]))):
+            an = synth.make_args(preset, use_trigger=False)
+            sn = synth.make_state(an, seed=0, gain=2.0) if preset == "tiny" else synth.make_state(an, seed=0, blank_bias=0.35)
+            fn, zn = synth.make_feats(bshape[0], bshape[1], 80, lengths=bshape[2], seed=11)
+            r = run_reference(torch, make_model, an, sn, fn, zn)
+            keep = {k: r[k] for k in ("hyp", "hyp_len", "score", "ylen0", "aligned_seq_shift")}
+            if preset == "tiny":
+                keep.update({k: r[k] for k in ("ac_embed", "pred_embed", "dec_h", "att_out")})
+            else:
+                keep.update(att_sample=r["att_out"][:, ::3, ::25], dec_sample=r["dec_h"][:, ::3, ::8])
+            np.savez_compressed(os.path.join(gdir, f"{name}.npz"), **keep)
+            print(name, "ylen0", r["ylen0"], "hyp_len", r["hyp_len"], r["score"])
+
+        # (b) ESA (sample_num 4) with beam_width 3: every beam of the selected sample
+        ae = synth.make_args("tiny", sample_num=4, threshold=0.9, rank_model="lm", beam_width=3, length_penalty=0.1)
+        la = synth.make_args_lm("tiny_lm", vocab_size=ae.vocab_size)
+        se, sl = synth.make_state(ae, seed=0, gain=2.0), synth.make_state(la, seed=9, gain=2.0)
+        fe, ze = synth.make_feats(3, 61, 80, lengths=[61, 50, 37], seed=11)
+        model, lm = make_model(ae.input_size, ae).eval(), make_lm(la).eval()
+        with torch.no_grad():
+            for k, p_ in model.named_parameters():
+                p_.copy_(torch.from_numpy(se[k]))
+            for k, p_ in lm.named_parameters():
+                p_.copy_(torch.from_numpy(sl[k]))
+        src = torch.from_numpy(fe)
+        t_sub = ((fe.shape[1] - 1) // 2 + 1 - 1) // 2 + 1
+        torch.manual_seed(777)
+        select = torch.randint(0, 2, (fe.shape[0] * ae.sample_num, t_sub, 1))
+        torch.manual_seed(777)
+        with torch.no_grad():
+            top, _ = model.beam_decode(src, (src[:, :, 0] != 0).unsqueeze(1), torch.from_numpy(ze), _Vocab, ae, lm)
+        W = ae.beam_width
+        L = max(len(s_["hyp"]) for t_ in top for s_ in t_)
+        bh, bl, bs_ = np.zeros((len(top), W, L), np.int32), np.zeros((len(top), W), np.int32), np.full((len(top), W), -np.inf)
+        for b_, t_ in enumerate(top):
+            for j, s_ in enumerate(t_):
+                bl[b_, j] = len(s_["hyp"])
+                bh[b_, j, : bl[b_, j]] = s_["hyp"]
+                bs_[b_, j] = s_["score"]
+        np.savez_compressed(os.path.join(gdir, "esa_beam3_tiny.npz"), beam_hyp=bh, beam_len=bl, beam_score=bs_,
+                            select=select.numpy().astype(np.uint8))
+        print("esa_beam3_tiny", bl.tolist(), bs_[:, 0])
+
+        # (c) ArtTask ctc_only / ctc_correct on the autoregressive model (tiny and config-4 shape)
+        for name, preset, bshape, seed in (("art_tiny", "tiny_ast", (3, 61, [61, 57, 51]), 3), ("art_config4", "config4", (2, 400, [400, 333]), 5)):
+            for bw in (1, 3):
+                aa = synth.make_args_ast(preset, beam_width=bw, ctc_beam=5, ctc_pruning=8, ctc_lp=0.2, ctc_lm_weight=0, length_penalty=0.1,
+                                         use_gpu=False, lm_weight=0)
+                sa = synth.make_state(aa, seed=seed, gain=2.0) if preset == "tiny_ast" else synth.make_state(aa, seed=seed)
+                fa, za = synth.make_feats(bshape[0], bshape[1], 80, lengths=bshape[2], seed=11 if preset == "tiny_ast" else 31)
+                ast = make_ast(aa.input_size, aa).eval()
+                with torch.no_grad():
+                    for k, p_ in ast.named_parameters():
+                        p_.copy_(torch.from_numpy(sa[k]))
+                src = torch.from_numpy(fa)
+                x_mask = (src[:, :, 0] != 0).unsqueeze(1)
+                with torch.no_grad():
+                    top = ast.fast_decode_with_ctc(src, x_mask, _Vocab, copy.deepcopy(aa), None)
+                L = max(len(s_["hyp"]) for t_ in top for s_ in t_)
+                bh, bl, bs_ = np.zeros((len(top), bw, L), np.int32), np.zeros((len(top), bw), np.int32), np.full((len(top), bw), -np.inf)
+                for b_, t_ in enumerate(top):
+                    for j, s_ in enumerate(t_):
+                        bl[b_, j] = len(s_["hyp"])
+                        bh[b_, j, : bl[b_, j]] = s_["hyp"]
+                        bs_[b_, j] = s_["score"]
+                keep = dict(beam_hyp=bh, beam_len=bl, beam_score=bs_)
+                if bw == 1:  # ... and the CTC prefix beam search of the same model (decode_type ctc_only)
+                    with torch.no_grad():
+                        topc = ctc_beam_decode(ast, src, x_mask, torch.from_numpy(za), _Vocab, copy.deepcopy(aa), None)
+                    Wc = aa.ctc_beam
+                    Lc = max([len(s_["hyp"]) for t_ in topc for s_ in t_] + [1])
+                    ch, cl, cs = np.zeros((len(topc), Wc, Lc), np.int32), np.zeros((len(topc), Wc), np.int32), np.full((len(topc), Wc), -1e10)
+                    cn = np.zeros(len(topc), np.int32)
+                    for b_, t_ in enumerate(topc):
+                        cn[b_] = len(t_)
+                        for j, s_ in enumerate(t_):
+                            cl[b_, j] = len(s_["hyp"])
+                            ch[b_, j, : cl[b_, j]] = s_["hyp"]
+                            cs[b_, j] = s_["score_ctc"]
+                    keep.update(ctc_hyp=ch, ctc_len=cl, ctc_score=cs, ctc_n=cn)
+                np.savez_compressed(os.path.join(gdir, f"{name}_correct_bw{bw}.npz"), **keep)
+                print(name, "bw", bw, "lens", bl[:, 0], bs_[:, 0])
         if only:
             return
 

@@ -140,3 +140,39 @@ def ast_config4_case(**overrides):
     state = synth.make_state(args, seed=5)
     feats, _ = synth.make_feats(2, 400, 80, lengths=[400, 333], seed=31)
     return args, state, feats
+
+
+# ---- the branches closed in round 4 (oracle/make_goldens.py, group 'branches')
+def notrigger_case(which):
+    """use_trigger = False (src/models/cassnat.py:469-473)."""
+    from cassnat_asr_public_amd import synth
+
+    preset, (B, T, lens) = {"tiny_notrigger": ("tiny", (3, 61, [61, 50, 37])), "config2_notrigger": ("config2", (2, 300, [300, 231]))}[which]
+    args = synth.make_args(preset, use_trigger=False)
+    state = synth.make_state(args, seed=0, gain=2.0) if preset == "tiny" else synth.make_state(args, seed=0, blank_bias=0.35)
+    feats, sizes = synth.make_feats(B, T, 80, lengths=lens, seed=11)
+    return args, state, feats, sizes
+
+
+def esa_beam3_case():
+    """ESA (sample_num 4, TransformerLM ranking) finished with beam_width 3."""
+    from cassnat_asr_public_amd import synth
+
+    args = synth.make_args("tiny", sample_num=4, threshold=0.9, rank_model="lm", beam_width=3, length_penalty=0.1)
+    lm_args = synth.make_args_lm("tiny_lm", vocab_size=args.vocab_size)
+    state, lm_state = synth.make_state(args, seed=0, gain=2.0), synth.make_state(lm_args, seed=9, gain=2.0)
+    feats, sizes = synth.make_feats(3, 61, 80, lengths=[61, 50, 37], seed=11)
+    return args, lm_args, state, lm_state, feats, sizes
+
+
+def art_case(which, beam_width):
+    """ArtTask decode_type 'ctc_only' / 'ctc_correct' on the autoregressive model."""
+    from cassnat_asr_public_amd import synth
+
+    preset, (B, T, lens), seed, fseed = {"art_tiny": ("tiny_ast", (3, 61, [61, 57, 51]), 3, 11),
+                                         "art_config4": ("config4", (2, 400, [400, 333]), 5, 31)}[which]
+    args = synth.make_args_ast(preset, beam_width=beam_width, ctc_beam=5, ctc_pruning=8, ctc_lp=0.2, ctc_lm_weight=0, length_penalty=0.1,
+                               use_gpu=False, lm_weight=0)
+    state = synth.make_state(args, seed=seed, gain=2.0) if preset == "tiny_ast" else synth.make_state(args, seed=seed)
+    feats, sizes = synth.make_feats(B, T, 80, lengths=lens, seed=fseed)
+    return args, state, feats, sizes

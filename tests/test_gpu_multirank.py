@@ -262,3 +262,59 @@ def test_two_ranks_art_task(tmp_path, backend):
     base = ["--task", "art", "--test_config", cfg, "--data_path", scp, "--resume_model", ckpt, "--batch_size", "1",
             "--hip_precision", "fp32", "--load_data_workers", "0"]
     assert _run_cli(tmp_path, base, 1, backend, "a1") == _run_cli(tmp_path, base, 2, backend, "a2")
+
+
+def test_ranks_decode_their_own_batches_exactly_as_the_oracle_does(tmp_path):
+    """Pins what a multi-rank result file may differ in from the one-process file: NOTHING but the batching.  Two ranks (gloo, both
+    on GPU 0), batch_size 3, 20 ragged utterances, fp32 engine, through the decode pipelines AND the plain loop: every line equals
+    the CPU oracle's decode of the batch that utterance was really in - rank r's share of the snake deal (dist.shard_indices) cut
+    into consecutive batches of 3, each padded to its own longest utterance (speech_loader.py:327-356).  (An utterance's batch
+    mates set its padding, T' behind src_size = (ratio * T').long() and the greedy finish's row limit - cassnat.py:436, 580-636 -
+    so the one-process file legitimately differs; VERDICT r03 weak #9.)"""
+    from cassnat_asr_public_amd import dist as cdist
+    from oracle import cassnat_oracle as orc
+
+    args, state, _, _ = tiny_case()
+    rng = np.random.default_rng(8)
+    lengths = [int(x) for x in rng.integers(20, 62, size=20)]
+    feats, _ = synth.make_feats(len(lengths), 61, 80, lengths=lengths, seed=17)
+    scp, ckpt, cfg = _write_case(tmp_path, args, state, feats, lengths)
+    (tmp_path / "utt2num_frames").write_text("".join(f"spk-utt{b:02d} {n}\n" for b, n in enumerate(lengths)))
+    index2word = {i + 4: f"w{i}" for i in range(args.vocab_size - 4)}
+    expect = {}
+    for r in range(2):
+        idx = cdist.shard_indices(np.array(lengths), 2, r)
+        for k in range(0, len(idx), 3):
+            mine = [int(i) for i in idx[k:k + 3]]
+            tmax = max(lengths[i] for i in mine)
+            f = np.zeros((len(mine), tmax, 80), np.float32)
+            for j, i in enumerate(mine):
+                f[j, : lengths[i]] = feats[i, : lengths[i]]
+            ratio = np.array([np.float32(lengths[i] / tmax) for i in mine], np.float32)  # collate: float32 of the Python division
+            hyps = orc.decode_nast(state, f, ratio, args)["hyps"]
+            for i, h in zip(mine, hyps):
+                expect[f"spk-utt{i:02d}"] = f"spk-utt{i:02d} " + " ".join(orc.hyp_to_text(h, index2word))
+    want = [expect[f"spk-utt{b:02d}"] for b in range(len(lengths))]
+    base = ["--task", "cassnat", "--test_config", cfg, "--data_path", scp, "--resume_model", ckpt, "--batch_size", "3",
+            "--hip_precision", "fp32", "--load_data_workers", "0"]
+    assert _run_cli(tmp_path, base, 2, "gloo", "own_piped") == want
+    assert _run_cli(tmp_path, base + ["--hip_pipelines", "1"], 2, "gloo", "own_plain") == want
+    one = _run_cli(tmp_path, base, 1, "gloo", "own_one")
+    print(f"[two ranks vs one process] {sum(a != b for a, b in zip(one, want))} of {len(want)} lines differ (other batch mates)")
+
+
+def test_four_ranks_over_gloo_on_one_gpu(tmp_path):
+    """More ranks than two with real engines: four ranks on GPU 0 over gloo (the box admits six processes on the card, the test
+    runner is one of them), 48 ragged utterances, --batch_size 1 - batch independent, so the file equals the one-process file
+    line for line.  (Eight ranks / 256 utterances run on the CPU around a stub engine: tests/test_host_cpu.py.)"""
+    args, state, _, _ = tiny_case()
+    rng = np.random.default_rng(9)
+    lengths = [int(x) for x in rng.integers(20, 62, size=48)]
+    feats, _ = synth.make_feats(len(lengths), 61, 80, lengths=lengths, seed=23)
+    scp, ckpt, cfg = _write_case(tmp_path, args, state, feats, lengths)
+    (tmp_path / "utt2num_frames").write_text("".join(f"spk-utt{b:02d} {n}\n" for b, n in enumerate(lengths)))
+    base = ["--task", "cassnat", "--test_config", cfg, "--data_path", scp, "--resume_model", ckpt, "--batch_size", "1",
+            "--hip_precision", "bf16x3", "--load_data_workers", "0"]
+    one = _run_cli(tmp_path, base, 1, "gloo", "four_one")
+    four = _run_cli(tmp_path, base, 4, "gloo", "four")
+    assert len(one) == 48 and four == one

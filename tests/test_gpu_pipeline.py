@@ -22,7 +22,7 @@ LOGIT_TOL = 1e-3  # north_star: "within 1e-3 on encoder logits"
 # margin < 2 max|d log-posterior| over ALL logits.  The fixtures hold a strided sample of the logits (every st-th frame, every
 # sv-th label), whose maximum error is a little below the full maximum; FLIP_K x the sampled error is the gate (the tests print
 # the measured ratio beside the flip counts).
-FLIP_K = 3.0
+FLIP_K = 1.5  # (measured, GPUTEST r04: largest flip margin = 0.22 .. 0.89 x the sampled error, bf16 and every fp8 scope)
 
 
 class Vocab:
@@ -466,8 +466,7 @@ def test_config5_fp8_encoder_products(capsys):
     # FLIP_K x its own measured logit error, and none flips a frame of margin >= 0.2 (a trained model's typical frame)
     for k, v in rows.items():
         assert_flips_explained(v["margins"], v["err"], FLIP_K, k)
-        assert v["margins"]["flips_margin_ge_0.2"] == 0, (k, v["margins"])
-    assert rows["bf16"]["margins"]["flips_margin_ge_0.05"] == 0
+        assert v["margins"]["flips_margin_ge_0.2"] == 0 and v["margins"]["flips_margin_ge_0.05"] == 0, (k, v["margins"])
 
 
 def test_fp8_scope_strings():
@@ -642,3 +641,65 @@ def test_decode_asr_cli_cmvn_on_a_float64_archive(tmp_path):
     index2word = {i + 4: f"w{i}" for i in range(args.vocab_size - 4)}
     hyps = [orc.decode_nast(state, ((m - mean) / std).astype(np.float32)[None], np.ones(1, np.float32), args)["hyps"][0] for m in raw]
     assert got == [f"spk-utt{b} " + " ".join(orc.hyp_to_text(h, index2word)) for b, h in enumerate(hyps)]
+
+
+# ------------------------------------------------------------------------------------------- branches closed in round 4
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("which", ["tiny_notrigger", "config2_notrigger"])
+def test_use_trigger_false(which, prec):
+    """args.use_trigger == False (src/models/cassnat.py:469-473): the extractor attends over every valid frame (trigger_mask =
+    src_mask) and the row counts are best_path_align's own.  fp32 / bf16x3: stages, hypotheses and scores equal the reference's;
+    bf16 (config-2 size: row chains and the fused kernels on this option): runs, same row counts unless the alignment flipped."""
+    from conftest import notrigger_case
+
+    g = load_golden(which)
+    args, state, feats, sizes = notrigger_case(which)
+    model = build(args, state, prec, capture=(prec != "bf16"))
+    out = decode(model, args, feats, sizes)
+    eng = model._engine
+    if prec == "bf16":
+        if (eng.fetch("aligned_seq_shift") == g["aligned_seq_shift"]).all():
+            np.testing.assert_array_equal(eng.fetch("ylen"), g["ylen0"])
+            assert [len(s[0]["hyp"]) for s in out] == g["hyp_len"].tolist()
+        return
+    np.testing.assert_array_equal(eng.fetch("aligned_seq_shift"), g["aligned_seq_shift"])
+    np.testing.assert_array_equal(eng.fetch("ylen"), g["ylen0"])
+    assert int(eng.fetch("ymax")[0]) == int(g["ylen0"].max())
+    if which == "tiny_notrigger":
+        for name, tol in (("ac_embed", 5e-4), ("pred_embed", 5e-4), ("dec_h", 1e-4), ("att_out", LOGIT_TOL)):
+            assert maxerr(eng.fetch(name), g[name]) < tol, name
+    else:
+        assert maxerr(eng.fetch("att_out")[:, ::3, ::25], g["att_sample"]) < LOGIT_TOL
+    for b, seqs in enumerate(out):
+        assert seqs[0]["hyp"] == g["hyp"][b, : g["hyp_len"][b]].tolist()
+        assert abs(seqs[0]["score"] - g["score"][b]) < 2e-2
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_esa_finished_with_beam_width_3(prec):
+    """ESA (sample_num 4, TransformerLM ranking) with beam_width 3 (src/models/cassnat.py:556-561, 574-637): every beam of every
+    utterance up to the position the reference reads from an all-zero row (an implementation-defined torch.topk of equal
+    values), scores in full."""
+    from conftest import esa_beam3_case
+    from cassnat_asr_public_amd.models.lm import make_model as make_lm
+
+    g = load_golden("esa_beam3_tiny")
+    args, lm_args, state, lm_state, feats, sizes = esa_beam3_case()
+    args.esa_select = g["select"]
+    lm_args.hip_precision = prec
+    model = build(args, state, prec)
+    lm = make_lm(lm_args).cuda()
+    with torch.no_grad():
+        for k, p in lm.named_parameters():
+            p.copy_(torch.from_numpy(lm_state[k]))
+    src = torch.from_numpy(feats)
+    with torch.no_grad():
+        out, _ = model.beam_decode(src.cuda(), (src[:, :, 0] != 0).unsqueeze(1).cuda(), torch.from_numpy(sizes).cuda(), Vocab, args, lm)
+    ylen = model._engine.fetch("ylen")
+    for b, beams in enumerate(out):
+        assert len(beams) == 3
+        n = int(ylen[b]) + 1
+        for j, s in enumerate(beams):
+            assert len(s["hyp"]) == g["beam_len"][b, j]
+            assert s["hyp"][:n] == g["beam_hyp"][b, j, :n].tolist(), (b, j)
+            assert abs(s["score"] - g["beam_score"][b, j]) < 2e-3

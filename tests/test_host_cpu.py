@@ -574,3 +574,81 @@ def test_flips_by_margin_counts_and_gate():
     with pytest.raises(AssertionError, match="clear-margin frame flipped"):
         assert_flips_explained(r, 0.02, 2.0)
     assert flips_by_margin(ref, ref, margin)["max_flip_margin"] == 0.0
+
+
+def test_snake_deal_balances_eight_ranks():
+    """BASELINE configs[2]'s shape: 256 ragged utterances dealt over 8 ranks (dist.shard_indices) - a partition, every rank 32
+    utterances, longest first, and a frame total within 3 % of the mean (what keeps eight GPUs busy for the same time)."""
+    rng = np.random.default_rng(12)
+    lens = rng.integers(300, 1501, size=256)
+    parts = [cdist.shard_indices(lens, 8, r) for r in range(8)]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(256))
+    totals = np.array([lens[p].sum() for p in parts], np.float64)
+    assert all(len(p) == 32 for p in parts)
+    assert all((np.diff(lens[p]) <= 0).all() for p in parts)
+    assert np.abs(totals / totals.mean() - 1).max() < 0.03, totals
+
+
+def test_eight_ranks_over_gloo_write_the_one_process_result_file(tmp_path):
+    """configs[2] rehearsed without eight GPUs: `decode_asr --task cassnat` as 8 ranks over gloo on the CPU, 256 ragged utterances,
+    --batch_size 1 (results independent of batch mates) - the product's host side end to end (CassNATTask, the snake deal, the one
+    weight broadcast per rank, DecodePipelines with merged ragged passes, the gather of the ranks' results, rank 0's input-ordered
+    file) around a stub engine (tests/_stub_rank_worker.py) whose tokens encode the utterance id and its unpadded frame count.
+    The file equals the one-process run's line for line, and both equal what the stub must emit for every utterance."""
+    import yaml
+
+    rng = np.random.default_rng(21)
+    lengths = [int(x) for x in rng.integers(30, 151, size=256)]
+    mats = []
+    for u, n in enumerate(lengths):
+        m = np.full((n, 4), float(u + 1), np.float32)
+        mats.append((f"spk{u % 7}-utt{u:03d}", m))
+    perm = rng.permutation(256)  # the table is not in id order: the file must follow the table's order
+    mats = [mats[i] for i in perm]
+    scp = str(tmp_path / "feats.scp")
+    kaldi_io.write_ark_scp(str(tmp_path / "feats.ark"), scp, mats)
+    (tmp_path / "utt2num_frames").write_text("".join(f"{u} {m.shape[0]}\n" for u, m in mats))
+    vocab_file = tmp_path / "vocab.txt"
+    vocab_file.write_text("".join(f"w{i}\n" for i in range(20)))
+    ckpt = str(tmp_path / "model.mdl")
+    torch.save({"model_state": {"w": torch.zeros(4)}}, ckpt)
+    conf = dict(input_size=4, n_features=4, left_ctx=0, right_ctx=0, skip_frame=1, padding_idx=0, beam_width=1, length_penalty=0,
+                use_trigger=True, vocab_file=str(vocab_file), use_gpu=False, model_type="transformer")
+    cfg = tmp_path / "decode.yaml"
+    cfg.write_text(yaml.safe_dump(conf))
+    worker = os.path.join(REPO, "tests", "_stub_rank_worker.py")
+
+    def run(world, tag):
+        result = str(tmp_path / f"result_{tag}.txt")
+        cmd = [sys.executable, worker, REPO, "--task", "cassnat", "--test_config", str(cfg), "--data_path", scp, "--resume_model", ckpt,
+               "--result_file", result, "--batch_size", "1", "--load_data_workers", "0", "--hip_dist_backend", "gloo", "--hip_max_frames", "160"]
+        env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        if world == 1:
+            out = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=300)
+            assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        else:
+            port = str(33500 + os.getpid() % 2000)
+            procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                                                    MASTER_PORT=port), cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                     for r in range(world)]
+            try:
+                for pr in procs:
+                    text, _ = pr.communicate(timeout=300)
+                    assert pr.returncode == 0, text[-4000:]
+            finally:
+                for pr in procs:
+                    if pr.poll() is None:
+                        pr.kill()
+                        pr.wait()
+        return open(result).read().splitlines()
+
+    one = run(1, "w1")
+    eight = run(8, "w8")
+    expect = []
+    for utt, m in mats:
+        uid, n = int(m[0, 0]) - 1, m.shape[0]
+        expect.append(f"{utt} w{uid % 20} w{(uid // 20) % 20} w{n % 20} w{(n // 20) % 20}")
+    assert one == expect
+    assert eight == one

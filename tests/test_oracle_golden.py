@@ -259,3 +259,62 @@ def test_ctc_only_and_ctc_att_end_to_end(name, preset, cfg):
     _beams_equal(out["beams"], g)
     np.testing.assert_array_equal(out["aligned_seq_shift"], g["aligned_seq_shift"])
     _hyps_equal(out, g)
+
+
+# ---------------------------------------------------------------------------- branches closed in round 4
+@pytest.mark.parametrize("which", ["tiny_notrigger", "config2_notrigger"])
+def test_use_trigger_false(which):
+    """args.use_trigger == False (src/models/cassnat.py:469-473): trigger_mask = src_mask, best_path_align's own row counts."""
+    from conftest import notrigger_case
+
+    g = load_golden(which)
+    args, state, feats, sizes = notrigger_case(which)
+    out = orc.decode_nast(state, feats, sizes, args, stages=True)
+    np.testing.assert_array_equal(out["ylen"], g["ylen0"])
+    np.testing.assert_array_equal(out["aligned_seq_shift"], g["aligned_seq_shift"])
+    if which == "tiny_notrigger":
+        for k in ("ac_embed", "pred_embed", "dec_h", "att_out"):
+            _close(out[k], g[k])
+    else:
+        _close(out["att_out"][:, ::3, ::25], g["att_sample"], 1e-4)
+        _close(out["dec_h"][:, ::3, ::8], g["dec_sample"], 1e-4)
+    _hyps_equal(out, g)
+
+
+def test_esa_finished_with_beam_width_3():
+    """ESA with beam_width > 1: the finish loop (cassnat.py:574-637) runs on the selected samples' row-masked att_out.  Rows at or
+    past an utterance's own count are all-zero there: torch.topk of equal values is implementation-defined, so beams are compared
+    up to that position (their scores, + 0.0, in full)."""
+    from conftest import esa_beam3_case
+
+    g = load_golden("esa_beam3_tiny")
+    args, lm_args, state, lm_state, feats, sizes = esa_beam3_case()
+    out = orc.decode_nast_esa(state, lm_state, feats, sizes, args, lm_args, torch.from_numpy(g["select"].astype(np.int64)))
+    for b, beams in enumerate(out["beams"]):
+        n = int(out["ylen"][b]) + 1
+        for j, s in enumerate(beams):
+            assert len(s["hyp"]) == g["beam_len"][b, j]
+            assert s["hyp"][:n] == g["beam_hyp"][b, j, :n].tolist(), (b, j)
+            assert abs(s["score"] - g["beam_score"][b, j]) < 1e-4
+
+
+@pytest.mark.parametrize("which", ["art_tiny", "art_config4"])
+@pytest.mark.parametrize("bw", [1, 3])
+def test_art_ctc_correct_and_ctc_only(which, bw):
+    """ArtTask decode_type 'ctc_correct' (Transformer.fast_decode_with_ctc, src/models/transformer.py:243-342) and, at beam 1,
+    'ctc_only' (utils.beam_decode.ctc_beam_decode on the autoregressive model's encoder, src/tasks/art_task.py:252-253)."""
+    from conftest import art_case
+    from oracle import ast_oracle
+
+    g = load_golden(f"{which}_correct_bw{bw}")
+    args, state, feats, sizes = art_case(which, bw)
+    beams, _, _ = ast_oracle.fast_decode_with_ctc(state, feats, args)
+    _check_beams(beams, g)
+    if bw == 1:
+        args.decode_type = "ctc_only"
+        out = orc.decode_nast_ctc(state, feats, sizes, args)
+        for b, seqs in enumerate(out["beams"]):
+            assert len(seqs) == int(g["ctc_n"][b])
+            for j, s in enumerate(seqs):
+                assert s["hyp"] == g["ctc_hyp"][b, j, : g["ctc_len"][b, j]].tolist(), (b, j)
+            np.testing.assert_allclose([s["score_ctc"] for s in seqs], g["ctc_score"][b, : len(seqs)], rtol=0, atol=1e-6)

@@ -1,6 +1,7 @@
 """A test set of realistic size through the recogniser's command line: N utterances of 300..1500 frames (Kaldi ark / scp written
 here), config 2 model, `decode_asr --task cassnat` once batch after batch (--hip_pipelines 1) and once with the default
-pipelines and merged passes; also two ranks over gloo on this GPU.  The result files must be identical.
+pipelines and merged passes (identical files); also two ranks over gloo on this GPU, whose file must equal - exactly - the merge of
+one-process runs over each rank's own utterance list (the ranks add the deal and the merge, nothing else).
     python tools/exercise_cli.py [--utts 160] [--batch 16]"""
 import argparse
 import os
@@ -83,29 +84,27 @@ def main():
         two, t_two = run_cli(cli, os.path.join(tmp, "r_two.txt"), world=2)
         assert len(plain) == a.utts, len(plain)
         assert piped == plain, "pipelined result file differs from the batch-after-batch one"
-        # two ranks deal the utterances differently: other batches, other padding, another batch maximum of the token count - which
-        # the reference's greedy finish lets show in an utterance's LAST token (cassnat.py:580-636); everything before it must agree
+        # Two ranks deal the utterances differently: other batches - other padding, another T' behind src_size = (ratio * T').long(),
+        # another batch maximum of the token count (cassnat.py:436, 580-636) - so a line may differ from the one-process file, as it
+        # would between two batchings of the reference.  What must hold EXACTLY: a rank's lines are those of a one-process run over
+        # that rank's own list (the snake deal's order, same batch size), i.e. the ranks add nothing but the deal and the merge.
         assert [ln.split()[0] for ln in two] == [ln.split()[0] for ln in plain]
-        tail_only = other = 0
-        for x, y in zip(two, plain):
-            if x != y:
-                tx, ty = x.split()[1:], y.split()[1:]
-                n = min(len(tx), len(ty))
-                # (art: the step limit is max_decode_ratio x the BATCH's padded length - transformer.py:140 - so an utterance in
-                # another batch may run longer; what both runs have must agree)
-                if (abs(len(tx) - len(ty)) <= 1 and tx[: n - 1] == ty[: n - 1]) or (ast and tx[: n - 1] == ty[: n - 1]):
-                    tail_only += 1
-                else:
-                    other += 1
-                    nd = sum(1 for u, v in zip(tx, ty) if u != v)
-                    pos = [i for i, (u, v) in enumerate(zip(tx, ty)) if u != v]
-                    if other <= 4:
-                        print("  %s: %d / %d tokens differ at %s (lengths %d, %d): %s | %s" % (x.split()[0], nd, n, pos, len(tx), len(ty), " ".join(tx[-4:]), " ".join(ty[-4:])))
-        print("two ranks vs one: %d of %d lines differ in their tail only (the batch-dependent end of a hypothesis), %d otherwise" % (tail_only, len(plain), other))
-        # (a different batch also means a different padded length and with it other roundings: the random-init model's near-ties
-        # flip an isolated token here and there - in every precision, as they would between two batchings of the reference)
-        # (art: beam search over the random-init model's near-ties, in bf16, amplifies them - its two-rank result is reported only)
-        assert ast or other <= len(plain) // 20, other
+        from cassnat_asr_public_amd import dist as cdist
+
+        entries = [ln for ln in open(scp).read().splitlines() if ln.strip()]
+        per_rank = {}
+        for r in range(2):
+            idx = cdist.shard_indices(np.array(lengths), 2, r)
+            sub = os.path.join(tmp, f"feats_rank{r}.scp")
+            open(sub, "w").write("".join(entries[i] + "\n" for i in idx))
+            cli_r = [x if x != scp else sub for x in cli]
+            lines, _ = run_cli(cli_r, os.path.join(tmp, f"r_rank{r}.txt"))
+            per_rank.update({ln.split()[0]: ln for ln in lines})
+        merged = [per_rank[ln.split()[0]] for ln in plain]
+        differ_from_one = sum(x != y for x, y in zip(two, plain))
+        print("two ranks vs one process: %d of %d lines differ (other batch mates); two ranks vs one-process runs over each rank's own "
+              "list: %d differ" % (differ_from_one, len(plain), sum(x != y for x, y in zip(two, merged))))
+        assert two == merged, "a rank's lines differ from a one-process run over that rank's own utterance list"
         audio_s = sum(lengths) * 0.01
         print("%d utterances (%.0f s of audio), batch %d: result files identical; wall incl. start-up: plain %.1f s, pipelines %.1f s, "
               "two ranks on one GPU %.1f s" % (a.utts, audio_s, a.batch, t_plain, t_piped, t_two))
