@@ -18,7 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "kernels.h"
+#include "proj_x3_phase.h"
 
 struct FfnX3Params {
     float* x;             // [M][256] residual stream, in place
@@ -33,6 +33,12 @@ struct FfnX3Params {
     int M, dff;
     float eps;
     int rotate;
+    // row-chain form (template PRO / TAIL; proj_x3_phase.h): the attention's output projection onto the residual stream in front
+    // of the sublayer - x <- x + Wo . ctx + bo on the workgroup's rows, ctx split-bf16 [M][ldctx] - and the next attention's
+    // projection (Q|K|V, split-bf16 output) of LN_next(x) behind it, on rows that never leave LDS
+    const unsigned char* ctx;
+    long long ldctx_bytes;
+    PxPhase pro, tail;
 #ifdef FX_STAMPS
     unsigned long long* stamps;  // [workgroup][wave][8]: kernel entry, main loop entry, main loop exit, kernel exit (s_memtime);
                                  // then the main loop's cycles by phase: W1 blocks, bias / ReLU (first half), W2 blocks
@@ -55,6 +61,12 @@ constexpr int FX_LDS_MAIN = 2 * FX_PLANE + FX_MAX_DFF * 4;
 constexpr int FX_LDS_PART = 4 * 32 * FX_P_STRIDE * 4;
 constexpr int FX_LDS = FX_LDS_MAIN > FX_LDS_PART ? FX_LDS_MAIN : FX_LDS_PART;
 static_assert(FX_LDS <= 160 * 1024, "LDS budget");
+// TAIL form: the partial rows at a stride of exactly 256 floats with an XOR swizzle of the 16-byte chunks instead of the padding
+// (131072 bytes), which leaves the CU's last 32 KiB for the first M-tile's LN_next fragments; the second M-tile's go to offset 0
+// once the partials are dead
+constexpr int FX_PART_TAIL = 4 * 32 * FX_D * 4;
+constexpr int FX_LDS_TAIL = FX_PART_TAIL + 32768;
+static_assert(FX_LDS_TAIL == 160 * 1024, "LDS budget (row-chain form)");
 
 #define FX_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 // The kernel holds 18 accumulator tiles (16 of out^T, 2 of the hidden tile) = 288 registers.  The compiler selects every MFMA
@@ -67,6 +79,7 @@ static_assert(FX_LDS <= 160 * 1024, "LDS budget");
 #define FX_MFMA_V(a, b, c) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
 #define FX_MFMA_V0(a, b, c) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b))
 
+template <bool PRO, bool TAIL>
 __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xn_s = smem;                                          // [plane][mt][16 k-steps][64 lanes][16 B]
@@ -78,6 +91,14 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
     const int m0 = blockIdx.x * 32 * FX_MT;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     FX_STAMP(0)
+    if constexpr (PRO) {
+        // x <- x + Wo . ctx + bo on this workgroup's 64 rows (wave w: output column tiles w and w + 4), written through to global
+        // memory; the barrier's vmcnt(0) makes the rows visible to the waves of this workgroup that read them below (one L1)
+        px_stage_rows<FX_MT>(p.ctx, p.ldctx_bytes, m0, p.M, smem, tid);
+        __syncthreads();
+        px_tiles<FX_MT, false, true>(p.pro, smem, smem + 32768, m0, 0, FX_D / 32, wave_u, lane);
+        __syncthreads();
+    }
 
     const int tiles_per_wave = p.dff / 32 / 4;
     const int ft0 = wave_u * tiles_per_wave;
@@ -342,7 +363,8 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
             xv[i] = *reinterpret_cast<const f32x4*>(p.x + (long long)m * FX_D + 4 * lane);
         }
         __syncthreads();  // xn fragments (mt == 0) or the previous round's partials are no longer read
-        float* mine = part + (wave * 32 + l31) * FX_P_STRIDE;
+        constexpr int PSTR = TAIL ? FX_D : FX_P_STRIDE;
+        float* mine = part + (wave * 32 + l31) * PSTR;
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
@@ -350,7 +372,8 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = acc[mt][nt][4 * g + e];
-                *reinterpret_cast<f32x4*>(mine + 32 * nt + 8 * g + 4 * half) = o;
+                const int ch = 8 * nt + 2 * g + half;  // 16-byte chunk of the row (TAIL: swizzled by the row's low bits)
+                *reinterpret_cast<f32x4*>(mine + 4 * (TAIL ? ch ^ (l31 & 7) : ch)) = o;
             }
         __syncthreads();
 #pragma unroll
@@ -360,7 +383,7 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
             f32x4 v = xv[i];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(part + (w * 32 + r) * FX_P_STRIDE + 4 * lane);
+                const f32x4 q = *reinterpret_cast<const f32x4*>(part + (w * 32 + r) * PSTR + 4 * (TAIL ? lane ^ (r & 7) : lane));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += q[j];
             }
@@ -368,6 +391,12 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
             for (int j = 0; j < 4; ++j) v[j] += b2v[j];
             if (m < p.M) *reinterpret_cast<f32x4*>(p.x + (long long)m * FX_D + 4 * lane) = v;  // wave-uniform
             xv[i] = v;
+        }
+        // TAIL: LN_next(x) stays in LDS as the projection's fragments - M-tile 0 in the 32 KiB behind the partials, M-tile 1 at
+        // offset 0, once every wave has read the last round's partials
+        unsigned char* nfrag = smem + (mt == 0 ? FX_PART_TAIL : 0);
+        if constexpr (TAIL) {
+            if (mt == FX_MT - 1) __syncthreads();
         }
         if (p.nln_a) {
 #pragma unroll
@@ -393,7 +422,11 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
                     for (int j = 0; j < 4; ++j) o[j] = ng[j] * (xv[i0 + q][j] - mean[q]) * inv + nb[j];
                     bf16x4 hi, lo;
                     cn_split4(o, hi, lo);
-                    if (m < p.M) {
+                    if constexpr (TAIL) {  // (rows past M hold the last row's values: their projections are never stored)
+                        unsigned char* ob = nfrag + px_frag_off(wave + 4 * (i0 + q), 4 * lane);
+                        *reinterpret_cast<bf16x4*>(ob) = hi;
+                        *reinterpret_cast<bf16x4*>(ob + 1024) = lo;
+                    } else if (m < p.M) {
                         unsigned char* ob = p.xn_out + (long long)m * FX_D * 4 + cn_split_off((size_t)(4 * lane));
                         *reinterpret_cast<bf16x4*>(ob) = hi;
                         *reinterpret_cast<bf16x4*>(ob + 64) = lo;
@@ -401,6 +434,11 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
                 }
             }
         }
+    }
+    if constexpr (TAIL) {
+        // the next attention's projection of LN_next(x): wave w computes column tiles w, w + 4, ... (split-bf16 rows to global)
+        __syncthreads();
+        px_tiles<FX_MT, true, true>(p.tail, smem + FX_PART_TAIL, smem, m0, 0, p.tail.N >> 5, wave_u, lane);
     }
     FX_STAMP(3)
 }
@@ -445,13 +483,39 @@ int launch_ffn_x3(const FfnX3Args& a, hipStream_t s) {
     p.stamps = stamps_dev;
     g_fx_stamps = stamps_dev;
 #endif
-    static CnAttrOnce attr_once;
-    int attr_dev;
-    if (attr_once.need(&attr_dev)) {
-        CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS));
-        attr_once.mark(attr_dev);
+    const bool pro = a.ctx != nullptr, tail = a.tail_p != nullptr;
+    if (pro && (!a.wo_p || !a.bo || a.ldctx % 32 != 0)) {
+        cn_set_error("ffn_x3: the output-projection form needs its packed weights, its bias and a 32-element ctx row stride");
+        return -1;
     }
-    hipLaunchKernelGGL(ffn_x3_kernel, dim3(cn_ceil_div(p.M, 32 * FX_MT)), dim3(256), FX_LDS, s, p);
+    if (tail && (!a.nln_a || !a.tail_b || !a.tail_out || a.tail_n < 128 || a.tail_n % 128 != 0 || a.tail_n > 1024 || a.ld_tail % 32 != 0)) {
+        cn_set_error("ffn_x3: the tail-projection form needs the next LayerNorm, a bias, an output and 128 <= tail_n <= 1024, a multiple of 128");
+        return -1;
+    }
+    if ((long long)a.M * FX_D * 4 >= (1ll << 31)) {
+        cn_set_error("ffn_x3: residual stream beyond 2 GiB");
+        return -1;
+    }
+    p.ctx = reinterpret_cast<const unsigned char*>(a.ctx);
+    p.ldctx_bytes = (long long)a.ldctx * 4;
+    p.pro = PxPhase{reinterpret_cast<const unsigned char*>(a.wo_p), a.bo, a.x, FX_D, a.x, FX_D, 1.f, a.M, FX_D};
+    p.tail = PxPhase{reinterpret_cast<const unsigned char*>(a.tail_p), a.tail_b, a.tail_out, a.ld_tail, nullptr, 0, 1.f, a.M, a.tail_n};
+    const dim3 grid(cn_ceil_div(p.M, 32 * FX_MT));
+#define FX_LAUNCH(PRO_, TAIL_, LDS_)                                                                                       \
+    {                                                                                                                      \
+        static CnAttrOnce attr_once;                                                                                       \
+        int attr_dev;                                                                                                      \
+        if (attr_once.need(&attr_dev)) {                                                                                   \
+            CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_x3_kernel<PRO_, TAIL_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_)); \
+            attr_once.mark(attr_dev);                                                                                      \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((ffn_x3_kernel<PRO_, TAIL_>), grid, dim3(256), LDS_, s, p);                                      \
+    }
+    if (pro && tail) FX_LAUNCH(true, true, FX_LDS_TAIL)
+    else if (pro) FX_LAUNCH(true, false, FX_LDS)
+    else if (tail) FX_LAUNCH(false, true, FX_LDS_TAIL)
+    else FX_LAUNCH(false, false, FX_LDS)
+#undef FX_LAUNCH
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -252,6 +252,18 @@ struct FfnX3Args {
     void* xn_out = nullptr;  // [M][256] split-bf16 (when nln_a)
     int M = 0, d = 0, dff = 0;
     float eps = 1e-6f;
+    // row-chain form (the encoder / self-attention layer of the split-bf16 engine in one launch around the attention kernel):
+    // ctx != null: x <- x + Wo . ctx + bo first (ctx split-bf16 [M][ldctx], wo_p = pack_proj_x3 stream of the 256 x 256 output
+    // projection, bo its bias); tail_p != null: instead of writing LN_next(x), project it - tail_out (split-bf16 rows of
+    // ld_tail elements) <- Wt . LN_next(x) + bt, tail_n columns (a multiple of 128, pack_proj_x3 stream); needs nln_a
+    const void* ctx = nullptr;
+    int ldctx = 256;
+    const void* wo_p = nullptr;
+    const float* bo = nullptr;
+    const void* tail_p = nullptr;
+    const float* tail_b = nullptr;
+    void* tail_out = nullptr;
+    int tail_n = 0, ld_tail = 0;
 };
 bool ffn_x3_applies(int d, int dff);
 int launch_ffn_x3(const FfnX3Args& a, hipStream_t s);

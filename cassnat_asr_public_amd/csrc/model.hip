@@ -1393,6 +1393,45 @@ int run_ffn(cn_model* m, const Layer& L, const Norm& n, float* x, int M, const N
     return 0;
 }
 
+// Split-bf16 engine, the row-chain form of a self-attention layer's tail (fused_x3.hip, PRO / TAIL): in ONE launch behind the
+// attention kernel  x += Wo . ctx + bo;  x += FFN(LN1 x);  then either LN_next(x) -> next_out (split-bf16 rows) or, with `tail`, the
+// next attention's projection of it -> tail_out (the activations between the three products never leave LDS / registers).
+bool x3_chain_applies(const cn_model* m, const Layer& L, const Linear* tail) {
+    return m->prec == CN_PREC_X3 && L.wx3 && L.self_o.px3 && L.self_o.N == 256 && L.self_o.K == 256 &&
+           (!tail || (tail->px3 && tail->K == 256 && tail->N % 128 == 0 && tail->N <= 1024));
+}
+int run_x3_chain(cn_model* m, const Layer& L, const Norm& n1, float* x, int M, const Norm& next, void* next_out, const Linear* tail,
+                 void* tail_out, int ld_tail, const char* tag, hipStream_t s) {
+    const int d = m->cfg.d_model, tn = tail ? tail->N : 0;
+    const double macs = (double)d * d + 2.0 * d * L.w1.N + (double)d * tn;
+    ProfScope ps(m, tag, 2.0 * M * macs, (double)M * d * (4 + 8) + (double)M * (tail ? tn : d) * 4 + 4.0 * macs, s);
+    FfnX3Args a;
+    a.x = x;
+    a.ln_a = n1.a;
+    a.ln_b = n1.b;
+    a.wst = L.wx3;
+    a.b1 = L.w1.b;
+    a.b2 = L.w2.b;
+    a.nln_a = next.a;
+    a.nln_b = next.b;
+    a.xn_out = next_out;
+    a.M = M;
+    a.d = d;
+    a.dff = L.w1.N;
+    a.ctx = m->ctx;
+    a.ldctx = d;
+    a.wo_p = L.self_o.px3;
+    a.bo = L.self_o.b;
+    if (tail) {
+        a.tail_p = tail->px3;
+        a.tail_b = tail->b;
+        a.tail_out = tail_out;
+        a.tail_n = tn;
+        a.ld_tail = ld_tail;
+    }
+    return launch_ffn_x3(a, s);
+}
+
 // ctx <- Attn(q, k, v) on the fused [M][3d] projection buffer m->qkv
 int run_self_attn_core(cn_model* m, int B, int Lseq, const unsigned char* keymask, const int* klen, int causal,
                        hipStream_t s, bool blocked = false) {
@@ -1953,6 +1992,11 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
             CN_TRY(run_linear(m, "qkv_proj", m->enc[0].qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
         }
     }
+    // split-bf16 engine: every encoder layer in the row-chain form (all layers or none: the Q|K|V hand-over is layer to layer)
+    static const bool no_x3_chain = cn_exp_env("CASSNAT_NO_X3_CHAIN") != nullptr;
+    bool x3_rows = !chain && !cap && !no_x3_chain && m->prec == CN_PREC_X3 && !m->enc.empty() && m->enc[0].qkv.px3;
+    for (size_t n = 0; x3_rows && n < m->enc.size(); ++n)
+        x3_rows = x3_chain_applies(m, m->enc[n], n + 1 < m->enc.size() ? &m->enc[n + 1].qkv : nullptr);
     for (size_t n = 0; n < m->enc.size(); ++n) {
         const Layer& L = m->enc[n];
         const bool last = n + 1 == m->enc.size();
@@ -1969,6 +2013,18 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
                 CN_TRY(run_chain(m, m->enc_chain[n], m->x, M, last ? m->enc_h : m->qkv, last ? d : 3 * d, true, xm, s, nullptr, 0,
                                  blk && !last));
             }
+        } else if (x3_rows) {
+            // split-bf16 engine: attention, then ONE launch for the out-projection, the feed-forward sublayer and the next layer's
+            // Q|K|V (the last layer: enc_h).  (A capture run keeps the unfused kernels: the fused path's reference in the tests.)
+            if (n == 0) {
+                CN_TRY(run_ln(m, L.n[0], m->x, m->xn, M, s));
+                CN_TRY(run_linear(m, "qkv_proj", L.qkv, m->xn, d, m->qkv, 3 * d, 0, M, 0, nullptr, 0, s));
+            }
+            CN_TRY(run_self_attn_core(m, B, Tp, m->keymask, nullptr, 0, s));
+            if (last)
+                CN_TRY(run_x3_chain(m, L, L.n[1], m->x, M, m->enc_norm, m->enc_h, nullptr, nullptr, 0, "row_chain_x3", s));
+            else
+                CN_TRY(run_x3_chain(m, L, L.n[1], m->x, M, m->enc[n + 1].n[0], nullptr, &m->enc[n + 1].qkv, m->qkv, 3 * d, "row_chain_x3", s));
         } else {
             CN_TRY(run_self_attn(m, L, n == 0 ? &L.n[0] : nullptr, m->x, B, Tp, m->keymask, nullptr, 0, s));
             CN_TRY(run_ffn(m, L, L.n[1], m->x, M, last ? &m->enc_norm : &m->enc[n + 1].n[0], last ? m->enc_h : m->xn, s));
@@ -3525,6 +3581,77 @@ extern "C" int cn_op_ffn_x3(float* x_dev, const float* ln_a_dev, const float* ln
     (void)hipFree(dw);
     if (rc == 0 && e != hipSuccess) {
         cn_set_error(std::string("cn_op_ffn_x3: ") + hipGetErrorString(e));
+        rc = -2;
+    }
+    return rc;
+}
+
+// The row-chain form of the split-bf16 engine as one op (fused_x3.hip PRO / TAIL): x += Wo . ctx + bo; x += FFN(LN1 x); then
+// LN_next(x) -> xn_out_dev (wt_host null) or its projection Wt . LN_next(x) + bt -> tail_out_dev (split-bf16 rows of tail_n
+// elements).  ctx_dev: split-bf16 [M][256] or null (no output projection); weight matrices on the host (fp32, nn.Linear layout),
+// vectors on the device.
+extern "C" int cn_op_x3_chain(float* x_dev, const void* ctx_dev, const float* wo_host, const float* bo_dev, const float* ln_a_dev,
+                              const float* ln_b_dev, const float* w1_host, const float* b1_dev, const float* w2_host,
+                              const float* b2_dev, const float* nln_a_dev, const float* nln_b_dev, void* xn_out_dev,
+                              const float* wt_host, const float* bt_dev, void* tail_out_dev, int32_t tail_n, int32_t M, int32_t dff,
+                              float eps, void* stream) {
+    if (!ffn_x3_applies(256, dff) || (wt_host && !proj_x3_applies(tail_n, 256))) {
+        cn_set_error("cn_op_x3_chain: d_ff a multiple of 128 (<= 2048), tail_n a multiple of 32 (<= 1024)");
+        return -1;
+    }
+    std::vector<void*> dev;
+    auto upload = [&](const void* h, size_t bytes, void** out) -> int {
+        CN_HIP_CHECK(hipMalloc(out, bytes));
+        dev.push_back(*out);
+        CN_HIP_CHECK(hipMemcpy(*out, h, bytes, hipMemcpyHostToDevice));
+        return 0;
+    };
+    FfnX3Args a;
+    int rc = 0;
+    {
+        std::vector<uint16_t> h(ffn_x3_stream_bytes(dff) / 2);
+        pack_ffn_x3(w1_host, w2_host, dff, h.data());
+        void* dw = nullptr;
+        rc = upload(h.data(), h.size() * 2, &dw);
+        a.wst = dw;
+    }
+    if (rc == 0 && ctx_dev) {
+        std::vector<unsigned char> h((size_t)256 * 1024);
+        pack_proj_x3(wo_host, 256, h.data());
+        void* dw = nullptr;
+        rc = upload(h.data(), h.size(), &dw);
+        a.ctx = ctx_dev;
+        a.wo_p = dw;
+        a.bo = bo_dev;
+    }
+    if (rc == 0 && wt_host) {
+        std::vector<unsigned char> h((size_t)tail_n * 1024);
+        pack_proj_x3(wt_host, tail_n, h.data());
+        void* dw = nullptr;
+        rc = upload(h.data(), h.size(), &dw);
+        a.tail_p = dw;
+        a.tail_b = bt_dev;
+        a.tail_out = tail_out_dev;
+        a.tail_n = tail_n;
+        a.ld_tail = tail_n;
+    }
+    a.x = x_dev;
+    a.ln_a = ln_a_dev;
+    a.ln_b = ln_b_dev;
+    a.b1 = b1_dev;
+    a.b2 = b2_dev;
+    a.nln_a = nln_a_dev;
+    a.nln_b = nln_b_dev;
+    a.xn_out = xn_out_dev;
+    a.M = M;
+    a.d = 256;
+    a.dff = dff;
+    a.eps = eps;
+    if (rc == 0) rc = launch_ffn_x3(a, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    for (void* q : dev) (void)hipFree(q);
+    if (rc == 0 && e != hipSuccess) {
+        cn_set_error(std::string("cn_op_x3_chain: ") + hipGetErrorString(e));
         rc = -2;
     }
     return rc;

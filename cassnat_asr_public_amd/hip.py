@@ -140,6 +140,7 @@ def lib():
                            C.POINTER(C.c_int32)]
     L.cn_op_ffn_fused.argtypes = [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
     L.cn_op_ffn_x3.argtypes = [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p]
+    L.cn_op_x3_chain.argtypes = [C.c_void_p] * 16 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     L.cn_op_chain.argtypes = ([C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 13 +
                               [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p])
     L.cn_op_genmax.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -390,6 +391,8 @@ class Engine:
 
     def ast_ctc_correct(self, feats, opts, k):
         """Transformer.fast_decode_with_ctc's device half: -> (length (B,) int32 cuda, tok (B, U, k) int32 cuda, val (B, U, k) f32 cuda)."""
+        import torch
+
         B, T, F = feats.shape
         Tp = ((T - 1) // 2 + 1 - 1) // 2 + 1
         tok = torch.empty(B * (Tp + 1) * k, dtype=torch.int32, device=feats.device)

@@ -352,6 +352,13 @@ int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, 
 int cn_op_ffn_x3(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, const float* w1_host, const float* b1_dev,
                  const float* w2_host, const float* b2_dev, const float* nln_a_dev, const float* nln_b_dev, void* xn_out_dev,
                  int32_t M, int32_t dff, float eps, void* stream);
+/* the row-chain form of the split-bf16 engine (fused_x3.hip): attention output projection + residual, feed-forward sublayer, next
+ * LayerNorm and (wt_host != null) the next attention's projection of it, in one launch; ctx_dev split-bf16 [M][256] or null;
+ * weight matrices on the host, vectors on the device (positionff.py:15-16, attention.py:57-66, norm.py:15-18) */
+int cn_op_x3_chain(float* x_dev, const void* ctx_dev, const float* wo_host, const float* bo_dev, const float* ln_a_dev,
+                   const float* ln_b_dev, const float* w1_host, const float* b1_dev, const float* w2_host, const float* b2_dev,
+                   const float* nln_a_dev, const float* nln_b_dev, void* xn_out_dev, const float* wt_host, const float* bt_dev,
+                   void* tail_out_dev, int32_t tail_n, int32_t M, int32_t dff, float eps, void* stream);
 /* fused generator tail, bf16 / d_model 256: arg[m] = argmax_v, maxlp[m] = max_v of log_softmax(W h[m] + b); h_dev bf16 [M][256],
  * W/b HOST fp32 nn.Linear parameters (packed and uploaded by the call; the model packs once at cn_model_finalize). */
 int cn_op_genmax(const void* h_dev, const float* w_host, const float* b_host, int32_t M, int32_t V, int32_t* arg_dev,

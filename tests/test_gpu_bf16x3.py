@@ -243,3 +243,46 @@ def test_ffn_fused_x3(M, dff, with_next):
     assert relerr(xd, ref) < 2e-5
     if with_next:
         assert relerr(from_split(xn), layer_norm(ref, a2.double(), b2n.double())) < 3e-5
+
+
+@pytest.mark.parametrize("M,dff,with_ctx,tail_n", [(8000, 2048, True, 768), (8000, 2048, True, 0), (45, 256, True, 768), (2304, 2048, False, 256),
+                                                   (65, 128, True, 512), (1, 1024, True, 768), (20031, 2048, True, 768)])
+def test_x3_row_chain(M, dff, with_ctx, tail_n):
+    """fused_x3.hip, row-chain form: x += Wo ctx + bo; x += W2 relu(W1 LN(x) + b1) + b2; then the next LayerNorm or the next
+    attention's projection of it - against fp64 on the unrounded operands (ctx as the split-bf16 values the attention kernel
+    leaves).  Partial last tiles, one row, several rounds of workgroups."""
+    from oracle.cassnat_oracle import layer_norm
+
+    g = torch.Generator().manual_seed(3 * M + dff + tail_n)
+    x = torch.randn(M, 256, generator=g) * 2
+    ctx = torch.randn(M, 256, generator=g)
+    wo, bo = torch.randn(256, 256, generator=g) / 16, torch.randn(256, generator=g) * 0.1
+    a1, b1n = torch.randn(256, generator=g) * 0.5 + 1, torch.randn(256, generator=g) * 0.2
+    a2, b2n = torch.randn(256, generator=g) * 0.5 + 1, torch.randn(256, generator=g) * 0.2
+    w1, bb1 = torch.randn(dff, 256, generator=g) / 16, torch.randn(dff, generator=g) * 0.1
+    w2, bb2 = torch.randn(256, dff, generator=g) / math.sqrt(dff), torch.randn(256, generator=g) * 0.1
+    wt, bt = torch.randn(max(tail_n, 32), 256, generator=g) / 16, torch.randn(max(tail_n, 32), generator=g) * 0.1
+    xd = x.cuda()
+    ctx_s = to_split(ctx)
+    ctx_v = from_split(ctx_s)  # the values the kernel reads
+    devs = [t.cuda() for t in (bo, a1, b1n, bb1, bb2, a2, b2n, bt)]
+    xn = torch.zeros(M, 256, dtype=torch.int32, device="cuda")
+    tail = torch.zeros(M, max(tail_n, 32), dtype=torch.int32, device="cuda")
+    hosts = [t.contiguous() for t in (wo, w1, w2, wt)]
+    hp = lambda t: C.c_void_p(t.data_ptr())
+    hip.check(hip.lib().cn_op_x3_chain(p(xd), p(ctx_s) if with_ctx else None, hp(hosts[0]), p(devs[0]), p(devs[1]), p(devs[2]), hp(hosts[1]),
+                                       p(devs[3]), hp(hosts[2]), p(devs[4]), p(devs[5]), p(devs[6]), p(xn), hp(hosts[3]) if tail_n else None,
+                                       p(devs[7]), p(tail), tail_n, M, dff, 1e-6, stream()))
+    torch.cuda.synchronize()
+    xr = x.double()
+    if with_ctx:
+        xr = xr + F.linear(ctx_v.double(), wo.double(), bo.double())
+    h = F.relu(F.linear(layer_norm(xr, a1.double(), b1n.double()), w1.double(), bb1.double()))
+    ref = xr + F.linear(h, w2.double(), bb2.double())
+    assert relerr(xd, ref) < 2e-5
+    nxt = layer_norm(ref, a2.double(), b2n.double())
+    if tail_n:
+        assert relerr(from_split(tail), F.linear(nxt, wt.double(), bt.double())) < 4e-5
+        assert int(xn.abs().max()) == 0  # LN_next(x) itself is not written in the tail form
+    else:
+        assert relerr(from_split(xn), nxt) < 3e-5
