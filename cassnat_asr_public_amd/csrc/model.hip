@@ -7,6 +7,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cassnat_hip.h"
@@ -3484,6 +3485,51 @@ extern "C" int cn_op_cmvn(float* feats_dev, const int32_t* len_dev, const double
         return -1;
     }
     return launch_cmvn(feats_dev, len_dev, mean_dev, std_dev, B, T, F, (hipStream_t)stream);
+}
+
+// Host side of the packed reader: n byte ranges (an utterance's rows inside the memory map of an archive) copied back to back into a
+// page-locked staging buffer in ONE call - ctypes releases the GIL for its duration, so the decode pipelines' host threads copy side
+// by side (numpy's slice assignment holds it: two threads took turns, 5 ms a turn).  threads > 1: the ranges are dealt over that
+// many std::threads in equal byte shares (--load_data_workers on this path).
+extern "C" int cn_host_gather(void* dst, const uint64_t* src_ptrs, const uint64_t* dst_offsets, const uint64_t* nbytes, int32_t n,
+                              int32_t threads) {
+    if (!dst || !src_ptrs || !dst_offsets || !nbytes || n < 0) {
+        cn_set_error("cn_host_gather: null argument");
+        return -1;
+    }
+    auto run = [&](int lo, int hi) {
+        for (int i = lo; i < hi; ++i)
+            memcpy(static_cast<unsigned char*>(dst) + dst_offsets[i], reinterpret_cast<const void*>(src_ptrs[i]), nbytes[i]);
+    };
+    const int nt = std::max(1, std::min<int>(threads, n));
+    if (nt == 1) {
+        run(0, n);
+        return 0;
+    }
+    uint64_t total = 0;
+    for (int i = 0; i < n; ++i) total += nbytes[i];
+    std::vector<std::thread> pool;
+    int lo = 0;
+    uint64_t acc = 0;
+    for (int t = 0; t < nt; ++t) {
+        int hi = lo;
+        const uint64_t want = total * (uint64_t)(t + 1) / (uint64_t)nt;
+        while (hi < n && (t + 1 == nt || acc + nbytes[hi] <= want || hi == lo)) acc += nbytes[hi++];
+        if (t + 1 < nt) pool.emplace_back(run, lo, hi);
+        else run(lo, hi);
+        lo = hi;
+    }
+    for (auto& th : pool) th.join();
+    return 0;
+}
+
+extern "C" int cn_op_unpack_rows(const float* packed_dev, const int32_t* off_dev, const int32_t* len_dev, float* out_dev, int32_t rows,
+                                 int32_t T, int32_t F, float pad, const double* mean_dev, const double* std_dev, void* stream) {
+    if (!packed_dev || !off_dev || !len_dev || !out_dev || (!mean_dev) != (!std_dev)) {
+        cn_set_error("cn_op_unpack_rows: null argument (mean and std come together)");
+        return -1;
+    }
+    return launch_unpack_rows(packed_dev, off_dev, len_dev, out_dev, rows, T, F, pad, mean_dev, std_dev, (hipStream_t)stream);
 }
 
 extern "C" int cn_op_quantize_fp8(const void* src_bf16_dev, int32_t ld, void* dst_dev, int32_t M, int32_t K, float scale,

@@ -623,6 +623,61 @@ __global__ void cmvn_kernel(float* __restrict__ x, const int* __restrict__ len, 
     }
 }
 
+// The reader's hand-over (SuperviseLoader.collate_fn, src/data/speech_loader.py:327-356, and the global CMVN of :109-115, 147-149) on
+// the device: the utterances of an engine pass arrive PACKED - their archive rows back to back, exactly as they lie in the .ark, one
+// DMA - and are spread over the padded batch here: out[r][t][:] = t < len[r] ? norm(packed[off[r] + t][:]) : pad, with
+// norm(x) = float((double(x) - mean) / std) when statistics are given (the dataset's float64 arithmetic, one rounding: bit for
+// bit) and x itself otherwise.  Replaces the host-side padded collate, the per-batch device copies and the separate CMVN pass.
+// One workgroup per (utterance, 32-frame chunk); 16-byte accesses when F % 4 == 0.
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const float* __restrict__ packed, const int* __restrict__ off, const int* __restrict__ len,
+                                                          float* __restrict__ out, int T, int F, float pad, const double* __restrict__ mean,
+                                                          const double* __restrict__ sd) {
+    const int r = blockIdx.y;
+    const int n = len[r] < 0 ? 0 : (len[r] > T ? T : len[r]);
+    const long long t0 = (long long)blockIdx.x * 32;
+    if (t0 >= T) return;
+    const int tn = (int)((T - t0) < 32 ? (T - t0) : 32);
+    const float* src = packed + ((long long)off[r] + t0) * F;
+    float* dst = out + ((long long)r * T + t0) * F;
+    const int total = tn * F, valid = (int)((n - t0) <= 0 ? 0 : ((n - t0) < tn ? (n - t0) : tn)) * F;
+    if ((F & 3) == 0 && (((size_t)src | (size_t)dst) & 15) == 0) {
+        for (int i = 4 * threadIdx.x; i < total; i += 4 * 256) {
+            f32x4 v = {pad, pad, pad, pad};
+            if (i < valid) {  // (valid is a multiple of F, F of 4: a quad never straddles the utterance's end)
+                v = *reinterpret_cast<const f32x4*>(src + i);
+                if (mean) {
+                    const int f = i % F;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (float)(((double)v[e] - mean[f + e]) / sd[f + e]);
+                }
+            }
+            *reinterpret_cast<f32x4*>(dst + i) = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < total; i += 256) {
+            float v = pad;
+            if (i < valid) {
+                v = src[i];
+                if (mean) v = (float)(((double)v - mean[i % F]) / sd[i % F]);
+            }
+            dst[i] = v;
+        }
+    }
+}
+
+int launch_unpack_rows(const float* packed, const int* off, const int* len, float* out, int rows, int T, int F, float pad,
+                       const double* mean, const double* sd, hipStream_t s) {
+    if (rows <= 0 || T <= 0 || F <= 0) return 0;
+    if (rows > 65535) {
+        cn_set_error("unpack_rows: more than 65535 utterances in one pass");
+        return -1;
+    }
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)cn_ceil_div(T, 32), (unsigned)rows), dim3(256), 0, s, packed, off, len, out, T, F,
+                       pad, mean, sd);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_cmvn(float* x, const int* len, const double* mean, const double* sd, int B, int T, int F, hipStream_t s) {
     if (B <= 0 || T <= 0 || F <= 0) return 0;
     const int per = cn_ceil_div(T * F, 256);

@@ -119,6 +119,8 @@ def lib():
     L.cn_op_gemm_fp8.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                  C.c_int32, C.POINTER(C.c_float), C.c_void_p]
     L.cn_op_cmvn.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]
+    L.cn_host_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    L.cn_op_unpack_rows.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_op_quantize_fp8.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     L.cn_op_logsoftmax_topk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cn_model_create.argtypes = [C.POINTER(CnConfig), C.POINTER(C.c_void_p)]
@@ -209,6 +211,30 @@ def cmvn_(feats, lens, mean, std):
     assert feats.is_contiguous() and feats.dtype.is_floating_point and feats.element_size() == 4 and lens.numel() >= B
     check(lib().cn_op_cmvn(_ptr(feats), _ptr(lens), _ptr(mean), _ptr(std), B, T, F, current_stream()), "cn_op_cmvn")
     return feats
+
+
+def host_gather(dst_ptr, srcs, threads=1):
+    """Copy the numpy arrays ``srcs`` (C-contiguous; e.g. read-only views into a memory-mapped archive) back to back to the host
+    address ``dst_ptr`` in one GIL-free call (cn_host_gather); returns the byte offsets of the pieces."""
+    n = len(srcs)
+    ptrs = np.fromiter((a.ctypes.data for a in srcs), np.uint64, n)
+    sizes = np.fromiter((a.nbytes for a in srcs), np.uint64, n)
+    offs = np.zeros(n, np.uint64)
+    np.cumsum(sizes[:-1], out=offs[1:])
+    check(lib().cn_host_gather(C.c_void_p(int(dst_ptr)), ptrs.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p),
+                               sizes.ctypes.data_as(C.c_void_p), n, int(threads)), "cn_host_gather")
+    return offs
+
+
+def unpack_rows(packed, off, lens, out, pad, mean=None, std=None):
+    """The reader's collate on the device (cn_op_unpack_rows): ``packed`` float32 CUDA rows of F features, utterance r at row off[r]
+    with lens[r] frames -> the padded (rows, T, F) batch ``out`` on the current stream; with ``mean`` / ``std`` (float64, (F,)) the
+    global CMVN is applied in float64 on the way."""
+    rows, T, F = out.shape
+    assert out.is_contiguous() and packed.is_contiguous() and off.numel() >= rows and lens.numel() >= rows
+    check(lib().cn_op_unpack_rows(_ptr(packed), _ptr(off), _ptr(lens), _ptr(out), rows, T, F, float(pad), _ptr(mean), _ptr(std),
+                                  current_stream()), "cn_op_unpack_rows")
+    return out
 
 
 class Engine:

@@ -50,6 +50,36 @@ class _NoStream:
         pass
 
 
+class PackedBatch:
+    """A batch the reader has NOT collated: the utterances' archive rows as they lie in the .ark - read-only float32 views (n_b, F)
+    into the memory map of the archive (``data.kaldi_io.load_mat_view``) - in the batch's order.  It stands where the padded
+    (B, T, F) tensor of ``SuperviseLoader.collate_fn`` (src/data/speech_loader.py:327-356) would: ``shape`` is that tensor's shape,
+    ``ratios()`` its float32 length ratios.  The decode pipelines copy the rows of a whole engine pass back to back into page-locked
+    memory (one straight memcpy per utterance, no padding), send them with one DMA and spread them over the padded batch on the
+    device (``hip.unpack_rows``: padding and, when asked for, the global CMVN in float64 happen there)."""
+
+    __slots__ = ("views", "lens", "shape", "dtype", "is_cuda")
+
+    def __init__(self, views):
+        self.views = views
+        self.lens = [int(v.shape[0]) for v in views]
+        self.shape = (len(views), max(self.lens), int(views[0].shape[1]))
+        self.dtype = torch.float32
+        self.is_cuda = False
+
+    def ratios(self):
+        """collate's ``ratios[b] = feat.shape[0] / t_max``: the Python (double) quotient rounded to float32"""
+        t_max = self.shape[1]
+        return torch.tensor([n / t_max for n in self.lens], dtype=torch.float32)
+
+    def padded(self, pad=0.0, cmvn=None):
+        """The collated tensor itself (host): what the packed path must reproduce; used by the CPU rehearsal and the tests."""
+        out = np.full(self.shape, float(pad), np.float32)
+        for b, v in enumerate(self.views):
+            out[b, : v.shape[0]] = v if cmvn is None else ((v.astype(np.float64) - cmvn[0]) / cmvn[1]).astype(np.float32)
+        return torch.from_numpy(out)
+
+
 class _Job:
     """One ``records()`` call: the shared iterator and the bookkeeping its workers and its consumer meet on."""
 
@@ -87,7 +117,7 @@ class _Pass:
 
 class DecodePipelines:
     def __init__(self, model, n_pipelines, batch, frames, with_weights=True, after_engine=None, coalesce=1, share_from=None,
-                 ragged=0.75, predict_rows=True, area_frames=None, cmvn=None):
+                 ragged=0.75, predict_rows=True, area_frames=None, cmvn=None, copy_threads=0):
         """``model``: a CassNAT holding the parameters; ``batch`` x ``frames``: the largest single batch a pipeline must take.
         The pipelines of one GPU share ONE device copy of the packed weights (``cn_model_create_shared``): the first engine
         packs them - or, with ``with_weights=False`` + ``after_engine(engine)`` (multi-GPU start-up), receives them by RCCL
@@ -105,8 +135,12 @@ class DecodePipelines:
         per pass.  ``share_from``: an engine of the same model whose device copy of the weights ALL pipelines of this object use.
         ``cmvn`` = (mean, std) float64 arrays: the batches arrive RAW (a SpeechDataset with ``device_cmvn``) and the global CMVN is
         applied on the device right behind the host-to-device copy (``hip.cmvn_``: the reference's float64 arithmetic bit for bit)
-        - the loader's float64 passes over the features were three quarters of its time."""
+        - the loader's float64 passes over the features were three quarters of its time.
+        ``copy_threads`` > 1: the archive rows of a pass of ``PackedBatch``es are copied into page-locked memory by that many host
+        threads (inside ``cn_host_gather``) - what ``--load_data_workers`` means on the packed reader path."""
         self.model = model
+        self.copy_threads = max(0, int(copy_threads))
+        self._packed = [{} for _ in range(max(1, int(n_pipelines)))]  # per pipeline: packed-pass staging buffers by slot
         self.cmvn = None if cmvn is None else (np.ascontiguousarray(cmvn[0], dtype=np.float64), np.ascontiguousarray(cmvn[1], dtype=np.float64))
         self._cmvn_dev = {}
         self.n = max(1, int(n_pipelines))
@@ -262,7 +296,7 @@ class DecodePipelines:
             f = nxt[0]
             T = int(f.shape[1])
             hi, lo = max(tmax, T), min(tmin, T)
-            ok = (tuple(f.shape[2:]) == tuple(f0.shape[2:]) and f.dtype == f0.dtype and nxt[1].dtype == items[0][1].dtype
+            ok = (type(f) is type(f0) and tuple(f.shape[2:]) == tuple(f0.shape[2:]) and f.dtype == f0.dtype and nxt[1].dtype == items[0][1].dtype
                   and lo >= self.ragged * hi and self.fits(rows + int(f.shape[0]), hi))
             if ok and ahead.acquire(blocking=False):
                 items.append(nxt)
@@ -276,9 +310,70 @@ class DecodePipelines:
         state["next"] += len(items)
         return i, items
 
+    def _stage_packed(self, k, slot, items, pad):
+        """A pass of ``PackedBatch``es: every utterance's archive rows go back to back into this slot's page-locked buffer (a
+        straight copy out of the memory map; with ``copy_threads`` the utterances are dealt over helper threads), ONE DMA takes them
+        to the device, and ``hip.unpack_rows`` spreads them over the padded merged batch - frames past an utterance's length get
+        the padding value, and the global CMVN (float64, the dataset's arithmetic) is applied on the way when the pipelines have
+        the statistics.  No padded batch ever exists on the host."""
+        on_gpu, device = self._on_gpu, self._device
+        batches = [x[0] for x in items]
+        rows = sum(b.shape[0] for b in batches)
+        tmax = max(b.shape[1] for b in batches)
+        F = batches[0].shape[2]
+        if not on_gpu:  # CPU rehearsal of the host logic: the collated tensors themselves
+            feats = torch.full((rows, tmax, F), float(pad))
+            o = 0
+            for b in batches:
+                feats[o:o + b.shape[0], : b.shape[1]] = b.padded(pad, self.cmvn)
+                o += b.shape[0]
+            return feats, torch.cat([x[1] for x in items], 0)
+        dev_ = torch.device("cuda", device)
+        views = [v for b in batches for v in b.views]
+        lens = [n for b in batches for n in b.lens]
+        total = sum(lens)
+        bufs = self._packed[k].get(slot)
+        cap = max(total, self.max_batch * self.frames_cap)
+        if bufs is None or bufs["cap"] < total or bufs["F"] != F or bufs["utts"] < rows:
+            utts = max(rows, self.max_utts)
+            bufs = {"cap": cap, "F": F, "utts": utts,
+                    "host": torch.empty(cap * F, dtype=torch.float32, pin_memory=True),
+                    "dev": torch.empty(cap * F, dtype=torch.float32, device=dev_),
+                    # per utterance: row offset, frames, float32 ratio (as int32 bits) - one small DMA
+                    "meta_h": torch.empty(3 * utts, dtype=torch.int32, pin_memory=True),
+                    "meta_d": torch.empty(3 * utts, dtype=torch.int32, device=dev_),
+                    "out": torch.empty(max(rows * tmax, self.max_batch * self.frames_cap) * F, dtype=torch.float32, device=dev_)}
+            self._packed[k][slot] = bufs
+        if bufs["out"].numel() < rows * tmax * F:
+            bufs["out"] = torch.empty(rows * tmax * F, dtype=torch.float32, device=dev_)
+        offs = np.zeros(rows, np.int64)
+        np.cumsum(lens[:-1], out=offs[1:])
+        from . import hip
+
+        # one GIL-free call copies the pass's rows out of the page cache (numpy's slice assignment holds the GIL: the two pipelines'
+        # threads took turns); copy_threads > 1 deals the utterances over that many host threads inside the call
+        hip.host_gather(bufs["host"].data_ptr(), views, max(1, self.copy_threads))
+        meta = bufs["meta_h"].numpy()
+        utts = bufs["utts"]
+        meta[:rows] = offs
+        meta[utts:utts + rows] = lens
+        meta[2 * utts:2 * utts + rows] = torch.cat([x[1] for x in items], 0).numpy().view(np.int32)
+        bufs["dev"][: total * F].copy_(bufs["host"][: total * F], non_blocking=True)
+        bufs["meta_d"].copy_(bufs["meta_h"], non_blocking=True)
+        feats = bufs["out"][: rows * tmax * F].view(rows, tmax, F)
+        stats = (None, None)
+        if self.cmvn is not None:
+            stats = self._cmvn_dev.get(device)
+            if stats is None:
+                stats = self._cmvn_dev[device] = (torch.from_numpy(self.cmvn[0]).to(dev_), torch.from_numpy(self.cmvn[1]).to(dev_))
+        hip.unpack_rows(bufs["dev"], bufs["meta_d"][:utts], bufs["meta_d"][utts:2 * utts], feats, pad, stats[0], stats[1])
+        return feats, bufs["meta_d"][2 * utts:2 * utts + rows].view(torch.float32)
+
     def _stage_inputs(self, k, slot, items, pad):
         """The merged input of a pass: the batches one after the other, padded to the longest with padding frames, in a buffer
         of the pipeline's full capacity (two of them: two passes in flight), allocated at the first merged pass."""
+        if isinstance(items[0][0], PackedBatch):
+            return self._stage_packed(k, slot, items, pad)
         on_gpu, device = self._on_gpu, self._device
         dev_ = torch.device("cuda", device) if on_gpu else None
         f0, r0 = items[0][0], items[0][1]
@@ -397,7 +492,7 @@ class DecodePipelines:
                 p.frames = [int(x[0].shape[1]) for x in p.items]
                 p.ticket = None
                 t_ = time.perf_counter()
-                if len(p.items) == 1 and self.cmvn is None:  # (raw batches are normalised in the staging buffer, alone or not)
+                if len(p.items) == 1 and self.cmvn is None and not isinstance(p.items[0][0], PackedBatch):  # (raw / packed batches go through the staging buffer, alone or not)
                     p.feats, p.ratio = p.items[0][0], p.items[0][1]
                 else:
                     cs = self._copy_streams[k]

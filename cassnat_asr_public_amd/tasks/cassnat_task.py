@@ -197,21 +197,32 @@ class CassNATTask(BaseTask):
         # global CMVN on the device, behind the host-to-device copy (the reference's float64 arithmetic bit for bit: hip.cmvn_), when
         # nothing else sits between the archive and the batch: the loader then moves raw float32 rows and nothing more
         ds = getattr(self.test_loader, "dataset", None)
-        dev_cmvn = bool(ds is not None and getattr(ds, "use_cmvn", False) and hasattr(ds, "can_defer_cmvn") and ds.can_defer_cmvn()
-                        and getattr(self.test_loader, "num_workers", 0) == 0 and int(getattr(args, "hip_device_cmvn", 1)))
+        # The packed reader (pipeline.PackedBatch): nothing but a copy sits between the archive and the device - the utterances'
+        # rows go from the memory map of the .ark into page-locked memory as they are, a pass at a time, and padding + CMVN happen
+        # on the device.  It applies to the shipped configuration (float32 archives, no splicing, no frame skipping) and replaces
+        # the DataLoader altogether - its worker PROCESSES had to pickle every batch through shared memory (8.5k utt/s and nine
+        # seconds to the first batch with the recipes' `--load_data_workers 4`); that flag now sets the number of copy THREADS.
+        defer_ok = bool(ds is not None and hasattr(ds, "can_defer_cmvn") and ds.can_defer_cmvn() and int(getattr(args, "hip_device_cmvn", 1)))
+        packed = bool(defer_ok and int(getattr(args, "hip_packed_reader", 1)) and hasattr(self.test_loader, "batch_sampler"))
+        dev_cmvn = bool(defer_ok and getattr(ds, "use_cmvn", False) and (packed or getattr(self.test_loader, "num_workers", 0) == 0))
         if dev_cmvn:
             ds.device_cmvn = True
         try:
-            return self._decode_pipelined_run(args, n_pipes, results, batch_time, progress, sos, (ds.mean, ds.std) if dev_cmvn else None)
+            return self._decode_pipelined_run(args, n_pipes, results, batch_time, progress, sos, (ds.mean, ds.std) if dev_cmvn else None, packed)
         finally:
             if dev_cmvn:
                 ds.device_cmvn = False
 
-    def _decode_pipelined_run(self, args, n_pipes, results, batch_time, progress, sos, cmvn):
-        from ..pipeline import DecodePipelines
+    def _decode_pipelined_run(self, args, n_pipes, results, batch_time, progress, sos, cmvn, packed=False):
+        from ..data import kaldi_io
+        from ..pipeline import DecodePipelines, PackedBatch
 
-        first = next(iter(self.test_loader))
-        max_frames = max(getattr(args, "hip_max_frames", 4096), first[1].shape[1])
+        ds = getattr(self.test_loader, "dataset", None)
+        if packed:
+            first_len = max(kaldi_io.mat_rows(ds._items[i][1]) for i in list(self.test_loader.batch_sampler)[0])
+        else:
+            first_len = next(iter(self.test_loader))[1].shape[1]
+        max_frames = max(getattr(args, "hip_max_frames", 4096), first_len)
         # consecutive batches share an engine pass while they fit the workspace area (hip_coalesce batches of batch_size x 1024
         # frames) and their frame counts are within hip_ragged of each other; passes are filled by area, not by a batch count
         # ... and the pipelines' engines hold their own packed weights and CMVN statistics: a changed parameter (load_state_dict,
@@ -220,30 +231,38 @@ class CassNATTask(BaseTask):
 
         cmvn_id = None if cmvn is None else hashlib.sha1(np.ascontiguousarray(cmvn[0]).tobytes() + np.ascontiguousarray(cmvn[1]).tobytes()).hexdigest()
         key = (n_pipes, args.batch_size, max_frames, int(getattr(args, "hip_coalesce", 10)), float(getattr(args, "hip_ragged", 0.75)),
-               cmvn_id, self.model.weights_key())
+               cmvn_id, self.model.weights_key(), packed, int(getattr(args, "load_data_workers", 0)) if packed else 0)
         pipes = getattr(self, "_pipes", None)
         if pipes is None or self._pipes_key != key:  # (kept for further decode() calls on this task: engines, threads, streams)
             if pipes is not None:
                 pipes.close()
             pipes = DecodePipelines(self.model, n_pipes, args.batch_size, max_frames, with_weights=(self.rank == 0),
                                     after_engine=(lambda e: cdist.broadcast_weights(e, src=0)) if self.world > 1 else None,
-                                    coalesce=-max(1, key[3]), ragged=key[4], cmvn=cmvn)
+                                    coalesce=-max(1, key[3]), ragged=key[4], cmvn=cmvn, copy_threads=key[-1])
             self._pipes, self._pipes_key = pipes, key
         stats0 = dict(pipes.stats)
         meta, frames, i, end = {}, 0, -1, time.time()
 
         def batches():
+            if packed:  # the loader's batches (same utterances, same order) as views into the archives' memory maps
+                for j, idx in enumerate(self.test_loader.batch_sampler):
+                    items = [ds._items[i] for i in idx]
+                    pb = PackedBatch([kaldi_io.load_mat_view(spec) for _, spec, _ in items])
+                    # (utt2diff reads the width of the PADDED label row, src/tasks/cassnat_task.py:358-360)
+                    meta[j] = ([u for u, _, _ in items], [None] * len(items), pb.shape[0] * pb.shape[1], max(len(t) for _, _, t in items))
+                    yield pb, pb.ratios(), j
+                return
             for j, (utt_list, feats, labels, feat_sizes, label_sizes) in enumerate(self.test_loader):
-                meta[j] = (utt_list, labels, int(feats.shape[0] * feats.shape[1]))
+                meta[j] = (utt_list, labels, int(feats.shape[0] * feats.shape[1]), int(labels.shape[1]))
                 yield feats, feat_sizes, j
 
         table = np.array([self.vocab.index2word[k] for k in range(self.vocab.n_words)], dtype=object)
         for i, (toks, lens), _scores in pipes.decode(batches(), args, sos=sos, as_lists=False):
-            utt_list, labels, nfr = meta.pop(i)
+            utt_list, labels, nfr, lab_width = meta.pop(i)
             frames += nfr
             words = hyps_to_words_batch(toks, lens, self.vocab, args.padding_idx, table)
-            for utt, w, n, lab in zip(utt_list, words, lens.tolist(), labels):
-                results[utt] = (w, n - len(lab))
+            for utt, w, n in zip(utt_list, words, lens.tolist()):
+                results[utt] = (w, n - lab_width)
             batch_time.update(time.time() - end)
             end = time.time()
             if i % args.print_freq == 0 and self.rank == 0:

@@ -42,6 +42,10 @@ class DecodeParser(object):
                        help="1: form the batches from the utterance list sorted by length (frame counts from <scp dir>/utt2num_frames "
                             "or the ark headers) instead of file order - less padding per batch, neighbours that merge well; the "
                             "result file stays in file order.  0 (default): the reference's batches")
+        p.add_argument("--hip_packed_reader", default=1, type=int,
+                       help="1 (default): the pipelined decoder reads the utterances' rows straight from the memory-mapped archives into "
+                            "page-locked memory, a pass at a time, and pads / normalises on the device (float32 archives without splicing "
+                            "or frame skipping; --load_data_workers then sets the number of copy threads); 0: the DataLoader's collated batches")
         p.add_argument("--hip_device_cmvn", default=1, type=int,
                        help="1 (default): the pipelined decoder applies the global CMVN on the device, behind the host-to-device copy "
                             "(float64 arithmetic, bit-identical to the dataset's), when the dataset neither splices nor skips frames "

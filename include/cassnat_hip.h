@@ -391,6 +391,15 @@ int cn_op_gemm_fp8(const void* a_bf16_dev, int32_t lda, const float* w_host, con
  * float32 at collate) bit for bit; later frames (padding) are left alone.  mean / std: F doubles on the device. */
 int cn_op_cmvn(float* feats_dev, const int32_t* len_dev, const double* mean_dev, const double* std_dev, int32_t B, int32_t T, int32_t F,
                void* stream);
+/* The reader's collate on the device (SuperviseLoader.collate_fn, src/data/speech_loader.py:327-356; global CMVN :109-115, 147-149):
+ * the utterances of an engine pass arrive packed - archive rows back to back, utterance r at row off_dev[r], len_dev[r] frames - and
+ * are spread over the padded batch out_dev (rows, T, F): frames past an utterance's length are `pad`; with statistics (float64, [F])
+ * a frame becomes float((double(x) - mean) / std), the dataset's arithmetic bit for bit. */
+int cn_op_unpack_rows(const float* packed_dev, const int32_t* off_dev, const int32_t* len_dev, float* out_dev, int32_t rows, int32_t T,
+                      int32_t F, float pad, const double* mean_dev, const double* std_dev, void* stream);
+/* host side of the same reader: n byte ranges (an utterance's rows in the memory map of its archive) copied back to back into a
+ * staging buffer (dst + dst_offsets[i]) by one GIL-free call; threads > 1 deals them over that many host threads */
+int cn_host_gather(void* dst, const uint64_t* src_ptrs, const uint64_t* dst_offsets, const uint64_t* nbytes, int32_t n, int32_t threads);
 int cn_op_quantize_fp8(const void* src_bf16_dev, int32_t ld, void* dst_dev, int32_t M, int32_t K, float scale, void* stream);
 /* generator tail of the autoregressive step (src/models/transformer.py:48-51, 199-200): log_softmax(logits / T) and its per-row
  * top-k (sorted descending, ties: lower index) in one pass; the logits [M][V] are left untouched */

@@ -901,3 +901,24 @@ def test_generator_argmax_ties_go_to_the_lower_index(M, V):
     top2 = torch.topk(ref, 2, dim=-1).values
     clear = (top2[:, 0] - top2[:, 1]) > 1e-4
     assert (a[clear] == ref.argmax(-1)[clear].int()).all()
+
+
+@pytest.mark.parametrize("F,with_cmvn", [(80, True), (80, False), (7, True), (83, False)])
+def test_unpack_rows_is_collate_and_cmvn_on_the_device(F, with_cmvn):
+    """cn_op_unpack_rows: the packed archive rows of a pass -> the padded batch, bit for bit what SuperviseLoader.collate_fn
+    (src/data/speech_loader.py:327-356) builds from the dataset's float64-normalised matrices (:109-115, 147-149)."""
+    from cassnat_asr_public_amd.pipeline import PackedBatch
+
+    rng = np.random.default_rng(F)
+    lens = [61, 1, 33, 64, 32, 47, 96]
+    T = 96
+    views = [(rng.standard_normal((n, F)) * 3 + 0.5).astype(np.float32) for n in lens]
+    mean, std = rng.standard_normal(F), rng.random(F) + 0.5
+    want = PackedBatch(views).padded(0.0, (mean, std) if with_cmvn else None).numpy()
+    packed = torch.from_numpy(np.concatenate(views, 0)).cuda()
+    off = torch.tensor(np.concatenate([[0], np.cumsum(lens)[:-1]]), dtype=torch.int32, device="cuda")
+    ln = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    out = torch.full((len(lens), T, F), 7.0, device="cuda")
+    hip.unpack_rows(packed, off, ln, out, 0.0, torch.from_numpy(mean).cuda() if with_cmvn else None, torch.from_numpy(std).cuda() if with_cmvn else None)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), want)

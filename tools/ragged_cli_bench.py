@@ -94,11 +94,17 @@ def main():
                 "--print_freq", "100000"]
         audio_s = sum(lengths) * 0.01
         results = {}
+        # pipelined* = the packed reader (archive rows -> page-locked memory -> device, padding and CMVN on the device);
+        # *_dataloader = round 3's form (the DataLoader's collated batches, CMVN on the device); *_cmvn_in_dataset = the reference's
         for name, extra, preload in (("plain", ["--hip_pipelines", "1", "--load_data_workers", "0"], False),
                                      ("pipelined", ["--load_data_workers", "0"], False),
+                                     ("pipelined_2_copy_threads", ["--load_data_workers", "2"], False),
+                                     ("pipelined_4_loader_workers", ["--load_data_workers", "4"], False),
+                                     ("pipelined_8_copy_threads", ["--load_data_workers", "8"], False),
+                                     ("pipelined_dataloader", ["--load_data_workers", "0", "--hip_packed_reader", "0"], False),
                                      ("pipelined_cmvn_in_dataset", ["--load_data_workers", "0", "--hip_device_cmvn", "0"], False),
                                      ("pipelined_again", ["--load_data_workers", "0"], False),
-                                     ("pipelined_4_loader_workers", ["--load_data_workers", "4"], False), ("preloaded", ["--load_data_workers", "0"], True)):
+                                     ("preloaded", ["--load_data_workers", "0"], True)):
             print(f"[ragged_cli_bench] {name} ...", file=sys.stderr, flush=True)
             res = os.path.join(tmp, f"result_{name}.txt")
             task, args = make_task(base + extra + ["--result_file", res], conf)
@@ -135,6 +141,8 @@ def main():
         assert results["pipelined"] == results["plain"], "result files differ between the merged-pass decoder and the plain loop"
         assert results["preloaded"] == results["plain"] and results["pipelined_4_loader_workers"] == results["plain"]
         assert results["pipelined_cmvn_in_dataset"] == results["plain"]
+        for name in ("pipelined_2_copy_threads", "pipelined_8_copy_threads", "pipelined_dataloader", "pipelined_again"):
+            assert results[name] == results["plain"], name
         out["result_files_identical"] = True
     out.update(global_cmvn=bool(a.cmvn), utterances=a.utts, batch_size=a.batch, precision=a.precision, frames_min_max=[min(lengths), max(lengths)],
                mean_frames=round(float(np.mean(lengths)), 1), audio_seconds=round(audio_s, 1),
