@@ -652,3 +652,28 @@ def test_eight_ranks_over_gloo_write_the_one_process_result_file(tmp_path):
         expect.append(f"{utt} w{uid % 20} w{(uid // 20) % 20} w{n % 20} w{(n // 20) % 20}")
     assert one == expect
     assert eight == one
+
+
+def test_host_gather_copies_archive_rows_back_to_back(tmp_path):
+    """cn_host_gather (the host half of the packed reader; no GPU involved): read-only views into a memory-mapped archive copied
+    back to back into one buffer by a single GIL-free call, alone and dealt over several threads; and pipeline.PackedBatch's
+    shape / ratios / padded tensor against the dataset's collate."""
+    from cassnat_asr_public_amd.pipeline import PackedBatch
+
+    rng = np.random.default_rng(4)
+    mats = [(f"u{i}", rng.standard_normal((int(n), 7)).astype(np.float32)) for i, n in enumerate(rng.integers(1, 90, size=37))]
+    scp = str(tmp_path / "f.scp")
+    kaldi_io.write_ark_scp(str(tmp_path / "f.ark"), scp, mats)
+    views = [kaldi_io.load_mat_view(spec) for _, spec in kaldi_io.read_scp(scp)]
+    assert all(not v.flags.writeable and v.dtype == np.float32 for v in views)
+    want = np.concatenate([m for _, m in mats], 0)
+    for threads in (1, 3, 8, 64):
+        dst = np.full(want.shape, np.nan, np.float32)
+        offs = hip.host_gather(dst.ctypes.data, views, threads)
+        np.testing.assert_array_equal(dst, want)
+        assert offs.tolist() == np.concatenate([[0], np.cumsum([m.nbytes for _, m in mats])[:-1]]).tolist()
+    assert hip.host_gather(np.empty(4, np.float32).ctypes.data, [], 4).size == 0
+    # the batch object stands where collate's padded tensor would
+    pb = PackedBatch(views[:5])
+    utts, feats, _, ratios, _ = collate([(u, m, [1]) for u, m in mats[:5]], padding_idx=0)
+    assert pb.shape == tuple(feats.shape) and torch.equal(pb.ratios(), ratios) and torch.equal(pb.padded(0.0), feats)
