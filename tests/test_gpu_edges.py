@@ -682,3 +682,39 @@ def test_a_ticket_expires_instead_of_returning_another_passes_counts():
     with pytest.raises(hip.HipError, match="expired"):
         eng.ticket(tickets[0])
     assert eng.ticket(tickets[1]) == counts[1]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_merged_pass_without_trigger_rows_equals_separate_passes(prec):
+    """use_trigger = False (cassnat.py:469-473) through merged engine passes and the packed reader's batch objects: per batch the
+    hypotheses and scores of a pass of its own (the extractor's mask is the utterance's own frame range, the row counts carry no
+    EOS row).  Batches without a CTC token are left out: the reference itself raises on them (a scatter at index -1, :477)."""
+    from cassnat_asr_public_amd.pipeline import DecodePipelines, PackedBatch
+
+    args = synth.make_args("tiny", use_trigger=False)
+    args.hip_max_batch, args.hip_max_frames = 4, 96
+    state = synth.make_state(args, seed=0, gain=2.0)
+    model = build(args, state, capture=False, prec=prec)
+    rng = np.random.default_rng(33)
+    shapes = [(3, 61), (4, 64), (2, 62), (3, 65), (4, 57), (2, 41), (3, 44), (4, 42), (3, 96), (2, 90), (4, 77), (3, 80)]
+    data = []
+    for k, (B, T) in enumerate(shapes):
+        lens = sorted((int(x) for x in rng.integers(T // 2, T + 1, size=B)), reverse=True)
+        lens[0] = T
+        data.append(synth.make_feats(B, T, 80, lengths=lens, seed=2100 + k))
+    want = _separate(model, args, data)
+    assert all(len(h) >= 2 for hyps, _ in want for h in hyps)
+    items = [(torch.from_numpy(f), torch.from_numpy(s), k) for k, (f, s) in enumerate(data)]
+    # the same batches as the packed reader hands them over: unpadded rows per utterance
+    packed = []
+    for k, (f, s) in enumerate(data):
+        T = f.shape[1]
+        pb = PackedBatch([np.ascontiguousarray(f[b, : int(round(float(s[b]) * T))]) for b in range(f.shape[0])])
+        assert pb.shape == f.shape and torch.equal(pb.ratios(), torch.from_numpy(s))
+        packed.append((pb, pb.ratios(), k))
+    for batches in (items, packed):
+        with DecodePipelines(model, 2, 4, 96, coalesce=5, ragged=0.5, copy_threads=2) as pipes:
+            got = list(pipes.decode(batches, args, sos=1))
+            assert pipes.stats["merged_ragged"] >= 2, pipes.stats
+        for (tag, hyps, scores), (wh, ws) in zip(got, want):
+            assert hyps == wh and list(scores) == ws, (tag, shapes[tag])
