@@ -86,8 +86,11 @@ __device__ long long attn_stamps[8];
 // (second launch bound = waves per SIMD the register budget must allow: the resident 8-wave form runs two workgroups per CU - one
 // loading while the other computes - which needs <= 128 VGPRs; the allocator otherwise lets the seldom-taken full mask path
 // push it to 132 and halves the occupancy: -2 % on the whole benchmark)
+// (split-bf16, the staged 4-wave form - the split-bf16 engine's encoder self attention: left alone the allocator takes 300 registers
+// = one wave per SIMD = ONE 256-thread workgroup per CU, with two barriers and a global load round trip per key tile and nothing to
+// overlap them with; bounded to 256 registers two workgroups share a CU)
 template <typename T, int NW, bool RES, bool REL = false>
-__global__ __launch_bounds__(64 * NW, (RES && NW == 8) ? 4 : 1) void attention_kernel(AttnParams p) {
+__global__ __launch_bounds__(64 * NW, (RES && NW == 8) ? 4 : ((__is_same(T, split_t) && NW == 4 && !REL) ? 2 : 1)) void attention_kernel(AttnParams p) {
     typedef AttnCfg<T> Cfg;
     typedef typename Frag<T>::type frag_t;
     constexpr bool SPLIT = __is_same(T, split_t);
