@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-predict", action="store_true", help="decode every pass with the mid-pass host sync on the row count (round 2's form)")
     ap.add_argument("--ragged", type=float, default=0.75, help="--hip_ragged of the CLI for the ragged leg (its default)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on the host threads of the cpu_baseline leg")
+    ap.add_argument("--host-timeline", action="store_true", help="stderr: what the pipelines' host threads did when, in the timed region")
     ap.add_argument("--plan", default="", help="explicit pass sizes of the timed run, e.g. 8,8,4 (default: equal shares)")
     a = ap.parse_args()
 
@@ -190,10 +191,18 @@ def main():
     # of them the event traffic itself costs a few percent of throughput)
     for e in engines[:1]:
         e.profile_begin(ROOF_TAGS)
+    if a.host_timeline:
+        pipes.timeline = []
     t0 = time.perf_counter()
     run_steps(a.steps)
+    t_run = time.perf_counter()
     fence()
     elapsed = time.perf_counter() - t0
+    if a.host_timeline and rank == 0:
+        tl, pipes.timeline = pipes.timeline, None
+        for label, k, t in sorted(tl, key=lambda x: x[2]):
+            print("%9.3f ms  %-12s %s" % ((t - t0) * 1e3, label, "" if k < 0 else "pipeline %d" % k), file=sys.stderr)
+        print("%9.3f ms  run_steps returned\n%9.3f ms  fenced" % ((t_run - t0) * 1e3, elapsed * 1e3), file=sys.stderr)
     pass_stats = {k: pipes.stats[k] - stats0[k] for k in stats0}
     if a.exit_after_timed:
         if rank == 0:

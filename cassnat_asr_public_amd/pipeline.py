@@ -94,18 +94,19 @@ class _Job:
         self.plan = plan  # explicit pass sizes, in the order they are taken (records(plan=...); bench.py --plan)
         self.lock = threading.Lock()
         self.cv = threading.Condition()
-        self.slots = {}          # index -> queue of one (tag, records, event)
+        self.slots = {}          # index of a pass's first batch -> (tags, records per batch, event, the pass's record tensor); under cv
         self.state = {"next": 0, "done": False, "err": None, "held": None}
         # batches taken but not yet consumed (bounds the device memory held by records): two passes in flight per pipeline plus
         # as many waiting for the consumer
         self.ahead = threading.Semaphore(4 * n * max(1, per_pass or coalesce) + 2)
         self.finished = threading.Semaphore(0)       # released once by every worker when it has left the job
 
-    def slot(self, i):
+    def hand_out(self, first, tags, recs, ev, whole):
+        """A drained pass goes to the consumer as ONE item (a queue per batch cost the end of a short job 10 us per batch: the
+        passes of all pipelines drain together there, and everything after them is serial host time)."""
         with self.cv:
-            if i not in self.slots:
-                self.slots[i] = queue.Queue(1)
-            return self.slots[i]
+            self.slots[first] = (tags, recs, ev, whole)
+            self.cv.notify_all()
 
 
 class _Pass:
@@ -177,9 +178,15 @@ class DecodePipelines:
         self._rows = {"ratio": None}  # row-count predictor shared by the pipelines: largest tokens-per-frame ratio seen
         self._rows_lock = threading.Lock()
         self._stats_lock = threading.Lock()
+        self.timeline = None  # a list: the workers and the consumer append (label, pipeline, perf_counter) - bench.py --host-timeline
         self.stats = {"passes": 0, "batches": 0, "predicted": 0, "missed": 0, "merged_ragged": 0,
                       # host seconds of the worker threads, by what they were doing (summed over the pipelines)
                       "s_take": 0.0, "s_stage": 0.0, "s_launch": 0.0, "s_retire_wait": 0.0}
+
+    def _mark(self, label, k=-1):
+        tl = self.timeline
+        if tl is not None:
+            tl.append((label, k, time.perf_counter()))
 
     def _bump(self, key, v):
         """The counters are shared by the worker threads: a read-modify-write on the dict is not atomic across them."""
@@ -433,6 +440,7 @@ class DecodePipelines:
             hbuf = torch.empty(rec.shape, dtype=rec.dtype, device="cpu", pin_memory=True)
             hbuf.copy_(rec, non_blocking=True)
             rec = hbuf
+        p.rec = rec
         o, p.recs = 0, []
         for nb in p.rows:
             p.recs.append(rec[o:o + nb])
@@ -448,6 +456,7 @@ class DecodePipelines:
             t_ = time.perf_counter()
             p.ev.synchronize()
             self._bump("s_retire_wait", time.perf_counter() - t_)
+            self._mark("drained", k)
         if p.ticket is not None and p.ticket >= 0:
             ymax, used = self.engines[k].ticket(p.ticket)
             self._bump("passes", 1)
@@ -462,8 +471,8 @@ class DecodePipelines:
                     p.ev.synchronize()
             else:
                 self._learn(ymax, max(p.frames))
-        for j, item in enumerate(p.items):
-            job.slot(p.first + j).put((item[2], p.recs[j], p.ev))
+        job.hand_out(p.first, [item[2] for item in p.items], p.recs, p.ev, p.rec)
+        self._mark("handed out", k)
 
     def _work(self, k, st, job):
         state, lock, ahead = job.state, job.lock, job.ahead
@@ -486,6 +495,7 @@ class DecodePipelines:
                 self._bump("s_take", time.perf_counter() - t_)
                 if got is None:
                     break
+                self._mark("taken", k)
                 p = _Pass()
                 p.first, p.items = got
                 p.rows = [int(x[0].shape[0]) for x in p.items]
@@ -512,8 +522,10 @@ class DecodePipelines:
                 n_pass += 1
                 t1_ = time.perf_counter()
                 self._bump("s_stage", t1_ - t_)
+                self._mark("staged", k)
                 self._launch(k, st, job, p)
                 self._bump("s_launch", time.perf_counter() - t1_)
+                self._mark("launched", k)
                 inflight.append(p)
                 if len(inflight) >= 2:  # two passes in flight: this one's launches are queued behind the older one's kernels
                     self._retire(k, st, job, inflight.pop(0))
@@ -547,6 +559,17 @@ class DecodePipelines:
         host tensors instead (pinned; sent by the producing pipeline on its own stream, one copy per engine pass, and complete when
         they are yielded) - what a single-GPU consumer wants, which would otherwise pay one blocking copy per batch.
         ``plan``: explicit pass sizes (batches per pass, in the order the passes are taken)."""
+        passes = self._passes(batches, args, sos, host, plan)
+        try:
+            for tags, recs, _ in passes:
+                for tag, rec in zip(tags, recs):
+                    yield tag, rec
+        finally:
+            passes.close()  # (an abandoned iterator still waits for the workers to leave the job)
+
+    def _passes(self, batches, args, sos=1, host=False, plan=None):
+        """The engine passes of ``records()`` in order, one item each: ``(tags, records per batch, the pass's whole record
+        tensor)``."""
         self._start()
         job = _Job(iter(batches), args, sos, self.n, total=len(batches) if hasattr(batches, "__len__") else None,
                    coalesce=self.coalesce, host=host, plan=list(plan) if plan else None, per_pass=64 if self.by_area else None)
@@ -554,6 +577,7 @@ class DecodePipelines:
         if not self._busy.acquire(timeout=60.0):
             raise RuntimeError("DecodePipelines.records(): the previous records() iterator was never finished or closed")
         try:
+            self._mark("job posted")
             for q in self._inbox:
                 q.put(job)
             i = 0
@@ -566,20 +590,23 @@ class DecodePipelines:
                         raise err
                     if finished:
                         break
-                    try:
-                        tag, rec, ev = job.slot(i).get(timeout=0.05)
-                    except queue.Empty:
-                        continue
                     with job.cv:
-                        job.slots.pop(i, None)
+                        got = job.slots.pop(i, None)
+                        if got is None:
+                            job.cv.wait(0.05)  # (a hand-out or a worker's error wakes it)
+                            got = job.slots.pop(i, None)
+                    if got is None:
+                        continue
+                    tags, recs, ev, whole = got
                     if ev is not None:
                         if job.host:
                             ev.synchronize()
                         else:
                             ev.wait(torch.cuda.current_stream())
-                    job.ahead.release()
-                    yield tag, rec
-                    i += 1
+                    job.ahead.release(len(tags))
+                    self._mark("yield %d" % i)
+                    yield tags, recs, whole
+                    i += len(tags)
             finally:
                 with lock:
                     state["done"] = True
@@ -587,6 +614,7 @@ class DecodePipelines:
                 for _ in range(self.n):  # every worker has left the job (its stream is drained) before the next one starts
                     if not job.finished.acquire(timeout=300.0):
                         stuck += 1
+                self._mark("workers left")
                 if stuck:
                     raise RuntimeError(f"DecodePipelines: {stuck} pipeline(s) did not leave the job within 300 s (stuck inside a device call?)")
         finally:
@@ -601,9 +629,20 @@ class DecodePipelines:
         same sequence of collectives on every rank whatever the pipelines' timing; every rank must decode the same number of
         steps."""
         if not gather:
-            for tag, rec in self.records(batches, args, sos, host=True, plan=plan):
-                hyps, scores = cdist.unpack_records(rec, as_lists=as_lists)
-                yield tag, hyps, scores
+            passes = self._passes(batches, args, sos, host=True, plan=plan)
+            try:
+                for tags, recs, whole in passes:  # one unpacking per engine pass, a batch is a slice of it
+                    (toks, lens), scores = cdist.unpack_records(whole, as_lists=False)
+                    o = 0
+                    for tag, rec in zip(tags, recs):
+                        nb = rec.shape[0]
+                        if as_lists:
+                            yield tag, [toks[b, : lens[b]].tolist() for b in range(o, o + nb)], scores[o:o + nb]
+                        else:
+                            yield tag, (toks[o:o + nb], lens[o:o + nb]), scores[o:o + nb]
+                        o += nb
+            finally:
+                passes.close()
             return
         group = max(1, int(gather_every or self.coalesce))
         pending = []
