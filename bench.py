@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--frames", type=int, default=1000)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8", "bf16x3"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8", "bf16x3", "fp16"],
                     help="fp8: BASELINE config 5's mode - the bf16 engine with the encoder layers' products on the e4m3fn MFMA")
     ap.add_argument("--fp8-scope", default="all", help="--precision fp8: which products take e4m3 operands (--hip_fp8_scope of the CLI)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -285,7 +285,7 @@ def main():
     # ---- extra (never `value`; N = 1 only): what decode_asr meets - a length-sorted list of batches of DIFFERENT frame counts
     # (300..1500, every batch padded to its own longest utterance), merged into engine passes by workspace area
     ragged_leg = None
-    if not a.no_ragged_leg and world == 1 and not dist_on and a.precision in ("bf16", "bf16x3"):
+    if not a.no_ragged_leg and world == 1 and not dist_on and a.precision in ("bf16", "bf16x3", "fp16"):
         rng = np.random.default_rng(99)
         n_b = 192  # 6144 utterances: the size of a test set (dev-clean + dev-other); neighbouring batches of the sorted list differ by ~6 frames
         lens = np.sort(rng.integers(300, 1501, size=n_b * B))[::-1]
@@ -331,7 +331,7 @@ def main():
     audio_s = utts * T * 0.01
     flops = flops_per_batch(B, T, F, U, args)
     # (the non-scaled fp8 MFMA of gfx950 runs at the bf16 rate: same peak)
-    peak = PEAK_BF16_DENSE_TFLOPS if a.precision in ("bf16", "fp8", "bf16x3") else 157.3
+    peak = PEAK_BF16_DENSE_TFLOPS if a.precision in ("bf16", "fp8", "bf16x3", "fp16") else 157.3
 
     def merged(table, tags):  # one row for several profile tags (the chain kernel's encoder-side + decoder-side launches)
         rows = [table[t] for t in tags if table.get(t) and table[t].get("count")]
@@ -517,6 +517,16 @@ def main():
                                  "[bf16x3-*]: 0 arg-max flips, 1e-5 logit error, hypotheses token-exact); `hyp_agreement` = whole "
                                  "hypotheses of the benchmark batch equal to the fp32 CPU oracle's")
 
+    # the bf16 engine's kernels with IEEE half operands (libcassnat_hip_f16.so, csrc/common.h): the same matrix pipe at the same
+    # rate, operand roundings 8 x smaller - CTC log-posteriors within north_star's 1e-3 of the fp32 reference
+    # (tests/test_gpu_pipeline.py::test_fp16_engine_meets_the_logit_tolerance); range +-65504
+    fp16_engine = None
+    if world == 1 and not a.no_parity_engine and a.precision == "bf16":
+        fp16_engine = time_engine("fp16")
+        fp16_engine["speedup_over_value"] = round(fp16_engine["value"] / value, 3)
+        fp16_engine["note"] = ("half-precision (11-bit) MFMA operands in the bf16 engine's kernels, fp32 accumulation / residual stream / "
+                               "LayerNorm / softmax as there; `ctc_argmax_vs_cpu`: its flips against the fp32 CPU oracle by margin")
+
     # BASELINE configs[4]'s arithmetic on this workload: the fp8 engine (e4m3 feed-forward products inside the chain kernel and an
     # e4m3 conv front-end on the block-scaled K = 64 MFMA) through the same pipelines - a throughput form without a parity
     # claim (its agreement with the fp32 reference is measured by tests/test_gpu_pipeline.py::test_config5_fp8_encoder_products)
@@ -555,7 +565,7 @@ def main():
         # algorithmic FLOP/s of the whole path against the chip's peak for this precision's products (bf16x3: three MFMAs each)
         "mfma_frac_end_to_end": round(flops / B * value / (world * peak * 1e12 / (3.0 if a.precision == "bf16x3" else 1.0)), 5),
         "roofline": roofline, "roofline_conv2": roofline_conv2, "cpu_baseline": cpu, "parity_engine": parity_engine,
-        "fp32_engine": fp32_engine, "fp8_engine": fp8_engine, "one_batch_per_pass": uncoalesced, "ragged_set": ragged_leg, "steady_state": steady,
+        "fp32_engine": fp32_engine, "fp16_engine": fp16_engine, "fp8_engine": fp8_engine, "one_batch_per_pass": uncoalesced, "ragged_set": ragged_leg, "steady_state": steady,
         "stage_ms": stage_ms,
         "weight_blob_mb": round(blob_bytes / 1e6, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
     }

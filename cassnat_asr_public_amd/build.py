@@ -1,4 +1,5 @@
-"""Builds libcassnat_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Builds libcassnat_hip.so - and libcassnat_hip_f16.so, the same sources with half-precision MFMA operands (csrc/common.h:
+-DCN_OP16_F16; the engine `--hip_precision fp16`) - in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
 import os
 import shutil
 import subprocess
@@ -7,6 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcassnat_hip.so")
+LIB_F16 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcassnat_hip_f16.so")
 SOURCES = ["gemm.hip", "fbank.hip", "conv2.hip", "conv1.hip", "rowops.hip", "attention.hip", "ctc_align.hip", "ctc_beam.hip", "fused.hip", "fused_x3.hip", "genmax.hip", "proj_x3.hip", "conformer.hip", "chain.hip", "ast.hip", "model.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # conv1.hip: its matrix-core kernel converts every accumulator right behind the MFMAs - with the results in VGPRs (not AGPRs) the
@@ -54,6 +56,15 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir=None):
     return lib
 
 
+def build_f16(force=False, verbose=False):
+    """The second product library: every source once more with -DCN_OP16_F16 (objects in csrc/build_f16)."""
+    return build(force=force, verbose=verbose, extra_flags=["-DCN_OP16_F16"], lib=LIB_F16, objdir=os.path.join(CSRC, "build_f16"))
+
+
+def build_all(force=False, verbose=False):
+    return build(force=force, verbose=verbose), build_f16(force=force, verbose=verbose)
+
+
 def experiments_lib(extra_flags=(), tag="exp"):
     """The -DCASSNAT_EXPERIMENTS build of the library (csrc/common.h: cn_exp_env) for the measurement tools: reads the CASSNAT_*
     experiment switches from the environment, which the product library does not.  Built into ab/ (git-ignored; travels to the
@@ -68,4 +79,5 @@ if __name__ == "__main__":
     if "--experiments" in sys.argv:
         print(experiments_lib())
         sys.exit(0)
-    print(build(force="--force" in sys.argv, verbose=True))
+    for path in build_all(force="--force" in sys.argv, verbose=True):
+        print(path)

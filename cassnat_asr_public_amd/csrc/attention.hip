@@ -448,9 +448,9 @@ __global__ __launch_bounds__(64 * NW, (RES && NW == 8) ? 4 : ((__is_same(T, spli
                             cat[4] = r2[0]; cat[5] = r2[1]; cat[6] = r2[2]; cat[7] = r2[3];
                             vf[pl_] = __builtin_bit_cast(bf16x8, cat);
                         }
-                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], ph, o_acc[d], 0, 0, 0);
-                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pl, o_acc[d], 0, 0, 0);
-                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], ph, o_acc[d], 0, 0, 0);
+                        o_acc[d] = CN_MFMA16(vf[1], ph, o_acc[d], 0, 0, 0);
+                        o_acc[d] = CN_MFMA16(vf[0], pl, o_acc[d], 0, 0, 0);
+                        o_acc[d] = CN_MFMA16(vf[0], ph, o_acc[d], 0, 0, 0);
                     }
                 }
             } else if constexpr (sizeof(T) == 2) {
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64 * NW, (RES && NW == 8) ? 4 : ((__is_same(T, spli
                         cat[0] = r1[0]; cat[1] = r1[1]; cat[2] = r1[2]; cat[3] = r1[3];
                         cat[4] = r2[0]; cat[5] = r2[1]; cat[6] = r2[2]; cat[7] = r2[3];
                         const bf16x8 vf = __builtin_bit_cast(bf16x8, cat);
-                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o_acc[d], 0, 0, 0);
+                        o_acc[d] = CN_MFMA16(vf, pb, o_acc[d], 0, 0, 0);
                     }
                 }
             } else {

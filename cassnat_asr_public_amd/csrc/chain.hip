@@ -409,7 +409,7 @@ __device__ __forceinline__ void ch_layernorm_pack8(f32x16 (&acc)[8], unsigned ta
 //     u+7's slot; those of odd positions only set M0 (CH_PRE_BE / CH_PRE_BO).
 // The compiler pads its own MFMA -> vector-read sequences with wait states (s_nop 11 for this MFMA) but cannot see
 // into asm: a block whose accumulators the compiler may touch next ends with them itself (CH_DRAIN).
-#define CH_MF "v_mfma_f32_32x32x16_bf16 "
+#define CH_MF CN_MFMA16_ASM
 #define CH_DRAIN "s_nop 13\n\t"
 #define CH_NODRAIN ""
 #ifdef CH_EXP_NO_READ  // timing experiment: the blocks without their fragment reads (stale registers: wrong results)
@@ -1200,13 +1200,7 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
 }
 
 // ---- host-side packing --------------------------------------------------------------------------------------
-static inline uint16_t ch_bf16_bits(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+static inline uint16_t ch_bf16_bits(float f) { return cn_host_op16(f); }  // (the engine's 16-bit operand: common.h)
 
 size_t chain_stream_units(int has_outproj, int dff, int tail_n, int f8) {
     return (has_outproj ? 8 : 0) + (f8 ? 1 : 2) * (dff / 32) + tail_n / 32;

@@ -14,9 +14,55 @@ static inline const char* cn_exp_env(const char* name) { return getenv(name); }
 static inline const char* cn_exp_env(const char*) { return nullptr; }
 #endif
 
-typedef __bf16 bf16;
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// The 16-bit MFMA operand of the fast engine.  These sources are built into TWO libraries: libcassnat_hip.so, where it is bfloat16
+// (the engines "bf16" and "fp8", beside the split-bf16 and fp32 engines), and libcassnat_hip_f16.so (-DCN_OP16_F16), where it is
+// IEEE half precision - 11 significant bits instead of 8 on the same matrix pipe at the same rate (v_mfma_f32_32x32x16_f16), the
+// engine "fp16": the operand roundings are 8 x smaller (CTC log-posteriors within 1e-3 of the fp32 reference on the benchmark model,
+// where bfloat16 operands give 5e-3), the price is the range (|v| <= 65504: LayerNorm outputs, ReLU activations, softmax
+// probabilities, Q / K / V and weights of a model of this family sit many orders below it; the residual stream, every
+// accumulator, LayerNorm and softmax stay fp32 in both).  Everything below - layouts, LDS images, fragment maps, schedules - is
+// the same for both: the kernels name the type `bf16` throughout; in the -DCN_OP16_F16 build that name IS the half type.
+#ifdef CN_OP16_F16
+typedef _Float16 op16;
+#define CN_MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define CN_MFMA16_ASM "v_mfma_f32_32x32x16_f16 "
+#define CN_OP16_NAME "fp16"
+#else
+typedef __bf16 op16;
+#define CN_MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define CN_MFMA16_ASM "v_mfma_f32_32x32x16_bf16 "
+#define CN_OP16_NAME "bf16"
+#endif
+typedef op16 bf16;
+typedef op16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef op16 bf16x8 __attribute__((ext_vector_type(8)));
+// host side: fp32 -> the operand's 16 bits, round to nearest even (weight packing)
+static inline uint16_t cn_host_op16(float f) {
+#ifdef CN_OP16_F16
+    const _Float16 h = (_Float16)f;  // (IEEE conversion: overflow gives infinity - a weight of a usable model is nowhere near)
+    uint16_t b;
+    __builtin_memcpy(&b, &h, 2);
+    return b;
+#else
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+#endif
+}
+static inline float cn_host_op16_value(uint16_t b) {
+#ifdef CN_OP16_F16
+    _Float16 h;
+    __builtin_memcpy(&h, &b, 2);
+    return (float)h;
+#else
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+#endif
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -78,9 +124,9 @@ template <> struct Frag<split_t> {
     static constexpr int ELEMS = 8;
 };
 __device__ __forceinline__ f32x16 mfma_frag(const split_frag& a, const split_frag& b, f32x16 c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);  // (small terms first)
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+    c = CN_MFMA16(a.lo, b.hi, c, 0, 0, 0);  // (small terms first)
+    c = CN_MFMA16(a.hi, b.lo, c, 0, 0, 0);
+    c = CN_MFMA16(a.hi, b.hi, c, 0, 0, 0);
     return c;
 }
 // v -> (hi, lo); four consecutive elements -> 8 bytes of hi and 8 bytes of lo
@@ -98,7 +144,7 @@ __device__ __forceinline__ f32x16 mfma_frag(i64x2 a, i64x2 b, f32x16 c) {
     return c;
 }
 __device__ __forceinline__ f32x16 mfma_frag(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    return CN_MFMA16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x16 mfma_frag(f32x4 a, f32x4 b, f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);

@@ -317,9 +317,9 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict
                 f32x16 acc;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[nt], xf, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf, acc, 0, 0, 0);
+                acc = CN_MFMA16(wl[nt], xf, acc, 0, 0, 0);
+                acc = CN_MFMA16(wf[nt], xl, acc, 0, 0, 0);
+                acc = CN_MFMA16(wf[nt], xf, acc, 0, 0, 0);
                 // registers 0..15 of lane half h = channels 32 nt + 16 h + (0..15) of cell l31
                 if constexpr (OUT8) {  // ReLU + saturation, e4m3, one 16-byte piece
                     unsigned w[4];

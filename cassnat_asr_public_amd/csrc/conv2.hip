@@ -61,7 +61,7 @@ constexpr int C2_LIN8_KSTEPS = 40;  // K steps (of 128 bytes) of the e4m3 linear
 
 #define C2_STR2(x) #x
 #define C2_STR(x) C2_STR2(x)
-#define C2_MF "v_mfma_f32_32x32x16_bf16 "
+#define C2_MF CN_MFMA16_ASM
 #define C2_DMA(src, dst)                                                                              \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),          \
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)

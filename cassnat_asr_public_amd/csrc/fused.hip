@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnParams p) {
     // tile's group 0 block does issue).  Every wait is a literal vmcnt on the wave's own queue.
 #define FF_STR2(x) #x
 #define FF_STR(x) FF_STR2(x)
-#define FF_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define FF_MFMA(a, b, c) c = CN_MFMA16(a, b, c, 0, 0, 0)
 #define FF_REFILL_W1(g) { _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
         FF_DMA(w1 + ((long long)tnext * 16 + 4 * (g) + j) * 64, 4 * (g) + j); }
 #define FF_REFILL_W2(g) { _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
@@ -460,13 +460,7 @@ int launch_ffn_reduce(float* x, const float* partial, int nslice, const float* b
 }
 
 // ---- host-side packing of nn.Linear weights into the fragment streams above -----------------------------
-static inline uint16_t bf16_bits(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+static inline uint16_t bf16_bits(float f) { return cn_host_op16(f); }  // (the engine's 16-bit operand: common.h)
 
 // W1 [dff][256] fp32 -> [dff/32][16][64][8] bf16 :  frag(ft, ks, lane)[j] = W1[32ft + (lane&31)][16ks + 8(lane>>5) + j]
 void pack_ffn_w1(const float* w1, int dff, uint16_t* out) {

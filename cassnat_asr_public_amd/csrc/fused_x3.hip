@@ -68,7 +68,7 @@ constexpr int FX_PART_TAIL = 4 * 32 * FX_D * 4;
 constexpr int FX_LDS_TAIL = FX_PART_TAIL + 32768;
 static_assert(FX_LDS_TAIL == 160 * 1024, "LDS budget (row-chain form)");
 
-#define FX_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define FX_MFMA(a, b, c) c = CN_MFMA16(a, b, c, 0, 0, 0)
 // The kernel holds 18 accumulator tiles (16 of out^T, 2 of the hidden tile) = 288 registers.  The compiler selects every MFMA
 // builtin with an AGPR destination (there are 256) and, left alone, parks the hidden tile there too and shuttles output tiles
 // between the register files every iteration (96-160 v_accvgpr moves per hidden tile, plus the reads the VALU needs to see
@@ -76,8 +76,8 @@ static_assert(FX_LDS_TAIL == 160 * 1024, "LDS budget (row-chain form)");
 // tiles then fill the AGPRs exactly and never move.  Written-out instructions are opaque to the hazard recogniser and to
 // sched_group_barrier: the W1 blocks are ordered by sched_barrier fences instead, and the one read-after-MFMA the
 // compiler cannot see (bias / ReLU on the finished tile) gets its own s_nop.
-#define FX_MFMA_V(a, b, c) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
-#define FX_MFMA_V0(a, b, c) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b))
+#define FX_MFMA_V(a, b, c) asm(CN_MFMA16_ASM "%0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+#define FX_MFMA_V0(a, b, c) asm(CN_MFMA16_ASM "%0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b))
 
 template <bool PRO, bool TAIL>
 __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {

@@ -188,10 +188,10 @@ __global__ __launch_bounds__(256, 2) void genmax_kernel(GenmaxParams p) {
 #define GM_GROUP(g, WS, XS, WN, XN, NT, NG)                                                            \
     GM_LDX(XN, ((g) + 1) & 3) GM_LDW_LOOP(WN, NT, NG)                                                  \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                \
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##a, XS[mt][0], acc[mt], 0, 0, 0);      \
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##b, XS[mt][1], acc[mt], 0, 0, 0);      \
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##c, XS[mt][2], acc[mt], 0, 0, 0);      \
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##d, XS[mt][3], acc[mt], 0, 0, 0);      \
+        acc[mt] = CN_MFMA16(w##WS##a, XS[mt][0], acc[mt], 0, 0, 0);      \
+        acc[mt] = CN_MFMA16(w##WS##b, XS[mt][1], acc[mt], 0, 0, 0);      \
+        acc[mt] = CN_MFMA16(w##WS##c, XS[mt][2], acc[mt], 0, 0, 0);      \
+        acc[mt] = CN_MFMA16(w##WS##d, XS[mt][3], acc[mt], 0, 0, 0);      \
     }                                                                                                  \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
         _Pragma("unroll") for (int r_ = 0; r_ < MT; ++r_) {                                            \
@@ -356,12 +356,12 @@ __global__ __launch_bounds__(512, 1) void genmax_x3_kernel(GenmaxParams p) {
 #define GM3_GROUP(g, WS, XS, WN, XN, NT, NG)                                                           \
     GM3_LDX(XN, ((g) + 1) & 7) GM3_LDW(WN, NT, NG)                                                     \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                \
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##a, XS[mt][1], acc[mt], 0, 0, 0);      \
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##b, XS[mt][0], acc[mt], 0, 0, 0);      \
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##c, XS[mt][3], acc[mt], 0, 0, 0);      \
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##d, XS[mt][2], acc[mt], 0, 0, 0);      \
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##a, XS[mt][0], acc[mt], 0, 0, 0);      \
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w##WS##c, XS[mt][2], acc[mt], 0, 0, 0);      \
+        acc[mt] = CN_MFMA16(w##WS##a, XS[mt][1], acc[mt], 0, 0, 0);      \
+        acc[mt] = CN_MFMA16(w##WS##b, XS[mt][0], acc[mt], 0, 0, 0);      \
+        acc[mt] = CN_MFMA16(w##WS##c, XS[mt][3], acc[mt], 0, 0, 0);      \
+        acc[mt] = CN_MFMA16(w##WS##d, XS[mt][2], acc[mt], 0, 0, 0);      \
+        acc[mt] = CN_MFMA16(w##WS##a, XS[mt][0], acc[mt], 0, 0, 0);      \
+        acc[mt] = CN_MFMA16(w##WS##c, XS[mt][2], acc[mt], 0, 0, 0);      \
     }                                                                                                  \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
         _Pragma("unroll") for (int r_ = 0; r_ < MT; ++r_) {                                            \
@@ -483,13 +483,7 @@ int launch_genmax(const GenmaxArgs& a, hipStream_t s) {
     return a.M > 32 ? launch_genmax_variant<2, false, true>(p, s) : launch_genmax_variant<1, false, true>(p, s);
 }
 
-static inline uint16_t gm_bf16_bits(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+static inline uint16_t gm_bf16_bits(float f) { return cn_host_op16(f); }  // (the engine's 16-bit operand: common.h)
 
 // W [V][256] fp32 -> [4][vtw][16][64][8] bf16: frag(w, t, ks, lane)[j] = W[32(w*vtw + t) + (lane&31)][16ks + 8(lane>>5) + j]
 // (zero rows past V);  b [V] -> [4*vtw*32] fp32 with -inf past V.

@@ -82,6 +82,8 @@ int launch_layernorm_fp8(const float* x, const float* a2, const float* b2, void*
                          hipStream_t s);
 int launch_quantize_fp8(const void* src_bf16, int ld, void* dst, int M, int K, float scale, hipStream_t s);
 int launch_cmvn(float* x, const int* len, const double* mean, const double* sd, int B, int T, int F, hipStream_t s);
+// fp16 build: *fault = 1 (device-visible host word) when some |x[i]| > *limit (device word; <= 0: no check)
+int launch_feature_range(const float* x, size_t n, const float* limit, unsigned int* fault, hipStream_t s);
 // packed archive rows of a pass -> padded (rows, T, F) batch, optional global CMVN in float64 (the reader's collate on the device)
 int launch_unpack_rows(const float* packed, const int* off, const int* len, float* out, int rows, int T, int F, float pad,
                        const double* mean, const double* sd, hipStream_t s);

@@ -16,7 +16,25 @@
 static thread_local std::string g_last_error;
 void cn_set_error(const std::string& msg) { g_last_error = msg; }
 extern "C" const char* cn_last_error(void) { return g_last_error.c_str(); }
-extern "C" const char* cn_version(void) { return "cassnat_hip 0.1 (gfx950)"; }
+extern "C" const char* cn_version(void) { return "cassnat_hip 0.1 (gfx950, 16-bit operand " CN_OP16_NAME ")"; }
+extern "C" const char* cn_operand16(void) { return CN_OP16_NAME; }
+
+// The library exists in two builds that differ in the 16-bit MFMA operand (common.h): this one's engines of the 16-bit kind are
+// CN_PRECISION_BF16 (+ FP8, BF16X3, F32) - or, built with -DCN_OP16_F16, CN_PRECISION_F16 and nothing else.  Returns the internal
+// precision of a request, -1 (error set) when it belongs to the other build.
+static int cn_own_precision(int32_t precision, const char* who) {
+#ifdef CN_OP16_F16
+    if (precision == CN_PRECISION_F16) return CN_PREC_BF16;  // (the 16-bit path; its operand type is this build's)
+    cn_set_error(std::string(who) + ": this build of the library (libcassnat_hip_f16.so) holds the fp16 engine only (CN_PRECISION_F16)");
+    return -1;
+#else
+    if (precision == CN_PRECISION_F16) {
+        cn_set_error(std::string(who) + ": CN_PRECISION_F16 engines live in libcassnat_hip_f16.so (the -DCN_OP16_F16 build of these sources)");
+        return -1;
+    }
+    return precision;
+#endif
+}
 
 #define CN_TRY(expr)                \
     do {                            \
@@ -111,13 +129,7 @@ struct Capture {
     long long call = -1;  // the engine call (cn_model::call_id) that produced it
 };
 
-inline uint16_t f32_to_bf16_host(float f) {
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+inline uint16_t f32_to_bf16_host(float f) { return cn_host_op16(f); }  // (the engine's 16-bit operand: common.h)
 
 }  // namespace
 
@@ -203,6 +215,12 @@ struct cn_model {
     float* cv_f = nullptr;
     double* gn_stats = nullptr;
     int* ymax_pinned = nullptr;  // page-locked host word for the one data-dependent readback per batch
+    // fp16 build only (CN_OP16_F16): half-precision operands have a range.  What drives magnitudes from outside is the scale of the
+    // features (everything behind linear_out is LayerNorm-ed in fp32 first), so every pass checks them against the largest value
+    // for which neither subsampling convolution's output can leave the half range (op16_feat_limit: a word of the weight blob,
+    // from the convolutions' weight row sums) and raises a sticky flag in device-visible page-locked memory (cn_take_range_fault)
+    const float* op16_feat_limit = nullptr;
+    unsigned int* op16_fault = nullptr;
     // CTC prefix beam / forced alignment scratch (cn_ctc_beam, cn_decode_nast_forced): grown on demand
     std::map<std::string, std::pair<void*, size_t>> scratch;
 
@@ -797,6 +815,35 @@ int build_weights(cn_model* m) {
         }
         m->conv2.b = pk.vec({"src_embed.conv.2.bias"}, C);
     }
+    if (!lm) {
+        // |conv1 out| <= fmax A1 + B1 and |conv2 out| <= |conv1 out| A2 + B2 with A = the largest row sum of |weights|, B = the
+        // largest |bias|: the feature magnitude that keeps both under half of 65504 (0: weights unknown here - no check)
+        const size_t at = pk.reserve(16);
+        if (pk.fill) {
+            float lim = 0.f;
+            const HostTensor* w1 = pk.find("src_embed.conv.0.weight", {C, 1, 3, 3});
+            const HostTensor* b1 = pk.find("src_embed.conv.0.bias", {C});
+            const HostTensor* w2 = pk.find("src_embed.conv.2.weight", {C, C, 3, 3});
+            const HostTensor* b2 = pk.find("src_embed.conv.2.bias", {C});
+            if (w1 && b1 && w2 && b2) {
+                double A1 = 0, B1 = 0, A2 = 0, B2 = 0;
+                for (int64_t ch = 0; ch < C; ++ch) {
+                    double r1 = 0, r2 = 0;
+                    for (int k = 0; k < 9; ++k) r1 += std::fabs((double)w1->data[ch * 9 + k]);
+                    for (int64_t k = 0; k < 9 * C; ++k) r2 += std::fabs((double)w2->data[ch * 9 * C + k]);
+                    A1 = std::max(A1, r1);
+                    A2 = std::max(A2, r2);
+                    B1 = std::max(B1, std::fabs((double)b1->data[ch]));
+                    B2 = std::max(B2, std::fabs((double)b2->data[ch]));
+                }
+                const double half_max = 65504.0 / 2;
+                const double c1 = std::min(half_max, A2 > 0 ? (half_max - B2) / A2 : half_max);  // the bound on conv1's output
+                lim = (float)std::max(0.0, A1 > 0 ? (c1 - B1) / A1 : 3e38);
+            }
+            std::memcpy(&pk.host[at], &lim, 4);
+        }
+        m->op16_feat_limit = reinterpret_cast<const float*>(at);
+    }
     // linear_out: column c*F2+f of the reference (embedding.py:118) -> column f*C+c (the conv2 GEMM's natural output)
     if (!lm) {
         std::vector<int> perm((size_t)(C * F2));
@@ -1080,6 +1127,7 @@ int build_weights(cn_model* m) {
 
     unsigned char* base = m->blob;
     rebase(m->conv1_w, base);
+    rebase(m->op16_feat_limit, base);
     rebase(m->conv1_b, base);
     rebase_linear(m->conv2, base);
     rebase(m->conv2_x3w, base);
@@ -1248,6 +1296,10 @@ int build_workspace(cn_model* m) {
     m->gn_stats = (double*)get("gn_stats");
     CN_HIP_CHECK(hipHostMalloc((void**)&m->ymax_pinned, 64, hipHostMallocDefault));
     CN_HIP_CHECK(hipHostMalloc((void**)&m->ymax_ring, 64, hipHostMallocDefault));
+#ifdef CN_OP16_F16
+    CN_HIP_CHECK(hipHostMalloc((void**)&m->op16_fault, 64, hipHostMallocMapped));
+    *m->op16_fault = 0;
+#endif
     return 0;
 }
 
@@ -1860,6 +1912,9 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     m->Tp = Tp;
     m->U = 0;
     CN_TRY(launch_keymask(feats, B, T, F, Tp, 4, (float)o->padding_idx, m->keymask, s));
+#ifdef CN_OP16_F16
+    if (m->op16_fault && m->op16_feat_limit) CN_TRY(launch_feature_range(feats, (size_t)B * T * F, m->op16_feat_limit, m->op16_fault, s));
+#endif
     // conv1 writes its image with a zero halo when the LDS-DMA conv2 kernel consumes it (captures want the plain image)
     // (the split-bf16 engine: two bordered bf16 planes, hi and lo, for the same kernel's X3 form)
     const bool x3_planes = !cap && m->conv2_x3w && conv2_x3_applies(m->prec, d, d);
@@ -2260,10 +2315,12 @@ extern "C" int cn_model_create(const cn_config* cfg, cn_model** out) {
         return -1;
     }
     if (c.precision != CN_PRECISION_F32 && c.precision != CN_PRECISION_BF16 && c.precision != CN_PRECISION_FP8 &&
-        c.precision != CN_PRECISION_BF16X3) {
+        c.precision != CN_PRECISION_BF16X3 && c.precision != CN_PRECISION_F16) {
         cn_set_error("cn_model_create: unknown precision");
         return -1;
     }
+    const int own_prec = cn_own_precision(c.precision, "cn_model_create");
+    if (own_prec < 0) return -1;
     if (c.precision == CN_PRECISION_BF16X3 && (c.d_encff % 32 || c.d_decff % 32 || c.d_model % 32 || c.d_ff % 32)) {
         cn_set_error("cn_model_create: the split-bf16 (bf16x3) engine needs d_model and the feed-forward widths to be multiples of 32");
         return -1;
@@ -2287,7 +2344,7 @@ extern "C" int cn_model_create(const cn_config* cfg, cn_model** out) {
     // fp8: a bf16 engine (storage, decoder side, conv front-end) whose encoder-layer products take e4m3fn operands
     m->fp8_enc = c.precision == CN_PRECISION_FP8;
     m->fp8_scope = c.fp8_scope ? c.fp8_scope : (CN_FP8_CONV2 | CN_FP8_LINEAR | CN_FP8_FFN);
-    m->prec = m->fp8_enc ? CN_PREC_BF16 : (c.precision == CN_PRECISION_BF16X3 ? CN_PREC_X3 : c.precision);
+    m->prec = m->fp8_enc ? CN_PREC_BF16 : (c.precision == CN_PRECISION_BF16X3 ? CN_PREC_X3 : own_prec);
     m->es = cn_elem_size(m->prec);
     m->maxB = c.max_batch;
     m->maxT = c.max_frames;
@@ -2333,6 +2390,7 @@ extern "C" void cn_model_destroy(cn_model* m) {
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->ymax_pinned) (void)hipHostFree(m->ymax_pinned);
     if (m->ymax_ring) (void)hipHostFree(m->ymax_ring);
+    if (m->op16_fault) (void)hipHostFree(m->op16_fault);
     for (void* q : m->ast_allocs) (void)hipFree(q);
     for (auto& kv : m->scratch)
         if (kv.second.first) (void)hipFree(kv.second.first);
@@ -2529,6 +2587,21 @@ extern "C" int cn_decode_ticket(cn_model* m, int32_t ticket, int32_t* ymax_host,
     }
     if (ymax_host) *ymax_host = m->ymax_ring[slot];
     if (rows_used_host) *rows_used_host = m->ticket_U[slot];
+    return 0;
+}
+
+// fp16 engines: has a pass since the last call seen features beyond the range the engine's half-precision operands hold (then
+// its results are not to be used)?  Valid once the passes' stream work is done; clears the flag.  Other engines: always 0.
+extern "C" int cn_take_range_fault(cn_model* m, int32_t* fault_host, float* feature_limit_host) {
+    if (!m || !fault_host) {
+        cn_set_error("cn_take_range_fault: bad arguments");
+        return -1;
+    }
+    *fault_host = 0;
+    if (feature_limit_host) *feature_limit_host = 0.f;
+    if (!m->op16_fault) return 0;
+    *fault_host = (int32_t)__atomic_exchange_n(m->op16_fault, 0u, __ATOMIC_ACQ_REL);
+    if (feature_limit_host && m->op16_feat_limit) CN_HIP_CHECK(hipMemcpy(feature_limit_host, m->op16_feat_limit, 4, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -3126,6 +3199,7 @@ extern "C" int cn_op_gemm(int32_t precision, const void* A, int32_t lda, const v
                           int32_t ldc, int32_t c_is_f32, int32_t M, int32_t N, int32_t K, int32_t relu,
                           const float* resid, int32_t ldr, const float* pe, int32_t pe_period, float scale,
                           void* stream) {
+    if ((precision = cn_own_precision(precision, "cn_op_gemm")) < 0) return -1;
     GemmArgs g;
     g.A = A;
     g.lda = lda;
@@ -3147,6 +3221,7 @@ extern "C" int cn_op_gemm(int32_t precision, const void* A, int32_t lda, const v
 }
 
 extern "C" int cn_op_convert(int32_t precision, const void* src, void* dst, int64_t n, int32_t to_f32, void* stream) {
+    if ((precision = cn_own_precision(precision, "cn_op_convert")) < 0) return -1;
     if (n < 0 || !src || !dst) {
         cn_set_error("cn_op_convert: bad argument");
         return -1;
@@ -3157,6 +3232,7 @@ extern "C" int cn_op_convert(int32_t precision, const void* src, void* dst, int6
 
 extern "C" int cn_op_conv1(int32_t precision, const float* x, const float* w9c, const float* bias, void* out, int32_t B,
                            int32_t T, int32_t F, int32_t C, void* stream) {
+    if ((precision = cn_own_precision(precision, "cn_op_conv1")) < 0) return -1;
     return launch_conv1(precision, x, w9c, bias, out, B, T, F, (T - 1) / 2 + 1, (F - 1) / 2 + 1, C, 0, (hipStream_t)stream);
 }
 
@@ -3246,6 +3322,7 @@ extern "C" int cn_op_linear256_fp8(const void* a8_dev, const float* w_host, cons
 
 extern "C" int cn_op_conv2(int32_t precision, const void* conv1_out, const void* w_khwc, const float* bias, void* out,
                            int32_t B, int32_t T1, int32_t F1, int32_t C, void* stream) {
+    if ((precision = cn_own_precision(precision, "cn_op_conv2")) < 0) return -1;
     GemmArgs g;
     const int T2 = (T1 - 1) / 2 + 1, F2 = (F1 - 1) / 2 + 1;
     g.A = conv1_out;
@@ -3289,6 +3366,7 @@ extern "C" int cn_op_conv2(int32_t precision, const void* conv1_out, const void*
 
 extern "C" int cn_op_layernorm(int32_t precision, const float* x, const float* a2, const float* b2, void* y, int32_t M,
                                int32_t d, float eps, void* stream) {
+    if ((precision = cn_own_precision(precision, "cn_op_layernorm")) < 0) return -1;
     return launch_layernorm(precision, x, a2, b2, y, 0, M, d, eps, (hipStream_t)stream);
 }
 
@@ -3296,6 +3374,7 @@ extern "C" int cn_op_attention(int32_t precision, const void* Q, int32_t ldq, co
                                int32_t ldv, void* O, int32_t ldo, int32_t B, int32_t H, int32_t Lq, int32_t Lk,
                                const uint8_t* keymask, const int32_t* klen, const int32_t* intervals, int32_t iv_stride,
                                int32_t causal, float scale, void* stream) {
+    if ((precision = cn_own_precision(precision, "cn_op_attention")) < 0) return -1;
     AttnArgs a;
     a.Q = Q;
     a.K = K;

@@ -82,8 +82,8 @@ __device__ __forceinline__ void px_tiles(const PxPhase& p, const unsigned char* 
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int j = 0; j < 4; ++j)    \
         X_[mt][j] = *reinterpret_cast<const bf16x8*>(xfrag[mt] + ((4 * (g) + j) * 64) * 16);
 #define PX_MFMA(w_, x_, c_)                                                                            \
-    if constexpr (SPLIT_OUT) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, x_, c_, 0, 0, 0);        \
-    else c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, w_, c_, 0, 0, 0);
+    if constexpr (SPLIT_OUT) c_ = CN_MFMA16(w_, x_, c_, 0, 0, 0);        \
+    else c_ = CN_MFMA16(x_, w_, c_, 0, 0, 0);
     // group g: 6 MT MFMAs (the small cross terms first) on set WS / XS; requests group g + 3 (set WN) and reads group g + 1's
     // activations (XN) in the MFMA gaps
 #define PX_GROUP(g, WS, XS, WN, XN, NT, NG)                                                            \

@@ -685,3 +685,31 @@ int launch_cmvn(float* x, const int* len, const double* mean, const double* sd, 
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// ---- fp16 engine: the features against the range its half-precision operands hold (model.hip: op16_feat_limit) -------------------
+__global__ __launch_bounds__(256) void feature_range_kernel(const float* __restrict__ x, size_t n4, size_t n, const float* __restrict__ limit,
+                                                            unsigned int* fault) {
+    const float lim = *limit;
+    if (!(lim > 0.f)) return;
+    float m = 0.f;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = x4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
+    if (m > lim) *fault = 1u;  // (racing writers store the same word; page-locked host memory, read after the stream has drained)
+}
+
+int launch_feature_range(const float* x, size_t n, const float* limit, unsigned int* fault, hipStream_t s) {
+    if (n == 0) return 0;
+    if (reinterpret_cast<uintptr_t>(x) & 15) {
+        cn_set_error("feature range check: the feature batch must be 16-byte aligned");
+        return -1;
+    }
+    const size_t n4 = n / 4;
+    const int grid = (int)std::min<size_t>(2048, (n4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(feature_range_kernel, dim3(grid), dim3(256), 0, s, x, n4, n, limit, fault);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}

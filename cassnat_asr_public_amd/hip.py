@@ -11,9 +11,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (CASSNAT_HIP_LIB: another build of the same library - A/B measurements of kernel variants, tools/scripts/ab_bench.sh)
 LIB_PATH = os.environ.get("CASSNAT_HIP_LIB") or os.path.join(_HERE, "libcassnat_hip.so")
+# the second build of the same sources (csrc/common.h: -DCN_OP16_F16): the fast engine with IEEE half-precision MFMA operands -
+# --hip_precision fp16.  Same C ABI; an engine keeps the library it was created in.
+LIB_PATH_F16 = os.path.join(_HERE, "libcassnat_hip_f16.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cassnat_hip.h")
 
-PRECISION = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp8": 2, "bf16x3": 3}
+PRECISION = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp8": 2, "bf16x3": 3, "fp16": 4, "float16": 4}
 DTYPES = {0: np.float32, 1: np.int32, 2: np.uint8, 3: np.float64}
 FP8_SCOPE_BITS = {"conv2": 1, "linear": 2, "ffn": 4}
 
@@ -69,7 +72,7 @@ class HipError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
 
 
 def declared_symbols():
@@ -79,21 +82,29 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(cn_[a-z0-9_]+)\s*\(", text)) - {"cn_model", "cn_config", "cn_decode_opts"})
 
 
-def lib():
-    """Load the shared library (built by __graft_entry__.build / cassnat_asr_public_amd.build)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise HipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+def lib_for(precision):
+    """The library that holds engines of ``precision`` (a name of ``PRECISION`` or its number)."""
+    code = PRECISION[precision] if isinstance(precision, str) else int(precision)
+    return lib("f16" if code == PRECISION["fp16"] else None)
+
+
+def lib(flavour=None):
+    """Load the shared library (built by __graft_entry__.build / cassnat_asr_public_amd.build).  ``flavour`` "f16": the build with
+    half-precision operands (libcassnat_hip_f16.so) - everything that is not an fp16 engine uses the default library."""
+    path = LIB_PATH_F16 if flavour == "f16" else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise HipError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback for the CASS-NAT hot path)")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     L.cn_last_error.restype = C.c_char_p
     L.cn_version.restype = C.c_char_p
+    L.cn_operand16.restype = C.c_char_p
     L.cn_model_destroy.restype = None
     for name in declared_symbols():
         fn = getattr(L, name)  # AttributeError here = header and library disagree
-        if name not in ("cn_last_error", "cn_version", "cn_model_destroy"):
+        if name not in ("cn_last_error", "cn_version", "cn_operand16", "cn_model_destroy"):
             fn.restype = C.c_int
     L.cn_op_gemm.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                              C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
@@ -136,6 +147,7 @@ def lib():
                                         C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     L.cn_decode_ticket.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.cn_take_range_fault.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
     L.cn_encode_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(CnDecodeOpts), C.POINTER(C.c_int32), C.c_void_p]
     L.cn_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
@@ -182,14 +194,28 @@ def lib():
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
     L.cn_profile_begin.argtypes = [C.c_void_p, C.c_char_p]
     L.cn_profile_end.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
-    _lib = L
+    want = "fp16" if flavour == "f16" else "bf16"
+    if L.cn_operand16().decode() != want:
+        raise HipError(f"{path}: the library's 16-bit operand is {L.cn_operand16().decode()}, expected {want}")
+    _libs[path] = L
     return L
 
 
-def check(rc, what=""):
+def check(rc, what="", L=None):
+    """``L``: the library the failing call was made in (its cn_last_error() holds the message); default: the bf16 build."""
     if rc != 0:
-        msg = lib().cn_last_error().decode(errors="replace")
+        msg = (L or lib()).cn_last_error().decode(errors="replace")
         raise HipError(f"{what or 'libcassnat_hip'} failed (rc={rc}): {msg}")
+
+
+def check_fp16_range(scores, what="decode"):
+    """Second line behind ``Engine.check_range`` (which guards what the features' scale drives): a value beyond +-65504 in front of
+    a matrix product INSIDE the layers - a matter of the checkpoint, not of the input - becomes an infinity; where that reaches a
+    hypothesis score as a NaN the engine fails loudly instead of returning the hypothesis (a ReLU can still turn a NaN into a 0:
+    a model whose activations leave the half range belongs on the bf16 engine)."""
+    if not np.isfinite(np.asarray(scores, dtype=np.float64)).all():
+        raise HipError(f"{what}: non-finite hypothesis score from the fp16 engine - an MFMA operand left the half-precision range "
+                       "(+-65504); use --hip_precision bf16 / bf16x3 for this model or these features")
 
 
 def _ptr(t):
@@ -243,7 +269,7 @@ class Engine:
     def __init__(self, args, precision="bf16", max_batch=32, max_frames=2048, device=0, esa_group=1, share_with=None):
         """``share_with``: a finalized Engine of the same model - the new handle uses ITS device copy of the packed weights
         (reference counted in the library) and only allocates a workspace of its own; it is ready to decode."""
-        self.L = lib()
+        self.L = lib_for(precision)
         ast = int(getattr(args, "ast", 0))
         self.cfg = CnConfig(
             input_size=args.input_size, d_model=args.d_model, n_head=args.n_head, d_encff=args.d_encff,
@@ -260,11 +286,14 @@ class Engine:
         if share_with is not None:
             if not share_with.finalized or not share_with.handle:
                 raise HipError("share_with needs a finalized engine")
-            check(self.L.cn_model_create_shared(C.byref(self.cfg), share_with.handle, C.byref(self.handle)), "cn_model_create_shared")
+            self._chk(self.L.cn_model_create_shared(C.byref(self.cfg), share_with.handle, C.byref(self.handle)), "cn_model_create_shared")
             self.finalized = True
         else:
-            check(self.L.cn_model_create(C.byref(self.cfg), C.byref(self.handle)), "cn_model_create")
+            self._chk(self.L.cn_model_create(C.byref(self.cfg), C.byref(self.handle)), "cn_model_create")
             self.finalized = False
+
+    def _chk(self, rc, what=""):
+        check(rc, what, self.L)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -282,21 +311,21 @@ class Engine:
         for name, w in state.items():
             a = np.ascontiguousarray(w.detach().cpu().numpy() if hasattr(w, "detach") else w, dtype=np.float32)
             shape = (C.c_int64 * a.ndim)(*a.shape)
-            check(self.L.cn_model_load_weights(self.handle, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim),
+            self._chk(self.L.cn_model_load_weights(self.handle, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim),
                   f"load {name}")
         pe = np.ascontiguousarray(pe_table.detach().cpu().numpy() if hasattr(pe_table, "detach") else pe_table,
                                   dtype=np.float32)
-        check(self.L.cn_model_load_pe(self.handle, pe.ctypes.data_as(C.c_void_p), pe.shape[0]), "load pe")
+        self._chk(self.L.cn_model_load_pe(self.handle, pe.ctypes.data_as(C.c_void_p), pe.shape[0]), "load pe")
         self.finalize()
 
     def finalize(self):
-        check(self.L.cn_model_finalize(self.handle), "cn_model_finalize")
+        self._chk(self.L.cn_model_finalize(self.handle), "cn_model_finalize")
         self.finalized = True
 
     def weight_blob(self):
         """(device pointer, bytes) of the packed weights - what RCCL broadcasts from rank 0."""
         p, n = C.c_void_p(), C.c_int64()
-        check(self.L.cn_model_weight_blob(self.handle, C.byref(p), C.byref(n)), "cn_model_weight_blob")
+        self._chk(self.L.cn_model_weight_blob(self.handle, C.byref(p), C.byref(n)), "cn_model_weight_blob")
         return p.value, n.value
 
     @staticmethod
@@ -310,7 +339,7 @@ class Engine:
     def decode(self, feats, size_ratio, opts, hyp, hyp_len, score):
         """feats (B,T,F) f32 cuda, size_ratio (B,) f32 cuda; outputs are caller-owned cuda tensors."""
         B, T, F = feats.shape
-        check(self.L.cn_decode_nast(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts), _ptr(hyp),
+        self._chk(self.L.cn_decode_nast(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts), _ptr(hyp),
                                     hyp.shape[1], _ptr(hyp_len), _ptr(score), current_stream()), "cn_decode_nast")
 
     def decode_merged(self, feats, size_ratio, opts, sub_rows, sub_frames, hyp, hyp_len, score, u_hint=0):
@@ -324,42 +353,53 @@ class Engine:
         rows = (C.c_int32 * max(1, n))(*[int(x) for x in (sub_rows or [])])
         frames = (C.c_int32 * max(1, n))(*[int(x) for x in (sub_frames or [])])
         ticket = C.c_int32(-1)
-        check(self.L.cn_decode_nast_merged(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts), n, rows, frames,
+        self._chk(self.L.cn_decode_nast_merged(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts), n, rows, frames,
                                            int(u_hint), _ptr(hyp), hyp.shape[1], _ptr(hyp_len), _ptr(score), current_stream(),
                                            C.byref(ticket)), "cn_decode_nast_merged")
         return ticket.value
 
+    def check_range(self, what="decode"):
+        """fp16 engines: raise if a pass since the last call saw features beyond the range the half-precision operands hold
+        (``cn_take_range_fault``; call it once the passes' results are on the host).  Other engines: nothing to check."""
+        if self.precision not in ("fp16", "float16"):
+            return
+        fault, limit = C.c_int32(), C.c_float()
+        self._chk(self.L.cn_take_range_fault(self.handle, C.byref(fault), C.byref(limit)), "cn_take_range_fault")
+        if fault.value:
+            raise HipError(f"{what}: features beyond the fp16 engine's half-precision range (|x| > {limit.value:.4g} lets a subsampling "
+                           "convolution's output pass 65504 / 2): normalise the features (CMVN) or decode with --hip_precision bf16 / bf16x3")
+
     def ticket(self, t):
         """(true row count, rows the decoder side ran on) of the pass that returned ticket ``t``; valid once its stream work is done."""
         ymax, used = C.c_int32(), C.c_int32()
-        check(self.L.cn_decode_ticket(self.handle, int(t), C.byref(ymax), C.byref(used)), "cn_decode_ticket")
+        self._chk(self.L.cn_decode_ticket(self.handle, int(t), C.byref(ymax), C.byref(used)), "cn_decode_ticket")
         return ymax.value, used.value
 
     def encode_align(self, feats, size_ratio, opts):
         B, T, F = feats.shape
         ymax = C.c_int32()
-        check(self.L.cn_encode_align(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts),
+        self._chk(self.L.cn_encode_align(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts),
                                      C.byref(ymax), current_stream()), "cn_encode_align")
         return ymax.value
 
     # ---- autoregressive (AST) path
     def ast_begin(self, feats, opts, want_ctc, max_len, max_slots, ctc_beam):
         B, T, F = feats.shape
-        check(self.L.cn_ast_begin(self.handle, _ptr(feats), B, T, F, C.byref(opts), int(want_ctc), max_len, max_slots,
+        self._chk(self.L.cn_ast_begin(self.handle, _ptr(feats), B, T, F, C.byref(opts), int(want_ctc), max_len, max_slots,
                                   ctc_beam, current_stream()), "cn_ast_begin")
 
     def ast_step(self, pos, tok, utt, anc, keyok, temperature, K, topk_idx, topk_val):
-        check(self.L.cn_ast_step(self.handle, tok.shape[0], pos, _ptr(tok), _ptr(utt), _ptr(anc), _ptr(keyok), anc.shape[1],
+        self._chk(self.L.cn_ast_step(self.handle, tok.shape[0], pos, _ptr(tok), _ptr(utt), _ptr(anc), _ptr(keyok), anc.shape[1],
                                  float(temperature), K, _ptr(topk_idx), _ptr(topk_val), current_stream()), "cn_ast_step")
 
     def ast_ctc_score(self, out_len, utt, last_tok, cand, prev_ref, parity, eos, score):
-        check(self.L.cn_ast_ctc_score(self.handle, cand.shape[0], out_len, _ptr(utt), _ptr(last_tok), _ptr(cand), cand.shape[1],
+        self._chk(self.L.cn_ast_ctc_score(self.handle, cand.shape[0], out_len, _ptr(utt), _ptr(last_tok), _ptr(cand), cand.shape[1],
                                       _ptr(prev_ref), parity, eos, _ptr(score), current_stream()), "cn_ast_ctc_score")
 
     # ---- ESA sampling + LM ranking
     def esa_begin(self, feats, opts):
         B, T, F = feats.shape
-        check(self.L.cn_esa_begin(self.handle, _ptr(feats), B, T, F, C.byref(opts), current_stream()), "cn_esa_begin")
+        self._chk(self.L.cn_esa_begin(self.handle, _ptr(feats), B, T, F, C.byref(opts), current_stream()), "cn_esa_begin")
 
     def esa_sample(self, select, threshold, size_ratio, opts, tok, val, ylen, force_U=0):
         """One pass over n sampled alignments per utterance (n <= cfg.esa_group): select uint8 (n, B, T') cuda draws (all-zero
@@ -370,20 +410,20 @@ class Engine:
         assert select.is_contiguous()
         if force_U >= 0 and opts.beam_width == 1:  # (beam_width > 1: the per-row top-k stays in the engine, nothing is copied out)
             assert tok.shape[0] == n and tok.is_contiguous() and val.is_contiguous() and ylen.is_contiguous()
-        check(self.L.cn_esa_sample(self.handle, _ptr(select), n, float(threshold), _ptr(size_ratio), C.byref(opts), _ptr(tok),
+        self._chk(self.L.cn_esa_sample(self.handle, _ptr(select), n, float(threshold), _ptr(size_ratio), C.byref(opts), _ptr(tok),
                                    _ptr(val), tok.shape[2] if tok is not None else 0, _ptr(ylen), C.byref(ymax), int(force_U),
                                    current_stream()), "cn_esa_sample")
         return ymax.value
 
     def lm_score(self, tok, tgt, length, U, score):
         """tok / tgt int32 (N, ld), length int32 (N,), score float32 (N, ld): log p(tgt[n][u] | tok[n][..u]) for u < U."""
-        check(self.L.cn_lm_score(self.handle, _ptr(tok), _ptr(tgt), _ptr(length), tok.shape[0], int(U), tok.shape[1], _ptr(score),
+        self._chk(self.L.cn_lm_score(self.handle, _ptr(tok), _ptr(tgt), _ptr(length), tok.shape[0], int(U), tok.shape[1], _ptr(score),
                                  current_stream()), "cn_lm_score")
 
     def ast_decode(self, feats, opts, ast_opts, hyp, hyp_len, score):
         """Whole beam search on the device: hyp int32 (B, beam, max_len), hyp_len int32 (B, beam), score float64 (B, beam)."""
         B, T, F = feats.shape
-        check(self.L.cn_decode_ast(self.handle, _ptr(feats), B, T, F, C.byref(opts), C.byref(ast_opts), _ptr(hyp),
+        self._chk(self.L.cn_decode_ast(self.handle, _ptr(feats), B, T, F, C.byref(opts), C.byref(ast_opts), _ptr(hyp),
                                    hyp.shape[2], _ptr(hyp_len), _ptr(score), current_stream()), "cn_decode_ast")
 
     # ---- decode_type ctc_only / ctc_att, rank_model at_baseline
@@ -399,20 +439,20 @@ class Engine:
         hlen = torch.empty(B, beam, dtype=torch.int32, device=dev)
         sc, pb, pnb = (torch.empty(B, beam, dtype=torch.float64, device=dev) for _ in range(3))
         nb = torch.empty(B, dtype=torch.int32, device=dev)
-        check(self.L.cn_ctc_beam(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts), int(beam), int(pruning),
+        self._chk(self.L.cn_ctc_beam(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts), int(beam), int(pruning),
                                  float(length_penalty), _ptr(hyp), cap, _ptr(hlen), _ptr(sc), _ptr(pb), _ptr(pnb), _ptr(nb),
                                  current_stream()), "cn_ctc_beam")
         return hyp, hlen, sc, pb, pnb, nb
 
     def decode_forced(self, feats, size_ratio, opts, labels, label_len, max_label_len, hyp, hyp_len, score):
         B, T, F = feats.shape
-        check(self.L.cn_decode_nast_forced(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts), _ptr(labels),
+        self._chk(self.L.cn_decode_nast_forced(self.handle, _ptr(feats), _ptr(size_ratio), B, T, F, C.byref(opts), _ptr(labels),
                                            _ptr(label_len), labels.shape[1], int(max_label_len), _ptr(hyp), hyp.shape[1],
                                            _ptr(hyp_len), _ptr(score), current_stream()), "cn_decode_nast_forced")
 
     def ast_teacher_score(self, feats, opts, tok, tgt, length, n_per_utt, U, score):
         B, T, F = feats.shape
-        check(self.L.cn_ast_teacher_score(self.handle, _ptr(feats), B, T, F, C.byref(opts), _ptr(tok), _ptr(tgt), _ptr(length),
+        self._chk(self.L.cn_ast_teacher_score(self.handle, _ptr(feats), B, T, F, C.byref(opts), _ptr(tok), _ptr(tgt), _ptr(length),
                                           int(n_per_utt), int(U), tok.shape[1], _ptr(score), current_stream()), "cn_ast_teacher_score")
 
     def ast_ctc_correct(self, feats, opts, k):
@@ -425,28 +465,28 @@ class Engine:
         val = torch.empty(B * (Tp + 1) * k, dtype=torch.float32, device=feats.device)
         length = torch.empty(B, dtype=torch.int32, device=feats.device)
         rows = C.c_int32()
-        check(self.L.cn_ast_ctc_correct(self.handle, _ptr(feats), B, T, F, C.byref(opts), int(k), _ptr(tok), _ptr(val), _ptr(length),
+        self._chk(self.L.cn_ast_ctc_correct(self.handle, _ptr(feats), B, T, F, C.byref(opts), int(k), _ptr(tok), _ptr(val), _ptr(length),
                                         C.byref(rows), current_stream()), "cn_ast_ctc_correct")
         U = rows.value
         return length, tok[: B * U * k].view(B, U, k), val[: B * U * k].view(B, U, k)
 
     def profile_begin(self, tags=None):
         """Start HIP-event timing of the tagged kernels (None = all) on the launch stream."""
-        check(self.L.cn_profile_begin(self.handle, None if not tags else "|".join(tags).encode()), "cn_profile_begin")
+        self._chk(self.L.cn_profile_begin(self.handle, None if not tags else "|".join(tags).encode()), "cn_profile_begin")
 
     def profile_end(self):
         """-> {tag: {count, ms, flops, bytes}} accumulated since profile_begin (synchronises the device)."""
         import json
 
         buf = C.create_string_buffer(1 << 16)
-        check(self.L.cn_profile_end(self.handle, buf, len(buf)), "cn_profile_end")
+        self._chk(self.L.cn_profile_end(self.handle, buf, len(buf)), "cn_profile_end")
         return json.loads(buf.value.decode())
 
     def fetch(self, name):
         shape = (C.c_int64 * 4)()
         ndim, dtype = C.c_int32(), C.c_int32()
-        check(self.L.cn_fetch(self.handle, name.encode(), None, 0, shape, C.byref(ndim), C.byref(dtype)), f"fetch {name}")
+        self._chk(self.L.cn_fetch(self.handle, name.encode(), None, 0, shape, C.byref(ndim), C.byref(dtype)), f"fetch {name}")
         out = np.empty([shape[i] for i in range(ndim.value)], dtype=DTYPES[dtype.value])
-        check(self.L.cn_fetch(self.handle, name.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes, shape,
+        self._chk(self.L.cn_fetch(self.handle, name.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes, shape,
                               C.byref(ndim), C.byref(dtype)), f"fetch {name}")
         return out

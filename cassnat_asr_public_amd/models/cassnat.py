@@ -386,6 +386,11 @@ class CassNAT(nn.Module):
             raise NotImplementedError("use_unimask with the conformer decoder: the reference itself cannot run it "
                                       "(cassnat.py:486-488 indexes the (x, pos_embed) tuple)")
 
+    def _range_ok(self):
+        """fp16 engine: the features of the call just finished were inside the range its half-precision operands hold."""
+        if self.hip_precision == "fp16" and self._engine is not None:
+            self._engine.check_range("beam_decode")
+
     def decode_device(self, src, src_size, args, sos=1, engine=None, sub_batch=0, sub_rows=None, sub_frames=None, u_hint=0,
                       want_ticket=False):
         """The device half of beam_decode: returns cuda tensors (hyp (B,S) int32, hyp_len (B,) int32, score (B,) f64).
@@ -425,14 +430,21 @@ class CassNAT(nn.Module):
         assert vocab.word2index["blank"] == args.padding_idx, "CTC blank id and padding_idx must agree"
         if getattr(args, "sample_num", 0) > 1:
             with _OneHostThread():
-                return self._esa_decode(src, src_size, args, lm_model, sos, vocab), args
+                out = self._esa_decode(src, src_size, args, lm_model, sos, vocab)
+            self._range_ok()
+            return out, args
         if getattr(args, "decode_type", "att_only") == "ctc_att":
             hyp, hyp_len, score = self._decode_forced(src, src_size, args, sos, ctc_top_seqs)
         else:
             hyp, hyp_len, score = self.decode_device(src, src_size, args, sos)
         if args.beam_width > 1:
-            return self._host_beam(self._engine, args, sos), args
+            out = self._host_beam(self._engine, args, sos)
+            self._range_ok()
+            return out, args
         hyp_h, len_h, score_h = hyp.cpu().numpy(), hyp_len.cpu().numpy(), score.cpu().numpy()
+        self._range_ok()
+        if self.hip_precision == "fp16":
+            hip.check_fp16_range(score_h, "beam_decode")
         ys = torch.ones(1, 1).fill_(sos).long()
         out = []
         for b in range(hyp_h.shape[0]):

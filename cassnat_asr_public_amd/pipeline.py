@@ -30,6 +30,7 @@ import numpy as np
 import torch
 
 from . import dist as cdist
+from . import hip as _hip
 
 
 def subsampled(T):
@@ -140,6 +141,7 @@ class DecodePipelines:
         ``copy_threads`` > 1: the archive rows of a pass of ``PackedBatch``es are copied into page-locked memory by that many host
         threads (inside ``cn_host_gather``) - what ``--load_data_workers`` means on the packed reader path."""
         self.model = model
+        self._fp16 = getattr(model, "hip_precision", "") == "fp16"  # (its scores are checked for the half range: hip.check_fp16_range)
         self.copy_threads = max(0, int(copy_threads))
         self._packed = [{} for _ in range(max(1, int(n_pipelines)))]  # per pipeline: packed-pass staging buffers by slot
         self.cmvn = None if cmvn is None else (np.ascontiguousarray(cmvn[0], dtype=np.float64), np.ascontiguousarray(cmvn[1], dtype=np.float64))
@@ -457,6 +459,8 @@ class DecodePipelines:
             p.ev.synchronize()
             self._bump("s_retire_wait", time.perf_counter() - t_)
             self._mark("drained", k)
+        if self._fp16:
+            self.engines[k].check_range("DecodePipelines")  # (features beyond the half range: the pass is not handed out)
         if p.ticket is not None and p.ticket >= 0:
             ymax, used = self.engines[k].ticket(p.ticket)
             self._bump("passes", 1)
@@ -633,6 +637,8 @@ class DecodePipelines:
             try:
                 for tags, recs, whole in passes:  # one unpacking per engine pass, a batch is a slice of it
                     (toks, lens), scores = cdist.unpack_records(whole, as_lists=False)
+                    if self._fp16:
+                        _hip.check_fp16_range(scores, "DecodePipelines.decode")
                     o = 0
                     for tag, rec in zip(tags, recs):
                         nb = rec.shape[0]

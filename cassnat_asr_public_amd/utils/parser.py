@@ -21,8 +21,8 @@ class DecodeParser(object):
         p.add_argument("--lm_weight", type=float, default=0.0)
         p.add_argument("--seed", default=1, type=int)
         # engine switches (not in the reference)
-        p.add_argument("--hip_precision", default="bf16", choices=["bf16", "fp32", "fp8", "bf16x3"],
-                       help="bf16 MFMA (throughput), bf16x3 (split-bf16: the reference's tolerance at MFMA speed), fp32 (exact-f32 MFMA), "
+        p.add_argument("--hip_precision", default="bf16", choices=["bf16", "fp32", "fp8", "bf16x3", "fp16"],
+                       help="fp16: the bf16 engine with half-precision MFMA operands (same speed, operand roundings 8x smaller, range +-65504); bf16 MFMA (throughput), bf16x3 (split-bf16: the reference's tolerance at MFMA speed), fp32 (exact-f32 MFMA), "
                             "fp8 (e4m3 encoder products of the NAT recogniser, BASELINE config 5; a ranking LM / AT model or the "
                             "autoregressive recogniser of --task art run bf16 under it)")
         p.add_argument("--hip_fp8_scope", default="all",

@@ -23,7 +23,11 @@ extern "C" {
 
 typedef struct cn_model cn_model;
 
-enum { CN_PRECISION_F32 = 0, CN_PRECISION_BF16 = 1, CN_PRECISION_FP8 = 2, CN_PRECISION_BF16X3 = 3 };
+enum { CN_PRECISION_F32 = 0, CN_PRECISION_BF16 = 1, CN_PRECISION_FP8 = 2, CN_PRECISION_BF16X3 = 3, CN_PRECISION_F16 = 4 };
+/* CN_PRECISION_F16: the bf16 engine's kernels with IEEE half-precision MFMA operands (11 significant bits instead of 8, same matrix
+ * pipe and rate; range +-65504).  It lives in a second build of the same sources, libcassnat_hip_f16.so (-DCN_OP16_F16), which
+ * exports this same interface and accepts no other precision; libcassnat_hip.so refuses CN_PRECISION_F16.  cn_operand16() names
+ * a library's 16-bit operand ("bf16" / "fp16"). */
 enum { CN_DTYPE_F32 = 0, CN_DTYPE_I32 = 1, CN_DTYPE_U8 = 2, CN_DTYPE_F64 = 3 };
 
 /* Model hyper-parameters: the subset of the flat `args` bag that make_model reads for the transformer
@@ -83,6 +87,7 @@ typedef struct cn_decode_opts {
 
 const char* cn_last_error(void);
 const char* cn_version(void);
+const char* cn_operand16(void);
 
 /* replaces models.cassnat.make_model (src/models/cassnat.py:21) */
 int cn_model_create(const cn_config* cfg, cn_model** out);
@@ -138,6 +143,15 @@ int cn_decode_nast_merged(cn_model* m, const float* feats_dev, const float* size
                           int32_t u_hint, int32_t* hyp_out_dev, int32_t hyp_stride, int32_t* hyp_len_dev, double* score_dev,
                           void* stream, int32_t* ticket_out);
 int cn_decode_ticket(cn_model* m, int32_t ticket, int32_t* ymax_host, int32_t* rows_used_host);
+
+/* CN_PRECISION_F16 engines (libcassnat_hip_f16.so): half-precision operands have a range (+-65504).  What drives magnitudes from
+ * outside is the scale of the features - everything behind linear_out is LayerNorm-ed in fp32 first -, so every pass compares them
+ * with the largest |feature| for which neither subsampling convolution's output can leave half of that range (from the
+ * convolutions' weight row sums; a word of the weight blob) and raises a sticky flag.  *fault = 1: a pass since the last call saw
+ * such features - its results are not to be used (decode on a bf16 / bf16x3 engine, or normalise the features).  Valid once the
+ * passes' stream work is done; clears the flag.  *feature_limit (may be null): that largest |feature|, 0 if unknown.  Engines of
+ * every other precision: *fault = 0. */
+int cn_take_range_fault(cn_model* m, int32_t* fault, float* feature_limit);
 
 /* stage-level entry: src_embed + encoder + ctc_generator + alignment only (src/models/cassnat.py:431-468) */
 int cn_encode_align(cn_model* m, const float* feats_dev, const float* size_ratio_dev, int32_t B, int32_t T, int32_t F,

@@ -54,7 +54,7 @@ def test_conformer_tiny_variants_fp32(name, seed, ov):
                 assert s["hyp"] == g["beam_hyp"][b, j, : g["beam_len"][b, j]].tolist(), (b, j)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16", "fp16"])
 def test_conformer_shipped_shape(prec, capsys):
     g = load_golden("conf_small")
     args, state, feats, sizes = conf_small_case()
@@ -73,6 +73,8 @@ def test_conformer_shipped_shape(prec, capsys):
         np.testing.assert_array_equal(eng.fetch("ylen"), g["ylen"])
         assert maxerr(eng.fetch("dec_h")[:, ::3, ::8], g["dec_sample"]) < 5e-4
         assert exact == len(out)
+    elif prec == "fp16":  # half-precision operands (the second library): an order of magnitude inside the bf16 engine's error
+        assert flips <= 0.02 * clear.sum() and ctc_err < 5e-3  # (measured: 2 of 199, 1.6e-3; the bf16 engine: see the log line)
     else:
         assert flips <= 0.1 * clear.sum() and ctc_err < 0.2
 

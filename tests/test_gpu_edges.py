@@ -416,7 +416,7 @@ def test_randomised_shapes_bf16_fast_path_against_the_fp32_engine():
     assert same_path >= 4
 
 
-@pytest.mark.parametrize("prec", ["bf16", "bf16x3", "fp32"])
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3", "fp32", "fp16"])
 def test_merged_pass_equals_separate_passes_when_rows_change_workgroups(prec):
     """The config-2 model at a size where a merged engine pass puts an utterance's rows into other workgroups than a pass of
     its own does (400 frames -> 100 rows per utterance, 128-row workgroups, three ragged batches of 4): hypotheses AND scores
@@ -471,7 +471,7 @@ def _ragged_batches(rng, shapes, seed0, holes=False):
     return data
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16", "fp16"])
 def test_merged_pass_of_different_frame_counts_equals_separate_passes(prec):
     """cn_decode_nast_merged: batches of DIFFERENT frame counts (every residue of the two stride-2 subsamplings, different
     utterance counts, very short utterances, zeroed frames inside an utterance) through ONE engine pass give, per batch, exactly
@@ -510,7 +510,7 @@ def test_merged_pass_of_different_frame_counts_equals_separate_passes(prec):
         assert hyps == wh and list(scores) == ws, tag
 
 
-@pytest.mark.parametrize("prec", ["bf16", "bf16x3", "fp8"])
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3", "fp8", "fp16"])
 def test_merged_ragged_pass_config2_size(prec):
     """The same equality on the config-2 model at sizes where the fast kernels run (row chain, LDS-DMA convolution, fused
     generator; 128-/256-row tiles cut across batches of 100-, 91- and 78-row utterances).  fp8: the e4m3 forms of the front end
@@ -684,7 +684,7 @@ def test_a_ticket_expires_instead_of_returning_another_passes_counts():
     assert eng.ticket(tickets[1]) == counts[1]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_merged_pass_without_trigger_rows_equals_separate_passes(prec):
     """use_trigger = False (cassnat.py:469-473) through merged engine passes and the packed reader's batch objects: per batch the
     hypotheses and scores of a pass of its own (the extractor's mask is the utterance's own frame range, the row counts carry no
@@ -718,3 +718,53 @@ def test_merged_pass_without_trigger_rows_equals_separate_passes(prec):
             assert pipes.stats["merged_ragged"] >= 2, pipes.stats
         for (tag, hyps, scores), (wh, ws) in zip(got, want):
             assert hyps == wh and list(scores) == ws, (tag, shapes[tag])
+
+
+def test_fp16_engine_fails_loudly_outside_the_half_range():
+    """The fp16 engine's MFMA operands have a range (+-65504) and do not saturate.  What drives magnitudes from outside is the scale
+    of the features, so every pass checks them against the bound under which neither subsampling convolution's output can pass
+    65504 / 2 (from the convolutions' weight row sums; csrc/model.hip op16_feat_limit): `beam_decode` and the decode pipelines
+    raise instead of returning hypotheses of such a pass; inside the bound the engine decodes, and the same features decode on the
+    bf16 engine (range of fp32)."""
+    from cassnat_asr_public_amd.pipeline import DecodePipelines
+
+    args = synth.make_args("tiny")
+    state = synth.make_state(args, seed=0, gain=2.0)
+    feats, sizes = synth.make_feats(3, 61, 80, lengths=[61, 50, 37], seed=11)
+    ratio = torch.from_numpy(sizes).cuda()
+    model = build(args, state, capture=False, prec="fp16")
+    src0 = torch.from_numpy(feats).cuda()
+    mask = (src0[:, :, 0] != args.padding_idx).unsqueeze(1)
+    ok, _ = model.beam_decode(src0, mask, ratio, Vocab, args)  # in range: decodes
+    assert all(np.isfinite(o[0]["score"]) for o in ok)
+    fault, limit = hip.C.c_int32(), hip.C.c_float()
+    eng = model._engine
+    hip.check(eng.L.cn_take_range_fault(eng.handle, hip.C.byref(fault), hip.C.byref(limit)), "cn_take_range_fault", eng.L)
+    # the bound follows from the weights: |conv1| <= fmax A1 + B1, |conv2| <= |conv1| A2 + B2, both <= 32752
+    w1, b1 = state["src_embed.conv.0.weight"], state["src_embed.conv.0.bias"]
+    w2, b2 = state["src_embed.conv.2.weight"], state["src_embed.conv.2.bias"]
+    A1, A2 = np.abs(w1).reshape(w1.shape[0], -1).sum(1).max(), np.abs(w2).reshape(w2.shape[0], -1).sum(1).max()
+    c1 = min(32752.0, (32752.0 - np.abs(b2).max()) / A2)
+    want = (c1 - np.abs(b1).max()) / A1
+    assert fault.value == 0 and abs(limit.value - want) < 1e-3 * want, (limit.value, want)
+    scale = 1.05 * limit.value / np.abs(feats).max()
+    just_in = torch.from_numpy((feats * (0.95 / 1.05 * scale)).astype(np.float32)).cuda()
+    model.beam_decode(just_in, mask, ratio, Vocab, args)
+    big = torch.from_numpy((feats * scale).astype(np.float32)).cuda()
+    with pytest.raises(hip.HipError, match="half-precision range"):
+        model.beam_decode(big, mask, ratio, Vocab, args)
+    model.beam_decode(src0, mask, ratio, Vocab, args)  # (the flag was taken: the next call is judged on its own features)
+    pipes = DecodePipelines(model, 1, 3, 61, coalesce=2)
+    try:
+        with pytest.raises(hip.HipError, match="half-precision range"):
+            list(pipes.decode([(src0, ratio, 0), (big, ratio, 1)], args))
+    finally:
+        pipes.close()
+    wide = build(args, state, capture=False, prec="bf16")
+    out, _ = wide.beam_decode(big, mask, ratio, Vocab, args)
+    assert all(np.isfinite(o[0]["score"]) for o in out)
+    # an engine that received its weights as a blob (a non-zero rank) carries the bound too: it is a word of the blob
+    eng2 = hip.Engine(args, precision="fp16", max_batch=3, max_frames=61)
+    eng2.load_state(state, torch.zeros(5000, args.d_model))
+    hip.check(eng2.L.cn_take_range_fault(eng2.handle, hip.C.byref(fault), hip.C.byref(limit)), "cn_take_range_fault", eng2.L)
+    assert abs(limit.value - want) < 1e-3 * want

@@ -112,7 +112,7 @@ def test_broadcast_receiver_never_repacks_its_unloaded_parameters():
         dst.build_engine(3, 64)
 
 
-@pytest.mark.parametrize("prec,scope", [("bf16", "all"), ("bf16x3", "all"), ("fp8", "all"), ("fp8", "conv2+ffn:1")])
+@pytest.mark.parametrize("prec,scope", [("bf16", "all"), ("bf16x3", "all"), ("fp8", "all"), ("fp8", "conv2+ffn:1"), ("fp16", "all")])
 def test_blob_carries_everything_a_receiving_rank_needs(prec, scope):
     """The rank-0 -> rank-n hand-off is ONE buffer (cn_model_weight_blob): every packed form an engine reads - bf16 / split-bf16
     matrices, the chain kernels' weight streams and tables, the fp8 engine's e4m3 copies with their scale words - has to live

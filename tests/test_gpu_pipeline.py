@@ -205,6 +205,40 @@ def test_bf16_agreement_report(case, name, strides, capsys):
     assert m["flips_margin_ge_0.05"] == 0 and m["flips_margin_ge_0.2"] == 0, m
 
 
+@pytest.mark.parametrize("case,name,strides", [
+    (config2_b8_case, "config2_b8", (10, 50, 4)),
+    (config2_b32_case, "config2_b32", (25, 100, 8)),
+    (config5_shape_case, "config5_shape", (10, 50, 4)),
+])
+def test_fp16_engine_meets_the_logit_tolerance(case, name, strides, capsys):
+    """The fp16 engine = the bf16 engine's kernels with IEEE half operands (libcassnat_hip_f16.so: csrc/common.h, -DCN_OP16_F16):
+    same schedules, same speed, 11 significant bits per operand instead of 8.  Against the reference's fp32 goldens its CTC
+    log-posteriors stay within north_star's 1e-3; what may still flip is a frame whose fp32 top-2 margin is of the size of that
+    error (a random-weight model has such frames, a trained one's posteriors are peaked)."""
+    g = load_golden(name)
+    args, state, feats, sizes = case()
+    model = build(args, state, "fp16", capture=True)
+    rep = check_against_golden(model, args, feats, sizes, g, *strides, fp32=False)
+    assert model._engine.L.cn_operand16() == b"fp16"
+    with capsys.disabled():
+        print(f"\n[agreement fp16] {name}: {rep}")
+    assert rep["ctc_logit_err"] < 1e-3, rep
+    assert rep["flips"] / rep["frames"] < 0.003, rep  # (measured: 4 / 2000 - all four on frames of margin < 1e-4 -, 3 / 8000, 0 / 600)
+    m = rep["margins"]
+    assert_flips_explained(m, rep["ctc_logit_err"], FLIP_K, f"fp16 {name}")
+    assert m["max_flip_margin"] < 2e-3 and m["flips_margin_ge_0.05"] == 0 and m["flips_margin_ge_0.2"] == 0, m
+
+
+def test_the_two_libraries_refuse_each_others_engines():
+    args, state, feats, sizes = tiny_case()
+    assert hip.lib().cn_operand16() == b"bf16" and hip.lib("f16").cn_operand16() == b"fp16"
+    cfg = hip.Engine(args, precision="fp16", max_batch=2, max_frames=64).cfg
+    h = hip.C.c_void_p()
+    assert hip.lib().cn_model_create(hip.C.byref(cfg), hip.C.byref(h)) != 0 and b"libcassnat_hip_f16.so" in hip.lib().cn_last_error()
+    cfg.precision = hip.PRECISION["bf16"]
+    assert hip.lib("f16").cn_model_create(hip.C.byref(cfg), hip.C.byref(h)) != 0 and b"fp16 engine only" in hip.lib("f16").cn_last_error()
+
+
 def test_full_size_properties_bf16():
     """BASELINE config 2 at full size: size-independent properties of the integer outputs."""
     args, state, feats, sizes = config2_b32_case()
@@ -263,10 +297,12 @@ def test_weight_blob_handoff_reproduces_rank0_engine():
     assert [s[0]["score"] for s in out_a] == [s[0]["score"] for s in out_b]
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
 @pytest.mark.parametrize("batch_size", [3, 1])
-def test_decode_asr_cli_end_to_end(tmp_path, batch_size):
+def test_decode_asr_cli_end_to_end(tmp_path, batch_size, prec):
     """decode_asr.py --task cassnat on a synthetic Kaldi table: result file == oracle hypotheses as text.  batch_size 3: one
-    batch, the plain loop; batch_size 1: three batches through the decode pipelines (pipeline.DecodePipelines)."""
+    batch, the plain loop; batch_size 1: three batches through the decode pipelines (pipeline.DecodePipelines).  fp16: the engine
+    of the second library (half-precision operands) behind the same command line - on this model (no near-tie frame) the same text."""
     import yaml
 
     from cassnat_asr_public_amd.bin import decode_asr
@@ -290,7 +326,7 @@ def test_decode_asr_cli_end_to_end(tmp_path, batch_size):
     cfg.write_text(yaml.safe_dump(conf))
     result = str(tmp_path / "token_results.txt")
     rc = decode_asr.main(["--task", "cassnat", "--test_config", str(cfg), "--data_path", scp, "--resume_model", ckpt,
-                          "--result_file", result, "--batch_size", str(batch_size), "--hip_precision", "fp32",
+                          "--result_file", result, "--batch_size", str(batch_size), "--hip_precision", prec,
                           "--load_data_workers", "0"])
     assert rc == 0
     index2word = {i + 4: f"w{i}" for i in range(args.vocab_size - 4)}

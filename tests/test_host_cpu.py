@@ -22,12 +22,14 @@ from cassnat_asr_public_amd.utils.parser import DecodeParser
 
 # ------------------------------------------------------------------------------------------- C ABI surface
 def test_library_exports_every_declared_symbol():
-    L = hip.lib()  # raises if include/cassnat_hip.h declares something the .so does not export
     names = hip.declared_symbols()
     assert len(names) >= 20
-    for n in names:
-        assert hasattr(L, n), n
-    assert L.cn_version().startswith(b"cassnat_hip")
+    # both builds of the sources (bf16 operands; half-precision operands: the fp16 engine) export the one interface
+    for flavour, operand in ((None, b"bf16"), ("f16", b"fp16")):
+        L = hip.lib(flavour)  # raises if include/cassnat_hip.h declares something the .so does not export
+        for n in names:
+            assert hasattr(L, n), n
+        assert L.cn_version().startswith(b"cassnat_hip") and L.cn_operand16() == operand
 
 
 def test_product_library_reads_no_environment_variable():
@@ -36,10 +38,11 @@ def test_product_library_reads_no_environment_variable():
     loader-level CASSNAT_HIP_LIB (which library file to load)."""
     import re
 
-    out = subprocess.run(["nm", "-D", "--undefined-only", hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    assert not re.search(r"\bgetenv\b", out)
-    blob = open(hip.LIB_PATH, "rb").read()
-    assert b"CASSNAT_" not in blob
+    for path in (hip.LIB_PATH, hip.LIB_PATH_F16):
+        out = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+        assert not re.search(r"\bgetenv\b", out)
+        blob = open(path, "rb").read()
+        assert b"CASSNAT_" not in blob
     pkg = os.path.join(REPO, "cassnat_asr_public_amd")
     used = set()
     for root, _, files in os.walk(pkg):
@@ -75,10 +78,13 @@ def test_fp8_scope_strings():
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
-    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "_libs", {})
     monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(hip, "LIB_PATH_F16", str(tmp_path / "nope_f16.so"))
     with pytest.raises(hip.HipError, match="no CPU fallback"):
         hip.lib()
+    with pytest.raises(hip.HipError, match="nope_f16.so is missing"):
+        hip.lib_for("fp16")
 
 
 # ------------------------------------------------------------------------------------------- model surface
