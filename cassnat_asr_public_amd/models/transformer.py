@@ -146,6 +146,7 @@ class Transformer(nn.Module):
             score = torch.empty(B, bw, dtype=torch.float64, device=dev)
             eng.ast_decode(feats, opts, ao, hyp, hlen, score)
             hyp, hlen, score = hyp.cpu().numpy(), hlen.cpu().numpy(), score.cpu().numpy()
+            eng.check_range("Transformer.beam_decode")  # (fp16 engines: the features were inside the half-precision range)
             out = []
             for b in range(B):
                 row = []
@@ -207,6 +208,7 @@ class Transformer(nn.Module):
                 else:
                     cand[b].sort(key=lambda x: x["score"], reverse=True)
                 beams[b] = cand[b][:bw]
+        eng.check_range("Transformer.beam_decode")
         return [[{"ys": torch.tensor([s["hyp"]], dtype=torch.long), "score": s["score"], "hyp": s["hyp"]} for s in beams[b]]
                 for b in range(B)]
 
@@ -228,6 +230,7 @@ class Transformer(nn.Module):
         opts = hip.CnDecodeOpts(padding_idx=int(args.padding_idx), sos=sos, beam_width=1)
         length, tok, val = eng.ast_ctc_correct(feats, opts, bw)
         length, tok, val = length.cpu().numpy(), tok.cpu().numpy(), val.cpu().numpy()
+        eng.check_range("Transformer.fast_decode_with_ctc")
         lp = args.length_penalty
         ys = torch.ones(1, 1).fill_(sos).long()
         out = []

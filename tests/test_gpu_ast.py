@@ -74,10 +74,11 @@ def test_ast_config4_fp32_beam10(name, ov, prec, capsys):
         assert abs(utt[0]["score"] - g["beam_score"][b, 0]) < 5e-3
 
 
-def test_ast_config4_bf16_report(capsys):
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])  # (fp16: the same kernels with half-precision operands, the second library)
+def test_ast_config4_bf16_report(prec, capsys):
     g = load_golden("ast_config4_ctc")
     args, state, feats = ast_config4_case(ctc_weight=0.3)
-    beams = run(args, state, feats, "bf16")
+    beams = run(args, state, feats, prec)
     exact, total, top1 = agreement(beams, g)
     prefix = []
     for b, utt in enumerate(beams):
@@ -89,9 +90,10 @@ def test_ast_config4_bf16_report(capsys):
         prefix.append(k)
         assert len(got) == len(ref) and np.isfinite(utt[0]["score"])
     with capsys.disabled():
-        print(f"\n[AST bf16] beams identical {exact}/{total}, top-1 identical {top1}/{len(beams)}, common prefix of best {prefix}")
+        print(f"\n[AST {prec}] beams identical {exact}/{total}, top-1 identical {top1}/{len(beams)}, common prefix of best {prefix}")
     # constrained at about half of what this build measures (15/20 beams, both best hypotheses, 31-token common prefixes): a
     # regression of the bf16 step kernels shows as beams falling apart, not as a changed report line
+    # (fp16 measures 12/20: which of two near-tied beams comes first is decided below either engine's rounding)
     assert top1 == len(beams) and exact >= 8 and min(prefix) >= 15
 
 
@@ -106,11 +108,12 @@ def test_ast_host_beam_matches_golden(name, ov):
             assert s["hyp"] == g["beam_hyp"][b, j, : g["beam_len"][b, j]].tolist(), (b, j)
 
 
-def test_ast_device_beam_equals_host_beam_bf16():
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_ast_device_beam_equals_host_beam_bf16(prec):
     """Same engine, same kernels: the device-side bookkeeping must reproduce the host bookkeeping bit for bit."""
     args, state, feats = ast_config4_case(ctc_weight=0.3)
-    dev_b = run(args, state, feats, "bf16")
-    host_b = run(args, state, feats, "bf16", host_beam=True)
+    dev_b = run(args, state, feats, prec)
+    host_b = run(args, state, feats, prec, host_beam=True)
     for u, v in zip(dev_b, host_b):
         assert [s["hyp"] for s in u] == [s["hyp"] for s in v]
         assert [s["score"] for s in u] == [s["score"] for s in v]
