@@ -201,7 +201,7 @@ def test_rccl_branch_world_size_one():
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    for prec in ("bf16", "bf16x3"):
+    for prec in ("bf16", "bf16x3", "fp16"):  # (fp16: the blob of an engine of the second library travels the same way)
         out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_nccl_world1.py"), prec], env=env, cwd=REPO,
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
