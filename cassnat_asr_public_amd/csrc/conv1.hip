@@ -11,11 +11,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // PLANES (T = bf16): the split-bf16 image as two bf16 images, the hi halves at `out` and the lo halves `lo_off` elements
 // further, both in the bordered layout - what the LDS-DMA conv2 kernel reads in its split form (conv2.hip, X3)
-template <typename T, bool PLANES = false>
+// MIXP (T = bf16 as a 2-byte cell): the three planes of conv2's MIX form (conv2.hip) - half-precision hi values at `out`, then
+// (`lo_off` = the image's cell count) the bytes l = e4m3((v - hi) out_scale) at 2 lo_off and q = e4m3(v out_scale2) at 3 lo_off
+template <typename T, bool PLANES = false, bool MIXP = false>
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
                                                     const float* __restrict__ bias, T* __restrict__ out, int B, int Tn,
                                                     int F, int T1, int F1, int C, int halo, long long lo_off = 0,
-                                                    const UttMeta* __restrict__ utt_meta = nullptr, float out_scale = 1.f) {
+                                                    const UttMeta* __restrict__ utt_meta = nullptr, float out_scale = 1.f,
+                                                    float out_scale2 = 1.f) {
     // A thread keeps its 8 channels for the whole kernel, so the 72 tap weights + 8 biases live in registers (as pairs: the
     // 72 multiply-adds of an output position are 36 v_pk_fma_f32).  The three input rows of an output row are staged once in
     // LDS with their zero padding (index f + 1, f = -1 .. F), so a position's nine taps are nine unconditional LDS reads - the
@@ -70,6 +73,11 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
                 } else if constexpr (sizeof(T) == 2) {
                     *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
                     if constexpr (PLANES) *reinterpret_cast<uint4*>(dst + lo_off) = make_uint4(0, 0, 0, 0);
+                    if constexpr (MIXP) {
+                        unsigned char* b8 = reinterpret_cast<unsigned char*>(out) + 2 * lo_off + (dst - out);
+                        *reinterpret_cast<uint2*>(b8) = make_uint2(0, 0);
+                        *reinterpret_cast<uint2*>(b8 + lo_off) = make_uint2(0, 0);
+                    }
                 } else if constexpr (!__is_same(T, split_t)) {
                     *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
                     *reinterpret_cast<uint4*>(dst + 4) = make_uint4(0, 0, 0, 0);
@@ -117,6 +125,30 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ x,
                 unsigned char* db = reinterpret_cast<unsigned char*>(dst) + cn_split_off((size_t)c0);
                 __builtin_nontemporal_store(hi, reinterpret_cast<bf16x8*>(db));
                 __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8*>(db + 64));
+            } else if constexpr (MIXP) {
+                typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                h16x8 hv;
+                float lo[8], qv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    hv[j] = (_Float16)o[j];
+                    lo[j] = __builtin_amdgcn_fmed3f((o[j] - (float)hv[j]) * out_scale, -CN_FP8_MAX, CN_FP8_MAX);
+                    qv[j] = fminf(o[j] * out_scale2, CN_FP8_MAX);
+                }
+                __builtin_nontemporal_store(hv, reinterpret_cast<h16x8*>(dst));
+                unsigned l0 = 0, l1 = 0, q0 = 0, q1 = 0;
+                l0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], l0, false);
+                l0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], l0, true);
+                l1 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[4], lo[5], l1, false);
+                l1 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[6], lo[7], l1, true);
+                q0 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[0], qv[1], q0, false);
+                q0 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[2], qv[3], q0, true);
+                q1 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[4], qv[5], q1, false);
+                q1 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[6], qv[7], q1, true);
+                unsigned char* b8 = reinterpret_cast<unsigned char*>(out) + 2 * lo_off + (dst - out);
+                __builtin_nontemporal_store(u32x2{l0, l1}, reinterpret_cast<u32x2*>(b8));
+                __builtin_nontemporal_store(u32x2{q0, q1}, reinterpret_cast<u32x2*>(b8 + lo_off));
             } else if constexpr (sizeof(T) == 2) {
                 bf16x8 ob;
 #pragma unroll
@@ -186,6 +218,25 @@ int launch_conv1_planes(const float* x, const float* w9c, const float* bias, voi
     const long long plane = (long long)B * (T1 + 2) * (F1 + 2) * C;
     hipLaunchKernelGGL((conv1_kernel<bf16, true>), dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (bf16*)out, B, T, F, T1,
                        F1, C, halo, plane, utt_meta);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// the three planes of conv2's MIX form (conv2.hip): half-precision hi values, then l = e4m3((v - hi) scale_l) bytes, then
+// q = e4m3(v scale_q) bytes, each bordered ([B][T1 + 2][F1 + 2][C] cells); `out` holds 4 bytes per cell
+int launch_conv1_mixplanes(const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1, int F1, int C,
+                           int halo, float scale_l, float scale_q, hipStream_t s, const UttMeta* utt_meta) {
+    if (C % 8 != 0 || (256 % (C / 8)) != 0 || (halo != 1 && halo != 2)) {
+        cn_set_error("conv1 (mix planes): channel count must be a multiple of 8 with C/8 dividing 256; the image is always bordered");
+        return -1;
+    }
+    long long blocks = (long long)B * (T1 + 2);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    const size_t lds = (size_t)2 * 3 * (F + 2) * sizeof(float);
+    const long long cells = (long long)B * (T1 + 2) * (F1 + 2) * C;
+    hipLaunchKernelGGL((conv1_kernel<bf16, false, true>), dim3((unsigned)blocks), dim3(256), lds, s, x, w9c, bias, (bf16*)out, B, T, F, T1,
+                       F1, C, halo, cells, utt_meta, scale_l, scale_q);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -33,6 +33,12 @@ struct Conv2Params {
     // F8 (template; the fp8 engine of BASELINE config 5): A and W hold e4m3fn bytes (same layouts, 256 / 9 * 256 bytes per row),
     // q8 = the two E8M0 scale bytes of the products (device: they travel in the weight blob): 127 - log2(scale of W), 127 - log2(scale of A)
     const int* q8;
+    // MIX (template): A / W are the half-precision hi planes; the e4m3 planes of the cross terms - l = e4m3((v - hi) S_l),
+    // q = e4m3(v S_q), images bordered like A, weights [256][9 * 256] bytes - and q8 = the four E8M0 bytes {W_q, A_l, W_l, A_q}
+    const unsigned char* A8l;
+    const unsigned char* A8q;
+    const unsigned char* W8q;
+    const unsigned char* W8l;
     // F8 convolution: out8_scale > 0 = the output rows are e4m3fn bytes at that scale ([M][256] bytes: the A operand of linear_out's
     // e4m3 form) instead of bf16
     float out8_scale;
@@ -82,13 +88,13 @@ constexpr int C2_LIN8_KSTEPS = 40;  // K steps (of 128 bytes) of the e4m3 linear
 #define C2_DMA_I(i) "s_add_u32 m0, %[st], " C2_STR(i * 4096) "\n\tglobal_load_lds_dwordx4 %[vo" #i "], %[sb]\n\t"
 #endif
 #define C2_NODMA(i) ""
-#define C2_M(nt, mt) C2_MF "%[c" #nt #mt "], %[w" #nt "], %[a" #mt "], %[c" #nt #mt "]\n\t"
-#define C2_BLOCK(PRE, Ac, Wc, An, Wn, DMA, vo)                                                                 \
+#define C2_M(MF, nt, mt) MF "%[c" #nt #mt "], %[w" #nt "], %[a" #mt "], %[c" #nt #mt "]\n\t"
+#define C2_BLOCK_X(MF, PRE, Ac, Wc, An, Wn, DMA, vo)                                                          \
     asm volatile(PRE "s_waitcnt lgkmcnt(0)\n\t"                                                                \
-                 C2_M(0, 0) C2_RDA(0) C2_M(0, 1) C2_RDA(1) C2_M(0, 2) C2_RDA(2) C2_M(0, 3) C2_RDA(3)           \
-                 C2_M(1, 0) C2_RDW(0) C2_M(1, 1) C2_RDW(1) C2_M(1, 2) C2_RDW(2) C2_M(1, 3) C2_RDW(3)           \
-                 C2_M(2, 0) DMA(0) C2_M(2, 1) DMA(1) C2_M(2, 2) DMA(2) C2_M(2, 3) DMA(3)                       \
-                 C2_M(3, 0) DMA(4) C2_M(3, 1) DMA(5) C2_M(3, 2) DMA(6) C2_M(3, 3) DMA(7)                       \
+                 C2_M(MF, 0, 0) C2_RDA(0) C2_M(MF, 0, 1) C2_RDA(1) C2_M(MF, 0, 2) C2_RDA(2) C2_M(MF, 0, 3) C2_RDA(3)           \
+                 C2_M(MF, 1, 0) C2_RDW(0) C2_M(MF, 1, 1) C2_RDW(1) C2_M(MF, 1, 2) C2_RDW(2) C2_M(MF, 1, 3) C2_RDW(3)           \
+                 C2_M(MF, 2, 0) DMA(0) C2_M(MF, 2, 1) DMA(1) C2_M(MF, 2, 2) DMA(2) C2_M(MF, 2, 3) DMA(3)                       \
+                 C2_M(MF, 3, 0) DMA(4) C2_M(MF, 3, 1) DMA(5) C2_M(MF, 3, 2) DMA(6) C2_M(MF, 3, 3) DMA(7)                       \
                  : [c00] "+a"(acc[0]), [c01] "+a"(acc[1]), [c02] "+a"(acc[2]), [c03] "+a"(acc[3]), [c10] "+a"(acc[4]), \
                    [c11] "+a"(acc[5]), [c12] "+a"(acc[6]), [c13] "+a"(acc[7]), [c20] "+a"(acc[8]), [c21] "+a"(acc[9]), \
                    [c22] "+a"(acc[10]), [c23] "+a"(acc[11]), [c30] "+a"(acc[12]), [c31] "+a"(acc[13]),          \
@@ -100,6 +106,17 @@ constexpr int C2_LIN8_KSTEPS = 40;  // K steps (of 128 bytes) of the e4m3 linear
                    [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]),   \
                    [vo5] "v"(vo[5]), [vo6] "v"(vo[6]), [vo7] "v"(vo[7]), [st] "s"(st_), [sb] "s"(sb_)          \
                  : "memory", "scc")
+#define C2_BLOCK(PRE, Ac, Wc, An, Wn, DMA, vo) C2_BLOCK_X(C2_MF, PRE, Ac, Wc, An, Wn, DMA, vo)
+// the same block on half-precision operands whatever the library's own 16-bit type (the MIX form's hi x hi products)
+#define C2_BLOCK_H(PRE, Ac, Wc, An, Wn, DMA, vo) C2_BLOCK_X("v_mfma_f32_32x32x16_f16 ", PRE, Ac, Wc, An, Wn, DMA, vo)
+#define C2_BLK(PRE, Ac, Wc, An, Wn, DMA, vo)                      \
+    do {                                                          \
+        if constexpr (MIX) {                                      \
+            C2_BLOCK_H(PRE, Ac, Wc, An, Wn, DMA, vo);             \
+        } else {                                                  \
+            C2_BLOCK(PRE, Ac, Wc, An, Wn, DMA, vo);               \
+        }                                                         \
+    } while (0)
 
 // F8 form of a block: one 64-wide k sub-step = 16 x v_mfma_scale_f32_32x32x64_f8f6f4 (64 cycles each: the block takes as long as two
 // bf16 blocks and covers four times the contraction).  An operand is the pair of 16-byte fragments the bf16 kernel reads for
@@ -144,10 +161,17 @@ typedef int c2_v4i __attribute__((ext_vector_type(4)));
 // bf16 kernel with 108 K steps and another epilogue (bias + ReLU + hi / lo split, split-bf16 rows).
 // F8 (convolution only): e4m3 operands on the K = 64 block-scaled MFMA at twice the bf16 rate (C2_BLOCK8); slabs, stages and
 // requests as in the bf16 kernel, a slab row now being 128 channels: 18 K steps of two blocks each
-template <bool LINEAR, bool X3 = false, bool F8 = false>
+// MIX (convolution only; the split-bf16 engine's input planes in another arithmetic): a value v is kept as h = half(v) plus
+// two e4m3 bytes at fixed power-of-two scales, l = e4m3((v - h) S_l) and q = e4m3(v S_q), and a product is
+//     a b = h_a h_b + l_a q_b + q_a l_b            (the dropped l_a l_b is 2^-24 relative, the 4-bit significands of the cross
+// terms' factors cost 2^-16 each): 36 K steps of the 16-bit loop on v_mfma_f32_32x32x16_f16, then 2 x 18 e4m3 K steps - (A_l, W_q),
+// (A_q, W_l) - at twice the rate, on the same stages and accumulators: 2 MFMA units per product where X3 spends 3.  Output: the
+// split-bf16 rows of the X3 form (linear_out of that engine reads them).
+template <bool LINEAR, bool X3 = false, bool F8 = false, bool MIX = false>
 __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
     static_assert(!(LINEAR && X3) && !(F8 && X3), "the split form exists for the convolution only; e4m3: convolution and linear_out");
-    constexpr int ES = F8 ? 1 : 2;  // bytes per image / weight element
+    static_assert(!MIX || (!LINEAR && !X3 && !F8), "MIX is a form of the convolution of its own");
+    constexpr int ES = F8 ? 1 : 2;  // bytes per image / weight element (MIX: of the 16-bit phase; its e4m3 phase recomputes for 1)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,20 +194,20 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
     // every request): the rows of a tile are consecutive (b, t2, f2) positions, so they span a few image rows however large
     // the image (a merged engine pass of many batches exceeds 4 GiB; with absolute 32-bit offsets the reads wrapped silently)
     const int F1p = p.F1 + 2;
-    auto a_off = [&](int mm) -> long long {
+    auto a_off = [&](int mm, int es) -> long long {
         if constexpr (LINEAR) return (long long)mm * p.lda_bytes;
         const int f2 = mm % p.F2, bt = mm / p.F2;
         const int t2 = bt % p.T2, b = bt / p.T2;
-        return (((long long)b * (p.T1 + 2) + 2 * t2) * F1p + 2 * f2) * (C2_C * ES);
+        return (((long long)b * (p.T1 + 2) + 2 * t2) * F1p + 2 * f2) * (C2_C * es);
     };
-    const long long tile_off = a_off(m0);  // (m0 < M: the grid has ceil(M / 256) workgroups)
+    long long tile_off = a_off(m0, ES);  // (m0 < M: the grid has ceil(M / 256) workgroups)
     unsigned pa[8], pw[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int row = 8 * (wave + 4 * i) + r8;
         const int m = m0 + row;
         const int mc = m < p.M ? m : p.M - 1;  // rows past M compute on the last row's data and are never stored
-        pa[i] = (unsigned)(a_off(mc) - tile_off) + sw;
+        pa[i] = (unsigned)(a_off(mc, ES) - tile_off) + sw;
         if constexpr (LINEAR)
             pw[i] = (unsigned)(row * (p.ksteps * 128)) + sw;
         else
@@ -250,74 +274,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
 #define C2_PRE3 "s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier\n\t"
 #endif
 #define C2_PRE3_ALL "s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)\n\ts_barrier\n\t"
-    if constexpr (F8) {
-        // ---- e4m3 loop: two blocks per K step.  Block 0 (sub-step 0 of stage kt; reads sub-step 1) requests the A slab of step
-        // kt + 2; block 1 starts with the step's barrier (own fragments landed; everything but that A slab landed: vmcnt(8)), reads
-        // sub-step 0 of step kt + 1 behind it and requests the W slab of step kt + 2 into the W stage the barrier has just freed.
-        // So an A slab (HBM) has a step and a half to arrive, a W slab (L2) one step - as in the bf16 loop.
-        bf16x8 Az[4], Wz[4], Au[4], Wu[4];
-        const int qa_ = p.q8[0], qb_ = p.q8[1];
-        const unsigned wstep_ = LINEAR ? 32u * (unsigned)(p.ksteps * 128) : 32u * (9 * C2_C * ES);  // byte distance of consecutive W pieces (32 weight rows)
-        const unsigned pw0 = pw[0];
-        unsigned tv_ = pw0;
-        C2_ISSUE8(a_dst(0), pa, a_base(0))
-        C2_ISSUE8(w_dst(0), pw, w_base(0))
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        C2_ISSUE8(a_dst(1), pa, a_base(min(1, KL)))
-        C2_ISSUE8(w_dst(1), pw, w_base(min(1, KL)))
-        {  // fragments of step 0, sub-step 0 (chunks of the bf16 sub-steps 0 and 1), landed before anything else touches them
-            const unsigned an0_ = a_rd0, an1_ = C2_RD(a_rd0, 1, 0), wn0_ = w_rd0, wn1_ = C2_RD(w_rd0, 1, 0);
-            asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %16 offset:4096\n\tds_read_b128 %2, %16 offset:8192\n\t"
-                         "ds_read_b128 %3, %16 offset:12288\n\tds_read_b128 %4, %17\n\tds_read_b128 %5, %17 offset:4096\n\t"
-                         "ds_read_b128 %6, %17 offset:8192\n\tds_read_b128 %7, %17 offset:12288\n\t"
-                         "ds_read_b128 %8, %18\n\tds_read_b128 %9, %18 offset:4096\n\tds_read_b128 %10, %18 offset:8192\n\t"
-                         "ds_read_b128 %11, %18 offset:12288\n\tds_read_b128 %12, %19\n\tds_read_b128 %13, %19 offset:4096\n\t"
-                         "ds_read_b128 %14, %19 offset:8192\n\tds_read_b128 %15, %19 offset:12288\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(Ax[0]), "=&v"(Ax[1]), "=&v"(Ax[2]), "=&v"(Ax[3]), "=&v"(Wx[0]), "=&v"(Wx[1]), "=&v"(Wx[2]),
-                           "=&v"(Wx[3]), "=&v"(Ay[0]), "=&v"(Ay[1]), "=&v"(Ay[2]), "=&v"(Ay[3]), "=&v"(Wy[0]), "=&v"(Wy[1]),
-                           "=&v"(Wy[2]), "=&v"(Wy[3])
-                         : "v"(an0_), "v"(wn0_), "v"(an1_), "v"(wn1_)
-                         : "memory");
-        }
-        // (fully unrolled - 18 steps of two blocks: with a back edge hipcc gave the 256 accumulator registers another
-        // assignment at the loop's end than at its head and moved half of them through scratch, every iteration)
-        // (LINEAR: linear_out of the 20 x 256 = 5120-wide embedding input: 40 steps - the launcher checks)
-        constexpr int KS8 = LINEAR ? C2_LIN8_KSTEPS : C2_KSTEPS / 2;
-#pragma unroll
-        for (int kt = 0; kt < KS8; ++kt) {
-            const int k3 = kt % 3;
-            const int k3n = k3 == 2 ? 0 : k3 + 1, k3p = k3 == 0 ? 2 : k3 - 1;
-            const unsigned so_a = (unsigned)(k3 * C2_SLAB), so_w = (unsigned)((kt & 1) * C2_SLAB);
-            const unsigned sn_a = (unsigned)(k3n * C2_SLAB), sn_w = (unsigned)(((kt + 1) & 1) * C2_SLAB);
-            // (branch-free: past the last K step the requests repeat the last slabs into stages nobody reads any more - with the
-            // two forms of a block behind a branch, as in the bf16 loop, hipcc reshuffled all fragment sets through scratch at every
-            // join; the wait after the loop covers the redundant requests)
-            {
-                const unsigned an0_ = C2_RD(a_rd0, 2, so_a), an1_ = C2_RD(a_rd0, 3, so_a);
-                const unsigned wn0_ = C2_RD(w_rd0, 2, so_w), wn1_ = C2_RD(w_rd0, 3, so_w);
-                const unsigned* vo = pa;
-                const unsigned st_ = a_dst(k3p);  // (kt + 2) % 3
-                const unsigned char* sb_ = a_base(min(kt + 2, KL));
-                C2_BLOCK8("", Ax, Wx, Ay, Wy, Az, Wz, Au, Wu, C2_DMA_I, vo);
-            }
-            {
-                const unsigned an0_ = a_rd0 + sn_a, an1_ = C2_RD(a_rd0, 1, sn_a);
-                const unsigned wn0_ = w_rd0 + sn_w, wn1_ = C2_RD(w_rd0, 1, sn_w);
-                const unsigned* vo = pa;  // (not used by this block's requests)
-                const unsigned st_ = w_dst(kt + 2);
-                const unsigned char* sb_ = w_base(min(kt + 2, KL));
-                tv_ = pw0;
-                C2_BLOCK8(C2_PRE3, Az, Wz, Au, Wu, Ax, Wx, Ay, Wy, C2_DMA_W8, vo);
-            }
-        }
-        // a 16-pass MFMA's result is readable 19 wait states later; the last block's (unused) fragments land here
-        asm volatile("s_nop 15\n\ts_nop 4\n\ts_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)"
-                     : "+v"(Ax[0]), "+v"(Ax[1]), "+v"(Ax[2]), "+v"(Ax[3]), "+v"(Wx[0]), "+v"(Wx[1]), "+v"(Wx[2]), "+v"(Wx[3]),
-                       "+v"(Ay[0]), "+v"(Ay[1]), "+v"(Ay[2]), "+v"(Ay[3]), "+v"(Wy[0]), "+v"(Wy[1]), "+v"(Wy[2]), "+v"(Wy[3])
-                     :: "memory");
-        asm volatile("" : "+v"(Az[0]), "+v"(Az[1]), "+v"(Az[2]), "+v"(Az[3]), "+v"(Wz[0]), "+v"(Wz[1]), "+v"(Wz[2]), "+v"(Wz[3]),
-                     "+v"(Au[0]), "+v"(Au[1]), "+v"(Au[2]), "+v"(Au[3]), "+v"(Wu[0]), "+v"(Wu[1]), "+v"(Wu[2]), "+v"(Wu[3]) :: "memory");
-    } else {
+    if constexpr (!F8) {  // ---- the 16-bit K steps (MIX: the hi x hi products on half-precision operands)
     C2_ISSUE8(a_dst(0), pa, a_base(0))
     C2_ISSUE8(w_dst(0), pw, w_base(0))
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -350,11 +307,11 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
             if (LINEAR || kt + 1 < KSTEPS) {
                 const unsigned st_ = w_dst(kt + 1);
                 const unsigned char* sb_ = w_base(LINEAR ? min(kt + 1, KL) : kt + 1);
-                C2_BLOCK("", Ax, Wx, Ay, Wy, C2_DMA_I, vo);
+                C2_BLK("", Ax, Wx, Ay, Wy, C2_DMA_I, vo);
             } else {
                 const unsigned st_ = 0;
                 const unsigned char* sb_ = p.W;
-                C2_BLOCK("", Ax, Wx, Ay, Wy, C2_NODMA, vo);
+                C2_BLK("", Ax, Wx, Ay, Wy, C2_NODMA, vo);
             }
         }
         {
@@ -363,11 +320,11 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
             if (LINEAR || kt + 2 < KSTEPS) {
                 const unsigned st_ = a_dst(k3p);  // (kt + 2) % 3
                 const unsigned char* sb_ = a_base(LINEAR ? min(kt + 2, KL) : kt + 2);
-                C2_BLOCK("", Ay, Wy, Ax, Wx, C2_DMA_I, vo);
+                C2_BLK("", Ay, Wy, Ax, Wx, C2_DMA_I, vo);
             } else {
                 const unsigned st_ = 0;
                 const unsigned char* sb_ = p.W;
-                C2_BLOCK("", Ay, Wy, Ax, Wx, C2_NODMA, vo);
+                C2_BLK("", Ay, Wy, Ax, Wx, C2_NODMA, vo);
             }
         }
         {
@@ -375,7 +332,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
             const unsigned st_ = 0;
             const unsigned char* sb_ = p.W;
             const unsigned* vo = pw;
-            C2_BLOCK("", Ax, Wx, Ay, Wy, C2_NODMA, vo);
+            C2_BLK("", Ax, Wx, Ay, Wy, C2_NODMA, vo);
         }
         {
             const unsigned an_ = a_rd0 + sn_a, wn_ = w_rd0 + sn_w;
@@ -383,9 +340,9 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
             const unsigned char* sb_ = p.W;
             const unsigned* vo = pw;
             if (LINEAR || kt + 2 < KSTEPS) {  // the A slab of step kt + 2 is this wave's eight youngest requests
-                C2_BLOCK(C2_PRE3, Ay, Wy, Ax, Wx, C2_NODMA, vo);
+                C2_BLK(C2_PRE3, Ay, Wy, Ax, Wx, C2_NODMA, vo);
             } else {
-                C2_BLOCK(C2_PRE3_ALL, Ay, Wy, Ax, Wx, C2_NODMA, vo);
+                C2_BLK(C2_PRE3_ALL, Ay, Wy, Ax, Wx, C2_NODMA, vo);
             }
         }
         k3 = k3n;
@@ -397,6 +354,105 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
                  : "+v"(Ax[0]), "+v"(Ax[1]), "+v"(Ax[2]), "+v"(Ax[3]), "+v"(Wx[0]), "+v"(Wx[1]), "+v"(Wx[2]), "+v"(Wx[3]),
                    "+v"(Ay[0]), "+v"(Ay[1]), "+v"(Ay[2]), "+v"(Ay[3]), "+v"(Wy[0]), "+v"(Wy[1]), "+v"(Wy[2]), "+v"(Wy[3])
                  :: "memory");
+    }
+    if constexpr (F8 || MIX) {
+        // ---- e4m3 loop: two blocks per K step.  Block 0 (sub-step 0 of stage kt; reads sub-step 1) requests the A slab of step
+        // kt + 2; block 1 starts with the step's barrier (own fragments landed; everything but that A slab landed: vmcnt(8)), reads
+        // sub-step 0 of step kt + 1 behind it and requests the W slab of step kt + 2 into the W stage the barrier has just freed.
+        // So an A slab (HBM) has a step and a half to arrive, a W slab (L2) one step - as in the bf16 loop.
+        bf16x8 Az[4], Wz[4], Au[4], Wu[4];
+        constexpr int ES8 = 1;
+        if constexpr (MIX) {  // the lane offsets once more, for one-byte elements
+            tile_off = a_off(m0, ES8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 8 * (wave + 4 * i) + r8;
+                const int m = m0 + row;
+                const int mc = m < p.M ? m : p.M - 1;
+                pa[i] = (unsigned)(a_off(mc, ES8) - tile_off) + sw;
+                pw[i] = (unsigned)(row * (9 * C2_C * ES8)) + sw;
+            }
+        }
+        const unsigned wstep_ = LINEAR ? 32u * (unsigned)(p.ksteps * 128) : 32u * (9 * C2_C * ES8);  // byte distance of consecutive W pieces (32 weight rows)
+        const unsigned pw0 = pw[0];
+        unsigned tv_ = pw0;
+        // K steps of this phase (128 channels each).  MIX: two rounds of the 18 - (A_l, W_q) with q8[0..1], (A_q, W_l) with q8[2..3]
+        constexpr int KS8 = LINEAR ? C2_LIN8_KSTEPS : C2_KSTEPS / 2;
+        const int KL8 = KS8 - 1;
+#pragma unroll  // (both rounds unrolled: across a back edge hipcc joins the fragment sets with moves of registers whose reads are in flight)
+        for (int round = 0; round < (MIX ? 2 : 1); ++round) {
+        const int qa_ = p.q8[2 * round], qb_ = p.q8[2 * round + 1];
+        const unsigned char* const A8 = MIX ? (round ? p.A8q : p.A8l) + tile_off : p.A + tile_off;
+        const unsigned char* const W8 = MIX ? (round ? p.W8l : p.W8q) : p.W;
+        auto a_base8 = [&](int kt) -> const unsigned char* {
+            if constexpr (LINEAR) return A8 + (long long)kt * 128;
+            const int cb = kt / 9, tap = kt - 9 * cb;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            return A8 + (long long)((kh * F1p + kw) * (C2_C * ES8) + cb * 128);
+        };
+        auto w_base8 = [&](int kt) -> const unsigned char* {
+            if constexpr (LINEAR) return W8 + (long long)kt * 128;
+            const int cb = kt / 9, tap = kt - 9 * cb;
+            return W8 + (long long)(tap * C2_C * ES8 + cb * 128);
+        };
+        C2_ISSUE8(a_dst(0), pa, a_base8(0))
+        C2_ISSUE8(w_dst(0), pw, w_base8(0))
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        C2_ISSUE8(a_dst(1), pa, a_base8(min(1, KL8)))
+        C2_ISSUE8(w_dst(1), pw, w_base8(min(1, KL8)))
+        {  // fragments of step 0, sub-step 0 (chunks of the bf16 sub-steps 0 and 1), landed before anything else touches them
+            const unsigned an0_ = a_rd0, an1_ = C2_RD(a_rd0, 1, 0), wn0_ = w_rd0, wn1_ = C2_RD(w_rd0, 1, 0);
+            asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %16 offset:4096\n\tds_read_b128 %2, %16 offset:8192\n\t"
+                         "ds_read_b128 %3, %16 offset:12288\n\tds_read_b128 %4, %17\n\tds_read_b128 %5, %17 offset:4096\n\t"
+                         "ds_read_b128 %6, %17 offset:8192\n\tds_read_b128 %7, %17 offset:12288\n\t"
+                         "ds_read_b128 %8, %18\n\tds_read_b128 %9, %18 offset:4096\n\tds_read_b128 %10, %18 offset:8192\n\t"
+                         "ds_read_b128 %11, %18 offset:12288\n\tds_read_b128 %12, %19\n\tds_read_b128 %13, %19 offset:4096\n\t"
+                         "ds_read_b128 %14, %19 offset:8192\n\tds_read_b128 %15, %19 offset:12288\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(Ax[0]), "=&v"(Ax[1]), "=&v"(Ax[2]), "=&v"(Ax[3]), "=&v"(Wx[0]), "=&v"(Wx[1]), "=&v"(Wx[2]),
+                           "=&v"(Wx[3]), "=&v"(Ay[0]), "=&v"(Ay[1]), "=&v"(Ay[2]), "=&v"(Ay[3]), "=&v"(Wy[0]), "=&v"(Wy[1]),
+                           "=&v"(Wy[2]), "=&v"(Wy[3])
+                         : "v"(an0_), "v"(wn0_), "v"(an1_), "v"(wn1_)
+                         : "memory");
+        }
+        // (fully unrolled - 18 steps of two blocks: with a back edge hipcc gave the 256 accumulator registers another
+        // assignment at the loop's end than at its head and moved half of them through scratch, every iteration)
+        // (LINEAR: linear_out of the 20 x 256 = 5120-wide embedding input: 40 steps - the launcher checks)
+#pragma unroll
+        for (int kt = 0; kt < KS8; ++kt) {
+            const int k3 = kt % 3;
+            const int k3n = k3 == 2 ? 0 : k3 + 1, k3p = k3 == 0 ? 2 : k3 - 1;
+            const unsigned so_a = (unsigned)(k3 * C2_SLAB), so_w = (unsigned)((kt & 1) * C2_SLAB);
+            const unsigned sn_a = (unsigned)(k3n * C2_SLAB), sn_w = (unsigned)(((kt + 1) & 1) * C2_SLAB);
+            // (branch-free: past the last K step the requests repeat the last slabs into stages nobody reads any more - with the
+            // two forms of a block behind a branch, as in the bf16 loop, hipcc reshuffled all fragment sets through scratch at every
+            // join; the wait after the loop covers the redundant requests)
+            {
+                const unsigned an0_ = C2_RD(a_rd0, 2, so_a), an1_ = C2_RD(a_rd0, 3, so_a);
+                const unsigned wn0_ = C2_RD(w_rd0, 2, so_w), wn1_ = C2_RD(w_rd0, 3, so_w);
+                const unsigned* vo = pa;
+                const unsigned st_ = a_dst(k3p);  // (kt + 2) % 3
+                const unsigned char* sb_ = a_base8(min(kt + 2, KL8));
+                C2_BLOCK8("", Ax, Wx, Ay, Wy, Az, Wz, Au, Wu, C2_DMA_I, vo);
+            }
+            {
+                const unsigned an0_ = a_rd0 + sn_a, an1_ = C2_RD(a_rd0, 1, sn_a);
+                const unsigned wn0_ = w_rd0 + sn_w, wn1_ = C2_RD(w_rd0, 1, sn_w);
+                const unsigned* vo = pa;  // (not used by this block's requests)
+                const unsigned st_ = w_dst(kt + 2);
+                const unsigned char* sb_ = w_base8(min(kt + 2, KL8));
+                tv_ = pw0;
+                C2_BLOCK8(C2_PRE3, Az, Wz, Au, Wu, Ax, Wx, Ay, Wy, C2_DMA_W8, vo);
+            }
+        }
+        // a 16-pass MFMA's result is readable 19 wait states later; the last block's (unused) fragments land here
+        asm volatile("s_nop 15\n\ts_nop 4\n\ts_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)"
+                     : "+v"(Ax[0]), "+v"(Ax[1]), "+v"(Ax[2]), "+v"(Ax[3]), "+v"(Wx[0]), "+v"(Wx[1]), "+v"(Wx[2]), "+v"(Wx[3]),
+                       "+v"(Ay[0]), "+v"(Ay[1]), "+v"(Ay[2]), "+v"(Ay[3]), "+v"(Wy[0]), "+v"(Wy[1]), "+v"(Wy[2]), "+v"(Wy[3])
+                     :: "memory");
+        asm volatile("" : "+v"(Az[0]), "+v"(Az[1]), "+v"(Az[2]), "+v"(Az[3]), "+v"(Wz[0]), "+v"(Wz[1]), "+v"(Wz[2]), "+v"(Wz[3]),
+                     "+v"(Au[0]), "+v"(Au[1]), "+v"(Au[2]), "+v"(Au[3]), "+v"(Wu[0]), "+v"(Wu[1]), "+v"(Wu[2]), "+v"(Wu[3]) :: "memory");
+        if constexpr (MIX) __syncthreads();  // (the next round's first requests overwrite stages this round's last steps read)
+        }
     }
     if constexpr (LINEAR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant requests of the last steps (they write this workgroup's LDS)
 
@@ -427,7 +483,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         }
         return;
     }
-    if constexpr (X3) {
+    if constexpr (X3 || MIX) {
         // ---- split epilogue: + bias, ReLU, hi / lo split; a split-bf16 row is 1 KiB (per 32 channels 64 B of hi halves, then
         // 64 B of lo halves), so the tile goes through LDS in two halves of 128 rows (the waves wm = 0, then wm = 1) and leaves
         // as contiguous 1-KiB rows
@@ -677,6 +733,43 @@ int launch_conv2_x3(const void* in_hi, const void* in_lo, const void* w_hi, cons
     p.ntiles = cn_ceil_div(p.M, C2_BM);
     if (p.M <= 0) return 0;
     hipLaunchKernelGGL((conv2_kernel<false, true>), dim3(p.ntiles), dim3(256), C2_LDS, s, p);
+    CN_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// the split-bf16 engine's convolution in the MIX arithmetic (kernel comment): `img` = conv1's three bordered planes - half-precision
+// hi values ([B][T1 + 2][F1 + 2][256] x 2 bytes), then the l bytes, then the q bytes -, `w_hi` [256][9 * 256] half, `w8q` / `w8l` the
+// e4m3 matrices, `q8_dev` = {127 - log2 S(W_q), 127 - log2 S(A_l), 127 - log2 S(W_l), 127 - log2 S(A_q)}; out: split-bf16 rows
+bool conv2_mix_applies(int prec, int C, int N) { return prec == CN_PREC_X3 && C == C2_C && N == C2_N && !cn_exp_env("CASSNAT_NO_CONV2_MIX"); }
+
+int launch_conv2_mix(const void* img, const void* w_hi, const void* w8q, const void* w8l, const int* q8_dev, const float* bias, void* out,
+                     int B, int T1, int F1, int T2, int F2, hipStream_t s) {
+    static CnAttrOnce attr_once;
+    int attr_dev;
+    if (attr_once.need(&attr_dev)) {
+        CN_HIP_CHECK(hipFuncSetAttribute((const void*)conv2_kernel<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS));
+        attr_once.mark(attr_dev);
+    }
+    if (conv2_tile_span_too_large(T1, F1, F2)) return -1;
+    const size_t cells = (size_t)B * (T1 + 2) * (F1 + 2) * C2_C;
+    Conv2Params p = {};
+    p.A = (const unsigned char*)img;
+    p.A8l = p.A + 2 * cells;
+    p.A8q = p.A + 3 * cells;
+    p.W = (const unsigned char*)w_hi;
+    p.W8q = (const unsigned char*)w8q;
+    p.W8l = (const unsigned char*)w8l;
+    p.q8 = q8_dev;
+    p.bias = bias;
+    p.out = (bf16*)out;
+    p.M = B * T2 * F2;
+    p.T1 = T1;
+    p.F1 = F1;
+    p.T2 = T2;
+    p.F2 = F2;
+    p.ntiles = cn_ceil_div(p.M, C2_BM);
+    if (p.M <= 0) return 0;
+    hipLaunchKernelGGL((conv2_kernel<false, false, false, true>), dim3(p.ntiles), dim3(256), C2_LDS, s, p);
     CN_HIP_CHECK(hipGetLastError());
     return 0;
 }

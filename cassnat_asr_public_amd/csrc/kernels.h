@@ -58,6 +58,8 @@ int launch_conv1(int prec, const float* x, const float* w9c, const float* bias, 
 int launch_conv1_planes(const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1, int F1,
                         int C, int halo, hipStream_t s, const UttMeta* utt_meta = nullptr);
 // fp8 engine (BASELINE config 5): the bordered image as e4m3fn bytes at `scale`, for launch_conv2_f8
+int launch_conv1_mixplanes(const float* x, const float* w9c, const float* bias, void* out, int B, int T, int F, int T1, int F1, int C,
+                           int halo, float scale_l, float scale_q, hipStream_t s, const UttMeta* utt_meta = nullptr);
 int launch_conv1_f8(const float* x, const float* w9c, const float* bias, void* out8, int B, int T, int F, int T1, int F1, int C,
                     int halo, float scale, hipStream_t s, const UttMeta* utt_meta = nullptr);
 // bf16 engine: the bordered bf16 image on the matrix cores (the e4m3 form's kernel with 512-byte cells); C == 256, F1 + 2 >= 32
@@ -294,6 +296,9 @@ int launch_conv2_f8(const void* in8, const void* w8, const int* q8_dev, const fl
 bool linear256_f8_applies(int N, int K);
 int launch_linear256_f8(const void* A8, const void* W8, const int* q8_dev, const float* bias, float* out, int M, int K, float scale,
                         const float* pe, int pe_period, hipStream_t s);
+bool conv2_mix_applies(int prec, int C, int N);
+int launch_conv2_mix(const void* img, const void* w_hi, const void* w8q, const void* w8l, const int* q8_dev, const float* bias, void* out,
+                     int B, int T1, int F1, int T2, int F2, hipStream_t s);
 bool conv2_x3_applies(int prec, int C, int N);
 int launch_conv2_x3(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias, void* out, int B,
                     int T1, int F1, int T2, int F2, hipStream_t s);

@@ -73,6 +73,10 @@ struct ConvMod {
 // fp8 engine: scale of the e4m3 image conv1 writes for conv2's e4m3 form (ReLU outputs: x8, saturating at 56 - as the hidden
 // activations of the feed-forward products)
 constexpr float FP8_S_IMG = 8.f;
+// conv2's MIX form (conv2.hip): fixed power-of-two scales of the image's e4m3 planes - q = e4m3(v 2^MIX_LG_AQ) holds conv1 outputs
+// up to 448 (beyond it the cross term a_q w_l saturates: the product falls back towards half precision, not apart) and
+// l = e4m3((v - half(v)) 2^MIX_LG_AL), |v - half(v)| <= 2^-11 |v|
+constexpr int MIX_LG_AQ = 0, MIX_LG_AL = 11;
 struct ChainRef {
     void* w = nullptr;
     float* tab = nullptr;
@@ -166,6 +170,10 @@ struct cn_model {
     void* linear_f8w = nullptr;  // fp8 engine: linear_out's (column-permuted) matrix as e4m3fn bytes, and its two scale bytes
     int* linear_f8q = nullptr;   // {127 - log2(weight scale), 127 - log2(scale of conv2's e4m3 output)}
     void* conv2_x3w = nullptr;  // split-bf16 engine, 256 channels: the same matrix as two bf16 planes (hi, then lo) for conv2.hip's X3 form
+    // ... and for conv2.hip's MIX form (half-precision hi x hi + e4m3 cross terms: 2 MFMA units per product instead of 3): the
+    // half-precision matrix, then the q = e4m3(w S_q) and l = e4m3((w - hi) S_l) bytes; conv2_mixq = the four E8M0 scale bytes
+    void* conv2_mixw = nullptr;
+    int* conv2_mixq = nullptr;
     Linear linear_out;  // [d][F2*C] (f,c)
     std::vector<Layer> enc, extra, sad, mad;
     std::vector<ChainRef> enc_chain;  // one per encoder layer when the row-chain path applies, else empty
@@ -793,6 +801,33 @@ int build_weights(cn_model* m) {
             }
             m->conv2_x3w = reinterpret_cast<void*>(pat);
         }
+        if (conv2_mix_applies(m->prec, (int)C, (int)C)) {
+            const size_t n = (size_t)C * 9 * C, pat = pk.reserve(4 * n), qat = pk.reserve(16);
+            if (pk.fill) {
+                const HostTensor* t = pk.find("src_embed.conv.2.weight", {C, C, 3, 3});
+                if (t) {
+                    float mx = 0.f;
+                    for (float v : t->data) mx = std::max(mx, std::fabs(v));
+                    // q: the largest power-of-two scale that keeps the weights inside e4m3; l: |w - half(w)| <= 2^-11 |w|
+                    const int lg = mx > 0.f ? (int)std::floor(std::log2(448.f / mx)) : 0;
+                    const float sq = std::ldexp(1.f, lg), sl = std::ldexp(1.f, lg + 11);
+                    for (int64_t co = 0; co < C; ++co)
+                        for (int64_t ci = 0; ci < C; ++ci)
+                            for (int tap = 0; tap < 9; ++tap) {
+                                const float v = t->data[(co * C + ci) * 9 + tap];
+                                const _Float16 h = (_Float16)v;
+                                const size_t e = (size_t)(co * 9 * C + tap * C + ci);
+                                std::memcpy(&pk.host[pat + 2 * e], &h, 2);
+                                pk.host[pat + 2 * n + e] = cn_f32_to_e4m3_host(v * sq);
+                                pk.host[pat + 3 * n + e] = cn_f32_to_e4m3_host((v - (float)h) * sl);
+                            }
+                    const int q[4] = {127 - lg, 127 - MIX_LG_AL, 127 - (lg + 11), 127 - MIX_LG_AQ};  // {W_q, A_l, W_l, A_q}
+                    std::memcpy(&pk.host[qat], q, 16);
+                }
+            }
+            m->conv2_mixw = reinterpret_cast<void*>(pat);
+            m->conv2_mixq = reinterpret_cast<int*>(qat);
+        }
         if (m->fp8_enc && (m->fp8_scope & CN_FP8_CONV2) && conv2_f8_applies((int)C, (int)C)) {  // config 5: the second convolution on e4m3 operands (conv2.hip, F8)
             const size_t fat = pk.reserve((size_t)C * 9 * C), qat = pk.reserve(16);
             if (pk.fill) {
@@ -1131,6 +1166,8 @@ int build_weights(cn_model* m) {
     rebase(m->conv1_b, base);
     rebase_linear(m->conv2, base);
     rebase(m->conv2_x3w, base);
+    rebase(m->conv2_mixw, base);
+    rebase(m->conv2_mixq, base);
     rebase(m->conv2_f8w, base);
     rebase(m->conv2_f8q, base);
     rebase(m->linear_f8w, base);
@@ -1917,19 +1954,24 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
 #endif
     // conv1 writes its image with a zero halo when the LDS-DMA conv2 kernel consumes it (captures want the plain image)
     // (the split-bf16 engine: two bordered bf16 planes, hi and lo, for the same kernel's X3 form)
-    const bool x3_planes = !cap && m->conv2_x3w && conv2_x3_applies(m->prec, d, d);
+    // (the split-bf16 engine's planes in the MIX arithmetic of conv2.hip where it applies: half-precision hi values + two e4m3 planes)
+    const bool mix_planes = !cap && m->conv2_mixw && conv2_mix_applies(m->prec, d, d);
+    const bool x3_planes = !mix_planes && !cap && m->conv2_x3w && conv2_x3_applies(m->prec, d, d);
     // (the fp8 engine: an e4m3 image for the same kernel's F8 form - config 5's "fp8 MFMA encoder GEMMs" include the largest one)
     // (also under capture - the accuracy of the mode is measured on captures; the e4m3 image itself is then not captured)
     const bool f8_img = m->fp8_enc && m->conv2_f8w && conv2_f8_applies(d, d);
     const bool f8_lin = f8_img && m->linear_f8w && linear256_f8_applies(d, F2 * d);  // conv2 then hands its rows on as e4m3 too
-    const int halo = ((!cap && conv2_dma_applies(m->prec, d, d)) || x3_planes || f8_img) ? 1 : 0;
+    const int halo = ((!cap && conv2_dma_applies(m->prec, d, d)) || x3_planes || mix_planes || f8_img) ? 1 : 0;
     {
         // the halo cells of the image buffer are zero already when the previous haloed image had this very shape (and nothing
         // else wrote the buffer since): conv1 then writes the interior only (halo mode 2)
         const bool same = halo && m->c1_halo_B == B && m->c1_halo_T1 == T1;
         ProfScope ps(m, "conv1", 2.0 * 9 * B * T1 * F1 * d, (double)B * T * F * 4 + (double)B * T1 * F1 * d * m->es, s);
         const UttMeta* um = m->ragged ? m->utt_meta : nullptr;
-        if (x3_planes)
+        if (mix_planes)
+            CN_TRY(launch_conv1_mixplanes(feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : 1, std::ldexp(1.f, MIX_LG_AL),
+                                          std::ldexp(1.f, MIX_LG_AQ), s, um));
+        else if (x3_planes)
             CN_TRY(launch_conv1_planes(feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : 1, s, um));
         else if (f8_img)
             CN_TRY(launch_conv1_f8(feats, m->conv1_w, m->conv1_b, m->c1, B, T, F, T1, F1, d, same ? 2 : 1, FP8_S_IMG, s, um));
@@ -1962,7 +2004,11 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
         g.cF2 = F2;
         ProfScope ps(m, "conv2", 2.0 * g.M * g.N * g.K,
                      ((double)B * T1 * F1 * d + (double)g.N * g.K + (double)g.M * g.N) * m->es, s);
-        if (x3_planes) {
+        if (mix_planes) {
+            const size_t wn = (size_t)d * 9 * d;
+            const unsigned char* w = (const unsigned char*)m->conv2_mixw;
+            CN_TRY(launch_conv2_mix(m->c1, w, w + 2 * wn, w + 3 * wn, m->conv2_mixq, m->conv2.b, m->c2, B, T1, F1, Tp, F2, s));
+        } else if (x3_planes) {
             const size_t img = (size_t)B * (T1 + 2) * (F1 + 2) * d * 2, wpl = (size_t)d * 9 * d * 2;
             CN_TRY(launch_conv2_x3(m->c1, (const unsigned char*)m->c1 + img, m->conv2_x3w, (const unsigned char*)m->conv2_x3w + wpl,
                                    m->conv2.b, m->c2, B, T1, F1, Tp, F2, s));
@@ -3281,6 +3327,55 @@ extern "C" int cn_op_conv_frontend_fp8(const float* x_dev, const float* w1_9c_de
     (void)hipFree(img);
     if (rc == 0 && e != hipSuccess) {
         cn_set_error(std::string("cn_op_conv_frontend_fp8: ") + hipGetErrorString(e));
+        rc = -2;
+    }
+    return rc;
+}
+
+// The split-bf16 engine's conv front-end in the MIX arithmetic through the ABI (conv1.hip MIXP planes + conv2.hip MIX): x fp32 [B][T][F],
+// w2_host fp32 [C][3][3][C] (k = (kh * 3 + kw) * C + ci); out_dev: split-bf16 rows [B * T2 * F2][C] (cn_op_convert turns them into fp32);
+// img_out_dev (optional): conv1's three bordered planes, 4 bytes per cell of [B][T1 + 2][F1 + 2][C] (half values, l bytes, q bytes)
+extern "C" int cn_op_conv_frontend_mix(const float* x_dev, const float* w1_9c_dev, const float* b1_dev, const float* w2_host,
+                                       const float* b2_dev, void* out_dev, void* img_out_dev, int32_t B, int32_t T, int32_t F, int32_t C,
+                                       void* stream) {
+    if (!conv2_mix_applies(CN_PREC_X3, C, C)) {
+        cn_set_error("cn_op_conv_frontend_mix: 256 channels only (and not in the half-precision build of the library)");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int T1 = (T - 1) / 2 + 1, F1 = (F - 1) / 2 + 1, T2 = (T1 - 1) / 2 + 1, F2 = (F1 - 1) / 2 + 1;
+    const size_t n = (size_t)C * 9 * C;
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w2_host[i]));
+    const int lg = mx > 0.f ? (int)std::floor(std::log2(448.f / mx)) : 0;
+    const float sq = std::ldexp(1.f, lg), sl = std::ldexp(1.f, lg + 11);
+    std::vector<unsigned char> w(4 * n);
+    for (size_t i = 0; i < n; ++i) {
+        const _Float16 h = (_Float16)w2_host[i];
+        std::memcpy(&w[2 * i], &h, 2);
+        w[2 * n + i] = cn_f32_to_e4m3_host(w2_host[i] * sq);
+        w[3 * n + i] = cn_f32_to_e4m3_host((w2_host[i] - (float)h) * sl);
+    }
+    const int q[4] = {127 - lg, 127 - MIX_LG_AL, 127 - (lg + 11), 127 - MIX_LG_AQ};
+    const size_t img_bytes = (size_t)B * (T1 + 2) * (F1 + 2) * C * 4;
+    void *dw = nullptr, *dq = nullptr, *img = nullptr;
+    CN_HIP_CHECK(hipMalloc(&dw, w.size()));
+    CN_HIP_CHECK(hipMalloc(&dq, 16));
+    CN_HIP_CHECK(hipMalloc(&img, img_bytes));
+    CN_HIP_CHECK(hipMemcpy(dw, w.data(), w.size(), hipMemcpyHostToDevice));
+    CN_HIP_CHECK(hipMemcpy(dq, q, 16, hipMemcpyHostToDevice));
+    CN_HIP_CHECK(hipMemsetAsync(img, 0xff, img_bytes, s));  // (NaN bytes: conv1 must write every cell of every plane, border included)
+    int rc = launch_conv1_mixplanes(x_dev, w1_9c_dev, b1_dev, img, B, T, F, T1, F1, C, 1, std::ldexp(1.f, MIX_LG_AL), std::ldexp(1.f, MIX_LG_AQ), s);
+    if (rc == 0)
+        rc = launch_conv2_mix(img, dw, (const unsigned char*)dw + 2 * n, (const unsigned char*)dw + 3 * n, (const int*)dq, b2_dev, out_dev, B, T1, F1,
+                              T2, F2, s);
+    if (rc == 0 && img_out_dev) CN_HIP_CHECK(hipMemcpyAsync(img_out_dev, img, img_bytes, hipMemcpyDeviceToDevice, s));
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(dw);
+    (void)hipFree(dq);
+    (void)hipFree(img);
+    if (rc == 0 && e != hipSuccess) {
+        cn_set_error(std::string("cn_op_conv_frontend_mix: ") + hipGetErrorString(e));
         rc = -2;
     }
     return rc;

@@ -114,6 +114,7 @@ def lib(flavour=None):
     L.cn_op_conv1_bordered.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]
     L.cn_op_conv2.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]
     L.cn_op_conv_frontend_fp8.argtypes = [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.cn_op_conv_frontend_mix.argtypes = [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p]
     L.cn_op_linear256_fp8.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 2 + [C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.cn_op_layernorm.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     L.cn_op_attention.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,

@@ -322,6 +322,14 @@ int cn_op_conv1_bordered(const float* x, const float* w9c, const float* bias, vo
 int cn_op_conv_frontend_fp8(const float* x_dev, const float* w1_9c_dev, const float* b1_dev, const float* w2_host,
                             const float* b2_dev, void* out_dev, void* img8_out_dev, int32_t B, int32_t T, int32_t F, int32_t C,
                             float img_scale, float out8_scale, float* w_scale_out, void* stream);
+
+/* The split-bf16 engine's conv front-end in its MIX arithmetic (csrc/conv2.hip): a product is half(a) half(b) + l_a q_b + q_a l_b
+ * with l = e4m3((v - half(v)) S_l) and q = e4m3(v S_q) at fixed power-of-two scales - one half-precision MFMA plus two e4m3 MFMAs
+ * at twice the rate where the split-bf16 form spends three bf16 MFMAs.  x fp32 [B][T][F] (device), w1 [9][C] / b1 / b2 device,
+ * w2_host fp32 [C][3][3][C] (k = (kh * 3 + kw) * C + ci); out: split-bf16 rows [B * T2 * F2][C] (device).  C = 256. */
+int cn_op_conv_frontend_mix(const float* x, const float* w1_9c, const float* b1, const float* w2_host, const float* b2, void* out,
+                            void* img_out /* optional: conv1's planes, 4 bytes per bordered cell */, int32_t B, int32_t T, int32_t F,
+                            int32_t C, void* stream);
 /* (out8_scale > 0: out_dev receives e4m3fn bytes [B*T2*F2][C] at that scale instead of bf16 - the input of the next entry)
  * linear_out (src/models/modules/embedding.py:118-119) of the fp8 engine: a8_dev [M][K] e4m3fn at a_scale, K = 5120; w_host fp32
  * [256][K] quantised at the largest power-of-two scale in range (*w_scale_out); out fp32 [M][256] =

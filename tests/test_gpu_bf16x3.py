@@ -144,6 +144,31 @@ def test_conv1_conv2(B, T, Fd, Cc):
     assert relerr(from_split(out2).permute(0, 3, 1, 2), ref2) < 3e-5
 
 
+@pytest.mark.parametrize("B,T,Fd", [(2, 61, 80), (1, 9, 7), (3, 170, 80), (1, 1000, 80)])
+def test_conv_frontend_mix_arithmetic(B, T, Fd):
+    """The split-bf16 engine's conv front-end in the MIX arithmetic (conv1.hip MIXP planes, conv2.hip MIX): a product is
+    half(a) half(b) + l_a q_b + q_a l_b with e4m3 cross-term factors at fixed power-of-two scales - one half-precision MFMA and two
+    e4m3 MFMAs at twice the rate per 16 k where the X3 form spends three bf16 MFMAs - against the float64 convolution: the X3 form's
+    tolerance (cn_op_conv2 above: 3e-5) holds."""
+    Cc = 256
+    g = torch.Generator().manual_seed(B * T + 7)
+    x = torch.randn(B, T, Fd, generator=g)
+    w1, b1 = torch.randn(Cc, 1, 3, 3, generator=g) / 3, torch.randn(Cc, generator=g) * 0.1
+    w2, b2 = torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc), torch.randn(Cc, generator=g) * 0.1
+    ref1 = F.relu(F.conv2d(x.unsqueeze(1), w1, b1, stride=2, padding=1))
+    ref2 = F.relu(F.conv2d(ref1.double(), w2.double(), b2.double(), stride=2, padding=1))
+    T2, F2 = ref2.shape[2], ref2.shape[3]
+    out = torch.zeros(B, T2, F2, Cc, dtype=torch.int32, device="cuda")
+    w2k = w2.permute(0, 2, 3, 1).contiguous()  # [C][3][3][C] on the host
+    xd, w9c, b1d, b2d = x.cuda(), w1.reshape(Cc, 9).t().contiguous().cuda(), b1.cuda(), b2.cuda()
+    hip.check(hip.lib().cn_op_conv_frontend_mix(p(xd), p(w9c), p(b1d), C.c_void_p(w2k.data_ptr()), p(b2d), p(out), None, B, T, Fd, Cc,
+                                                stream()))
+    got = from_split(out).permute(0, 3, 1, 2)
+    err = relerr(got, ref2)
+    print(f"[conv front-end, MIX arithmetic] B {B} T {T}: relative error {err:.2e}")
+    assert err < 3e-5
+
+
 # ----------------------------------------------------------------------------------------------- attention
 def attention_reference(q, k, v, mask):
     scores = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) / 8.0
