@@ -386,7 +386,7 @@ def test_decode_asr_cli_with_global_cmvn_on_the_device(tmp_path):
     assert out[1] == [f"spk-utt{b} " + " ".join(orc.hyp_to_text(h, index2word)) for b, h in enumerate(hyps)]
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "bf16x3"])
 def test_bf16_production_path_against_golden(prec, capsys):
     """The path bench.py times (bf16, fused FFN sublayer, fused generator arg-max, no capture) on the benchmark workload:
     CTC arg-max agreement with the reference and hypothesis agreement on utterances whose alignment did not flip.  fp16: the same
@@ -413,7 +413,7 @@ def test_bf16_production_path_against_golden(prec, capsys):
     # keep: the encoder output as the generator's 16-bit operand (`enc_h_live`) times the weight rounded to the same type,
     # accumulated here in float64 (the kernel: fp32, another order) - against the reference's log-posteriors (sampled in the fixture)
     enc = torch.from_numpy(eng.fetch("enc_h_live")).double()
-    t16 = torch.float16 if prec == "fp16" else torch.bfloat16
+    t16 = {"fp16": torch.float16, "bf16": torch.bfloat16}.get(prec, torch.float32)  # (split-bf16: hi + lo carry the fp32 value to 2^-17)
     w = torch.from_numpy(state["ctc_generator.proj.weight"]).to(t16).double()
     logp = torch.log_softmax(enc @ w.T + torch.from_numpy(state["ctc_generator.proj.bias"]).double(), -1)
     rep["ctc_logit_err"] = float((logp[:, ::25, ::100].float() - torch.from_numpy(g["ctc_sample"])).abs().max())
@@ -424,6 +424,8 @@ def test_bf16_production_path_against_golden(prec, capsys):
     assert rep["ylen_max_abs_diff"] <= 3
     if tok_agree:
         assert rep["token_agreement_on_those"] > 0.9
+    if prec == "bf16x3":  # the parity engine on its production kernels (fused row chain, conv2 in the MIX arithmetic, fused generators)
+        assert not flips.any() and same_align.all() and rep["token_agreement_on_those"] == 1.0 and rep["ctc_logit_err"] < 5e-5, rep
     if prec == "fp16":  # measured: 3 flips of 8000 (margins <= 3.7e-4), 29 of 32 alignments identical
         assert rep["ctc_flip_rate"] < 0.001 and rep["utts_with_identical_alignment"] >= 26 and rep["token_agreement_on_those"] > 0.99
         assert (g["margin"].astype(np.float32)[flips] < 2e-3).all()
