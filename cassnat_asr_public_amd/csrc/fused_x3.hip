@@ -15,6 +15,8 @@
 //   * the four waves' out^T partials are summed through LDS, fused with b2, the residual and the next LayerNorm.
 // Per streamed byte this precision does 1.5x the MFMAs of the bf16 kernel, which moves the kernel from L2-stream-bound
 // towards MFMA-bound: 64 rows x 12.6 MFLOP per row x 3 = 2.4 GFLOP of MFMA work per 4 MiB of stream.
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -33,6 +35,9 @@ struct FfnX3Params {
     int M, dff;
     float eps;
     int rotate;
+    // MIXF (template): the sublayer's two products in the mixed arithmetic (below); the four E8M0 scale bytes of the weights'
+    // e4m3 parts {W1 q, W1 l, W2 q, W2 l} sit behind the stream (pack_ffn_x3)
+    const int* mixq;
     // row-chain form (template PRO / TAIL; proj_x3_phase.h): the attention's output projection onto the residual stream in front
     // of the sublayer - x <- x + Wo . ctx + bo on the workgroup's rows, ctx split-bf16 [M][ldctx] - and the next attention's
     // projection (Q|K|V, split-bf16 output) of LN_next(x) behind it, on rows that never leave LDS
@@ -79,7 +84,16 @@ static_assert(FX_LDS_TAIL == 160 * 1024, "LDS budget (row-chain form)");
 #define FX_MFMA_V(a, b, c) asm(CN_MFMA16_ASM "%0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
 #define FX_MFMA_V0(a, b, c) asm(CN_MFMA16_ASM "%0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b))
 
-template <bool PRO, bool TAIL>
+// MIXF: the two products of the sublayer in the arithmetic of conv2.hip's MIX form instead of three bf16 MFMAs per product - a value
+// v is h = half(v) plus two e4m3 bytes at fixed power-of-two scales, l = e4m3((v - h) 2^11 S) and q = e4m3(v S), and
+//     a b = h_a h_b + l_a q_b + q_a l_b :
+// per 32 k one v_mfma_f32_32x32x16_f16 per k-step of 16 and ONE v_mfma_scale_f32_32x32x64_f8f6f4 whose K = 64 is the two cross
+// terms side by side (k-block 0: q of the weights against l of the activations, k-block 1: l against q; the per-lane scale
+// operands differ by 2^11 between the blocks, the products' scales agree) - 2 MFMA units where the split form spends 3.  The
+// stream, the register sets, the LDS planes and the request / read pattern are the split form's: a weight group is
+// [hi(k0)][e4m3 bytes 0-15][hi(k1)][e4m3 bytes 16-31] per lane, the second LDS plane holds the activations' e4m3 fragments.
+// The hidden tile's e4m3 operand needs every lane's 32 hidden units: the half-waves trade their 16 (v_permlane32_swap).
+template <bool PRO, bool TAIL, bool MIXF = false>
 __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xn_s = smem;                                          // [plane][mt][16 k-steps][64 lanes][16 B]
@@ -175,11 +189,34 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
                 float o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = g[j] * (xrow[i0 + q][j] - mean[q]) * inv + bb[j];
-                bf16x4 hi, lo;
-                cn_split4(o, hi, lo);
                 unsigned char* dst = xn_s + (((r >> 5) * 16 + ks) * 64 + kh * 32 + (r & 31)) * 16 + kb;
-                *reinterpret_cast<bf16x4*>(dst) = hi;
-                *reinterpret_cast<bf16x4*>(dst + FX_PLANE) = lo;
+                if constexpr (MIXF) {
+                    typedef _Float16 fxh4 __attribute__((ext_vector_type(4)));
+                    fxh4 hh;
+                    float lo[4], qv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        hh[j] = (_Float16)o[j];
+                        lo[j] = __builtin_amdgcn_fmed3f((o[j] - (float)hh[j]) * 2048.f, -CN_FP8_MAX, CN_FP8_MAX);
+                        qv[j] = __builtin_amdgcn_fmed3f(o[j], -CN_FP8_MAX, CN_FP8_MAX);
+                    }
+                    *reinterpret_cast<fxh4*>(dst) = hh;
+                    unsigned l8 = 0, q8 = 0;
+                    l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], l8, false);
+                    l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], l8, true);
+                    q8 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[0], qv[1], q8, false);
+                    q8 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[2], qv[3], q8, true);
+                    // k = 4 lane + j: 32-k block lane >> 3, byte 4 (lane & 7) + j of the lane's 32 = sub-fragment (lane & 7) >> 2,
+                    // byte 4 (lane & 3); k-block 0 (lane slots 0..31) takes the l bytes, k-block 1 the q bytes
+                    unsigned char* f8 = xn_s + FX_PLANE + ((r >> 5) * 16 + 2 * (lane >> 3) + ((lane & 7) >> 2)) * 1024 + 4 * (lane & 3);
+                    *reinterpret_cast<unsigned*>(f8 + (r & 31) * 16) = l8;
+                    *reinterpret_cast<unsigned*>(f8 + (32 + (r & 31)) * 16) = q8;
+                } else {
+                    bf16x4 hi, lo;
+                    cn_split4(o, hi, lo);
+                    *reinterpret_cast<bf16x4*>(dst) = hi;
+                    *reinterpret_cast<bf16x4*>(dst + FX_PLANE) = lo;
+                }
             }
         }
     }
@@ -293,6 +330,73 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
 #define FX_BLOCK_BV(b, WS, WN, TILE, G, RG)                                                            \
     FX_LDW_LOOP(WN, TILE, G) FX_RELU_PACK(cur, RG) FX_MFMA_B(b, w##WS) FX_PIN_BV()                          \
     __builtin_amdgcn_sched_barrier(0);
+    // ---- MIXF forms of the blocks.  Register sets as above with another meaning of the fragments: weights a = hi(k0), b = e4m3
+    // bytes 0-15, c = hi(k1), d = e4m3 bytes 16-31 (W2 blocks: a = hi(s = 0), c = hi(s = 1) of output tile b); activations
+    // a / e = hi(k0) of M-tile 0 / 1, c / g = hi(k1), (b, d) / (f, h) = the e4m3 fragment
+    typedef int fxi4 __attribute__((ext_vector_type(4)));
+    typedef int fxi8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 fxh8 __attribute__((ext_vector_type(8)));
+#define FXM_J(lo_, hi_) __builtin_shufflevector(__builtin_bit_cast(fxi4, lo_), __builtin_bit_cast(fxi4, hi_), 0, 1, 2, 3, 4, 5, 6, 7)
+#define FXM_H(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(fxh8, a), __builtin_bit_cast(fxh8, b), c, 0, 0, 0)
+#define FXM_H_V(a, b, c) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+#define FXM_H_V0(a, b, c) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b))
+#define FXM_8_V(a8, b8, c, sa, sb) asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(a8), "v"(b8), "v"(sa), "v"(sb))
+#define FXM_8(a8, b8, c, sa, sb) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 0, 0, 0, sa, 0, sb)
+#define FXM_MFMA_A(W_, X_, M0, M1, Q0, Q1, Q2, Q3, R0, R1, R2, R3)                                     \
+    M0(W_##a, X_##a, xh[0]); M1(W_##a, X_##e, xh[1]); Q0 R0 FX_FENCE()                                 \
+    FXM_H_V(W_##c, X_##c, xh[0]); FXM_H_V(W_##c, X_##g, xh[1]); Q1 R1 FX_FENCE()                       \
+    { const fxi8 a8_ = FXM_J(W_##b, W_##d); const fxi8 b8_ = FXM_J(X_##b, X_##d); FXM_8_V(a8_, b8_, xh[0], sa1, sb1); } Q2 R2 FX_FENCE() \
+    { const fxi8 a8_ = FXM_J(W_##b, W_##d); const fxi8 b8_ = FXM_J(X_##f, X_##h); FXM_8_V(a8_, b8_, xh[1], sa1, sb1); } Q3 R3 FX_FENCE()
+#define FXM_BLOCK_A(AI_, WS, XS, WN, XN, M0, M1)                                                         \
+    FXM_MFMA_A(w##WS, x##XS, M0, M1,                                                                   \
+               FX_LDW1(WN, a, cur, (AI_) + 7, 0), FX_LDW1(WN, b, cur, (AI_) + 7, 1), FX_LDW1(WN, c, cur, (AI_) + 7, 2), FX_LDW1(WN, d, cur, (AI_) + 7, 3), \
+               FX_LDX2(XN, a, b, (AI_) + 1, 0, 0), FX_LDX2(XN, c, d, (AI_) + 1, 1, 0), FX_LDX2(XN, e, f, (AI_) + 1, 0, 16384), FX_LDX2(XN, g, h, (AI_) + 1, 1, 16384))
+#define FXM_BLOCK_A7(WS, XS, WN)                                                                       \
+    FXM_MFMA_A(w##WS, x##XS, FXM_H_V, FXM_H_V,                                                         \
+               FX_LDW1(WN, a, cur, 14, 0), FX_LDW1(WN, b, cur, 14, 1), FX_LDW1(WN, c, cur, 14, 2), FX_LDW1(WN, d, cur, 14, 3), , , , )
+    // W2 block b = output tile b: two half-precision k-steps and the e4m3 K = 64 on the two M-tiles' accumulators in turn
+#define FXM_MFMA_B(BI_, W_)                                                                            \
+    FXM_H(W_##a, pbh[0][0], acc[0][BI_]); FXM_H(W_##a, pbh[1][0], acc[1][BI_]);                        \
+    FXM_H(W_##c, pbh[0][1], acc[0][BI_]); FXM_H(W_##c, pbh[1][1], acc[1][BI_]);                        \
+    { const fxi8 a8_ = FXM_J(W_##b, W_##d); FXM_8(a8_, pb8[0], acc[0][BI_], sa2, sb2); FXM_8(a8_, pb8[1], acc[1][BI_], sa2, sb2); }
+#define FXM_PIN_B()                                                                                    \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);    \
+    }
+#define FXM_BLOCK_B(b, WS, WN, TILE, G)                                                                \
+    FX_LDW_LOOP(WN, TILE, G) FXM_MFMA_B(b, w##WS) FXM_PIN_B()                                          \
+    __builtin_amdgcn_sched_barrier(0);
+    // bias + ReLU on the hidden tile, then its three operand forms: half-precision fragments (as the split form's hi halves) and
+    // the e4m3 bytes - a lane has 16 of its column's 32 hidden units (accumulator register r: unit (r & 3) + 8 (r >> 2) + 4 half);
+    // L = its l bytes, Q = its q bytes (dword g = registers 4 g .. 4 g + 3); v_permlane32_swap(L, Q) leaves the lower half-wave
+    // with (L own, L partner) = the l bytes of all 32 units in the order [half 0's 16 | half 1's 16] - k-block 0 - and the upper
+    // one with (Q partner, Q own) = the q bytes in the same order - k-block 1
+#define FXM_RELU_PACK(tile)                                                                            \
+    _Pragma("unroll") for (int mt = 0; mt < FX_MT; ++mt) {                                              \
+        unsigned L_[4], Q_[4];                                                                         \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b1_s + 32 * (ft0 + (tile)) + 4 * half + 8 * g); \
+            float lo_[4], qv_[4];                                                                      \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
+                const float h_ = fmaxf(xh[mt][4 * g + e] + bv[e], 0.f);                                \
+                const _Float16 hh_ = (_Float16)h_;                                                     \
+                ph16[mt][g >> 1][4 * (g & 1) + e] = hh_;                                               \
+                lo_[e] = __builtin_amdgcn_fmed3f((h_ - (float)hh_) * 2048.f, -CN_FP8_MAX, CN_FP8_MAX); \
+                qv_[e] = fminf(h_, CN_FP8_MAX);                                                        \
+            }                                                                                          \
+            unsigned l8_ = 0, q8_ = 0;                                                                 \
+            l8_ = __builtin_amdgcn_cvt_pk_fp8_f32(lo_[0], lo_[1], l8_, false);                         \
+            l8_ = __builtin_amdgcn_cvt_pk_fp8_f32(lo_[2], lo_[3], l8_, true);                          \
+            q8_ = __builtin_amdgcn_cvt_pk_fp8_f32(qv_[0], qv_[1], q8_, false);                         \
+            q8_ = __builtin_amdgcn_cvt_pk_fp8_f32(qv_[2], qv_[3], q8_, true);                          \
+            const auto sw_ = __builtin_amdgcn_permlane32_swap(l8_, q8_, false, false);                 \
+            L_[g] = sw_[0];                                                                            \
+            Q_[g] = sw_[1];                                                                            \
+        }                                                                                              \
+        pb8[mt] = fxi8{(int)L_[0], (int)L_[1], (int)L_[2], (int)L_[3], (int)Q_[0], (int)Q_[1], (int)Q_[2], (int)Q_[3]}; \
+        pbh[mt][0] = __builtin_bit_cast(bf16x8, ph16[mt][0]);                                          \
+        pbh[mt][1] = __builtin_bit_cast(bf16x8, ph16[mt][1]);                                          \
+    }
     f32x16 xh[FX_MT];
     bf16x8 pbh[FX_MT][2], pbl[FX_MT][2];
     FX_LDX(0, 0)
@@ -300,6 +404,40 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
 #ifdef FX_STAMPS
     unsigned long long phase_[3] = {0, 0, 0}, last_ = __builtin_readcyclecounter();
 #endif
+    if constexpr (MIXF) {
+        fxh8 ph16[FX_MT][2];
+        fxi8 pb8[FX_MT];
+        // per-lane E8M0 scale bytes (a lane's 32 k are one scale block): weights {q, l} by k-block, activations {l at 2^11, q at 1}
+        const int sa1 = half ? p.mixq[1] : p.mixq[0], sa2 = half ? p.mixq[3] : p.mixq[2];
+        const int sb1 = half ? 127 : 127 - 11, sb2 = sb1;
+        for (int t = 0; t < tiles_per_wave; ++t) {
+            const int cur = FX_TT(t);
+            const int nxt = FX_TT(t + 1 < tiles_per_wave ? t + 1 : t);
+            FXM_BLOCK_A(0, 0, 0, 7, 1, FXM_H_V0, FXM_H_V0)
+            FXM_BLOCK_A(1, 1, 1, 0, 0, FXM_H_V, FXM_H_V)
+            FXM_BLOCK_A(2, 2, 0, 1, 1, FXM_H_V, FXM_H_V)
+            FXM_BLOCK_A(3, 3, 1, 2, 0, FXM_H_V, FXM_H_V)
+            FXM_BLOCK_A(4, 4, 0, 3, 1, FXM_H_V, FXM_H_V)
+            FXM_BLOCK_A(5, 5, 1, 4, 0, FXM_H_V, FXM_H_V)
+            FXM_BLOCK_A(6, 6, 0, 5, 1, FXM_H_V, FXM_H_V)
+            FXM_BLOCK_A7(7, 1, 6)
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" : "+v"(xh[0]), "+v"(xh[1]));  // MFMA results (16 passes) -> VALU
+            FX_PHASE(0)
+            FXM_RELU_PACK(cur)
+            __builtin_amdgcn_sched_barrier(0);
+            FX_PHASE(1)
+            FXM_BLOCK_B(0, 0, 7, cur, 15)
+            FXM_BLOCK_B(1, 1, 0, nxt, 0)
+            FXM_BLOCK_B(2, 2, 1, nxt, 1)
+            FXM_BLOCK_B(3, 3, 2, nxt, 2)
+            FXM_BLOCK_B(4, 4, 3, nxt, 3)
+            FXM_BLOCK_B(5, 5, 4, nxt, 4)
+            FXM_BLOCK_B(6, 6, 5, nxt, 5)
+            FX_LDX(0, 0)
+            FXM_BLOCK_B(7, 7, 6, nxt, 6)
+            FX_PHASE(2)
+        }
+    } else
     for (int t = 0; t < tiles_per_wave; ++t) {
         const int cur = FX_TT(t);
         const int nxt = FX_TT(t + 1 < tiles_per_wave ? t + 1 : t);  // after the last tile: seven groups requested again, unused
@@ -333,6 +471,12 @@ __global__ __launch_bounds__(256) void ffn_x3_kernel(FfnX3Params p) {
         for (int i = 0; i < 3; ++i) p.stamps[(blockIdx.x * 4 + wave) * 8 + 4 + i] = phase_[i];
 #endif
     FX_STAMP(2)
+#undef FXM_BLOCK_A
+#undef FXM_BLOCK_A7
+#undef FXM_BLOCK_B
+#undef FXM_MFMA_A
+#undef FXM_MFMA_B
+#undef FXM_RELU_PACK
 #undef FX_BLOCK_A
 #undef FX_BLOCK_A7
 #undef FX_BLOCK_B
@@ -501,20 +645,28 @@ int launch_ffn_x3(const FfnX3Args& a, hipStream_t s) {
     p.pro = PxPhase{reinterpret_cast<const unsigned char*>(a.wo_p), a.bo, a.x, FX_D, a.x, FX_D, 1.f, a.M, FX_D};
     p.tail = PxPhase{reinterpret_cast<const unsigned char*>(a.tail_p), a.tail_b, a.tail_out, a.ld_tail, nullptr, 0, 1.f, a.M, a.tail_n};
     const dim3 grid(cn_ceil_div(p.M, 32 * FX_MT));
-#define FX_LAUNCH(PRO_, TAIL_, LDS_)                                                                                       \
+    p.mixq = reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(a.wst) + (size_t)(a.dff / 32) * 64 * 1024);
+#define FX_LAUNCH(PRO_, TAIL_, MIX_, LDS_)                                                                                 \
     {                                                                                                                      \
         static CnAttrOnce attr_once;                                                                                       \
         int attr_dev;                                                                                                      \
         if (attr_once.need(&attr_dev)) {                                                                                   \
-            CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_x3_kernel<PRO_, TAIL_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_)); \
+            CN_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_x3_kernel<PRO_, TAIL_, MIX_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_)); \
             attr_once.mark(attr_dev);                                                                                      \
         }                                                                                                                  \
-        hipLaunchKernelGGL((ffn_x3_kernel<PRO_, TAIL_>), grid, dim3(256), LDS_, s, p);                                      \
+        hipLaunchKernelGGL((ffn_x3_kernel<PRO_, TAIL_, MIX_>), grid, dim3(256), LDS_, s, p);                                \
     }
-    if (pro && tail) FX_LAUNCH(true, true, FX_LDS_TAIL)
-    else if (pro) FX_LAUNCH(true, false, FX_LDS)
-    else if (tail) FX_LAUNCH(false, true, FX_LDS_TAIL)
-    else FX_LAUNCH(false, false, FX_LDS)
+    if (a.mix) {
+        if (pro && tail) FX_LAUNCH(true, true, true, FX_LDS_TAIL)
+        else if (pro) FX_LAUNCH(true, false, true, FX_LDS)
+        else if (tail) FX_LAUNCH(false, true, true, FX_LDS_TAIL)
+        else FX_LAUNCH(false, false, true, FX_LDS)
+    } else {
+        if (pro && tail) FX_LAUNCH(true, true, false, FX_LDS_TAIL)
+        else if (pro) FX_LAUNCH(true, false, false, FX_LDS)
+        else if (tail) FX_LAUNCH(false, true, false, FX_LDS_TAIL)
+        else FX_LAUNCH(false, false, false, FX_LDS)
+    }
 #undef FX_LAUNCH
     CN_HIP_CHECK(hipGetLastError());
     return 0;
@@ -536,13 +688,68 @@ static inline void fx_split(float v, uint16_t& hi, uint16_t& lo) {
     lo = fx_bf16_bits(v - hf);
 }
 
-size_t ffn_x3_stream_bytes(int dff) { return (size_t)(dff / 32) * 64 * 1024; }
+// (+ 64 bytes behind the tiles: the mixed form's E8M0 scale bytes of the weights' e4m3 parts, four ints)
+size_t ffn_x3_stream_bytes(int dff) { return (size_t)(dff / 32) * 64 * 1024 + 64; }
+bool ffn_mix_applies() { return !cn_exp_env("CASSNAT_NO_FFN_MIX"); }
+
+// the MIXF stream (kernel comment): per hidden tile ft, group a (0..7, W1 k-block a): [hi(k0 = 2a)][e4m3 bytes 0-15][hi(k1)][e4m3 bytes
+// 16-31] with hi(ks)[lane][j] = half(W1[32ft + (lane&31)][16ks + 8(lane>>5) + j]) and the lane's 32 e4m3 bytes p = k - 32a of row
+// 32ft + (lane&31): k-block (lane>>5) 0 = q = e4m3(w S_q), 1 = l = e4m3((w - half(w)) S_l); group 8 + b (output tile b of W2):
+// [hi(s = 0)][e4m3 0-15][hi(s = 1)][e4m3 16-31] with hi(s)[lane][j] = half(W2[32b + (lane&31)][32ft + 16s + 8(j>>2) + 4(lane>>5) + (j&3)])
+// and e4m3 byte p of row 32b + (lane&31): hidden unit 32ft + (p&3) + 8((p&15)>>2) + 4(p>>4) - the order in which the kernel's
+// half-wave exchange lines the hidden tile up
+static void pack_ffn_mix(const float* w1, const float* w2, int dff, unsigned char* out) {
+    auto h16 = [](float v) { const _Float16 h = (_Float16)v; uint16_t b; memcpy(&b, &h, 2); return b; };
+    auto hval = [](float v) { return (float)(_Float16)v; };
+    float m1 = 0.f, m2 = 0.f;
+    for (size_t i = 0; i < (size_t)dff * FX_D; ++i) { m1 = std::max(m1, std::fabs(w1[i])); m2 = std::max(m2, std::fabs(w2[i])); }
+    const int lg1 = m1 > 0.f ? (int)std::floor(std::log2(448.f / m1)) : 0, lg2 = m2 > 0.f ? (int)std::floor(std::log2(448.f / m2)) : 0;
+    const float s1q = std::ldexp(1.f, lg1), s1l = std::ldexp(1.f, lg1 + 11), s2q = std::ldexp(1.f, lg2), s2l = std::ldexp(1.f, lg2 + 11);
+    for (int ft = 0; ft < dff / 32; ++ft) {
+        unsigned char* tile = out + (size_t)ft * 64 * 1024;
+        for (int a = 0; a < 8; ++a)
+            for (int lane = 0; lane < 64; ++lane) {
+                const float* row = w1 + (size_t)(32 * ft + (lane & 31)) * FX_D;
+                for (int q = 0; q < 2; ++q)
+                    for (int j = 0; j < 8; ++j) {
+                        const uint16_t b = h16(row[16 * (2 * a + q) + 8 * (lane >> 5) + j]);
+                        memcpy(tile + ((size_t)(4 * a + 2 * q) * 64 + lane) * 16 + 2 * j, &b, 2);
+                    }
+                for (int pb = 0; pb < 32; ++pb) {
+                    const float v = row[32 * a + pb];
+                    const unsigned char e = (lane >> 5) ? cn_f32_to_e4m3_host((v - hval(v)) * s1l) : cn_f32_to_e4m3_host(v * s1q);
+                    tile[((size_t)(4 * a + 1 + 2 * (pb >> 4)) * 64 + lane) * 16 + (pb & 15)] = e;
+                }
+            }
+        for (int b = 0; b < 8; ++b)
+            for (int lane = 0; lane < 64; ++lane) {
+                const float* row = w2 + (size_t)(32 * b + (lane & 31)) * dff + 32 * ft;
+                for (int sx = 0; sx < 2; ++sx)
+                    for (int j = 0; j < 8; ++j) {
+                        const uint16_t hb = h16(row[16 * sx + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)]);
+                        memcpy(tile + ((size_t)(32 + 4 * b + 2 * sx) * 64 + lane) * 16 + 2 * j, &hb, 2);
+                    }
+                for (int pb = 0; pb < 32; ++pb) {
+                    const float v = row[(pb & 3) + 8 * ((pb & 15) >> 2) + 4 * (pb >> 4)];
+                    const unsigned char e = (lane >> 5) ? cn_f32_to_e4m3_host((v - hval(v)) * s2l) : cn_f32_to_e4m3_host(v * s2q);
+                    tile[((size_t)(32 + 4 * b + 1 + 2 * (pb >> 4)) * 64 + lane) * 16 + (pb & 15)] = e;
+                }
+            }
+    }
+    const int q[4] = {127 - lg1, 127 - (lg1 + 11), 127 - lg2, 127 - (lg2 + 11)};
+    memcpy(out + (size_t)(dff / 32) * 64 * 1024, q, 16);
+}
 
 // out: [dff/32][64 fragments][64 lanes][8] bf16.  Per hidden tile ft:
 //   fragments 4a + {0,1,2,3}      (a = 0..7): W1 hi(ks = 2a), lo(2a), hi(2a+1), lo(2a+1)      frag(ks)[lane][j] = W1[32ft + (lane&31)][16ks + 8(lane>>5) + j]
 //   fragments 32 + 4b + {0,1,2,3} (b = 0..7): s = b>>2, nt0 = 2(b&3): W2 hi(s,nt0), lo(s,nt0), hi(s,nt0+1), lo(s,nt0+1)
 //                                             frag(s,nt)[lane][j] = W2[32nt + (lane&31)][32ft + 16s + 8(j>>2) + 4(lane>>5) + (j&3)]
-void pack_ffn_x3(const float* w1, const float* w2, int dff, uint16_t* out) {
+void pack_ffn_x3(const float* w1, const float* w2, int dff, uint16_t* out, bool mix) {
+    if (mix) {
+        pack_ffn_mix(w1, w2, dff, reinterpret_cast<unsigned char*>(out));
+        return;
+    }
+    memset(reinterpret_cast<unsigned char*>(out) + (size_t)(dff / 32) * 64 * 1024, 0, 64);
     for (int ft = 0; ft < dff / 32; ++ft) {
         uint16_t* tile = out + (size_t)ft * 64 * 64 * 8;
         for (int a = 0; a < 8; ++a)

@@ -254,6 +254,7 @@ struct FfnX3Args {
     float* x = nullptr;
     const float *ln_a = nullptr, *ln_b = nullptr;
     const void* wst = nullptr;  // pack_ffn_x3 stream
+    bool mix = false;           // ... packed for the mixed arithmetic (half-precision hi x hi + e4m3 cross terms: fused_x3.hip MIXF)
     const float *b1 = nullptr, *b2 = nullptr;
     const float *nln_a = nullptr, *nln_b = nullptr;
     void* xn_out = nullptr;  // [M][256] split-bf16 (when nln_a)
@@ -275,7 +276,8 @@ struct FfnX3Args {
 bool ffn_x3_applies(int d, int dff);
 int launch_ffn_x3(const FfnX3Args& a, hipStream_t s);
 size_t ffn_x3_stream_bytes(int dff);
-void pack_ffn_x3(const float* w1, const float* w2, int dff, uint16_t* out);
+void pack_ffn_x3(const float* w1, const float* w2, int dff, uint16_t* out, bool mix = false);
+bool ffn_mix_applies();  // the split-bf16 engine's feed-forward sublayers run the mixed arithmetic (experiments: CASSNAT_NO_FFN_MIX)
 
 // ---- waveform -> log-mel filterbank (+ CMVN), Kaldi compute-fbank-feats semantics with dither 0 (fbank.hip)
 struct FbankOpts {

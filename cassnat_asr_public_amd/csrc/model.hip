@@ -524,7 +524,7 @@ struct Packer {
             if (fill) {
                 const HostTensor* t1 = find(p + ".feed_forward.w_1.weight", {dff, d});
                 const HostTensor* t2 = find(p + ".feed_forward.w_2.weight", {d, dff});
-                if (t1 && t2) pack_ffn_x3(t1->data.data(), t2->data.data(), (int)dff, reinterpret_cast<uint16_t*>(&host[ax]));
+                if (t1 && t2) pack_ffn_x3(t1->data.data(), t2->data.data(), (int)dff, reinterpret_cast<uint16_t*>(&host[ax]), ffn_mix_applies());
             }
             L.wx3 = reinterpret_cast<void*>(ax);
             L.w1.N = (int)dff;
@@ -1443,6 +1443,7 @@ int run_ffn(cn_model* m, const Layer& L, const Norm& n, float* x, int M, const N
         a.ln_a = n.a;
         a.ln_b = n.b;
         a.wst = L.wx3;
+        a.mix = ffn_mix_applies();
         a.b1 = L.w1.b;
         a.b2 = L.w2.b;
         if (next) {
@@ -1500,6 +1501,7 @@ int run_x3_chain(cn_model* m, const Layer& L, const Norm& n1, float* x, int M, c
     a.ln_a = n1.a;
     a.ln_b = n1.b;
     a.wst = L.wx3;
+    a.mix = ffn_mix_applies();
     a.b1 = L.w1.b;
     a.b2 = L.w2.b;
     a.nln_a = next.a;
@@ -3771,14 +3773,14 @@ extern "C" int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float*
 // the same sublayer in the split-bf16 precision (fused_x3.hip); xn_out_dev: split-bf16 [M][256] or NULL
 extern "C" int cn_op_ffn_x3(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, const float* w1_host, const float* b1_dev,
                             const float* w2_host, const float* b2_dev, const float* nln_a_dev, const float* nln_b_dev,
-                            void* xn_out_dev, int32_t M, int32_t dff, float eps, void* stream) {
+                            void* xn_out_dev, int32_t M, int32_t dff, float eps, int32_t mix, void* stream) {
     if (!ffn_x3_applies(256, dff)) {
         cn_set_error("cn_op_ffn_x3: d_ff must be a positive multiple of 128, at most 2048");
         return -1;
     }
     const size_t bytes = ffn_x3_stream_bytes(dff);
     std::vector<uint16_t> h(bytes / 2);
-    pack_ffn_x3(w1_host, w2_host, dff, h.data());
+    pack_ffn_x3(w1_host, w2_host, dff, h.data(), mix != 0);
     void* dw = nullptr;
     CN_HIP_CHECK(hipMalloc(&dw, bytes));
     CN_HIP_CHECK(hipMemcpy(dw, h.data(), bytes, hipMemcpyHostToDevice));
@@ -3787,6 +3789,7 @@ extern "C" int cn_op_ffn_x3(float* x_dev, const float* ln_a_dev, const float* ln
     a.ln_a = ln_a_dev;
     a.ln_b = ln_b_dev;
     a.wst = dw;
+    a.mix = mix != 0;
     a.b1 = b1_dev;
     a.b2 = b2_dev;
     a.nln_a = nln_a_dev;
@@ -3814,7 +3817,7 @@ extern "C" int cn_op_x3_chain(float* x_dev, const void* ctx_dev, const float* wo
                               const float* ln_b_dev, const float* w1_host, const float* b1_dev, const float* w2_host,
                               const float* b2_dev, const float* nln_a_dev, const float* nln_b_dev, void* xn_out_dev,
                               const float* wt_host, const float* bt_dev, void* tail_out_dev, int32_t tail_n, int32_t M, int32_t dff,
-                              float eps, void* stream) {
+                              float eps, int32_t mix, void* stream) {
     if (!ffn_x3_applies(256, dff) || (wt_host && !proj_x3_applies(tail_n, 256))) {
         cn_set_error("cn_op_x3_chain: d_ff a multiple of 128 (<= 2048), tail_n a multiple of 32 (<= 1024)");
         return -1;
@@ -3830,10 +3833,11 @@ extern "C" int cn_op_x3_chain(float* x_dev, const void* ctx_dev, const float* wo
     int rc = 0;
     {
         std::vector<uint16_t> h(ffn_x3_stream_bytes(dff) / 2);
-        pack_ffn_x3(w1_host, w2_host, dff, h.data());
+        pack_ffn_x3(w1_host, w2_host, dff, h.data(), mix != 0);
         void* dw = nullptr;
         rc = upload(h.data(), h.size() * 2, &dw);
         a.wst = dw;
+        a.mix = mix != 0;
     }
     if (rc == 0 && ctx_dev) {
         std::vector<unsigned char> h((size_t)256 * 1024);

@@ -154,8 +154,8 @@ def lib(flavour=None):
     L.cn_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                            C.POINTER(C.c_int32)]
     L.cn_op_ffn_fused.argtypes = [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
-    L.cn_op_ffn_x3.argtypes = [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p]
-    L.cn_op_x3_chain.argtypes = [C.c_void_p] * 16 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
+    L.cn_op_ffn_x3.argtypes = [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
+    L.cn_op_x3_chain.argtypes = [C.c_void_p] * 16 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
     L.cn_op_chain.argtypes = ([C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 13 +
                               [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p])
     L.cn_op_genmax.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]

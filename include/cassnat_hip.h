@@ -370,17 +370,20 @@ int cn_op_ffn_fused(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, 
                     const float* nln_b_dev, void* xn_out_dev, int32_t M, int32_t dff, float eps, int32_t nslice,
                     void* stream);
 /* the same sublayer in the split-bf16 precision (CN_PRECISION_BF16X3; fused_x3.hip): three MFMAs per product on hi + lo
- * operands; xn_out_dev is split-bf16 [M][256] (or NULL) */
+ * operands; xn_out_dev is split-bf16 [M][256] (or NULL).  mix != 0: the sublayer's two products in the engine's mixed arithmetic
+ * instead (what the engine runs) - half(a) half(b) + l_a q_b + q_a l_b with e4m3 l = (v - half(v)) 2^11 S and q = v S: one
+ * half-precision MFMA per 16 k and one K = 64 e4m3 MFMA per 32 k, 2 MFMA units per product */
 int cn_op_ffn_x3(float* x_dev, const float* ln_a_dev, const float* ln_b_dev, const float* w1_host, const float* b1_dev,
                  const float* w2_host, const float* b2_dev, const float* nln_a_dev, const float* nln_b_dev, void* xn_out_dev,
-                 int32_t M, int32_t dff, float eps, void* stream);
+                 int32_t M, int32_t dff, float eps, int32_t mix, void* stream);
 /* the row-chain form of the split-bf16 engine (fused_x3.hip): attention output projection + residual, feed-forward sublayer, next
  * LayerNorm and (wt_host != null) the next attention's projection of it, in one launch; ctx_dev split-bf16 [M][256] or null;
  * weight matrices on the host, vectors on the device (positionff.py:15-16, attention.py:57-66, norm.py:15-18) */
 int cn_op_x3_chain(float* x_dev, const void* ctx_dev, const float* wo_host, const float* bo_dev, const float* ln_a_dev,
                    const float* ln_b_dev, const float* w1_host, const float* b1_dev, const float* w2_host, const float* b2_dev,
                    const float* nln_a_dev, const float* nln_b_dev, void* xn_out_dev, const float* wt_host, const float* bt_dev,
-                   void* tail_out_dev, int32_t tail_n, int32_t M, int32_t dff, float eps, void* stream);
+                   void* tail_out_dev, int32_t tail_n, int32_t M, int32_t dff, float eps, int32_t mix /* as cn_op_ffn_x3 */,
+                   void* stream);
 /* fused generator tail, bf16 / d_model 256: arg[m] = argmax_v, maxlp[m] = max_v of log_softmax(W h[m] + b); h_dev bf16 [M][256],
  * W/b HOST fp32 nn.Linear parameters (packed and uploaded by the call; the model packs once at cn_model_finalize). */
 int cn_op_genmax(const void* h_dev, const float* w_host, const float* b_host, int32_t M, int32_t V, int32_t* arg_dev,

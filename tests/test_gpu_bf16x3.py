@@ -243,9 +243,12 @@ def test_attention_rescale_branch():
     assert relerr(run_attention(q, k, v), attention_reference(q, k, v, torch.ones(B, 1, Lk, dtype=torch.bool))) < ATT_TOL
 
 
+@pytest.mark.parametrize("mix", [0, 1])
 @pytest.mark.parametrize("M,dff,with_next", [(8000, 2048, True), (45, 256, False), (2304, 2048, True), (64, 128, True), (1, 1024, True)])
-def test_ffn_fused_x3(M, dff, with_next):
-    """fused_x3.hip: x += W2 relu(W1 LN(x) + b1) + b2 and the next LayerNorm, against fp64 on the unrounded operands."""
+def test_ffn_fused_x3(M, dff, with_next, mix):
+    """fused_x3.hip: x += W2 relu(W1 LN(x) + b1) + b2 and the next LayerNorm, against fp64 on the unrounded operands.  mix = 1:
+    the two products in the engine's mixed arithmetic (half-precision hi x hi + e4m3 cross terms, 2 MFMA units per product) -
+    the same tolerance."""
     from oracle.cassnat_oracle import layer_norm
 
     g = torch.Generator().manual_seed(M + dff)
@@ -260,19 +263,21 @@ def test_ffn_fused_x3(M, dff, with_next):
     w1c, w2c = w1.contiguous(), w2.contiguous()
     hip.check(hip.lib().cn_op_ffn_x3(p(xd), p(devs[0]), p(devs[1]), C.c_void_p(w1c.data_ptr()), p(devs[2]), C.c_void_p(w2c.data_ptr()),
                                      p(devs[3]), p(devs[4]) if with_next else None, p(devs[5]) if with_next else None,
-                                     p(xn) if with_next else None, M, dff, 1e-6, stream()))
+                                     p(xn) if with_next else None, M, dff, 1e-6, mix, stream()))
     torch.cuda.synchronize()
     xr = x.double()
     h = F.relu(F.linear(layer_norm(xr, a1.double(), b1n.double()), w1.double(), bb1.double()))
     ref = xr + F.linear(h, w2.double(), bb2.double())
+    print(f"[ffn_x3 mix={mix}] M {M} dff {dff}: relative error {relerr(xd, ref):.2e}")
     assert relerr(xd, ref) < 2e-5
     if with_next:
         assert relerr(from_split(xn), layer_norm(ref, a2.double(), b2n.double())) < 3e-5
 
 
+@pytest.mark.parametrize("mix", [0, 1])  # (1: the feed-forward products in the mixed arithmetic - what the engine runs)
 @pytest.mark.parametrize("M,dff,with_ctx,tail_n", [(8000, 2048, True, 768), (8000, 2048, True, 0), (45, 256, True, 768), (2304, 2048, False, 256),
                                                    (65, 128, True, 512), (1, 1024, True, 768), (20031, 2048, True, 768)])
-def test_x3_row_chain(M, dff, with_ctx, tail_n):
+def test_x3_row_chain(M, dff, with_ctx, tail_n, mix):
     """fused_x3.hip, row-chain form: x += Wo ctx + bo; x += W2 relu(W1 LN(x) + b1) + b2; then the next LayerNorm or the next
     attention's projection of it - against fp64 on the unrounded operands (ctx as the split-bf16 values the attention kernel
     leaves).  Partial last tiles, one row, several rounds of workgroups."""
@@ -297,7 +302,7 @@ def test_x3_row_chain(M, dff, with_ctx, tail_n):
     hp = lambda t: C.c_void_p(t.data_ptr())
     hip.check(hip.lib().cn_op_x3_chain(p(xd), p(ctx_s) if with_ctx else None, hp(hosts[0]), p(devs[0]), p(devs[1]), p(devs[2]), hp(hosts[1]),
                                        p(devs[3]), hp(hosts[2]), p(devs[4]), p(devs[5]), p(devs[6]), p(xn), hp(hosts[3]) if tail_n else None,
-                                       p(devs[7]), p(tail), tail_n, M, dff, 1e-6, stream()))
+                                       p(devs[7]), p(tail), tail_n, M, dff, 1e-6, mix, stream()))
     torch.cuda.synchronize()
     xr = x.double()
     if with_ctx:

@@ -7,6 +7,9 @@ residual, next LayerNorm), in shader cycles (s_memtime; the counters of differen
 """
 import ctypes as C
 import os
+
+MIX = int(os.environ.get("FFN_X3_MIX", "1"))  # (1: the mixed arithmetic the engine runs; 0: three bf16 MFMAs per product)
+import os
 import sys
 
 import numpy as np
@@ -24,7 +27,7 @@ def main():
     tag = "".join(c for c in "".join(extra) if c.isalnum())
     lib = B.build(extra_flags=["-DFX_STAMPS"] + extra, lib=os.path.join(out, "libcassnat_hip_stamps%s.so" % tag), objdir=os.path.join(out, "cn_stamps_obj" + tag))
     L = C.CDLL(lib)
-    L.cn_op_ffn_x3.argtypes = [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p]
+    L.cn_op_ffn_x3.argtypes = [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
     L.cn_debug_ffn_x3_stamps.argtypes = [C.c_void_p, C.c_int32]
     g = torch.Generator().manual_seed(0)
     x = (torch.randn(M, 256, generator=g) * 2).cuda()
@@ -34,7 +37,7 @@ def main():
     xn = torch.zeros(M, 256, dtype=torch.int32, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr())
     for _ in range(3):
-        rc = L.cn_op_ffn_x3(p(x), p(a1), p(b1n), p(w1), p(bb1), p(w2), p(bb2), p(a2), p(b2n), p(xn), M, dff, 1e-6, None)
+        rc = L.cn_op_ffn_x3(p(x), p(a1), p(b1n), p(w1), p(bb1), p(w2), p(bb2), p(a2), p(b2n), p(xn), M, dff, 1e-6, MIX, None)
         assert rc == 0, rc
     n_wg = (M + 63) // 64
     st = np.zeros((n_wg, 4, 8), dtype=np.uint64)
