@@ -515,7 +515,10 @@ def main():
         parity_engine["speedup_over_fp32_engine"] = round(parity_engine["value"] / fp32_engine["value"], 3)
         parity_engine["note"] = ("the fastest engine that passes north_star's gate (tests/test_gpu_pipeline.py::test_fp32_parity_gate"
                                  "[bf16x3-*]: 0 arg-max flips, 1e-5 logit error, hypotheses token-exact); `hyp_agreement` = whole "
-                                 "hypotheses of the benchmark batch equal to the fp32 CPU oracle's")
+                                 "hypotheses of the benchmark batch equal to the fp32 CPU oracle's.  Its conv2 and feed-forward "
+                                 "products run a mixed arithmetic - half-precision hi x hi + e4m3 cross terms, 2 MFMA units per "
+                                 "product instead of the split form's 3 (DESIGN 9) - so `mfma_peak_tflops` = peak / 3 understates "
+                                 "the roofline of those kernels (their own is peak / 2)")
 
     # the bf16 engine's kernels with IEEE half operands (libcassnat_hip_f16.so, csrc/common.h): the same matrix pipe at the same
     # rate, operand roundings 8 x smaller - CTC log-posteriors within north_star's 1e-3 of the fp32 reference
