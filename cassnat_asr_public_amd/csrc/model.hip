@@ -223,10 +223,11 @@ struct cn_model {
     float* cv_f = nullptr;
     double* gn_stats = nullptr;
     int* ymax_pinned = nullptr;  // page-locked host word for the one data-dependent readback per batch
-    // fp16 build only (CN_OP16_F16): half-precision operands have a range.  What drives magnitudes from outside is the scale of the
+    // fp16 build (CN_OP16_F16): half-precision operands have a range.  What drives magnitudes from outside is the scale of the
     // features (everything behind linear_out is LayerNorm-ed in fp32 first), so every pass checks them against the largest value
     // for which neither subsampling convolution's output can leave the half range (op16_feat_limit: a word of the weight blob,
-    // from the convolutions' weight row sums) and raises a sticky flag in device-visible page-locked memory (cn_take_range_fault)
+    // from the convolutions' weight row sums) and raises a sticky flag in device-visible page-locked memory (cn_take_range_fault).
+    // The other build uses the same guard for its split-bf16 engines: conv1's outputs against the e4m3 range of conv2's MIX form
     const float* op16_feat_limit = nullptr;
     unsigned int* op16_fault = nullptr;
     // CTC prefix beam / forced alignment scratch (cn_ctc_beam, cn_decode_nast_forced): grown on demand
@@ -871,8 +872,17 @@ int build_weights(cn_model* m) {
                     B1 = std::max(B1, std::fabs((double)b1->data[ch]));
                     B2 = std::max(B2, std::fabs((double)b2->data[ch]));
                 }
+#ifdef CN_OP16_F16
                 const double half_max = 65504.0 / 2;
                 const double c1 = std::min(half_max, A2 > 0 ? (half_max - B2) / A2 : half_max);  // the bound on conv1's output
+#else
+                // (this build: the split-bf16 engine's conv2 in the mixed arithmetic - conv1's outputs have to stay inside the
+                // e4m3 range of their q plane, 448 / 2^MIX_LG_AQ; beyond it the cross terms saturate and the product falls back
+                // towards half precision: the engine would keep decoding, below its tolerance)
+                (void)A2;
+                (void)B2;
+                const double c1 = 448.0 / std::ldexp(1.0, MIX_LG_AQ);
+#endif
                 lim = (float)std::max(0.0, A1 > 0 ? (c1 - B1) / A1 : 3e38);
             }
             std::memcpy(&pk.host[at], &lim, 4);
@@ -1333,10 +1343,16 @@ int build_workspace(cn_model* m) {
     m->gn_stats = (double*)get("gn_stats");
     CN_HIP_CHECK(hipHostMalloc((void**)&m->ymax_pinned, 64, hipHostMallocDefault));
     CN_HIP_CHECK(hipHostMalloc((void**)&m->ymax_ring, 64, hipHostMallocDefault));
+    bool range_guard = false;
 #ifdef CN_OP16_F16
-    CN_HIP_CHECK(hipHostMalloc((void**)&m->op16_fault, 64, hipHostMallocMapped));
-    *m->op16_fault = 0;
+    range_guard = true;
+#else
+    range_guard = conv2_mix_applies(m->prec, m->cfg.d_model, m->cfg.d_model) && m->cfg.ast != 2;
 #endif
+    if (range_guard) {
+        CN_HIP_CHECK(hipHostMalloc((void**)&m->op16_fault, 64, hipHostMallocMapped));
+        *m->op16_fault = 0;
+    }
     return 0;
 }
 
@@ -1951,9 +1967,8 @@ int stage_encode(cn_model* m, const float* feats, int B, int T, int F, const cn_
     m->Tp = Tp;
     m->U = 0;
     CN_TRY(launch_keymask(feats, B, T, F, Tp, 4, (float)o->padding_idx, m->keymask, s));
-#ifdef CN_OP16_F16
+    // (fp16 engines: the features against the half range; split-bf16 engines: against the e4m3 range of conv2's mixed arithmetic)
     if (m->op16_fault && m->op16_feat_limit) CN_TRY(launch_feature_range(feats, (size_t)B * T * F, m->op16_feat_limit, m->op16_fault, s));
-#endif
     // conv1 writes its image with a zero halo when the LDS-DMA conv2 kernel consumes it (captures want the plain image)
     // (the split-bf16 engine: two bordered bf16 planes, hi and lo, for the same kernel's X3 form)
     // (the split-bf16 engine's planes in the MIX arithmetic of conv2.hip where it applies: half-precision hi values + two e4m3 planes)

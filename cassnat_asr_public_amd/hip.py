@@ -362,10 +362,14 @@ class Engine:
     def check_range(self, what="decode"):
         """fp16 engines: raise if a pass since the last call saw features beyond the range the half-precision operands hold
         (``cn_take_range_fault``; call it once the passes' results are on the host).  Other engines: nothing to check."""
-        if self.precision not in ("fp16", "float16"):
+        if self.precision not in ("fp16", "float16", "bf16x3"):
             return
         fault, limit = C.c_int32(), C.c_float()
         self._chk(self.L.cn_take_range_fault(self.handle, C.byref(fault), C.byref(limit)), "cn_take_range_fault")
+        if fault.value and self.precision == "bf16x3":
+            raise HipError(f"{what}: features beyond the range the split-bf16 engine's mixed-arithmetic convolution holds at its "
+                           f"tolerance (|x| > {limit.value:.4g} lets conv1 outputs pass the e4m3 operands' 448): normalise the features "
+                           "(CMVN) or decode with --hip_precision fp32")
         if fault.value:
             raise HipError(f"{what}: features beyond the fp16 engine's half-precision range (|x| > {limit.value:.4g} lets a subsampling "
                            "convolution's output pass 65504 / 2): normalise the features (CMVN) or decode with --hip_precision bf16 / bf16x3")

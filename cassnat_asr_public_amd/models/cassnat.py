@@ -388,7 +388,7 @@ class CassNAT(nn.Module):
 
     def _range_ok(self):
         """fp16 engine: the features of the call just finished were inside the range its half-precision operands hold."""
-        if self.hip_precision == "fp16" and self._engine is not None:
+        if self.hip_precision in ("fp16", "bf16x3") and self._engine is not None:
             self._engine.check_range("beam_decode")
 
     def decode_device(self, src, src_size, args, sos=1, engine=None, sub_batch=0, sub_rows=None, sub_frames=None, u_hint=0,

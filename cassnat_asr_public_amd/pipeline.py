@@ -142,6 +142,7 @@ class DecodePipelines:
         threads (inside ``cn_host_gather``) - what ``--load_data_workers`` means on the packed reader path."""
         self.model = model
         self._fp16 = getattr(model, "hip_precision", "") == "fp16"  # (its scores are checked for the half range: hip.check_fp16_range)
+        self._guarded = getattr(model, "hip_precision", "") in ("fp16", "bf16x3")  # (engines with a feature-range guard: Engine.check_range)
         self.copy_threads = max(0, int(copy_threads))
         self._packed = [{} for _ in range(max(1, int(n_pipelines)))]  # per pipeline: packed-pass staging buffers by slot
         self.cmvn = None if cmvn is None else (np.ascontiguousarray(cmvn[0], dtype=np.float64), np.ascontiguousarray(cmvn[1], dtype=np.float64))
@@ -459,8 +460,8 @@ class DecodePipelines:
             p.ev.synchronize()
             self._bump("s_retire_wait", time.perf_counter() - t_)
             self._mark("drained", k)
-        if self._fp16:
-            self.engines[k].check_range("DecodePipelines")  # (features beyond the half range: the pass is not handed out)
+        if self._guarded:
+            self.engines[k].check_range("DecodePipelines")  # (features beyond the engine's operand range: the pass is not handed out)
         if p.ticket is not None and p.ticket >= 0:
             ymax, used = self.engines[k].ticket(p.ticket)
             self._bump("passes", 1)

@@ -149,8 +149,10 @@ int cn_decode_ticket(cn_model* m, int32_t ticket, int32_t* ymax_host, int32_t* r
  * with the largest |feature| for which neither subsampling convolution's output can leave half of that range (from the
  * convolutions' weight row sums; a word of the weight blob) and raises a sticky flag.  *fault = 1: a pass since the last call saw
  * such features - its results are not to be used (decode on a bf16 / bf16x3 engine, or normalise the features).  Valid once the
- * passes' stream work is done; clears the flag.  *feature_limit (may be null): that largest |feature|, 0 if unknown.  Engines of
- * every other precision: *fault = 0. */
+ * passes' stream work is done; clears the flag.  *feature_limit (may be null): that largest |feature|, 0 if unknown.
+ * CN_PRECISION_BF16X3 engines use the same guard: their second convolution runs a mixed arithmetic whose e4m3 cross-term operands
+ * hold conv1 outputs up to 448 (csrc/conv2.hip MIX); features beyond (448 - |b1|max) / (largest row sum of |w1|) would let them
+ * saturate and the engine fall below its tolerance.  Engines of every other precision: *fault = 0. */
 int cn_take_range_fault(cn_model* m, int32_t* fault, float* feature_limit);
 
 /* stage-level entry: src_embed + encoder + ctc_generator + alignment only (src/models/cassnat.py:431-468) */

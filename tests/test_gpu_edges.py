@@ -768,3 +768,28 @@ def test_fp16_engine_fails_loudly_outside_the_half_range():
     eng2.load_state(state, torch.zeros(5000, args.d_model))
     hip.check(eng2.L.cn_take_range_fault(eng2.handle, hip.C.byref(fault), hip.C.byref(limit)), "cn_take_range_fault", eng2.L)
     assert abs(limit.value - want) < 1e-3 * want
+
+
+def test_bf16x3_engine_guards_the_range_of_its_mixed_convolution():
+    """The split-bf16 engine's second convolution runs the mixed arithmetic of csrc/conv2.hip (half-precision hi x hi + e4m3 cross
+    terms at fixed scales): its e4m3 operands hold conv1 outputs up to 448.  Features that could push conv1 beyond that would not
+    break the decode - the cross terms saturate - but take the engine below its tolerance, silently; the feature-range guard
+    (cn_take_range_fault, the bound from conv1's weight row sums) makes `beam_decode` raise instead."""
+    args = synth.make_args("config2")
+    state = synth.make_state(args, seed=0, blank_bias=synth.BENCH_BLANK_BIAS)
+    feats, sizes = synth.make_feats(2, 120, 80, lengths=[120, 93], seed=5)
+    model = build(args, state, capture=False, prec="bf16x3")
+    src = torch.from_numpy(feats).cuda()
+    ratio = torch.from_numpy(sizes).cuda()
+    mask = (src[:, :, 0] != args.padding_idx).unsqueeze(1)
+    model.beam_decode(src, mask, ratio, Vocab, args)
+    eng = model._engine
+    fault, limit = hip.C.c_int32(), hip.C.c_float()
+    hip.check(eng.L.cn_take_range_fault(eng.handle, hip.C.byref(fault), hip.C.byref(limit)), "cn_take_range_fault", eng.L)
+    w1, b1 = state["src_embed.conv.0.weight"], state["src_embed.conv.0.bias"]
+    want = (448.0 - np.abs(b1).max()) / np.abs(w1).reshape(w1.shape[0], -1).sum(1).max()
+    assert fault.value == 0 and abs(limit.value - want) < 1e-3 * want, (limit.value, want)
+    big = torch.from_numpy((feats * (1.05 * limit.value / np.abs(feats).max())).astype(np.float32)).cuda()
+    with pytest.raises(hip.HipError, match="mixed-arithmetic convolution"):
+        model.beam_decode(big, mask, ratio, Vocab, args)
+    model.beam_decode(src, mask, ratio, Vocab, args)
