@@ -683,3 +683,12 @@ def test_host_gather_copies_archive_rows_back_to_back(tmp_path):
     pb = PackedBatch(views[:5])
     utts, feats, _, ratios, _ = collate([(u, m, [1]) for u, m in mats[:5]], padding_idx=0)
     assert pb.shape == tuple(feats.shape) and torch.equal(pb.ratios(), ratios) and torch.equal(pb.padded(0.0), feats)
+
+
+def test_fp16_score_check_refuses_non_finite_scores():
+    """Second line of the fp16 engine's range guard (hip.check_fp16_range): a NaN / infinite hypothesis score is an error, never a result."""
+    hip.check_fp16_range(np.array([-3.5, -120.25]))
+    for bad in (np.nan, np.inf, -np.inf):
+        with pytest.raises(hip.HipError, match="half-precision range"):
+            hip.check_fp16_range(np.array([-1.0, bad]))
+    assert hip.PRECISION["fp16"] == 4 and hip.lib_for("fp16") is hip.lib("f16") and hip.lib_for("bf16x3") is hip.lib()
