@@ -486,6 +486,8 @@ def main():
                 got[0] = h_
 
         runx(max(2, nsx * (1 if prec == "fp32" else CO)))
+        if px.predict and prec != "fp32":  # (as the headline: the first passes run exactly and teach the row-count predictor; one more, predicted, warms that form up)
+            runx(nsx * CO)
         fence()
         c0 = time.perf_counter()
         runx(a.steps)
