@@ -697,18 +697,16 @@ __global__ __launch_bounds__(256) void feature_range_kernel(const float* __restr
         const float4 v = x4[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
+    // what the 16-byte loads did not cover: the last n % 4 values - or everything, for a batch that does not start on a 16-byte
+    // boundary (a view into a larger tensor with an odd feature width)
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
     if (m > lim) *fault = 1u;  // (racing writers store the same word; page-locked host memory, read after the stream has drained)
 }
 
 int launch_feature_range(const float* x, size_t n, const float* limit, unsigned int* fault, hipStream_t s) {
     if (n == 0) return 0;
-    if (reinterpret_cast<uintptr_t>(x) & 15) {
-        cn_set_error("feature range check: the feature batch must be 16-byte aligned");
-        return -1;
-    }
-    const size_t n4 = n / 4;
-    const int grid = (int)std::min<size_t>(2048, (n4 + 255) / 256 + 1);
+    const size_t n4 = (reinterpret_cast<uintptr_t>(x) & 15) ? 0 : n / 4;
+    const int grid = (int)std::min<size_t>(2048, ((n4 ? n4 : n) + 255) / 256 + 1);
     hipLaunchKernelGGL(feature_range_kernel, dim3(grid), dim3(256), 0, s, x, n4, n, limit, fault);
     CN_HIP_CHECK(hipGetLastError());
     return 0;

@@ -763,6 +763,16 @@ def test_fp16_engine_fails_loudly_outside_the_half_range():
     wide = build(args, state, capture=False, prec="bf16")
     out, _ = wide.beam_decode(big, mask, ratio, Vocab, args)
     assert all(np.isfinite(o[0]["score"]) for o in out)
+    # a batch that does not start on a 16-byte boundary (a view into a larger buffer): the guard reads it all the same
+    base = torch.empty(src0.numel() + 1, device="cuda")
+    odd = base[1:].view_as(src0)
+    assert odd.data_ptr() % 16 == 4
+    odd.copy_(src0)
+    got, _ = model.beam_decode(odd, mask, ratio, Vocab, args)
+    assert [o[0]["hyp"] for o in got] == [o[0]["hyp"] for o in ok] and [o[0]["score"] for o in got] == [o[0]["score"] for o in ok]
+    odd.copy_(big)
+    with pytest.raises(hip.HipError, match="half-precision range"):
+        model.beam_decode(odd, mask, ratio, Vocab, args)
     # an engine that received its weights as a blob (a non-zero rank) carries the bound too: it is a word of the blob
     eng2 = hip.Engine(args, precision="fp16", max_batch=3, max_frames=61)
     eng2.load_state(state, torch.zeros(5000, args.d_model))
