@@ -229,6 +229,7 @@ struct cn_model {
     // from the convolutions' weight row sums) and raises a sticky flag in device-visible page-locked memory (cn_take_range_fault).
     // The other build uses the same guard for its split-bf16 engines: conv1's outputs against the e4m3 range of conv2's MIX form
     const float* op16_feat_limit = nullptr;
+    float op16_feat_limit_host = -1.f;  // (read back once, on the first cn_take_range_fault)
     unsigned int* op16_fault = nullptr;
     // CTC prefix beam / forced alignment scratch (cn_ctc_beam, cn_decode_nast_forced): grown on demand
     std::map<std::string, std::pair<void*, size_t>> scratch;
@@ -2496,6 +2497,7 @@ extern "C" int cn_model_finalize(cn_model* m) {
         return -1;
     }
     CN_HIP_CHECK(hipSetDevice(m->cfg.device));
+    m->op16_feat_limit_host = -1.f;  // (the range guard's bound is a word of the weights: read back again after this)
     if (m->pe_rows < m->maxTp + 1) {
         if (m->host.empty() && m->pe_rows == 0) {
             m->pe_rows = 5000;  // layout-only: table arrives with the broadcast blob (create_pe max_len)
@@ -2664,7 +2666,10 @@ extern "C" int cn_take_range_fault(cn_model* m, int32_t* fault_host, float* feat
     if (feature_limit_host) *feature_limit_host = 0.f;
     if (!m->op16_fault) return 0;
     *fault_host = (int32_t)__atomic_exchange_n(m->op16_fault, 0u, __ATOMIC_ACQ_REL);
-    if (feature_limit_host && m->op16_feat_limit) CN_HIP_CHECK(hipMemcpy(feature_limit_host, m->op16_feat_limit, 4, hipMemcpyDeviceToHost));
+    if (feature_limit_host && m->op16_feat_limit) {
+        if (m->op16_feat_limit_host < 0.f) CN_HIP_CHECK(hipMemcpy(&m->op16_feat_limit_host, m->op16_feat_limit, 4, hipMemcpyDeviceToHost));
+        *feature_limit_host = m->op16_feat_limit_host;
+    }
     return 0;
 }
 
