@@ -376,25 +376,33 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         const unsigned wstep_ = LINEAR ? 32u * (unsigned)(p.ksteps * 128) : 32u * (9 * C2_C * ES8);  // byte distance of consecutive W pieces (32 weight rows)
         const unsigned pw0 = pw[0];
         unsigned tv_ = pw0;
-        // K steps of this phase (128 channels each).  MIX: two rounds of the 18 - (A_l, W_q) with q8[0..1], (A_q, W_l) with q8[2..3]
-        constexpr int KS8 = LINEAR ? C2_LIN8_KSTEPS : C2_KSTEPS / 2;
+        // K steps of this phase (128 channels each).  MIX: ONE run of 2 x 18 steps - (A_l, W_q) with q8[0..1], then (A_q, W_l) with
+        // q8[2..3] - on the same stages: the second half's first slabs are requested by the first half's last steps
+        // (everything unrolled: across a back edge hipcc joins the fragment sets with moves of registers whose reads are in flight)
+        constexpr int KH8 = C2_KSTEPS / 2;
+        constexpr int KS8 = LINEAR ? C2_LIN8_KSTEPS : (MIX ? 2 * KH8 : KH8);
         const int KL8 = KS8 - 1;
-#pragma unroll  // (both rounds unrolled: across a back edge hipcc joins the fragment sets with moves of registers whose reads are in flight)
-        for (int round = 0; round < (MIX ? 2 : 1); ++round) {
-        const int qa_ = p.q8[2 * round], qb_ = p.q8[2 * round + 1];
-        const unsigned char* const A8 = MIX ? (round ? p.A8q : p.A8l) + tile_off : p.A + tile_off;
-        const unsigned char* const W8 = MIX ? (round ? p.W8l : p.W8q) : p.W;
+        const int q8a0 = p.q8[0], q8b0 = p.q8[1], q8a1 = MIX ? p.q8[2] : 0, q8b1 = MIX ? p.q8[3] : 0;
+        const unsigned char* const A8_0 = MIX ? p.A8l + tile_off : p.A + tile_off;
+        const unsigned char* const A8_1 = MIX ? p.A8q + tile_off : p.A + tile_off;
+        const unsigned char* const W8_0 = MIX ? p.W8q : p.W;
+        const unsigned char* const W8_1 = MIX ? p.W8l : p.W;
         auto a_base8 = [&](int kt) -> const unsigned char* {
-            if constexpr (LINEAR) return A8 + (long long)kt * 128;
+            if constexpr (LINEAR) return A8_0 + (long long)kt * 128;
+            const unsigned char* pl = (MIX && kt >= KH8) ? A8_1 : A8_0;
+            if (MIX && kt >= KH8) kt -= KH8;
             const int cb = kt / 9, tap = kt - 9 * cb;
             const int kh = tap / 3, kw = tap - 3 * kh;
-            return A8 + (long long)((kh * F1p + kw) * (C2_C * ES8) + cb * 128);
+            return pl + (long long)((kh * F1p + kw) * (C2_C * ES8) + cb * 128);
         };
         auto w_base8 = [&](int kt) -> const unsigned char* {
-            if constexpr (LINEAR) return W8 + (long long)kt * 128;
+            if constexpr (LINEAR) return W8_0 + (long long)kt * 128;
+            const unsigned char* pl = (MIX && kt >= KH8) ? W8_1 : W8_0;
+            if (MIX && kt >= KH8) kt -= KH8;
             const int cb = kt / 9, tap = kt - 9 * cb;
-            return W8 + (long long)(tap * C2_C * ES8 + cb * 128);
+            return pl + (long long)(tap * C2_C * ES8 + cb * 128);
         };
+        {
         C2_ISSUE8(a_dst(0), pa, a_base8(0))
         C2_ISSUE8(w_dst(0), pw, w_base8(0))
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -419,6 +427,7 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
         // (LINEAR: linear_out of the 20 x 256 = 5120-wide embedding input: 40 steps - the launcher checks)
 #pragma unroll
         for (int kt = 0; kt < KS8; ++kt) {
+            const int qa_ = (MIX && kt >= KH8) ? q8a1 : q8a0, qb_ = (MIX && kt >= KH8) ? q8b1 : q8b0;
             const int k3 = kt % 3;
             const int k3n = k3 == 2 ? 0 : k3 + 1, k3p = k3 == 0 ? 2 : k3 - 1;
             const unsigned so_a = (unsigned)(k3 * C2_SLAB), so_w = (unsigned)((kt & 1) * C2_SLAB);
@@ -451,7 +460,6 @@ __global__ __launch_bounds__(256) void conv2_kernel(Conv2Params p) {
                      :: "memory");
         asm volatile("" : "+v"(Az[0]), "+v"(Az[1]), "+v"(Az[2]), "+v"(Az[3]), "+v"(Wz[0]), "+v"(Wz[1]), "+v"(Wz[2]), "+v"(Wz[3]),
                      "+v"(Au[0]), "+v"(Au[1]), "+v"(Au[2]), "+v"(Au[3]), "+v"(Wu[0]), "+v"(Wu[1]), "+v"(Wu[2]), "+v"(Wu[3]) :: "memory");
-        if constexpr (MIX) __syncthreads();  // (the next round's first requests overwrite stages this round's last steps read)
         }
     }
     if constexpr (LINEAR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant requests of the last steps (they write this workgroup's LDS)
