@@ -436,6 +436,7 @@ def test_bf16_production_path_against_golden(prec, capsys):
 @pytest.mark.parametrize("which,prec", [("esa_tiny", "fp32"), ("esa_config2", "fp32"), ("esa_config2", "bf16"),
                                         ("esa_tiny", "bf16x3"), ("esa_config2", "bf16x3"),  # the split-bf16 engine: gated like fp32
                                         ("esa_config2", "fp8"),  # (the ranking LM of an fp8 recogniser runs bf16)
+                                        ("esa_config2", "fp16"),  # (recogniser and ranking LM as engines of the half-precision library)
                                         ("esa_conf_tiny", "fp32")])  # (conformer blocks under ESA: the shipped YAML's combination)
 def test_esa_sampling_with_lm_ranking(which, prec, capsys):
     """sample_num = 4 alignments per utterance (random draws = the fixture's, i.e. the reference's torch.randint stream),
